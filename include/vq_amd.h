@@ -1,0 +1,174 @@
+/*
+ * vq_amd.h -- C ABI of the MI355X-native hot path of PARC-projects/video-query-algorithms.
+ *
+ * The reference has no FFI of its own: its hot path sits behind two Python-level seams
+ * (SURVEY.md 8(b)).  This header is the boundary a maintainer binds underneath those seams
+ * (ctypes stub in INTEGRATION.md).  Every entry point names the reference code it replaces
+ * (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - every function returns VQ_OK (0) or a negative VQ_E_* code; vq_last_error() returns the
+ *     message of the last failure on the calling thread.  No C++ exception crosses the ABI.
+ *   - handles are opaque, bound to one HIP device, own their device memory, and are internally
+ *     locked (the reference's broker re-enters from timer threads, broker.py:91-92).
+ *   - "host" pointers are ordinary process memory owned by the caller; "dev" pointers are HIP
+ *     device addresses on the handle's device.  No torch types anywhere.
+ *   - all kernels are launched on the handle's stream (default: the null stream); set it with
+ *     vq_*_set_stream(handle, hipStream_t) to interoperate with a framework's stream.
+ */
+#ifndef VQ_AMD_H
+#define VQ_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQ_ABI_VERSION 1
+
+enum {
+    VQ_OK = 0,
+    VQ_E_INVALID = -1,      /* bad argument / shape mismatch            */
+    VQ_E_HIP = -2,          /* a HIP runtime call failed                 */
+    VQ_E_NOMEM = -3,        /* device or host allocation failed          */
+    VQ_E_STATE = -4,        /* call order violated (e.g. scan before query) */
+    VQ_E_UNSUPPORTED = -5   /* shape outside what the kernels were built for */
+};
+
+enum { VQ_F32 = 0, VQ_F64 = 1 };
+
+const char* vq_last_error(void);
+int vq_abi_version(void);
+int vq_device_count(int* count);
+/* Pure HIP-event timing helpers for bench.py (events recorded on the given stream). */
+int vq_timer_create(void** timer);
+int vq_timer_start(void* timer, void* stream);
+int vq_timer_stop(void* timer, void* stream);
+int vq_timer_elapsed_ms(void* timer, float* ms);       /* synchronises on the stop event */
+int vq_timer_destroy(void* timer);
+
+/* ------------------------------------------------------------------------------------------
+ * Hot path B: feature database, similarity scan, scoring, selection
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vq_db vq_db;
+
+/* A resident, row-major [N][S][E][D] feature block (N clips, S streams, E ensemble members
+ * ("splits"), D = feature length).  Replaces the nested dict the reference builds from one JSON
+ * GET per query in Ticket._get_candidate_features (src/models/ticket.py:358-382).
+ * dtype VQ_F32 (BASELINE configs) or VQ_F64 (exact values of the shipped CSVs). */
+int vq_db_create(int64_t n, int32_t S, int32_t E, int32_t D, int32_t dtype, int32_t device, vq_db** out);
+int vq_db_destroy(vq_db* db);
+int vq_db_set_stream(vq_db* db, void* hip_stream);
+int vq_db_shape(vq_db* db, int64_t* n, int32_t* S, int32_t* E, int32_t* D, int32_t* dtype);
+
+/* Fill rows [row0,row0+nrows) from host memory laid out [nrows][S][E][D]. */
+int vq_db_upload(vq_db* db, int64_t row0, int64_t nrows, const void* feats_host);
+/* Use caller-owned device memory ([N][S][E][D], e.g. the output of an RCCL all-gather of
+ * per-GPU feature blocks) instead of the handle's own allocation.  The memory must outlive db. */
+int vq_db_adopt_device(vq_db* db, void* feats_dev);
+/* Optional [N][S][E] presence mask (1 = this clip has this split); NULL restores "dense".
+ * Mirrors clips that lack a split in ticket.py:146-160 (n_e = number of splits present). */
+int vq_db_set_present(vq_db* db, const uint8_t* present_host);
+/* Synthetic rows generated on the device from a counter-based hash (too big to ship):
+ * value(row,s,e,d) = u24(hash(seed, flat index of global row)) * 2^-24 * scales[s]. */
+int vq_db_generate(vq_db* db, uint64_t seed, int64_t global_row0, const float* scales_host);
+int vq_db_feats_devptr(vq_db* db, void** dev_ptr);
+
+/* Query vectors t[S][E][D] (fp64): the reference's target_features,
+ * TargetClip.scaled_ref_clip_features / _scale_feature (src/models/target_clip.py:137-143,311-313). */
+int vq_db_set_query(vq_db* db, const double* t_host);
+/* Device-side restatement of _scale_feature for a ref clip that lives in the DB:
+ * t[s][e] = r / (r . r) with r = row `row` (fp64 arithmetic).  t_out_host may be NULL. */
+int vq_db_set_query_from_row(vq_db* db, int64_t row, double* t_out_host);
+
+/* One pass over the DB: sim[c][s][e] = t[s][e] . x[c][s][e]; avg[c][s] = sum_e sim / n_e;
+ * if w != NULL also score[c] = 1 - sqrt(sum_s (w_s (1 - avg))^2 / sum_s w_s^2).
+ * Replaces Ticket.compute_similarities (ticket.py:120-163) + compute_scores (ticket.py:165-180).
+ * keep_sims != 0 additionally keeps the per-split dot products for vq_db_read_similarities. */
+int vq_db_scan(vq_db* db, const double* w_host, int32_t keep_sims);
+/* score[c] from the cached avg[N][S] (no DB read): Ticket.compute_scores, ticket.py:165-180. */
+int vq_db_rescore(vq_db* db, const double* w_host);
+/* Copy results to the host.  Any pointer may be NULL.  avg [N][S], n_e [N][S], sims [N][S][E]. */
+int vq_db_read_similarities(vq_db* db, double* avg_host, int32_t* n_e_host, double* sims_host);
+int vq_db_read_scores(vq_db* db, double* scores_host);
+/* Device addresses of the result arrays (for an RCCL all-gather of score slices). */
+int vq_db_scores_devptr(vq_db* db, void** dev_ptr);
+int vq_db_avg_devptr(vq_db* db, void** dev_ptr);
+/* Replace the cached avg[N][S]/n_e (e.g. after gathering slices from other ranks). */
+int vq_db_write_avg(vq_db* db, const double* avg_host, const int32_t* n_e_host);
+
+/* out[g][l] = score of row rows[l] under weights w_grid[g][0..S): the 40 rescorings of
+ * Hyperparameter.optimize_weights (src/models/hyperparameter.py:57-58) restricted to the
+ * labelled clips that the loss (hyperparameter.py:60-64) actually reads. */
+int vq_db_scores_grid(vq_db* db, const double* w_grid_host, int32_t G, const int64_t* rows_host, int32_t L,
+                      double* out_host);
+
+/* Order-preserving partition of the scores, Ticket.select_clips_to_review (ticket.py:325-340):
+ * match = {v >= threshold}, near = {lower <= v < threshold}, near_argmax = first row of the
+ * largest near score (-1 if none).  Lists stay on the device until vq_db_select_fetch. */
+int vq_db_select(vq_db* db, double threshold, double lower, int64_t* n_match, int64_t* n_near,
+                 int64_t* near_argmax);
+int vq_db_select_fetch(vq_db* db, int64_t* match_rows_host, int64_t cap_match, int64_t* near_rows_host,
+                       int64_t cap_near);
+/* Rows of the k largest scores, descending, ties by ascending row (the stable sort of the final
+ * report, ticket.py:266).  *k_out = min(k, number of non-NaN scores). */
+int vq_db_topk(vq_db* db, int64_t k, int64_t* rows_host, double* vals_host, int64_t* k_out);
+/* min over rows[] of score (init 1), Ticket.lowest_scoring_user_match (ticket.py:301-309). */
+int vq_db_min_score(vq_db* db, const int64_t* rows_host, int32_t L, double* min_out);
+
+/* ------------------------------------------------------------------------------------------
+ * Hot path A: TSN BN-Inception forward + segment consensus
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vq_tsn vq_tsn;
+
+enum { VQ_OP_CONV = 1, VQ_OP_MAXPOOL = 2, VQ_OP_AVGPOOL = 3, VQ_OP_GLOBAL_AVGPOOL = 4 };
+
+/* One executed layer of the frozen network
+ * (src/features_GPU_compute/models/ucf101/tsn_bn_inception_{rgb,flow}_deploy.prototxt).
+ * Convolution + frozen BN + ReLU are one op (BN folded into weights/bias by the host);
+ * Concat is expressed by writing at a channel offset of the destination tensor. */
+typedef struct vq_layer_desc {
+    int32_t op;
+    int32_t src, dst;            /* tensor slots                                             */
+    int32_t src_coff, dst_coff;  /* first channel read / written inside the slot             */
+    int32_t cin, cout;           /* channels read / written                                  */
+    int32_t k, stride, pad;
+    int32_t relu;
+    int32_t ceil_mode;           /* pooling output size: Caffe ceil rule                     */
+    int64_t w_off;               /* floats into the blob: weights [cout][k][k][cin] (OHWI)   */
+    int64_t b_off;               /* floats into the blob: bias [cout]                        */
+} vq_layer_desc;
+
+typedef struct vq_tensor_desc {
+    int32_t h, w, c;             /* NHWC activations, fp32                                    */
+} vq_tensor_desc;
+
+/* Slot 0 is the network input (h x w x in_channels, produced from uint8 crops minus mean).
+ * `feature_slot` names the 1x1xD tensor that is the feature blob ("global_pool",
+ * calcSig_wOF.py:95,112,174-175).  Replaces CaffeNet(proto, weights, device) at
+ * calcSig_wOF.py:52,55. */
+int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_layer_desc* layers,
+                  int32_t n_layers, const float* blob_host, int64_t blob_floats, int32_t feature_slot,
+                  int32_t max_crops, int32_t device, vq_tsn** out);
+int vq_tsn_destroy(vq_tsn* net);
+int vq_tsn_set_stream(vq_tsn* net, void* hip_stream);
+/* crops: uint8 NHWC [n_crops][h][w][c] (host, or device if crops_on_device), n_crops = B*T with the
+ * T snippets of one clip contiguous.  mean[c] is subtracted per channel (BGR [104,117,123] /
+ * flow 128).  Outputs (host, may be NULL): per_snippet [n_crops][D] fp32 = the global_pool blob of
+ * each snippet (calcSig_wOF.py:95,112); feat [B][D] fp64 = the segment consensus
+ * np.array(frame_features).mean(axis=0) (calcSig_wOF.py:82).
+ * Replaces the per-snippet loop of rgbFeatureExtract / flowFeatureExtract (calcSig_wOF.py:88-113). */
+int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, int32_t n_crops, int32_t T,
+                   const float* mean_host, double* feat_host, float* per_snippet_host);
+/* Same, outputs left on the device (bench / all-gather path). */
+int vq_tsn_feat_devptr(vq_tsn* net, void** feat_dev /* double [B][D] */, void** per_snippet_dev);
+/* Copy an activation slot of the last forward to the host ([n_crops][h][w][c] fp32): per-layer parity. */
+int vq_tsn_read_tensor(vq_tsn* net, int32_t slot, int32_t n_crops, float* host);
+/* Algorithmic FLOPs (2*MACs of the conv layers) of one crop, for roofline accounting. */
+int vq_tsn_flops_per_crop(vq_tsn* net, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQ_AMD_H */

@@ -1,0 +1,69 @@
+"""CPU: the C-ABI library loads and exports every symbol include/vq_amd.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    with open(os.path.join(ROOT, "include", "vq_amd.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"^\s*(?:int|const char\*)\s+(vq_\w+)\s*\(", text, flags=re.M)))
+
+
+def test_header_declares_entry_points():
+    names = _declared()
+    assert len(names) >= 35
+    for must in ("vq_db_create", "vq_db_scan", "vq_db_select", "vq_db_topk", "vq_tsn_create", "vq_tsn_forward"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    import video_query_algorithms_amd as vqa
+    lib = vqa.load_library()
+    raw = ctypes.CDLL(vqa._lib.LIB_PATH)
+    for name in _declared():
+        assert hasattr(raw, name), "libvqamd.so does not export %s" % name
+    assert lib.vq_abi_version() == 1
+
+
+def test_ctypes_table_covers_the_header():
+    import video_query_algorithms_amd as vqa
+    assert sorted(vqa._lib.exported_symbols()) == _declared()
+
+
+def test_header_is_plain_c():
+    """The boundary must be consumable from C (cgo / JNI / ctypes): compile the header with gcc -std=c99."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        with open(src, "w") as f:
+            f.write('#include "vq_amd.h"\nint main(void){ vq_layer_desc l; (void)l; return VQ_OK; }\n')
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", src,
+                               "-o", os.path.join(d, "t.o")])
+
+
+def test_no_product_import_of_the_oracle():
+    """The shipped package must never route through oracle/ (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "video-query-algorithms_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                with open(os.path.join(dirpath, fn)) as f:
+                    text = f.read()
+                assert not re.search(r"^\s*(from|import)\s+(oracle|sim_oracle|tsn_oracle)\b", text, flags=re.M), fn
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    import video_query_algorithms_amd as vqa
+    monkeypatch.setattr(vqa._lib, "_lib", None)
+    monkeypatch.setenv("VQ_AMD_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        vqa._lib.load()
+    monkeypatch.delenv("VQ_AMD_LIB")
+    monkeypatch.setattr(vqa._lib, "_lib", None)
+    vqa._lib.load()

@@ -1,0 +1,114 @@
+"""ctypes binding of libvqamd.so (the C ABI declared in include/vq_amd.h).
+
+There is no CPU fallback: if the shared library is missing or fails to load the import raises,
+and every call that fails inside the library raises ``VqError`` with the library's message.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvqamd.so")
+
+VQ_F32, VQ_F64 = 0, 1
+VQ_OP_CONV, VQ_OP_MAXPOOL, VQ_OP_AVGPOOL, VQ_OP_GLOBAL_AVGPOOL = 1, 2, 3, 4
+
+_ERR_NAMES = {-1: "VQ_E_INVALID", -2: "VQ_E_HIP", -3: "VQ_E_NOMEM", -4: "VQ_E_STATE", -5: "VQ_E_UNSUPPORTED"}
+
+
+class VqError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (_ERR_NAMES.get(code, "VQ_E_?"), code, msg))
+        self.code = code
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [("op", C.c_int32), ("src", C.c_int32), ("dst", C.c_int32), ("src_coff", C.c_int32),
+                ("dst_coff", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("k", C.c_int32),
+                ("stride", C.c_int32), ("pad", C.c_int32), ("relu", C.c_int32), ("ceil_mode", C.c_int32),
+                ("w_off", C.c_int64), ("b_off", C.c_int64)]
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32)]
+
+
+_P = C.c_void_p
+_PP = C.POINTER(C.c_void_p)
+_I32, _I64, _U64, _F32, _F64 = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
+_pI32, _pI64, _pF32, _pF64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_double)
+
+# name -> argtypes; every function returns int (status) unless listed in _SPECIAL
+SIGNATURES = {
+    "vq_device_count": [_pI32],
+    "vq_timer_create": [_PP], "vq_timer_start": [_P, _P], "vq_timer_stop": [_P, _P],
+    "vq_timer_elapsed_ms": [_P, _pF32], "vq_timer_destroy": [_P],
+    "vq_db_create": [_I64, _I32, _I32, _I32, _I32, _I32, _PP],
+    "vq_db_destroy": [_P], "vq_db_set_stream": [_P, _P],
+    "vq_db_shape": [_P, _pI64, _pI32, _pI32, _pI32, _pI32],
+    "vq_db_upload": [_P, _I64, _I64, _P], "vq_db_adopt_device": [_P, _P], "vq_db_set_present": [_P, _P],
+    "vq_db_generate": [_P, _U64, _I64, _pF32], "vq_db_feats_devptr": [_P, _PP],
+    "vq_db_set_query": [_P, _P], "vq_db_set_query_from_row": [_P, _I64, _P],
+    "vq_db_scan": [_P, _P, _I32], "vq_db_rescore": [_P, _P],
+    "vq_db_read_similarities": [_P, _P, _P, _P], "vq_db_read_scores": [_P, _P],
+    "vq_db_scores_devptr": [_P, _PP], "vq_db_avg_devptr": [_P, _PP], "vq_db_write_avg": [_P, _P, _P],
+    "vq_db_scores_grid": [_P, _P, _I32, _P, _I32, _P],
+    "vq_db_select": [_P, _F64, _F64, _pI64, _pI64, _pI64], "vq_db_select_fetch": [_P, _P, _I64, _P, _I64],
+    "vq_db_topk": [_P, _I64, _P, _P, _pI64], "vq_db_min_score": [_P, _P, _I32, _pF64],
+    "vq_tsn_create": [C.POINTER(TensorDesc), _I32, C.POINTER(LayerDesc), _I32, _P, _I64, _I32, _I32, _I32, _PP],
+    "vq_tsn_destroy": [_P], "vq_tsn_set_stream": [_P, _P],
+    "vq_tsn_forward": [_P, _P, _I32, _I32, _I32, _pF32, _P, _P],
+    "vq_tsn_feat_devptr": [_P, _PP, _PP], "vq_tsn_read_tensor": [_P, _I32, _I32, _P],
+    "vq_tsn_flops_per_crop": [_P, _pF64],
+}
+_SPECIAL = {"vq_last_error": ([], C.c_char_p), "vq_abi_version": ([], C.c_int)}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def _preload_torch_hip():
+    """If torch is importable, import it first so that ONE HIP runtime (torch's bundled
+    libamdhip64.so.7) serves both torch and libvqamd; device pointers are then interchangeable."""
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
+def load(path: str | None = None):
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = path or os.environ.get("VQ_AMD_LIB", LIB_PATH)
+        if not os.path.exists(path):
+            raise ImportError("libvqamd.so not found at %s -- build it with `python __graft_entry__.py build` "
+                              "(there is no CPU fallback)" % path)
+        _preload_torch_hip()
+        lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        for name, (args, res) in _SPECIAL.items():
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = args, res
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError here = ABI mismatch; fail loudly
+            fn.argtypes, fn.restype = args, C.c_int
+        if lib.vq_abi_version() != 1:
+            raise ImportError("libvqamd.so ABI version %d != 1" % lib.vq_abi_version())
+        _lib = lib
+        return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise VqError(rc, (load().vq_last_error() or b"").decode("utf-8", "replace"))
+
+
+def call(name: str, *args):
+    check(getattr(load(), name)(*args))
+
+
+def exported_symbols():
+    return sorted(list(SIGNATURES) + list(_SPECIAL))

@@ -1,0 +1,61 @@
+// Shared host-side helpers of libvqamd (error plumbing, HIP call checking).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <mutex>
+#include <string>
+
+#include "vq_amd.h"
+
+namespace vq {
+
+std::string& last_error_ref();
+
+inline int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    last_error_ref() = buf;
+    return code;
+}
+
+#define VQ_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return ::vq::fail(e_ == hipErrorOutOfMemory ? VQ_E_NOMEM : VQ_E_HIP, "%s failed: %s (%s:%d)", #call, \
+                              hipGetErrorString(e_), __FILE__, __LINE__);                         \
+    } while (0)
+
+#define VQ_CHECK_LAUNCH()                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = hipGetLastError();                                                        \
+        if (e_ != hipSuccess)                                                                     \
+            return ::vq::fail(VQ_E_HIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define VQ_REQUIRE(cond, ...)                                  \
+    do {                                                       \
+        if (!(cond)) return ::vq::fail(VQ_E_INVALID, __VA_ARGS__); \
+    } while (0)
+
+// RAII: make `device` current for the duration of an API call.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) ok = (hipSetDevice(device) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace vq

@@ -1,0 +1,1069 @@
+// Hot path B on gfx950: resident feature DB, similarity scan, scoring, selection, top-k.
+//
+// Reference semantics restated here (paths relative to the reference checkout):
+//   src/models/ticket.py:120-163   compute_similarities  -> scan_kernel
+//   src/models/ticket.py:165-180   compute_scores        -> score_from_avg (scan epilogue, rescore_kernel)
+//   src/models/ticket.py:311-356   select_clips_to_review-> select_* kernels (stable partition + near argmax)
+//   src/models/ticket.py:266       final report ordering -> topk (radix select + stable compaction)
+//   src/models/target_clip.py:311-313 _scale_feature     -> scale_query_kernel
+//   src/models/hyperparameter.py:57-58 40 rescorings     -> grid_kernel
+//
+// The scan is an HBM-bound stream (2 FLOP per 4 bytes): every clip's S*E vectors are read exactly
+// once with 16-byte coalesced loads, multiplied against the fp64 query held in LDS, accumulated in
+// fp64 per lane and reduced across the 64-lane wavefront.  This file is compiled with
+// -ffp-contract=off: the score arithmetic must round exactly like the reference's numpy scalars;
+// fused multiply-adds are written explicitly where they are wanted (the dot products).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "vq_common.h"
+
+namespace vq {
+std::string& last_error_ref() {
+    static thread_local std::string s;
+    return s;
+}
+}  // namespace vq
+
+using namespace vq;
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ticket.py:172-180 -- same IEEE operations in the same order (contraction is off for this file).
+__device__ __forceinline__ double score_from_avg(const double* a, const double* w, int S) {
+    double ssum = 0.0, denom = 0.0;
+    for (int s = 0; s < S; ++s) {
+        const double term = w[s] * (1.0 - a[s]);
+        ssum = ssum + term * term;
+        denom = denom + w[s] * w[s];
+    }
+    return 1.0 - sqrt(ssum / denom);
+}
+
+// LDS image of the query: element k of vector v lives at lds_index(v, k).  Inside each 256-element
+// chunk the two 16-byte halves of a lane's 4 doubles are stored in separate lane-linear planes, so
+// both ds_read_b128 of a wave are 64 x 16 contiguous bytes (bank-conflict free).
+__device__ __forceinline__ int t_lds_index(int D, int v, int k) {
+    const int j = k >> 8, r = k & 255, lane = r >> 2, q = r & 3;
+    return v * D + (j << 8) + ((q >> 1) << 7) + (lane << 1) + (q & 1);
+}
+
+template <typename T>
+struct Quad;
+template <>
+struct Quad<float> {
+    float4 v;
+    __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ double x0() const { return (double)v.x; }
+    __device__ __forceinline__ double x1() const { return (double)v.y; }
+    __device__ __forceinline__ double x2() const { return (double)v.z; }
+    __device__ __forceinline__ double x3() const { return (double)v.w; }
+};
+template <>
+struct Quad<double> {
+    double2 a, b;
+    __device__ __forceinline__ void load(const double* p) {
+        a = *reinterpret_cast<const double2*>(p);
+        b = *reinterpret_cast<const double2*>(p + 2);
+    }
+    __device__ __forceinline__ double x0() const { return a.x; }
+    __device__ __forceinline__ double x1() const { return a.y; }
+    __device__ __forceinline__ double x2() const { return b.x; }
+    __device__ __forceinline__ double x3() const { return b.y; }
+};
+
+struct ScanArgs {
+    const void* feats;
+    const double* t;          // [NV][D] natural order, global
+    const uint8_t* present;   // [N][S][E] or null
+    const double* w;          // [S] or null
+    double* sims;             // [N][S][E] or null
+    double* avg;              // [N][S]
+    int32_t* ne;              // [N][S]
+    double* scores;           // [N] (written only if w)
+    int64_t n;
+    int32_t S, E, D;
+};
+
+// Per-clip bookkeeping, carried by every lane (wave-uniform values): ensemble mean
+// (ticket.py:155-160: sequential sum over the splits present, divided by their count) and the
+// weighted score (ticket.py:172-180).
+struct ClipAcc {
+    double acc = 0.0;
+    int cnt = 0;
+    double av[8];
+};
+
+__device__ __forceinline__ void clip_add(const ScanArgs& a, ClipAcc& st, int64_t c, int s, int e, double sim, int lane) {
+    const int64_t idx = (c * a.S + s) * a.E + e;
+    const bool p = a.present ? a.present[idx] != 0 : true;
+    if (p) {
+        st.acc = st.acc + sim;
+        ++st.cnt;
+    }
+    if (a.sims && lane == 0) a.sims[idx] = sim;
+}
+
+__device__ __forceinline__ double clip_close_stream(const ScanArgs& a, ClipAcc& st, int64_t c, int s, int lane) {
+    const double m = st.acc / (double)st.cnt;
+    if (lane == 0) {
+        a.avg[c * a.S + s] = m;
+        a.ne[c * a.S + s] = st.cnt;
+    }
+    st.acc = 0.0;
+    st.cnt = 0;
+    return m;
+}
+
+// One wavefront per clip, grid-strided.  S streams x E splits per clip and CH = D/256 chunks per
+// vector are compile-time, so every index is static and everything stays in registers.  The next
+// vector (possibly of the wave's next clip) is in flight while the current one is multiplied, so
+// every wave keeps 2 x CH x 1 KiB of HBM reads outstanding.
+template <typename T, int S, int E, int CH>
+__global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double t_lds[];
+    constexpr int NV = S * E;
+    constexpr int D = CH * 256;
+    for (int i = threadIdx.x; i < NV * D; i += blockDim.x) t_lds[t_lds_index(D, i / D, i % D)] = a.t[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const T* feats = static_cast<const T*>(a.feats);
+    constexpr int64_t clip_elems = (int64_t)NV * D;
+    double w[S];
+    if (a.w) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) w[s] = a.w[s];
+    }
+
+    Quad<T> cur[CH], nxt[CH];
+    int64_t c = wave;
+    if (c < a.n) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) cur[j].load(feats + c * clip_elems + j * 256 + lane * 4);
+    }
+    while (c < a.n) {
+        const int64_t cn = c + nwaves;
+        ClipAcc st;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const T* nb = (v + 1 < NV) ? feats + c * clip_elems + (int64_t)(v + 1) * D
+                                       : (cn < a.n ? feats + cn * clip_elems : nullptr);
+            if (nb) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) nxt[j].load(nb + j * 256 + lane * 4);
+            }
+            double p = 0.0;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const double2 ta = *reinterpret_cast<const double2*>(&t_lds[v * D + j * 256 + lane * 2]);
+                const double2 tb = *reinterpret_cast<const double2*>(&t_lds[v * D + j * 256 + 128 + lane * 2]);
+                p = fma(cur[j].x0(), ta.x, p);
+                p = fma(cur[j].x1(), ta.y, p);
+                p = fma(cur[j].x2(), tb.x, p);
+                p = fma(cur[j].x3(), tb.y, p);
+            }
+            clip_add(a, st, c, v / E, v % E, wave_sum(p), lane);
+            if (v % E == E - 1) st.av[v / E] = clip_close_stream(a, st, c, v / E, lane);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) cur[j] = nxt[j];
+        }
+        if (a.w && lane == 0) a.scores[c] = score_from_avg(st.av, w, S);
+        c = cn;
+    }
+}
+
+// Any shape with D % 4 == 0: runtime loops, query read from global memory (L2-resident).
+template <typename T>
+__global__ __launch_bounds__(256) void scan_generic_kernel(ScanArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const T* feats = static_cast<const T*>(a.feats);
+    const int NV = a.S * a.E, D = a.D;
+    double w[8];
+    if (a.w)
+        for (int s = 0; s < a.S; ++s) w[s] = a.w[s];
+    for (int64_t c = wave; c < a.n; c += nwaves) {
+        ClipAcc st;
+        for (int s = 0; s < a.S; ++s) {
+            for (int e = 0; e < a.E; ++e) {
+                const int v = s * a.E + e;
+                const T* x = feats + (c * NV + v) * (int64_t)D;
+                const double* t = a.t + (int64_t)v * D;
+                double p = 0.0;
+                for (int k = lane * 4; k < D; k += 256) {
+                    Quad<T> q;
+                    q.load(x + k);
+                    p = fma(q.x0(), t[k + 0], p);
+                    p = fma(q.x1(), t[k + 1], p);
+                    p = fma(q.x2(), t[k + 2], p);
+                    p = fma(q.x3(), t[k + 3], p);
+                }
+                clip_add(a, st, c, s, e, wave_sum(p), lane);
+            }
+            const double m = clip_close_stream(a, st, c, s, lane);
+            // runtime-indexed store into a small per-lane array; the generic path is not the fast path
+            st.av[s] = m;
+        }
+        if (a.w && lane == 0) a.scores[c] = score_from_avg(st.av, w, a.S);
+    }
+}
+
+__global__ void rescore_kernel(const double* avg, const double* w, double* scores, int64_t n, int S) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    double av[8];
+    for (int s = 0; s < S; ++s) av[s] = avg[c * S + s];
+    scores[c] = score_from_avg(av, w, S);
+}
+
+// out[g][l] = score(rows[l]; w_grid[g])  (hyperparameter.py:57-58 restricted to labelled clips)
+__global__ void grid_kernel(const double* avg, const double* w_grid, const int64_t* rows, double* out, int G, int L,
+                            int S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * L) return;
+    const int g = i / L, l = i % L;
+    double av[8], w[8];
+    for (int s = 0; s < S; ++s) {
+        av[s] = avg[rows[l] * S + s];
+        w[s] = w_grid[g * S + s];
+    }
+    out[i] = score_from_avg(av, w, S);
+}
+
+// target_clip.py:311-313: t = r / (r . r), one block per (s,e) vector of row `row`, fp64 throughout.
+template <typename T>
+__global__ __launch_bounds__(256) void scale_query_kernel(const T* feats, int64_t row, int NV, int D, double* t) {
+    __shared__ double part[4];
+    const int v = blockIdx.x;
+    const T* r = feats + (row * NV + v) * (int64_t)D;
+    double p = 0.0;
+    for (int k = threadIdx.x; k < D; k += blockDim.x) p = fma((double)r[k], (double)r[k], p);
+    p = wave_sum(p);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = p;
+    __syncthreads();
+    const double rr = ((part[0] + part[1]) + part[2]) + part[3];
+    for (int k = threadIdx.x; k < D; k += blockDim.x) t[(int64_t)v * D + k] = (double)r[k] / rr;
+}
+
+// counter-based synthetic rows (shared with oracle/sim_oracle.py::synth_features)
+__device__ __forceinline__ uint32_t synth_u24(uint64_t seed_mul, uint64_t idx) {
+    uint64_t z = idx + seed_mul;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 40);
+}
+
+template <typename T>
+__global__ void generate_kernel(T* feats, int64_t total, uint64_t seed_mul, uint64_t idx0, int per_stream /*E*D*/,
+                                int S, const float* scales) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= total) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t k = i + q;
+        if (k >= total) break;
+        const int s = (int)((k / per_stream) % S);
+        const float u = (float)synth_u24(seed_mul, idx0 + (uint64_t)k) * 5.9604644775390625e-08f;  // 2^-24
+        feats[k] = (T)(u * scales[s]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// selection: stable partition of the score array (ticket.py:325-340)
+// ------------------------------------------------------------------------------------------------
+constexpr int SEL_ITEMS = 8;                       // consecutive rows per thread (keeps order)
+constexpr int SEL_BLOCK = 256;
+constexpr int SEL_CHUNK = SEL_ITEMS * SEL_BLOCK;   // rows per block
+
+// predicate mode 0: bit0 = v >= th, bit1 = lower <= v < th   (select)
+// predicate mode 1: bit0 = key > pivot,  bit1 = key == pivot  (top-k; keys are order-mapped scores)
+__device__ __forceinline__ uint64_t order_key(double v) {
+    if (v != v) return 0ull;                                  // NaN sorts last
+    if (v == 0.0) v = 0.0;                                     // -0 == +0
+    uint64_t u = (uint64_t)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);       // ascending in v; > 0 for every non-NaN
+}
+
+struct SelPred {
+    int mode;
+    double th, lower;
+    uint64_t pivot;
+    __device__ __forceinline__ int operator()(double v) const {
+        if (mode == 0) return (v >= th ? 1 : 0) | ((lower <= v && v < th) ? 2 : 0);
+        const uint64_t k = order_key(v);
+        return (k > pivot ? 1 : 0) | ((k == pivot && k != 0ull) ? 2 : 0);
+    }
+};
+
+__device__ __forceinline__ int2 block_scan_excl2(int2 v, int2* total) {
+    // exclusive scan of two counters over the 256 threads of a block (4 waves)
+    __shared__ int2 wsum[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int2 inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int ax = __shfl_up(inc.x, off, 64), ay = __shfl_up(inc.y, off, 64);
+        if (lane >= off) {
+            inc.x += ax;
+            inc.y += ay;
+        }
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    int2 base = make_int2(0, 0), tot = make_int2(0, 0);
+    for (int i = 0; i < 4; ++i) {
+        if (i < wid) {
+            base.x += wsum[i].x;
+            base.y += wsum[i].y;
+        }
+        tot.x += wsum[i].x;
+        tot.y += wsum[i].y;
+    }
+    __syncthreads();
+    *total = tot;
+    return make_int2(base.x + inc.x - v.x, base.y + inc.y - v.y);
+}
+
+// pass 1: per-block counts of both classes + block-local first-argmax of class 1 (near band)
+__global__ __launch_bounds__(SEL_BLOCK) void select_count_kernel(const double* scores, int64_t n, SelPred pred,
+                                                                  int2* blk_cnt, double* blk_max, int64_t* blk_arg) {
+    const int64_t base = (int64_t)blockIdx.x * SEL_CHUNK + (int64_t)threadIdx.x * SEL_ITEMS;
+    int2 cnt = make_int2(0, 0);
+    double bmax = -INFINITY;
+    int64_t barg = -1;
+#pragma unroll
+    for (int i = 0; i < SEL_ITEMS; ++i) {
+        const int64_t r = base + i;
+        if (r < n) {
+            const double v = scores[r];
+            const int f = pred(v);
+            cnt.x += f & 1;
+            cnt.y += (f >> 1) & 1;
+            if ((f & 2) && (barg < 0 || v > bmax)) {
+                bmax = v;
+                barg = r;
+            }
+        }
+    }
+    int2 tot;
+    block_scan_excl2(cnt, &tot);
+    // first-argmax across the block: larger value wins, ties go to the smaller row
+    __shared__ double smax[SEL_BLOCK];
+    __shared__ int64_t sarg[SEL_BLOCK];
+    smax[threadIdx.x] = bmax;
+    sarg[threadIdx.x] = barg;
+    __syncthreads();
+    for (int off = SEL_BLOCK / 2; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) {
+            const double ov = smax[threadIdx.x + off];
+            const int64_t oa = sarg[threadIdx.x + off];
+            const int64_t ma = sarg[threadIdx.x];
+            if (oa >= 0 && (ma < 0 || ov > smax[threadIdx.x] || (ov == smax[threadIdx.x] && oa < ma))) {
+                smax[threadIdx.x] = ov;
+                sarg[threadIdx.x] = oa;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        blk_cnt[blockIdx.x] = tot;
+        blk_max[blockIdx.x] = smax[0];
+        blk_arg[blockIdx.x] = sarg[0];
+    }
+}
+
+// pass 2 (one block): exclusive scan of the block counts, totals and global first-argmax
+// result[0] = n_class0, result[1] = n_class1, result[2] = argmax row (-1 if none)
+__global__ __launch_bounds__(SEL_BLOCK) void select_scan_kernel(int2* blk_cnt, const double* blk_max,
+                                                                 const int64_t* blk_arg, int nblk, int64_t* result,
+                                                                 int64_t limit1 /* cap on class-1 picks, <0 = none */) {
+    __shared__ int2 carry;
+    __shared__ double gmax;
+    __shared__ int64_t garg;
+    if (threadIdx.x == 0) {
+        carry = make_int2(0, 0);
+        gmax = -INFINITY;
+        garg = -1;
+    }
+    __syncthreads();
+    for (int b0 = 0; b0 < nblk; b0 += SEL_BLOCK) {
+        const int b = b0 + threadIdx.x;
+        int2 v = b < nblk ? blk_cnt[b] : make_int2(0, 0);
+        int2 tot;
+        const int2 ex = block_scan_excl2(v, &tot);
+        const int2 c0 = carry;
+        if (b < nblk) blk_cnt[b] = make_int2(c0.x + ex.x, c0.y + ex.y);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            carry = make_int2(c0.x + tot.x, c0.y + tot.y);
+            for (int i = b0; i < min(nblk, b0 + SEL_BLOCK); ++i) {   // serial, in order: first max wins
+                if (blk_arg[i] >= 0 && (garg < 0 || blk_max[i] > gmax)) {
+                    gmax = blk_max[i];
+                    garg = blk_arg[i];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        result[0] = carry.x;
+        result[1] = (limit1 >= 0 && carry.y > limit1) ? limit1 : carry.y;
+        result[2] = garg;
+    }
+}
+
+// pass 3: scatter rows in original order.  class-1 rows beyond `limit1` (in order) are dropped.
+__global__ __launch_bounds__(SEL_BLOCK) void select_scatter_kernel(const double* scores, int64_t n, SelPred pred,
+                                                                    const int2* blk_off, int64_t* out0, int64_t* out1,
+                                                                    int64_t limit1) {
+    const int64_t base = (int64_t)blockIdx.x * SEL_CHUNK + (int64_t)threadIdx.x * SEL_ITEMS;
+    int flags[SEL_ITEMS];
+    int2 cnt = make_int2(0, 0);
+#pragma unroll
+    for (int i = 0; i < SEL_ITEMS; ++i) {
+        const int64_t r = base + i;
+        flags[i] = r < n ? pred(scores[r]) : 0;
+        cnt.x += flags[i] & 1;
+        cnt.y += (flags[i] >> 1) & 1;
+    }
+    int2 tot;
+    const int2 ex = block_scan_excl2(cnt, &tot);
+    int64_t o0 = (int64_t)blk_off[blockIdx.x].x + ex.x;
+    int64_t o1 = (int64_t)blk_off[blockIdx.x].y + ex.y;
+#pragma unroll
+    for (int i = 0; i < SEL_ITEMS; ++i) {
+        if (flags[i] & 1) out0[o0++] = base + i;
+        if (flags[i] & 2) {
+            if (limit1 < 0 || o1 < limit1) out1[o1] = base + i;
+            ++o1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// top-k: MSB-first radix select on the order-mapped scores, then the stable compaction above
+// ------------------------------------------------------------------------------------------------
+// state[0] = prefix (high bits fixed so far), state[1] = k still to find inside the prefix bucket
+__global__ __launch_bounds__(256) void topk_hist_kernel(const double* scores, int64_t n, int pass,
+                                                         const uint64_t* state, unsigned int* hist) {
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int shift = 56 - 8 * pass;
+    const uint64_t prefix = state[0];
+    const uint64_t mask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = order_key(scores[r]);
+        if (k != 0ull && (k & mask) == prefix) atomicAdd(&h[(k >> shift) & 255], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ void topk_pick_kernel(int pass, uint64_t* state, unsigned int* hist) {
+    if (threadIdx.x != 0) return;
+    const int shift = 56 - 8 * pass;
+    uint64_t need = state[1];
+    int b = 255;
+    for (; b > 0; --b) {
+        if (hist[b] >= need) break;
+        need -= hist[b];
+    }
+    state[0] |= (uint64_t)b << shift;
+    state[1] = need;
+    for (int i = 0; i < 256; ++i) hist[i] = 0;
+}
+
+__global__ void gather_scores_kernel(const double* scores, const int64_t* rows, int64_t cnt, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) out[i] = scores[rows[i]];
+}
+
+// ------------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------------
+struct vq_db {
+    std::mutex mu;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t n = 0;
+    int S = 0, E = 0, D = 0, dtype = VQ_F32;
+    int cus = 256;
+    void* feats = nullptr;
+    bool owns_feats = true;
+    uint8_t* present = nullptr;
+    double* t = nullptr;        // [S*E*D]
+    bool have_query = false, have_avg = false, have_scores = false, have_sims = false;
+    double* w = nullptr;        // [8]
+    double* sims = nullptr;     // lazily [N][S][E]
+    double* avg = nullptr;      // [N][S]
+    int32_t* ne = nullptr;      // [N][S]
+    double* scores = nullptr;   // [N]
+    // selection scratch
+    int nblk = 0;
+    int2* blk_cnt = nullptr;
+    double* blk_max = nullptr;
+    int64_t* blk_arg = nullptr;
+    int64_t* sel_result = nullptr;   // [3] device
+    int64_t* rows0 = nullptr;        // [N]
+    int64_t* rows1 = nullptr;        // [N]
+    int64_t last_n0 = 0, last_n1 = 0;
+    uint64_t* tk_state = nullptr;    // [2]
+    unsigned int* tk_hist = nullptr; // [256]
+    double* grid_buf = nullptr;      // scratch for grid / gathers
+    int64_t grid_cap = 0;
+    size_t elem() const { return dtype == VQ_F64 ? 8 : 4; }
+};
+
+static int db_free(vq_db* db) {
+    if (db->owns_feats && db->feats) (void)hipFree(db->feats);
+    void* ptrs[] = {db->present, db->t,       db->w,        db->sims,  db->avg,      db->ne,      db->scores, db->blk_cnt,
+                    db->blk_max, db->blk_arg, db->sel_result, db->rows0, db->rows1, db->tk_state, db->tk_hist, db->grid_buf};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    return VQ_OK;
+}
+
+extern "C" {
+
+const char* vq_last_error(void) { return last_error_ref().c_str(); }
+int vq_abi_version(void) { return VQ_ABI_VERSION; }
+
+int vq_device_count(int* count) {
+    VQ_REQUIRE(count, "count is NULL");
+    VQ_HIP(hipGetDeviceCount(count));
+    return VQ_OK;
+}
+
+struct vq_timer_t {
+    hipEvent_t a, b;
+};
+int vq_timer_create(void** timer) {
+    VQ_REQUIRE(timer, "timer is NULL");
+    auto* t = new vq_timer_t;
+    VQ_HIP(hipEventCreate(&t->a));
+    VQ_HIP(hipEventCreate(&t->b));
+    *timer = t;
+    return VQ_OK;
+}
+int vq_timer_start(void* timer, void* stream) {
+    VQ_HIP(hipEventRecord(static_cast<vq_timer_t*>(timer)->a, (hipStream_t)stream));
+    return VQ_OK;
+}
+int vq_timer_stop(void* timer, void* stream) {
+    VQ_HIP(hipEventRecord(static_cast<vq_timer_t*>(timer)->b, (hipStream_t)stream));
+    return VQ_OK;
+}
+int vq_timer_elapsed_ms(void* timer, float* ms) {
+    auto* t = static_cast<vq_timer_t*>(timer);
+    VQ_HIP(hipEventSynchronize(t->b));
+    VQ_HIP(hipEventElapsedTime(ms, t->a, t->b));
+    return VQ_OK;
+}
+int vq_timer_destroy(void* timer) {
+    auto* t = static_cast<vq_timer_t*>(timer);
+    if (!t) return VQ_OK;
+    (void)hipEventDestroy(t->a);
+    (void)hipEventDestroy(t->b);
+    delete t;
+    return VQ_OK;
+}
+
+int vq_db_create(int64_t n, int32_t S, int32_t E, int32_t D, int32_t dtype, int32_t device, vq_db** out) {
+    VQ_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    VQ_REQUIRE(n > 0 && S > 0 && E > 0 && D > 0, "n, S, E, D must be positive (got %lld, %d, %d, %d)", (long long)n, S, E, D);
+    VQ_REQUIRE(S <= 8, "at most 8 streams are supported (got %d)", S);
+    VQ_REQUIRE(S * E <= 64, "S*E must be <= 64 (got %d)", S * E);
+    VQ_REQUIRE(D % 4 == 0, "D must be a multiple of 4 (got %d)", D);
+    VQ_REQUIRE(dtype == VQ_F32 || dtype == VQ_F64, "dtype must be VQ_F32 or VQ_F64");
+    VQ_REQUIRE(n < (1ll << 31) * (long long)SEL_CHUNK, "n too large");
+    int ndev = 0;
+    VQ_HIP(hipGetDeviceCount(&ndev));
+    VQ_REQUIRE(device >= 0 && device < ndev, "device %d out of range (%d visible)", device, ndev);
+    DeviceGuard g(device);
+    auto* db = new vq_db;
+    db->device = device;
+    db->n = n;
+    db->S = S;
+    db->E = E;
+    db->D = D;
+    db->dtype = dtype;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) db->cus = prop.multiProcessorCount;
+    db->nblk = cdiv(n, SEL_CHUNK);
+    const size_t fbytes = (size_t)n * S * E * D * db->elem();
+#define A_(ptr, bytes)                                    \
+    do {                                                  \
+        hipError_t e_ = hipMalloc((void**)&(ptr), bytes); \
+        if (e_ != hipSuccess) {                           \
+            db_free(db);                                  \
+            delete db;                                    \
+            return fail(VQ_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", (size_t)(bytes), hipGetErrorString(e_)); \
+        }                                                 \
+    } while (0)
+    A_(db->feats, fbytes);
+    A_(db->t, (size_t)S * E * D * 8);
+    A_(db->w, 8 * 8);
+    A_(db->avg, (size_t)n * S * 8);
+    A_(db->ne, (size_t)n * S * 4);
+    A_(db->scores, (size_t)n * 8);
+    A_(db->blk_cnt, (size_t)db->nblk * sizeof(int2));
+    A_(db->blk_max, (size_t)db->nblk * 8);
+    A_(db->blk_arg, (size_t)db->nblk * 8);
+    A_(db->sel_result, 3 * 8);
+    A_(db->rows0, (size_t)n * 8);
+    A_(db->rows1, (size_t)n * 8);
+    A_(db->tk_state, 2 * 8);
+    A_(db->tk_hist, 256 * 4);
+#undef A_
+    *out = db;
+    return VQ_OK;
+}
+
+int vq_db_destroy(vq_db* db) {
+    if (!db) return VQ_OK;
+    {
+        DeviceGuard g(db->device);
+        (void)hipStreamSynchronize(db->stream);
+        db_free(db);
+    }
+    delete db;
+    return VQ_OK;
+}
+
+int vq_db_set_stream(vq_db* db, void* s) {
+    VQ_REQUIRE(db, "db is NULL");
+    std::lock_guard<std::mutex> lk(db->mu);
+    db->stream = (hipStream_t)s;
+    return VQ_OK;
+}
+
+int vq_db_shape(vq_db* db, int64_t* n, int32_t* S, int32_t* E, int32_t* D, int32_t* dtype) {
+    VQ_REQUIRE(db, "db is NULL");
+    if (n) *n = db->n;
+    if (S) *S = db->S;
+    if (E) *E = db->E;
+    if (D) *D = db->D;
+    if (dtype) *dtype = db->dtype;
+    return VQ_OK;
+}
+
+int vq_db_upload(vq_db* db, int64_t row0, int64_t nrows, const void* feats_host) {
+    VQ_REQUIRE(db && feats_host, "NULL argument");
+    VQ_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= db->n, "rows [%lld,%lld) outside [0,%lld)", (long long)row0,
+               (long long)(row0 + nrows), (long long)db->n);
+    std::lock_guard<std::mutex> lk(db->mu);
+    DeviceGuard g(db->device);
+    const size_t row_bytes = (size_t)db->S * db->E * db->D * db->elem();
+    VQ_HIP(hipMemcpyAsync((char*)db->feats + row0 * row_bytes, feats_host, nrows * row_bytes, hipMemcpyHostToDevice,
+                          db->stream));
+    VQ_HIP(hipStreamSynchronize(db->stream));
+    db->have_avg = db->have_scores = db->have_sims = false;
+    return VQ_OK;
+}
+
+int vq_db_adopt_device(vq_db* db, void* feats_dev) {
+    VQ_REQUIRE(db && feats_dev, "NULL argument");
+    VQ_REQUIRE(((uintptr_t)feats_dev & 15) == 0, "device feature block must be 16-byte aligned");
+    std::lock_guard<std::mutex> lk(db->mu);
+    DeviceGuard g(db->device);
+    if (db->owns_feats && db->feats) VQ_HIP(hipFree(db->feats));
+    db->feats = feats_dev;
+    db->owns_feats = false;
+    db->have_avg = db->have_scores = db->have_sims = false;
+    return VQ_OK;
+}
+
+int vq_db_set_present(vq_db* db, const uint8_t* present_host) {
+    VQ_REQUIRE(db, "db is NULL");
+    std::lock_guard<std::mutex> lk(db->mu);
+    DeviceGuard g(db->device);
+    const size_t bytes = (size_t)db->n * db->S * db->E;
+    if (!present_host) {
+        if (db->present) VQ_HIP(hipFree(db->present));
+        db->present = nullptr;
+    } else {
+        if (!db->present) VQ_HIP(hipMalloc((void**)&db->present, bytes));
+        VQ_HIP(hipMemcpyAsync(db->present, present_host, bytes, hipMemcpyHostToDevice, db->stream));
+        VQ_HIP(hipStreamSynchronize(db->stream));
+    }
+    db->have_avg = db->have_scores = db->have_sims = false;
+    return VQ_OK;
+}
+
+int vq_db_generate(vq_db* db, uint64_t seed, int64_t global_row0, const float* scales_host) {
+    VQ_REQUIRE(db && scales_host, "NULL argument");
+    std::lock_guard<std::mutex> lk(db->mu);
+    DeviceGuard g(db->device);
+    float* scales_dev = reinterpret_cast<float*>(db->w);   // 64 bytes of scratch; w is rewritten by every scan
+    VQ_HIP(hipMemcpyAsync(scales_dev, scales_host, db->S * sizeof(float), hipMemcpyHostToDevice, db->stream));
+    const int64_t per_row = (int64_t)db->S * db->E * db->D;
+    const int64_t total = db->n * per_row;
+    const uint64_t seed_mul = seed * 0x9E3779B97F4A7C15ull;
+    const int64_t threads = (total + 3) / 4;
+    const int64_t blocks = (threads + 255) / 256;
+    VQ_REQUIRE(blocks < (1ll << 31), "DB too large for one generate launch");
+    if (db->dtype == VQ_F32)
+        generate_kernel<float><<<(unsigned)blocks, 256, 0, db->stream>>>((float*)db->feats, total, seed_mul,
+                                                                          (uint64_t)(global_row0 * per_row),
+                                                                          db->E * db->D, db->S, scales_dev);
+    else
+        generate_kernel<double><<<(unsigned)blocks, 256, 0, db->stream>>>((double*)db->feats, total, seed_mul,
+                                                                           (uint64_t)(global_row0 * per_row),
+                                                                           db->E * db->D, db->S, scales_dev);
+    VQ_CHECK_LAUNCH();
+    VQ_HIP(hipStreamSynchronize(db->stream));
+    db->have_avg = db->have_scores = db->have_sims = false;
+    return VQ_OK;
+}
+
+int vq_db_feats_devptr(vq_db* db, void** p) {
+    VQ_REQUIRE(db && p, "NULL argument");
+    *p = db->feats;
+    return VQ_OK;
+}
+
+int vq_db_set_query(vq_db* db, const double* t_host) {
+    VQ_REQUIRE(db && t_host, "NULL argument");
+    std::lock_guard<std::mutex> lk(db->mu);
+    DeviceGuard g(db->device);
+    VQ_HIP(hipMemcpyAsync(db->t, t_host, (size_t)db->S * db->E * db->D * 8, hipMemcpyHostToDevice, db->stream));
+    VQ_HIP(hipStreamSynchronize(db->stream));
+    db->have_query = true;
+    db->have_avg = db->have_scores = db->have_sims = false;
+    return VQ_OK;
+}
+
+int vq_db_set_query_from_row(vq_db* db, int64_t row, double* t_out_host) {
+    VQ_REQUIRE(db, "db is NULL");
+    VQ_REQUIRE(row >= 0 && row < db->n, "row %lld outside [0,%lld)", (long long)row, (long long)db->n);
+    std::lock_guard<std::mutex> lk(db->mu);
+    DeviceGuard g(db->device);
+    const int NV = db->S * db->E;
+    if (db->dtype == VQ_F32)
+        scale_query_kernel<float><<<NV, 256, 0, db->stream>>>((const float*)db->feats, row, NV, db->D, db->t);
+    else
+        scale_query_kernel<double><<<NV, 256, 0, db->stream>>>((const double*)db->feats, row, NV, db->D, db->t);
+    VQ_CHECK_LAUNCH();
+    if (t_out_host) {
+        VQ_HIP(hipMemcpyAsync(t_out_host, db->t, (size_t)NV * db->D * 8, hipMemcpyDeviceToHost, db->stream));
+        VQ_HIP(hipStreamSynchronize(db->stream));
+    }
+    db->have_query = true;
+    db->have_avg = db->have_scores = db->have_sims = false;
+    return VQ_OK;
+}
+
+}  // extern "C"
+
+template <typename T, int S, int E, int CH>
+static int launch_scan_t(vq_db* db, const ScanArgs& a) {
+    const size_t lds = (size_t)S * E * CH * 256 * 8;
+    auto kern = scan_kernel<T, S, E, CH>;
+    VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
+    if (per_cu < 1) per_cu = 1;
+    const int64_t want = (a.n + 3) / 4;   // 4 waves (clips in flight) per block
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)db->cus * per_cu));
+    kern<<<grid, 256, lds, db->stream>>>(a);
+    VQ_CHECK_LAUNCH();
+    return VQ_OK;
+}
+
+template <typename T>
+static int launch_scan(vq_db* db, const ScanArgs& a) {
+    if (db->D == 1024) {
+#define C_(s_, e_) \
+    if (db->S == s_ && db->E == e_) return launch_scan_t<T, s_, e_, 4>(db, a);
+        C_(1, 1) C_(1, 2) C_(1, 3) C_(1, 4) C_(1, 5)
+        C_(2, 1) C_(2, 2) C_(2, 3) C_(2, 4) C_(2, 5)
+#undef C_
+    }
+    const int64_t want = (a.n + 3) / 4;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)db->cus * 8));
+    scan_generic_kernel<T><<<grid, 256, 0, db->stream>>>(a);
+    VQ_CHECK_LAUNCH();
+    return VQ_OK;
+}
+
+static int run_select(vq_db* db, const SelPred& pred, int64_t limit1, int64_t host_result[3]) {
+    select_count_kernel<<<db->nblk, SEL_BLOCK, 0, db->stream>>>(db->scores, db->n, pred, db->blk_cnt, db->blk_max,
+                                                                 db->blk_arg);
+    VQ_CHECK_LAUNCH();
+    select_scan_kernel<<<1, SEL_BLOCK, 0, db->stream>>>(db->blk_cnt, db->blk_max, db->blk_arg, db->nblk, db->sel_result,
+                                                         limit1);
+    VQ_CHECK_LAUNCH();
+    select_scatter_kernel<<<db->nblk, SEL_BLOCK, 0, db->stream>>>(db->scores, db->n, pred, db->blk_cnt, db->rows0,
+                                                                   db->rows1, limit1);
+    VQ_CHECK_LAUNCH();
+    VQ_HIP(hipMemcpyAsync(host_result, db->sel_result, 3 * 8, hipMemcpyDeviceToHost, db->stream));
+    VQ_HIP(hipStreamSynchronize(db->stream));
+    return VQ_OK;
+}
+
+extern "C" {
+
+int vq_db_scan(vq_db* db, const double* w_host, int32_t keep_sims) {
+    VQ_REQUIRE(db, "db is NULL");
+    std::lock_guard<std::mutex> lk(db->mu);
+    if (!db->have_query) return fail(VQ_E_STATE, "vq_db_scan: no query set (call vq_db_set_query first)");
+    DeviceGuard g(db->device);
+    if (keep_sims && !db->sims) VQ_HIP(hipMalloc((void**)&db->sims, (size_t)db->n * db->S * db->E * 8));
+    if (w_host) VQ_HIP(hipMemcpyAsync(db->w, w_host, db->S * 8, hipMemcpyHostToDevice, db->stream));
+    ScanArgs a;
+    a.feats = db->feats;
+    a.t = db->t;
+    a.present = db->present;
+    a.w = w_host ? db->w : nullptr;
+    a.sims = keep_sims ? db->sims : nullptr;
+    a.avg = db->avg;
+    a.ne = db->ne;
+    a.scores = db->scores;
+    a.n = db->n;
+    a.S = db->S;
+    a.E = db->E;
+    a.D = db->D;
+    const int rc = db->dtype == VQ_F32 ? launch_scan<float>(db, a) : launch_scan<double>(db, a);
+    if (rc != VQ_OK) return rc;
+    db->have_avg = true;
+    db->have_sims = keep_sims != 0;
+    db->have_scores = w_host != nullptr;
+    return VQ_OK;
+}
+
+int vq_db_rescore(vq_db* db, const double* w_host) {
+    VQ_REQUIRE(db && w_host, "NULL argument");
+    std::lock_guard<std::mutex> lk(db->mu);
+    if (!db->have_avg) return fail(VQ_E_STATE, "vq_db_rescore: no similarities cached (call vq_db_scan first)");
+    DeviceGuard g(db->device);
+    VQ_HIP(hipMemcpyAsync(db->w, w_host, db->S * 8, hipMemcpyHostToDevice, db->stream));
+    rescore_kernel<<<cdiv(db->n, 256), 256, 0, db->stream>>>(db->avg, db->w, db->scores, db->n, db->S);
+    VQ_CHECK_LAUNCH();
+    db->have_scores = true;
+    return VQ_OK;
+}
+
+int vq_db_read_similarities(vq_db* db, double* avg_host, int32_t* ne_host, double* sims_host) {
+    VQ_REQUIRE(db, "db is NULL");
+    std::lock_guard<std::mutex> lk(db->mu);
+    if (!db->have_avg) return fail(VQ_E_STATE, "no similarities cached (call vq_db_scan first)");
+    if (sims_host && !db->have_sims) return fail(VQ_E_STATE, "per-split similarities were not kept (scan with keep_sims=1)");
+    DeviceGuard g(db->device);
+    if (avg_host) VQ_HIP(hipMemcpyAsync(avg_host, db->avg, (size_t)db->n * db->S * 8, hipMemcpyDeviceToHost, db->stream));
+    if (ne_host) VQ_HIP(hipMemcpyAsync(ne_host, db->ne, (size_t)db->n * db->S * 4, hipMemcpyDeviceToHost, db->stream));
+    if (sims_host)
+        VQ_HIP(hipMemcpyAsync(sims_host, db->sims, (size_t)db->n * db->S * db->E * 8, hipMemcpyDeviceToHost, db->stream));
+    VQ_HIP(hipStreamSynchronize(db->stream));
+    return VQ_OK;
+}
+
+int vq_db_read_scores(vq_db* db, double* scores_host) {
+    VQ_REQUIRE(db && scores_host, "NULL argument");
+    std::lock_guard<std::mutex> lk(db->mu);
+    if (!db->have_scores) return fail(VQ_E_STATE, "no scores computed (scan with weights, or rescore)");
+    DeviceGuard g(db->device);
+    VQ_HIP(hipMemcpyAsync(scores_host, db->scores, (size_t)db->n * 8, hipMemcpyDeviceToHost, db->stream));
+    VQ_HIP(hipStreamSynchronize(db->stream));
+    return VQ_OK;
+}
+
+int vq_db_scores_devptr(vq_db* db, void** p) {
+    VQ_REQUIRE(db && p, "NULL argument");
+    *p = db->scores;
+    return VQ_OK;
+}
+int vq_db_avg_devptr(vq_db* db, void** p) {
+    VQ_REQUIRE(db && p, "NULL argument");
+    *p = db->avg;
+    return VQ_OK;
+}
+
+int vq_db_write_avg(vq_db* db, const double* avg_host, const int32_t* ne_host) {
+    VQ_REQUIRE(db && avg_host, "NULL argument");
+    std::lock_guard<std::mutex> lk(db->mu);
+    DeviceGuard g(db->device);
+    VQ_HIP(hipMemcpyAsync(db->avg, avg_host, (size_t)db->n * db->S * 8, hipMemcpyHostToDevice, db->stream));
+    if (ne_host) VQ_HIP(hipMemcpyAsync(db->ne, ne_host, (size_t)db->n * db->S * 4, hipMemcpyHostToDevice, db->stream));
+    VQ_HIP(hipStreamSynchronize(db->stream));
+    db->have_avg = true;
+    db->have_scores = false;
+    return VQ_OK;
+}
+
+static int ensure_grid_buf(vq_db* db, int64_t bytes) {
+    if (db->grid_cap >= bytes) return VQ_OK;
+    if (db->grid_buf) VQ_HIP(hipFree(db->grid_buf));
+    db->grid_buf = nullptr;
+    db->grid_cap = 0;
+    VQ_HIP(hipMalloc((void**)&db->grid_buf, bytes));
+    db->grid_cap = bytes;
+    return VQ_OK;
+}
+
+int vq_db_scores_grid(vq_db* db, const double* w_grid_host, int32_t G, const int64_t* rows_host, int32_t L,
+                      double* out_host) {
+    VQ_REQUIRE(db && w_grid_host && rows_host && out_host, "NULL argument");
+    VQ_REQUIRE(G > 0 && L > 0, "G and L must be positive");
+    for (int l = 0; l < L; ++l)
+        VQ_REQUIRE(rows_host[l] >= 0 && rows_host[l] < db->n, "rows[%d] = %lld outside [0,%lld)", l,
+                   (long long)rows_host[l], (long long)db->n);
+    std::lock_guard<std::mutex> lk(db->mu);
+    if (!db->have_avg) return fail(VQ_E_STATE, "no similarities cached (call vq_db_scan first)");
+    DeviceGuard g(db->device);
+    const int64_t wb = (int64_t)G * db->S * 8, rb = (int64_t)L * 8, ob = (int64_t)G * L * 8;
+    int rc = ensure_grid_buf(db, wb + rb + ob);
+    if (rc != VQ_OK) return rc;
+    char* base = (char*)db->grid_buf;
+    VQ_HIP(hipMemcpyAsync(base, w_grid_host, wb, hipMemcpyHostToDevice, db->stream));
+    VQ_HIP(hipMemcpyAsync(base + wb, rows_host, rb, hipMemcpyHostToDevice, db->stream));
+    grid_kernel<<<cdiv((int64_t)G * L, 256), 256, 0, db->stream>>>(db->avg, (const double*)base, (const int64_t*)(base + wb),
+                                                                    (double*)(base + wb + rb), G, L, db->S);
+    VQ_CHECK_LAUNCH();
+    VQ_HIP(hipMemcpyAsync(out_host, base + wb + rb, ob, hipMemcpyDeviceToHost, db->stream));
+    VQ_HIP(hipStreamSynchronize(db->stream));
+    return VQ_OK;
+}
+
+int vq_db_select(vq_db* db, double threshold, double lower, int64_t* n_match, int64_t* n_near, int64_t* near_argmax) {
+    VQ_REQUIRE(db, "db is NULL");
+    std::lock_guard<std::mutex> lk(db->mu);
+    if (!db->have_scores) return fail(VQ_E_STATE, "no scores computed (scan with weights, or rescore)");
+    DeviceGuard g(db->device);
+    SelPred pred;
+    pred.mode = 0;
+    pred.th = threshold;
+    pred.lower = lower;
+    pred.pivot = 0;
+    int64_t res[3];
+    const int rc = run_select(db, pred, -1, res);
+    if (rc != VQ_OK) return rc;
+    db->last_n0 = res[0];
+    db->last_n1 = res[1];
+    if (n_match) *n_match = res[0];
+    if (n_near) *n_near = res[1];
+    if (near_argmax) *near_argmax = res[2];
+    return VQ_OK;
+}
+
+int vq_db_select_fetch(vq_db* db, int64_t* match_rows_host, int64_t cap_match, int64_t* near_rows_host, int64_t cap_near) {
+    VQ_REQUIRE(db, "db is NULL");
+    std::lock_guard<std::mutex> lk(db->mu);
+    DeviceGuard g(db->device);
+    if (match_rows_host) {
+        VQ_REQUIRE(cap_match >= db->last_n0, "match buffer too small (%lld < %lld)", (long long)cap_match, (long long)db->last_n0);
+        if (db->last_n0) VQ_HIP(hipMemcpyAsync(match_rows_host, db->rows0, db->last_n0 * 8, hipMemcpyDeviceToHost, db->stream));
+    }
+    if (near_rows_host) {
+        VQ_REQUIRE(cap_near >= db->last_n1, "near buffer too small (%lld < %lld)", (long long)cap_near, (long long)db->last_n1);
+        if (db->last_n1) VQ_HIP(hipMemcpyAsync(near_rows_host, db->rows1, db->last_n1 * 8, hipMemcpyDeviceToHost, db->stream));
+    }
+    VQ_HIP(hipStreamSynchronize(db->stream));
+    return VQ_OK;
+}
+
+int vq_db_topk(vq_db* db, int64_t k, int64_t* rows_host, double* vals_host, int64_t* k_out) {
+    VQ_REQUIRE(db && rows_host && vals_host && k_out, "NULL argument");
+    VQ_REQUIRE(k > 0, "k must be positive");
+    std::lock_guard<std::mutex> lk(db->mu);
+    if (!db->have_scores) return fail(VQ_E_STATE, "no scores computed (scan with weights, or rescore)");
+    DeviceGuard g(db->device);
+    if (k > db->n) k = db->n;
+    // radix select: find the key of the k-th largest score
+    uint64_t st[2] = {0ull, (uint64_t)k};
+    VQ_HIP(hipMemcpyAsync(db->tk_state, st, 16, hipMemcpyHostToDevice, db->stream));
+    VQ_HIP(hipMemsetAsync(db->tk_hist, 0, 256 * 4, db->stream));
+    const unsigned hgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((db->n + 255) / 256, (int64_t)db->cus * 8));
+    for (int pass = 0; pass < 8; ++pass) {
+        topk_hist_kernel<<<hgrid, 256, 0, db->stream>>>(db->scores, db->n, pass, db->tk_state, db->tk_hist);
+        VQ_CHECK_LAUNCH();
+        topk_pick_kernel<<<1, 64, 0, db->stream>>>(pass, db->tk_state, db->tk_hist);
+        VQ_CHECK_LAUNCH();
+    }
+    VQ_HIP(hipMemcpyAsync(st, db->tk_state, 16, hipMemcpyDeviceToHost, db->stream));
+    VQ_HIP(hipStreamSynchronize(db->stream));
+    // st[0] = key of the k-th largest (0 if fewer than k non-NaN scores), st[1] = how many equal to it are needed
+    SelPred pred;
+    pred.mode = 1;
+    pred.th = pred.lower = 0.0;
+    pred.pivot = st[0];
+    int64_t res[3];
+    int rc = run_select(db, pred, (int64_t)st[1], res);
+    if (rc != VQ_OK) return rc;
+    const int64_t n_gt = res[0], n_eq = res[1];
+    const int64_t tot = n_gt + n_eq;
+    VQ_REQUIRE(tot <= k, "internal: top-k produced %lld > k=%lld rows", (long long)tot, (long long)k);
+    rc = ensure_grid_buf(db, std::max<int64_t>(tot, 1) * 8);
+    if (rc != VQ_OK) return rc;
+    std::vector<int64_t> rows((size_t)tot);
+    std::vector<double> vals((size_t)tot);
+    if (n_gt) VQ_HIP(hipMemcpyAsync(rows.data(), db->rows0, n_gt * 8, hipMemcpyDeviceToHost, db->stream));
+    if (n_eq) VQ_HIP(hipMemcpyAsync(rows.data() + n_gt, db->rows1, n_eq * 8, hipMemcpyDeviceToHost, db->stream));
+    if (n_gt) {
+        gather_scores_kernel<<<cdiv(n_gt, 256), 256, 0, db->stream>>>(db->scores, db->rows0, n_gt, (double*)db->grid_buf);
+        VQ_CHECK_LAUNCH();
+        VQ_HIP(hipMemcpyAsync(vals.data(), db->grid_buf, n_gt * 8, hipMemcpyDeviceToHost, db->stream));
+    }
+    VQ_HIP(hipStreamSynchronize(db->stream));
+    if (n_eq) {
+        gather_scores_kernel<<<cdiv(n_eq, 256), 256, 0, db->stream>>>(db->scores, db->rows1, n_eq, (double*)db->grid_buf);
+        VQ_CHECK_LAUNCH();
+        VQ_HIP(hipMemcpyAsync(vals.data() + n_gt, db->grid_buf, n_eq * 8, hipMemcpyDeviceToHost, db->stream));
+        VQ_HIP(hipStreamSynchronize(db->stream));
+    }
+    // final ordering of the k survivors: descending score, ties by ascending row (ticket.py:266)
+    std::vector<int64_t> order((size_t)tot);
+    for (int64_t i = 0; i < tot; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
+        if (vals[x] != vals[y]) return vals[x] > vals[y];
+        return rows[x] < rows[y];
+    });
+    for (int64_t i = 0; i < tot; ++i) {
+        rows_host[i] = rows[order[i]];
+        vals_host[i] = vals[order[i]];
+    }
+    *k_out = tot;
+    return VQ_OK;
+}
+
+int vq_db_min_score(vq_db* db, const int64_t* rows_host, int32_t L, double* min_out) {
+    VQ_REQUIRE(db && min_out, "NULL argument");
+    VQ_REQUIRE(L >= 0 && (L == 0 || rows_host), "bad rows");
+    for (int l = 0; l < L; ++l)
+        VQ_REQUIRE(rows_host[l] >= 0 && rows_host[l] < db->n, "rows[%d] outside the DB", l);
+    std::lock_guard<std::mutex> lk(db->mu);
+    if (!db->have_scores) return fail(VQ_E_STATE, "no scores computed");
+    DeviceGuard g(db->device);
+    double m = 1.0;   // ticket.py:302 min_score = 1
+    if (L > 0) {
+        int rc = ensure_grid_buf(db, (int64_t)L * 16);
+        if (rc != VQ_OK) return rc;
+        int64_t* rdev = (int64_t*)db->grid_buf;
+        double* vdev = (double*)((char*)db->grid_buf + (int64_t)L * 8);
+        VQ_HIP(hipMemcpyAsync(rdev, rows_host, (size_t)L * 8, hipMemcpyHostToDevice, db->stream));
+        gather_scores_kernel<<<cdiv(L, 256), 256, 0, db->stream>>>(db->scores, rdev, L, vdev);
+        VQ_CHECK_LAUNCH();
+        std::vector<double> v((size_t)L);
+        VQ_HIP(hipMemcpyAsync(v.data(), vdev, (size_t)L * 8, hipMemcpyDeviceToHost, db->stream));
+        VQ_HIP(hipStreamSynchronize(db->stream));
+        for (int l = 0; l < L; ++l) m = std::min(m, v[l]);   // Python min(a, b): b if b < a else a
+    }
+    *min_out = m;
+    return VQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,266 @@
+"""Resident feature database on one MI355X: the host-side handle over ``vq_db_*``.
+
+The reference keeps no database object: every query re-downloads all features of the search set
+as JSON and regroups them into ``{stream: {split: {clip: list}}}``
+(``Ticket._get_candidate_features``, src/models/ticket.py:358-382).  ``FeatureDB`` holds the same
+information as one ``[N][S][E][D]`` block in HBM plus the clip-id index and the order in which the
+reference would have met the clips (which fixes the iteration order of ``ticket.similarities`` and
+with it what ``random.sample`` draws in ``select_clips_to_review``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Mapping, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import VQ_F32, VQ_F64, call
+
+
+def _np_ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class FeatureDB:
+    """N clips x S streams x E ensemble slots x D floats, resident on ``device``."""
+
+    def __init__(self, n: int, n_streams: int, n_splits: int, dim: int = 1024, dtype=np.float32, device: int = 0,
+                 clip_ids: Sequence[int] | None = None):
+        self.n, self.S, self.E, self.D = int(n), int(n_streams), int(n_splits), int(dim)
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise TypeError("FeatureDB dtype must be float32 or float64")
+        self.device = int(device)
+        self._h = C.c_void_p()
+        call("vq_db_create", self.n, self.S, self.E, self.D, VQ_F64 if self.dtype == np.float64 else VQ_F32,
+             self.device, C.byref(self._h))
+        self.clip_ids = (np.arange(1, self.n + 1, dtype=np.int64) if clip_ids is None
+                         else np.asarray(clip_ids, dtype=np.int64).copy())
+        if self.clip_ids.shape != (self.n,):
+            raise ValueError("clip_ids must have shape (%d,)" % self.n)
+        self._row_of = None
+        self.present = None
+        self._keepalive = None
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_arrays(cls, feats: np.ndarray, clip_ids=None, present=None, device: int = 0) -> "FeatureDB":
+        feats = np.asarray(feats)
+        if feats.ndim != 4:
+            raise ValueError("feats must be [N,S,E,D]")
+        if feats.dtype not in (np.float32, np.float64):
+            feats = feats.astype(np.float32)
+        n, s, e, d = feats.shape
+        db = cls(n, s, e, d, feats.dtype, device, clip_ids)
+        db.upload(0, feats)
+        if present is not None:
+            db.set_present(present)
+        return db
+
+    @classmethod
+    def from_records(cls, records: Iterable[Mapping], target_features: Mapping, streams: Sequence[str],
+                     feature_name: str, dtype=np.float64, device: int = 0) -> "FeatureDB":
+        """Regroup API records exactly like ticket.py:358-382 + the walk of ticket.py:146-160.
+
+        Slot ``e`` of stream ``s`` is the e-th split of ``target_features[s]`` (dict order = the order
+        ``np.dot`` results are summed in at ticket.py:156); clips are numbered in the order the
+        reference first meets them (stream-major, split, record order).
+        """
+        splits = set()
+        for st in target_features:
+            splits.update(target_features[st].keys())
+        cand = {st: {sp: {} for sp in splits} for st in streams}
+        for tf in records:                                            # ticket.py:374-381
+            st = tf["dnn_stream_id"]
+            if st in streams and tf["name"] == feature_name and tf["dnn_stream_split"] in splits:
+                cand[st][tf["dnn_stream_split"]][tf["video_clip_id"]] = tf["feature_vector"]
+        stream_list = list(target_features.keys())                    # iteration order of ticket.py:146
+        slot_splits = [list(target_features[st].keys()) for st in stream_list]
+        n_slots = max((len(x) for x in slot_splits), default=0)
+        order = {}
+        for st, sps in zip(stream_list, slot_splits):                 # first-seen order, ticket.py:146-160
+            for sp in sps:
+                for clip in cand[st][sp]:
+                    if clip not in order:
+                        order[clip] = len(order)
+        n = len(order)
+        if n == 0 or n_slots == 0:
+            raise ValueError("no candidate features match the target's streams/splits")
+        dim = None
+        for st, sps in zip(stream_list, slot_splits):
+            for sp in sps:
+                for vec in cand[st][sp].values():
+                    dim = len(vec)
+                    break
+        feats = np.zeros((n, len(stream_list), n_slots, dim), dtype=dtype)
+        present = np.zeros((n, len(stream_list), n_slots), dtype=np.uint8)
+        for si, (st, sps) in enumerate(zip(stream_list, slot_splits)):
+            for ei, sp in enumerate(sps):
+                d = cand[st][sp]
+                if not d:
+                    continue
+                rows = np.fromiter((order[c] for c in d), dtype=np.int64, count=len(d))
+                feats[rows, si, ei] = np.asarray(list(d.values()), dtype=dtype)
+                present[rows, si, ei] = 1
+        db = cls(n, len(stream_list), n_slots, dim, dtype, device,
+                 np.fromiter(order.keys(), dtype=np.int64, count=n))
+        db.stream_names = stream_list
+        db.slot_splits = slot_splits
+        db.upload(0, feats)
+        if not present.all():
+            db.set_present(present)
+        return db
+
+    @classmethod
+    def synthetic(cls, n: int, n_streams: int, n_splits: int, dim: int = 1024, seed: int = 0,
+                  scales: Sequence[float] = (4.0, 1.0), row0: int = 0, dtype=np.float32, device: int = 0,
+                  clip_ids=None) -> "FeatureDB":
+        """Rows generated on the device by the counter-based hash (oracle.sim_oracle.synth_features)."""
+        db = cls(n, n_streams, n_splits, dim, dtype, device, clip_ids)
+        sc = np.ascontiguousarray(np.asarray(scales, dtype=np.float32))
+        if sc.shape != (n_streams,):
+            raise ValueError("scales must have one entry per stream")
+        call("vq_db_generate", db._h, C.c_uint64(seed), row0, sc.ctypes.data_as(C.POINTER(C.c_float)))
+        return db
+
+    # ------------------------------------------------------------------ data movement
+    def upload(self, row0: int, feats: np.ndarray):
+        a = np.ascontiguousarray(feats, dtype=self.dtype)
+        if a.shape[1:] != (self.S, self.E, self.D):
+            raise ValueError("rows must be [n,%d,%d,%d]" % (self.S, self.E, self.D))
+        call("vq_db_upload", self._h, int(row0), a.shape[0], _np_ptr(a))
+
+    def adopt_device(self, dev_ptr: int, keepalive=None):
+        """Use caller-owned device memory (e.g. a torch tensor holding all-gathered blocks)."""
+        call("vq_db_adopt_device", self._h, C.c_void_p(dev_ptr))
+        self._keepalive = keepalive
+
+    def set_present(self, present):
+        if present is None:
+            self.present = None
+            call("vq_db_set_present", self._h, None)
+            return
+        p = np.ascontiguousarray(np.asarray(present).astype(np.uint8))
+        if p.shape != (self.n, self.S, self.E):
+            raise ValueError("present must be [N,S,E]")
+        self.present = p
+        call("vq_db_set_present", self._h, _np_ptr(p))
+
+    def set_stream(self, hip_stream: int):
+        call("vq_db_set_stream", self._h, C.c_void_p(hip_stream))
+
+    def feats_devptr(self) -> int:
+        p = C.c_void_p()
+        call("vq_db_feats_devptr", self._h, C.byref(p))
+        return p.value
+
+    def scores_devptr(self) -> int:
+        p = C.c_void_p()
+        call("vq_db_scores_devptr", self._h, C.byref(p))
+        return p.value
+
+    def avg_devptr(self) -> int:
+        p = C.c_void_p()
+        call("vq_db_avg_devptr", self._h, C.byref(p))
+        return p.value
+
+    # ------------------------------------------------------------------ query
+    def set_query(self, t: np.ndarray):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        if t.shape != (self.S, self.E, self.D):
+            raise ValueError("query must be [%d,%d,%d]" % (self.S, self.E, self.D))
+        call("vq_db_set_query", self._h, _np_ptr(t))
+
+    def set_query_from_row(self, row: int, want: bool = True):
+        """t = r/(r.r) of a resident row (target_clip.py:311-313), computed on the device."""
+        out = np.empty((self.S, self.E, self.D), dtype=np.float64) if want else None
+        call("vq_db_set_query_from_row", self._h, int(row), _np_ptr(out) if want else None)
+        return out
+
+    def scan(self, weights: Sequence[float] | None = None, keep_sims: bool = False):
+        """One pass over the DB (ticket.py:120-163 [+ 165-180 when weights are given])."""
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        if w is not None and w.shape != (self.S,):
+            raise ValueError("one weight per stream")
+        call("vq_db_scan", self._h, _np_ptr(w) if w is not None else None, 1 if keep_sims else 0)
+
+    def rescore(self, weights: Sequence[float]):
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        if w.shape != (self.S,):
+            raise ValueError("one weight per stream")
+        call("vq_db_rescore", self._h, _np_ptr(w))
+
+    def similarities(self, sims: bool = False):
+        avg = np.empty((self.n, self.S), dtype=np.float64)
+        ne = np.empty((self.n, self.S), dtype=np.int32)
+        sm = np.empty((self.n, self.S, self.E), dtype=np.float64) if sims else None
+        call("vq_db_read_similarities", self._h, _np_ptr(avg), _np_ptr(ne), _np_ptr(sm) if sims else None)
+        return (avg, ne, sm) if sims else (avg, ne)
+
+    def write_avg(self, avg: np.ndarray, n_e: np.ndarray | None = None):
+        a = np.ascontiguousarray(avg, dtype=np.float64)
+        ne = None if n_e is None else np.ascontiguousarray(n_e, dtype=np.int32)
+        call("vq_db_write_avg", self._h, _np_ptr(a), _np_ptr(ne) if ne is not None else None)
+
+    def scores(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.float64)
+        call("vq_db_read_scores", self._h, _np_ptr(out))
+        return out
+
+    def scores_grid(self, w_grid: np.ndarray, rows: Sequence[int]) -> np.ndarray:
+        wg = np.ascontiguousarray(w_grid, dtype=np.float64)
+        r = np.ascontiguousarray(rows, dtype=np.int64)
+        if wg.ndim != 2 or wg.shape[1] != self.S:
+            raise ValueError("w_grid must be [G,%d]" % self.S)
+        out = np.empty((wg.shape[0], r.shape[0]), dtype=np.float64)
+        call("vq_db_scores_grid", self._h, _np_ptr(wg), wg.shape[0], _np_ptr(r), r.shape[0], _np_ptr(out))
+        return out
+
+    def select(self, threshold: float, lower: float):
+        """Order-preserving partition (ticket.py:325-340): (match_rows, near_rows, near_argmax)."""
+        nm, nn, am = C.c_int64(), C.c_int64(), C.c_int64()
+        call("vq_db_select", self._h, float(threshold), float(lower), C.byref(nm), C.byref(nn), C.byref(am))
+        m = np.empty(nm.value, dtype=np.int64)
+        r = np.empty(nn.value, dtype=np.int64)
+        call("vq_db_select_fetch", self._h, _np_ptr(m), m.size, _np_ptr(r), r.size)
+        return m, r, am.value
+
+    def topk(self, k: int):
+        k = int(min(k, self.n))
+        rows = np.empty(k, dtype=np.int64)
+        vals = np.empty(k, dtype=np.float64)
+        kk = C.c_int64()
+        call("vq_db_topk", self._h, k, _np_ptr(rows), _np_ptr(vals), C.byref(kk))
+        return rows[:kk.value], vals[:kk.value]
+
+    def min_score(self, rows: Sequence[int]) -> float:
+        r = np.ascontiguousarray(rows, dtype=np.int64)
+        out = C.c_double()
+        call("vq_db_min_score", self._h, _np_ptr(r) if r.size else None, r.size, C.byref(out))
+        return out.value
+
+    # ------------------------------------------------------------------ index
+    def row_of(self, clip_id: int) -> int:
+        if self._row_of is None:
+            self._row_of = {int(c): i for i, c in enumerate(self.clip_ids.tolist())}
+        return self._row_of[int(clip_id)]
+
+    def has_clip(self, clip_id) -> bool:
+        if self._row_of is None:
+            self.row_of(int(self.clip_ids[0]))
+        try:
+            return int(clip_id) in self._row_of
+        except (TypeError, ValueError):
+            return False
+
+    def close(self):
+        if self._h:
+            _lib.load().vq_db_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
