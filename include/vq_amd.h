@@ -144,17 +144,19 @@ typedef struct vq_tensor_desc {
     int32_t h, w, c;             /* NHWC activations, fp32                                    */
 } vq_tensor_desc;
 
-/* Slot 0 is the network input (h x w x in_channels, produced from uint8 crops minus mean).
+/* Slot 0 is the network input: h x w x (in_channels padded to a multiple of 4), produced on the device
+ * from uint8 crops of in_channels channels minus mean; the first convolution's weights are packed for
+ * the padded channel count (zeros in the pad).
  * `feature_slot` names the 1x1xD tensor that is the feature blob ("global_pool",
  * calcSig_wOF.py:95,112,174-175).  Replaces CaffeNet(proto, weights, device) at
  * calcSig_wOF.py:52,55. */
 int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_layer_desc* layers,
-                  int32_t n_layers, const float* blob_host, int64_t blob_floats, int32_t feature_slot,
-                  int32_t max_crops, int32_t device, vq_tsn** out);
+                  int32_t n_layers, const float* blob_host, int64_t blob_floats, int32_t in_channels,
+                  int32_t feature_slot, int32_t max_crops, int32_t device, vq_tsn** out);
 int vq_tsn_destroy(vq_tsn* net);
 int vq_tsn_set_stream(vq_tsn* net, void* hip_stream);
 /* crops: uint8 NHWC [n_crops][h][w][c] (host, or device if crops_on_device), n_crops = B*T with the
- * T snippets of one clip contiguous.  mean[c] is subtracted per channel (BGR [104,117,123] /
+ * T snippets of one clip contiguous.  mean[in_channels] is subtracted per channel (BGR [104,117,123] /
  * flow 128).  Outputs (host, may be NULL): per_snippet [n_crops][D] fp32 = the global_pool blob of
  * each snippet (calcSig_wOF.py:95,112); feat [B][D] fp64 = the segment consensus
  * np.array(frame_features).mean(axis=0) (calcSig_wOF.py:82).

@@ -1,0 +1,198 @@
+"""GPU: the HIP TSN forward (through the C ABI) against the CPU oracle (oracle/tsn_oracle.py, fp64).
+
+Tolerance (fp32 network, stated once): the convolutions are exact-fp32 FMA chains on the matrix cores
+(v_mfma_f32_32x32x2_f32) with BN folded into the weights; against an fp64 evaluation of the un-folded
+layer list the expected difference per layer is a few 1e-7 relative to the accumulated magnitude.
+  * single conv / pool layers:  |d| <= 2e-5 * max|y|   (K up to 2304, fp32 accumulation)
+  * whole network features:     |d| <= 2e-4 * max|y|   (69 layers deep)
+  * pooling: bit-exact vs the loop-level fp32 restatement (same operation order)
+  * consensus: bit-exact fp64 mean of the device's own fp32 per-snippet blobs.
+Parity of the network arithmetic against Caffe itself is UNPINNED (oracle header)."""
+import os
+
+import numpy as np
+import pytest
+
+import tsn_oracle as to
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tsn(gpu):
+    import video_query_algorithms_amd  # noqa: F401
+    from video_query_algorithms_amd.tsn import bn_inception, net
+    return bn_inception, net
+
+
+def _mini(bi, c, h, w, cout, k, s, p, pool=None):
+    """data -> conv+bn+relu [-> pool] -> global average pool (feature)."""
+    g = bi.Graph("mini", "data", (c, h, w))
+    g.layers.append(bi.Layer("c", "Convolution", ["data"], ["c"], cout, k, s, p))
+    g.layers.append(bi.Layer("c_bn", "BN", ["c"], ["c_bn"]))
+    g.layers.append(bi.Layer("c_relu", "ReLU", ["c_bn"], ["c_bn"]))
+    top = "c_bn"
+    ho, wo = to.conv_out(h, k, s, p), to.conv_out(w, k, s, p)
+    if pool:
+        kind, pk, ps_, pp = pool
+        g.layers.append(bi.Layer("p", "Pooling", [top], ["p"], kernel=pk, stride=ps_, pad=pp, pool=kind))
+        top = "p"
+        ho, wo = to.pool_out(ho, pk, ps_, pp), to.pool_out(wo, pk, ps_, pp)
+    assert ho == wo
+    g.layers.append(bi.Layer("gp", "Pooling", [top], ["gp"], kernel=ho, stride=1, pad=0, pool="AVE"))
+    return g
+
+
+def _nchw(a):
+    return np.ascontiguousarray(a.transpose(0, 3, 1, 2))
+
+
+CONV_CASES = [
+    # (cin, h, cout, k, s, p, n_crops)        what it stands for
+    (64, 14, 64, 1, 1, 0, 3),                 # 1x1 reduce
+    (192, 28, 96, 1, 1, 0, 2),                # 1x1, N = 96 (128x96 tile)
+    (64, 28, 96, 3, 1, 1, 2),                 # 3x3 s1 p1
+    (128, 28, 160, 3, 2, 1, 2),               # 3x3 s2 (3c)
+    (96, 14, 128, 3, 1, 1, 3),                # 14x14
+    (160, 7, 224, 3, 1, 1, 5),                # 7x7, M = 245 (ragged M tile)
+    (1056, 7, 352, 1, 1, 0, 2),               # K = 1056, N = 352 (ragged N tile)
+    (3, 32, 64, 7, 2, 3, 2),                  # stem, RGB (small-Cin path, K = 147 -> 224 padded)
+    (10, 32, 64, 7, 2, 3, 2),                 # stem, flow stack
+    (32, 9, 32, 3, 1, 1, 1),                  # tiny: single partial tile
+]
+
+
+@pytest.mark.parametrize("cin,h,cout,k,s,p,n", CONV_CASES)
+@pytest.mark.parametrize("tile", [None, "128x128", "128x96", "128x64", "128x32", "64x64", "64x128"])
+def test_conv_bn_relu_layer(tsn, monkeypatch, cin, h, cout, k, s, p, n, tile):
+    bi, net = tsn
+    if tile:
+        monkeypatch.setenv("VQ_TSN_TILE", tile)
+    else:
+        monkeypatch.delenv("VQ_TSN_TILE", raising=False)
+    g = _mini(bi, cin, h, h, cout, k, s, p)
+    w = net.synthetic_weights(g, seed=cin * 7 + k)
+    rng = np.random.default_rng(cin + h)
+    crops = rng.integers(0, 256, (n, h, h, cin), dtype=np.uint8)
+    mean = np.linspace(100.0, 130.0, cin).astype(np.float32)
+    m = net.TsnNet(g, w, max_crops=n, feature_blob="gp")
+    feat, ps = m.forward(crops, 1, mean)
+    got = _nchw(m.read_blob("c_bn", n))
+    want = to.forward(g.layers, "data", w, to.preprocess(crops, mean), keep=("c_bn", "gp"))
+    tol = 2e-5 * np.abs(want["c_bn"]).max()
+    assert got.shape == want["c_bn"].shape
+    assert np.abs(got - want["c_bn"]).max() <= tol
+    assert (got >= 0).all()
+    assert np.abs(ps - want["gp"].reshape(n, -1)).max() <= tol
+    m.close()
+
+
+@pytest.mark.parametrize("kind,k,s,p,h,c", [("MAX", 3, 2, 0, 28, 64), ("MAX", 3, 2, 0, 14, 96), ("AVE", 3, 1, 1, 14, 64),
+                                          ("MAX", 3, 1, 1, 7, 128), ("AVE", 3, 1, 1, 7, 32), ("MAX", 3, 2, 0, 9, 32)])
+def test_pooling_is_bit_exact(tsn, kind, k, s, p, h, c):
+    bi, net = tsn
+    g = _mini(bi, 32, h, h, c, 1, 1, 0, pool=(kind, k, s, p))
+    w = net.synthetic_weights(g, seed=3)
+    crops = np.random.default_rng(h).integers(0, 256, (3, h, h, 32), dtype=np.uint8)
+    mean = np.full(32, 120.0, dtype=np.float32)
+    m = net.TsnNet(g, w, max_crops=3, feature_blob="gp")
+    m.forward(crops, 3, mean)
+    x = _nchw(m.read_blob("c_bn", 3))                       # the device's own conv output, fp32
+    got = _nchw(m.read_blob("p", 3))
+    want = to.pool_direct(x, k, s, p, kind)                 # fp32, same accumulation order
+    assert got.shape == want.shape and (got == want).all()
+    # and the global average pool + consensus on top of it
+    feat, ps = m.forward(crops, 3, mean)
+    gp = to.pool_direct(got, got.shape[2], 1, 0, "AVE").reshape(3, -1)
+    assert (ps == gp).all()
+    assert (feat == to.consensus(ps, 3)).all()
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def rgb_case(tsn):
+    bi, net = tsn
+    g = bi.bn_inception(3)
+    w = net.synthetic_weights(g, seed=2)
+    crops = np.random.default_rng(1).integers(0, 256, (4, 224, 224, 3), dtype=np.uint8)
+    keep = ("conv1/7x7_s2_bn", "pool1/3x3_s2", "conv2/3x3_bn", "pool2/3x3_s2", "inception_3a/output",
+            "inception_3b/output", "inception_3c/output", "inception_4a/output", "inception_4c/output",
+            "inception_4e/output", "inception_5a/output", "inception_5b/output", "global_pool")
+    want = to.forward(g.layers, "data", w, to.preprocess(crops, net.RGB_MEAN), keep=keep)
+    return g, w, crops, keep, want
+
+
+def test_bn_inception_rgb_layerwise_and_features(tsn, rgb_case):
+    bi, net = tsn
+    g, w, crops, keep, want = rgb_case
+    m = net.TsnNet(g, w, max_crops=8)
+    feat, ps = m.forward(crops, 2, net.RGB_MEAN)
+    assert abs(m.flops_per_crop() - 2 * 2_031_576_064) < 1
+    worst = {}
+    for name in keep[:-1]:
+        got = _nchw(m.read_blob(name, 4))
+        d = np.abs(got - want[name]).max() / np.abs(want[name]).max()
+        worst[name] = d
+        assert d <= 2e-4, (name, d)
+    ref = want["global_pool"].reshape(4, -1)
+    assert ps.shape == (4, 1024) and feat.shape == (2, 1024)
+    assert np.abs(ps - ref).max() <= 2e-4 * np.abs(ref).max()
+    assert (ps >= 0).all() and np.isfinite(ps).all() and ps.max() > 0.05       # post-ReLU average, O(1) activations
+    assert (feat == to.consensus(ps, 2)).all()                                  # fp64 mean of the fp32 blobs
+    print("worst relative layer errors:", {k: float("%.2e" % v) for k, v in worst.items()})
+    # batch-size / order invariance: each crop's feature does not depend on its neighbours in the batch
+    feat1, ps1 = m.forward(crops[[2, 0]], 1, net.RGB_MEAN)
+    assert (ps1[0] == ps[2]).all() and (ps1[1] == ps[0]).all()
+    m.close()
+
+
+def test_bn_inception_flow_features(tsn):
+    bi, net = tsn
+    g = bi.bn_inception(10)
+    w = net.synthetic_weights(g, seed=5)
+    crops = np.random.default_rng(2).integers(0, 256, (3, 224, 224, 10), dtype=np.uint8)
+    want = to.forward(g.layers, "data", w, to.preprocess(crops, net.FLOW_MEAN), keep=("global_pool",))["global_pool"]
+    m = net.TsnNet(g, w, max_crops=3)
+    feat, ps = m.forward(crops, 3, net.FLOW_MEAN)
+    assert abs(m.flops_per_crop() - 2 * 2_306_941_952) < 1
+    ref = want.reshape(3, -1)
+    assert np.abs(ps - ref).max() <= 2e-4 * np.abs(ref).max()
+    assert (feat == to.consensus(ps, 3)).all()
+    m.close()
+
+
+def test_cfg2_shape_runs_and_is_deterministic(tsn):
+    """BASELINE config[1]: B = 32 clips x T = 3 snippets, RGB.  Two runs must agree bit for bit (no atomics,
+    fixed reduction order), features finite and non-negative."""
+    bi, net = tsn
+    g = bi.bn_inception(3)
+    w = net.synthetic_weights(g, seed=2)
+    crops = np.random.default_rng(1).integers(0, 256, (96, 224, 224, 3), dtype=np.uint8)
+    m = net.TsnNet(g, w, max_crops=96)
+    f1, p1 = m.forward(crops, 3, net.RGB_MEAN)
+    f2, p2 = m.forward(crops, 3, net.RGB_MEAN)
+    assert (f1 == f2).all() and (p1 == p2).all()
+    assert f1.shape == (32, 1024) and np.isfinite(f1).all() and (f1 >= 0).all()
+    # same crops in a smaller batch give the same bits (tile choice may differ with M: k-order is fixed)
+    m2 = net.TsnNet(g, w, max_crops=6)
+    f3, p3 = m2.forward(crops[:6], 3, net.RGB_MEAN)
+    assert (p3 == p1[:6]).all() and (f3 == f1[:2]).all()
+    m.close()
+    m2.close()
+
+
+def test_bad_shapes_are_rejected_before_launch(tsn):
+    bi, net = tsn
+    import video_query_algorithms_amd as vqa
+    g = _mini(bi, 32, 8, 8, 32, 3, 1, 1)
+    w = net.synthetic_weights(g, seed=1)
+    m = net.TsnNet(g, w, max_crops=2, feature_blob="gp")
+    with pytest.raises(ValueError):
+        m.forward(np.zeros((2, 8, 8, 31), dtype=np.uint8), 1, np.zeros(32, dtype=np.float32))
+    with pytest.raises(vqa.VqError):
+        m.forward(np.zeros((4, 8, 8, 32), dtype=np.uint8), 1, np.zeros(32, dtype=np.float32))   # > max_crops
+    bad = dict(w)
+    bad["c"] = {"W": w["c"]["W"][:, :16], "b": w["c"]["b"]}
+    with pytest.raises(ValueError):
+        net.TsnNet(g, bad, max_crops=2, feature_blob="gp")
+    m.close()

@@ -1,0 +1,110 @@
+"""CPU: pins the pieces of the hot-path-A oracle that CAN be pinned here -- the torch calls against loop-level
+restatements of the Caffe layer rules, the driver logic against calcSig_wOF.py's documented cases, and the
+built-in graph against the reference's own prototxt (when the reference checkout is present)."""
+import os
+
+import numpy as np
+import pytest
+
+import tsn_oracle as to
+
+REF_PROTO = "/root/reference/src/features_GPU_compute/models/ucf101/tsn_bn_inception_%s_deploy.prototxt"
+
+
+def test_frame_ticks_follow_calcsig():
+    # cnt=150: T=25 -> 1,7,...,145; T=7 -> 1,25,...,145; T=3 -> 1,75,149 (flow depth 5: 1,73,145)
+    assert to.frame_ticks(150, 25, 1) == list(range(1, 146, 6))
+    assert to.frame_ticks(150, 7, 1) == [1, 25, 49, 73, 97, 121, 145]
+    assert to.frame_ticks(150, 3, 1) == [1, 75, 149]
+    assert to.frame_ticks(150, 3, 5) == [1, 73, 145]
+    assert to.frame_ticks(150, 25, 5) == list(range(1, 146, 6))
+    assert to.frame_ticks(10, 25, 1) == [1] * 25                      # step == 0
+    assert to.frame_ticks(5, 3, 5) == [1, 1, 1]
+    with pytest.raises(ZeroDivisionError):
+        to.frame_ticks(150, 1, 1)                                      # the reference divides by zero too
+    assert to.flow_stack_indices(148, 150, 5) == [148, 149, 150, 150, 150]
+
+
+def test_pool_output_sizes_caffe_ceil_rule():
+    sizes = [112]
+    for _ in range(4):
+        sizes.append(to.pool_out(sizes[-1], 3, 2, 0))
+    assert sizes == [112, 56, 28, 14, 7]
+    assert to.pool_out(28, 3, 1, 1) == 28 and to.pool_out(7, 3, 1, 1) == 7 and to.pool_out(7, 7, 1, 0) == 1
+    assert to.conv_out(224, 7, 2, 3) == 112 and to.conv_out(28, 3, 2, 1) == 14 and to.conv_out(14, 3, 2, 1) == 7
+
+
+def test_torch_ops_match_loop_level_caffe_rules():
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 5, 9, 11))
+    for (k, s, p) in [(3, 1, 1), (3, 2, 1), (7, 2, 3), (1, 1, 0)]:
+        w = rng.standard_normal((4, 5, k, k))
+        b = rng.standard_normal(4)
+        got = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), stride=s, padding=p).numpy()
+        assert np.abs(got - to.conv_direct(x, w, b, s, p)).max() < 1e-12
+    for (k, s, p, mode) in [(3, 2, 0, "MAX"), (3, 1, 1, "AVE"), (3, 1, 1, "MAX"), (9, 1, 0, "AVE")]:
+        xx = x if k != 9 else x[:, :, :, :9]
+        t = torch.from_numpy(xx)
+        got = (F.max_pool2d(t, k, s, p, ceil_mode=True) if mode == "MAX"
+               else F.avg_pool2d(t, k, s, p, ceil_mode=True, count_include_pad=True)).numpy()
+        want = to.pool_direct(xx, k, s, p, mode)
+        assert got.shape == want.shape and np.abs(got - want).max() < 1e-12
+    # odd size with stride 2: ceil mode adds the partial window (8 -> 4 with k=3? (8-3)/2 = 2.5 -> 3+1 = 4)
+    t = torch.from_numpy(x[:, :, :8, :8])
+    assert F.max_pool2d(t, 3, 2, 0, ceil_mode=True).shape[-1] == to.pool_out(8, 3, 2, 0) == 4
+
+
+def test_consensus_is_fp64_mean_of_fp32_snippets():
+    rng = np.random.default_rng(1)
+    ps = rng.random((6, 16)).astype(np.float32)
+    c = to.consensus(ps, 3)
+    assert c.dtype == np.float64 and c.shape == (2, 16)
+    want = (ps[0].astype(np.float64) + ps[1] + ps[2]) / 3
+    assert (c[0] == want).all()
+
+
+def test_builtin_graph_equals_reference_prototxt():
+    if not os.path.exists(REF_PROTO % "rgb"):
+        pytest.skip("reference checkout not present (GPU box)")
+    from video_query_algorithms_amd.tsn import bn_inception as bi
+    for name, c in (("rgb", 3), ("flow", 10)):
+        ref = bi.load_prototxt(REF_PROTO % name)
+        assert ref.layers == bi.bn_inception(c).layers and ref.input_shape == (c, 224, 224)
+
+
+def test_plan_matches_survey_appendix_a():
+    from video_query_algorithms_amd.tsn import bn_inception as bi
+    p = bi.bn_inception(3).plan()
+    assert p.macs_per_crop() == 2_031_576_064                 # SURVEY Appendix A (fc-action excluded)
+    assert bi.bn_inception(10).plan().macs_per_crop() == 2_306_941_952
+    kinds = [o.kind for o in p.ops]
+    assert kinds.count("conv") == 69 and kinds.count("avgpool") == 7 and kinds.count("maxpool") == 5
+    assert kinds.count("gavgpool") == 1 and p.feature_dim == 1024
+    # concat is zero-copy: 3a's four branches land at offsets 0, 64, 128, 224 of one 256-channel slot
+    loc = p.blob_loc
+    s = loc["inception_3a/output"][0]
+    assert [loc[b] for b in ("inception_3a/1x1_bn", "inception_3a/3x3_bn", "inception_3a/double_3x3_2_bn",
+                             "inception_3a/pool_proj_bn")] == [(s, 0, 64), (s, 64, 64), (s, 128, 96), (s, 224, 32)]
+    assert p.tensors[s].c == 256 and (p.tensors[s].h, p.tensors[s].w) == (28, 28)
+    # reduction block 3c: max-pool passes through un-projected at offset 160+96
+    s3c = loc["inception_3c/output"][0]
+    assert loc["inception_3c/pool"] == (s3c, 256, 320) and p.tensors[s3c].c == 576
+
+
+def test_prototxt_parser_handles_comments_and_nesting():
+    from video_query_algorithms_amd.tsn import bn_inception as bi
+    text = '''name: "tiny"  # a comment
+    input: "data" input_dim: 1 input_dim: 3 input_dim: 8 input_dim: 8
+    layer { name: "c" type: "Convolution" bottom: "data" top: "c"
+      param { lr_mult: 1 } convolution_param { num_output: 32 pad: 1 kernel_size: 3 weight_filler { type: "xavier" } } }
+    layer { name: "c_bn" type: "BN" bottom: "c" top: "c_bn" bn_param { frozen: true } }
+    layer { name: "r" type: "ReLU" bottom: "c_bn" top: "c_bn" }
+    layer { name: "gp" type: "Pooling" bottom: "c_bn" top: "gp" pooling_param { pool: AVE kernel_size: 8 stride: 1 } }
+    '''
+    g = bi.parse_prototxt(text)
+    assert g.input_shape == (3, 8, 8) and [l.type for l in g.layers] == ["Convolution", "BN", "ReLU", "Pooling"]
+    p = g.plan("gp")
+    assert [o.kind for o in p.ops] == ["conv", "gavgpool"] and p.ops[0].relu and p.ops[0].bn == "c_bn"
+    assert p.feature_dim == 32

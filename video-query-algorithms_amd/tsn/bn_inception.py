@@ -1,0 +1,370 @@
+"""The TSN BN-Inception graph as data.
+
+Two sources give the same ``Graph``:
+
+* :func:`parse_prototxt` -- a small reader for Caffe's text format, so the drop-in command line can
+  take the very files the reference passes to ``CaffeNet``
+  (src/features_GPU_compute/models/ucf101/tsn_bn_inception_{rgb,flow}_deploy.prototxt;
+  calcSig_wOF.py:158-161);
+* :func:`bn_inception` -- the same topology generated from a compact table, for
+  when no prototxt is at hand (bench, smoke, GPU box).
+
+``Graph.plan()`` lowers the layer list to what the device executes: Convolution + frozen BN + ReLU
+become one op, Concat disappears (producers write at a channel offset of the concat tensor),
+Dropout is the identity in TEST phase, and ``fc-action`` -- computed by the reference but never read
+by the feature path (calcSig_wOF.py:95 reads ``global_pool``) -- is dropped.
+"""
+from __future__ import annotations
+
+import re
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+
+# ------------------------------------------------------------------------------------------------
+# graph model
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class Layer:
+    name: str
+    type: str                      # Convolution | BN | ReLU | Pooling | Concat | Dropout | InnerProduct
+    bottoms: List[str]
+    tops: List[str]
+    num_output: int = 0
+    kernel: int = 1
+    stride: int = 1
+    pad: int = 0
+    pool: str = ""                 # MAX | AVE
+
+
+@dataclass
+class Graph:
+    name: str
+    input_name: str
+    input_shape: Tuple[int, int, int]          # (C, H, W)
+    layers: List[Layer] = field(default_factory=list)
+
+    def conv_layers(self) -> List[Layer]:
+        return [l for l in self.layers if l.type == "Convolution"]
+
+    def plan(self, feature_blob: str = "global_pool") -> "Plan":
+        return _lower(self, feature_blob)
+
+
+@dataclass
+class Tensor:
+    h: int
+    w: int
+    c: int
+    name: str
+
+
+@dataclass
+class Op:
+    kind: str                      # conv | maxpool | avgpool | gavgpool
+    name: str                      # name of the producing layer (weights are keyed by it)
+    src: int
+    dst: int
+    src_coff: int
+    dst_coff: int
+    cin: int
+    cout: int
+    k: int = 1
+    stride: int = 1
+    pad: int = 0
+    relu: bool = False
+    bn: Optional[str] = None       # name of the folded BN layer
+    out_blob: str = ""
+
+
+@dataclass
+class Plan:
+    tensors: List[Tensor]
+    ops: List[Op]
+    feature_slot: int
+    feature_dim: int
+    blob_loc: Dict[str, Tuple[int, int, int]]     # blob -> (slot, channel offset, channels)
+
+    def macs_per_crop(self) -> int:
+        total = 0
+        for op in self.ops:
+            if op.kind == "conv":
+                t = self.tensors[op.dst]
+                total += t.h * t.w * op.cout * op.cin * op.k * op.k
+        return total
+
+
+def conv_out(size: int, k: int, s: int, p: int) -> int:
+    """Caffe convolution output size: floor((in + 2p - k)/s) + 1."""
+    return (size + 2 * p - k) // s + 1
+
+
+def pool_out(size: int, k: int, s: int, p: int) -> int:
+    """Caffe pooling output size: ceil((in + 2p - k)/s) + 1, minus one if the last window would
+    start in the padding (pooling_layer.cpp)."""
+    out = -(-(size + 2 * p - k) // s) + 1
+    if p > 0 and (out - 1) * s >= size + p:
+        out -= 1
+    return out
+
+
+def _lower(g: Graph, feature_blob: str) -> Plan:
+    c0, h0, w0 = g.input_shape
+    shapes: Dict[str, Tuple[int, int, int]] = {g.input_name: (c0, h0, w0)}     # blob -> (C,H,W)
+    # pass 1: shapes + which blobs live inside a concat output
+    inside: Dict[str, Tuple[str, int]] = {}                                     # blob -> (concat top, channel offset)
+    for l in g.layers:
+        if l.type == "Convolution":
+            c, h, w = shapes[l.bottoms[0]]
+            shapes[l.tops[0]] = (l.num_output, conv_out(h, l.kernel, l.stride, l.pad), conv_out(w, l.kernel, l.stride, l.pad))
+        elif l.type in ("BN", "ReLU", "Dropout"):
+            shapes[l.tops[0]] = shapes[l.bottoms[0]]
+        elif l.type == "Pooling":
+            c, h, w = shapes[l.bottoms[0]]
+            shapes[l.tops[0]] = (c, pool_out(h, l.kernel, l.stride, l.pad), pool_out(w, l.kernel, l.stride, l.pad))
+        elif l.type == "Concat":
+            off = 0
+            hw = None
+            for b in l.bottoms:
+                c, h, w = shapes[b]
+                if hw is None:
+                    hw = (h, w)
+                if (h, w) != hw:
+                    raise ValueError("Concat %s: spatial mismatch" % l.name)
+                if b in inside:
+                    raise ValueError("blob %s feeds two Concat layers" % b)
+                inside[b] = (l.tops[0], off)
+                off += c
+            shapes[l.tops[0]] = (off, hw[0], hw[1])
+        elif l.type == "InnerProduct":
+            shapes[l.tops[0]] = (l.num_output, 1, 1)
+        else:
+            raise ValueError("unsupported layer type %s (%s)" % (l.type, l.name))
+    if feature_blob not in shapes:
+        raise KeyError("feature blob %r is not produced by this network" % feature_blob)
+
+    tensors: List[Tensor] = []
+    loc: Dict[str, Tuple[int, int, int]] = {}
+
+    def slot_for(blob: str) -> Tuple[int, int, int]:
+        if blob in loc:
+            return loc[blob]
+        c, h, w = shapes[blob]
+        if blob in inside:
+            parent, off = inside[blob]
+            ps, pc, _ = slot_for(parent)
+            loc[blob] = (ps, pc + off, c)
+        else:
+            tensors.append(Tensor(h, w, c, blob))
+            loc[blob] = (len(tensors) - 1, 0, c)
+        return loc[blob]
+
+    slot_for(g.input_name)          # slot 0 = network input
+    ops: List[Op] = []
+    by_top: Dict[str, Op] = {}      # blob -> op that produced it (for BN / ReLU folding)
+    for l in g.layers:
+        if l.type == "Convolution":
+            src = slot_for(l.bottoms[0])
+            # the conv's own top is never materialised if a BN consumes it: decide at BN time
+            op = Op("conv", l.name, src[0], -1, src[1], 0, src[2], l.num_output, l.kernel, l.stride, l.pad,
+                    out_blob=l.tops[0])
+            ops.append(op)
+            by_top[l.tops[0]] = op
+        elif l.type == "BN":
+            op = by_top.get(l.bottoms[0])
+            if op is None or op.kind != "conv" or op.bn is not None:
+                raise ValueError("BN %s does not follow a Convolution" % l.name)
+            op.bn = l.name
+            op.out_blob = l.tops[0]
+            by_top[l.tops[0]] = op
+        elif l.type == "ReLU":
+            op = by_top.get(l.bottoms[0])
+            if op is None or op.kind != "conv" or l.tops[0] != l.bottoms[0]:
+                raise ValueError("ReLU %s is not an in-place activation of a Convolution" % l.name)
+            op.relu = True
+        elif l.type == "Pooling":
+            src = slot_for(l.bottoms[0])
+            c, h, w = shapes[l.bottoms[0]]
+            is_global = (l.pool == "AVE" and l.kernel == h and l.kernel == w and l.pad == 0)
+            kind = "gavgpool" if is_global else ("maxpool" if l.pool == "MAX" else "avgpool")
+            op = Op(kind, l.name, src[0], -1, src[1], 0, c, c, l.kernel, l.stride, l.pad, out_blob=l.tops[0])
+            ops.append(op)
+            by_top[l.tops[0]] = op
+        elif l.type == "Dropout":
+            if l.tops[0] != l.bottoms[0]:
+                loc[l.tops[0]] = slot_for(l.bottoms[0])
+        elif l.type in ("Concat", "InnerProduct"):
+            pass
+    # resolve destinations now that BN renaming is known; drop ops whose output nobody needs
+    needed = {feature_blob}
+    keep: List[Op] = []
+    consumers: Dict[str, int] = {}
+    for l in g.layers:
+        if l.type in ("Convolution", "Pooling", "Concat"):
+            for b in l.bottoms:
+                consumers[b] = consumers.get(b, 0) + 1
+    for op in ops:
+        blob = op.out_blob
+        if blob != feature_blob and consumers.get(blob, 0) == 0:
+            continue                                             # e.g. nothing: fc-action is not an op
+        d = slot_for(blob)
+        op.dst, op.dst_coff = d[0], d[1]
+        keep.append(op)
+    fs = slot_for(feature_blob)
+    if fs[1] != 0 or tensors[fs[0]].h != 1 or tensors[fs[0]].w != 1:
+        raise ValueError("feature blob must be a 1x1 tensor of its own")
+    return Plan(tensors, keep, fs[0], fs[2], dict(loc))
+
+
+# ------------------------------------------------------------------------------------------------
+# prototxt reader (protobuf text format: `key: value` and `key { ... }`, '#' comments)
+# ------------------------------------------------------------------------------------------------
+_TOKEN = re.compile(r'\s*(?:(#[^\n]*)|([A-Za-z_][\w\-/.]*)|("(?:[^"\\]|\\.)*")|([-+]?[0-9][\w.+-]*)|([{}:]))')
+
+
+def _tokens(text: str):
+    pos = 0
+    n = len(text)
+    while pos < n:
+        m = _TOKEN.match(text, pos)
+        if not m:
+            if text[pos:].strip() == "":
+                return
+            raise ValueError("prototxt: cannot tokenise at %r" % text[pos:pos + 30])
+        pos = m.end()
+        if m.group(1):
+            continue
+        yield next(g for g in m.groups()[1:] if g is not None)
+
+
+def _parse_message(toks, top=False):
+    msg: List[Tuple[str, object]] = []
+    for tok in toks:
+        if tok == "}":
+            if top:
+                raise ValueError("prototxt: unbalanced '}'")
+            return msg
+        key = tok
+        nxt = next(toks)
+        if nxt == ":":
+            val = next(toks)
+            if val == "{":
+                msg.append((key, _parse_message(toks)))
+            else:
+                msg.append((key, val[1:-1] if val.startswith('"') else val))
+        elif nxt == "{":
+            msg.append((key, _parse_message(toks)))
+        else:
+            raise ValueError("prototxt: expected ':' or '{' after %s" % key)
+    if not top:
+        raise ValueError("prototxt: missing '}'")
+    return msg
+
+
+def _get(msg, key, default=None):
+    for k, v in msg:
+        if k == key:
+            return v
+    return default
+
+
+def _all(msg, key):
+    return [v for k, v in msg if k == key]
+
+
+def parse_prototxt(text: str) -> Graph:
+    msg = _parse_message(_tokens(text), top=True)
+    dims = [int(v) for v in _all(msg, "input_dim")]
+    if len(dims) != 4:
+        shape = _get(msg, "input_shape")
+        dims = [int(v) for v in _all(shape, "dim")] if shape else dims
+    if len(dims) != 4:
+        raise ValueError("prototxt: need 4 input_dim values")
+    g = Graph(_get(msg, "name", "net"), _get(msg, "input", "data"), (dims[1], dims[2], dims[3]))
+    for lm in _all(msg, "layer") + _all(msg, "layers"):
+        l = Layer(_get(lm, "name"), _get(lm, "type"), _all(lm, "bottom"), _all(lm, "top"))
+        if l.type == "Convolution":
+            p = _get(lm, "convolution_param", [])
+            l.num_output = int(_get(p, "num_output"))
+            l.kernel = int(_get(p, "kernel_size", 1))
+            l.stride = int(_get(p, "stride", 1))
+            l.pad = int(_get(p, "pad", 0))
+        elif l.type == "Pooling":
+            p = _get(lm, "pooling_param", [])
+            l.pool = str(_get(p, "pool", "MAX"))
+            l.kernel = int(_get(p, "kernel_size", 1))
+            l.stride = int(_get(p, "stride", 1))
+            l.pad = int(_get(p, "pad", 0))
+        elif l.type == "InnerProduct":
+            l.num_output = int(_get(_get(lm, "inner_product_param", []), "num_output"))
+        g.layers.append(l)
+    return g
+
+
+def load_prototxt(path: str) -> Graph:
+    with open(path) as f:
+        return parse_prototxt(f.read())
+
+
+# ------------------------------------------------------------------------------------------------
+# built-in BN-Inception (TSN deploy topology)
+# ------------------------------------------------------------------------------------------------
+# block -> (1x1, 3x3_reduce, 3x3, double_reduce, double_3x3 (both), pool kind, pool_proj); reduction
+# blocks (stride 2, no 1x1, max-pool passed through un-projected) have 1x1 = 0 and pool_proj = 0.
+_BLOCKS = [
+    ("3a", 64, 64, 64, 64, 96, "AVE", 32),
+    ("3b", 64, 64, 96, 64, 96, "AVE", 64),
+    ("3c", 0, 128, 160, 64, 96, "MAX", 0),
+    ("4a", 224, 64, 96, 96, 128, "AVE", 128),
+    ("4b", 192, 96, 128, 96, 128, "AVE", 128),
+    ("4c", 160, 128, 160, 128, 160, "AVE", 128),
+    ("4d", 96, 128, 192, 160, 192, "AVE", 128),
+    ("4e", 0, 128, 192, 192, 256, "MAX", 0),
+    ("5a", 352, 192, 320, 160, 224, "AVE", 128),
+    ("5b", 352, 192, 320, 192, 224, "MAX", 128),
+]
+
+
+def bn_inception(in_channels: int = 3, size: int = 224, with_fc: bool = True) -> Graph:
+    g = Graph("BN-Inception", "data", (in_channels, size, size))
+
+    def conv(name, bottom, n, k=1, s=1, p=0, relu_name=None):
+        g.layers.append(Layer(name, "Convolution", [bottom], [name], n, k, s, p))
+        g.layers.append(Layer(name + "_bn", "BN", [name], [name + "_bn"]))
+        rn = relu_name or (name.rsplit("/", 1)[0] + "/relu_" + name.rsplit("/", 1)[1])
+        g.layers.append(Layer(rn, "ReLU", [name + "_bn"], [name + "_bn"]))
+        return name + "_bn"
+
+    def pool(name, bottom, kind, k, s, p=0):
+        g.layers.append(Layer(name, "Pooling", [bottom], [name], kernel=k, stride=s, pad=p, pool=kind))
+        return name
+
+    x = conv("conv1/7x7_s2", "data", 64, 7, 2, 3, "conv1/relu_7x7")
+    x = pool("pool1/3x3_s2", x, "MAX", 3, 2)
+    x = conv("conv2/3x3_reduce", x, 64)
+    x = conv("conv2/3x3", x, 192, 3, 1, 1)
+    x = pool("pool2/3x3_s2", x, "MAX", 3, 2)
+    for blk, c1, c3r, c3, cdr, cd, pk, pp in _BLOCKS:
+        pre = "inception_%s/" % blk
+        reduction = c1 == 0
+        s2 = 2 if reduction else 1
+        outs = []
+        if c1:
+            outs.append(conv(pre + "1x1", x, c1))
+        t = conv(pre + "3x3_reduce", x, c3r)
+        outs.append(conv(pre + "3x3", t, c3, 3, s2, 1))
+        t = conv(pre + "double_3x3_reduce", x, cdr)
+        t = conv(pre + "double_3x3_1", t, cd, 3, 1, 1)
+        outs.append(conv(pre + "double_3x3_2", t, cd, 3, s2, 1))
+        if reduction:
+            outs.append(pool(pre + "pool", x, "MAX", 3, 2))
+        else:
+            t = pool(pre + "pool", x, pk, 3, 1, 1)
+            outs.append(conv(pre + "pool_proj", t, pp))
+        g.layers.append(Layer(pre + "output", "Concat", outs, [pre + "output"]))
+        x = pre + "output"
+    g.layers.append(Layer("global_pool", "Pooling", [x], ["global_pool"], kernel=7, stride=1, pad=0, pool="AVE"))
+    g.layers.append(Layer("dropout", "Dropout", ["global_pool"], ["global_pool"]))
+    if with_fc:
+        g.layers.append(Layer("fc-action", "InnerProduct", ["global_pool"], ["fc-action"], num_output=101))
+    return g

@@ -1,0 +1,177 @@
+"""Host side of the TSN forward pass: weights -> device blob, graph -> layer table, crops -> features.
+
+``TsnNet`` is the handle over ``vq_tsn_*``.  It plays the role ``CaffeNet(net_proto, net_weights, gpu)``
+plays in the reference (calcSig_wOF.py:52,55), but takes ALL B*T crops of a batch at once instead of one
+snippet per call, and returns both the per-snippet ``global_pool`` blob (calcSig_wOF.py:95,112) and the
+fp64 segment consensus (calcSig_wOF.py:82).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Sequence
+
+import numpy as np
+
+from .. import _lib
+from .._lib import LayerDesc, TensorDesc, call
+from .bn_inception import Graph, Plan
+
+BK = 32                      # K granularity of the implicit-GEMM kernel (csrc/vq_tsn.hip)
+RGB_MEAN = (104.0, 117.0, 123.0)      # BGR order, as cv2.imread delivers frames
+FLOW_MEAN = (128.0,) * 10
+_OPS = {"conv": _lib.VQ_OP_CONV, "maxpool": _lib.VQ_OP_MAXPOOL, "avgpool": _lib.VQ_OP_AVGPOOL,
+        "gavgpool": _lib.VQ_OP_GLOBAL_AVGPOOL}
+
+
+def synthetic_weights(graph: Graph, seed: int = 2) -> Dict[str, Dict[str, np.ndarray]]:
+    """Random-init weights of the right architecture (SURVEY.md 8(d) cfg 2): conv ~ N(0, sqrt(2/fan_in)),
+    small biases, frozen-BN statistics that keep activations O(1) through the 69 layers."""
+    rng = np.random.default_rng(seed)
+    w: Dict[str, Dict[str, np.ndarray]] = {}
+    shapes = {graph.input_name: graph.input_shape[0]}
+    for l in graph.layers:
+        if l.type == "Convolution":
+            cin = shapes[l.bottoms[0]]
+            fan_in = cin * l.kernel * l.kernel
+            w[l.name] = {
+                "W": (rng.standard_normal((l.num_output, cin, l.kernel, l.kernel)) * np.sqrt(2.0 / fan_in)).astype(np.float32),
+                "b": (rng.standard_normal(l.num_output) * 0.05).astype(np.float32)}
+            shapes[l.tops[0]] = l.num_output
+        elif l.type == "BN":
+            c = shapes[l.bottoms[0]]
+            w[l.name] = {"scale": rng.uniform(0.5, 1.5, c).astype(np.float32),
+                         "shift": (rng.standard_normal(c) * 0.1).astype(np.float32),
+                         "mean": (rng.standard_normal(c) * 0.1).astype(np.float32),
+                         "var": rng.uniform(0.5, 1.5, c).astype(np.float32)}
+            shapes[l.tops[0]] = c
+        elif l.type == "Concat":
+            shapes[l.tops[0]] = sum(shapes[b] for b in l.bottoms)
+        elif l.type == "InnerProduct":
+            shapes[l.tops[0]] = l.num_output
+        else:
+            shapes[l.tops[0]] = shapes[l.bottoms[0]]
+    return w
+
+
+def fold_bn(conv: Dict[str, np.ndarray], bn: Dict[str, np.ndarray] | None, eps: float = 1e-5):
+    """Frozen BN is a per-channel affine; fold it into the convolution: W' = a W, b' = a (b - mean) + shift."""
+    W = conv["W"].astype(np.float64)
+    b = conv["b"].astype(np.float64)
+    if bn is not None:
+        a = bn["scale"].astype(np.float64) / np.sqrt(bn["var"].astype(np.float64) + eps)
+        W = W * a[:, None, None, None]
+        b = a * (b - bn["mean"].astype(np.float64)) + bn["shift"].astype(np.float64)
+    return W.astype(np.float32), b.astype(np.float32)
+
+
+def pad4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+class TsnNet:
+    def __init__(self, graph: Graph, weights: Dict[str, Dict[str, np.ndarray]], max_crops: int = 96, device: int = 0,
+                 feature_blob: str = "global_pool", bn_eps: float = 1e-5):
+        self.graph = graph
+        self.plan: Plan = graph.plan(feature_blob)
+        self.in_channels = graph.input_shape[0]
+        self.max_crops = int(max_crops)
+        self.device = device
+        plan = self.plan
+        cin_pad = pad4(self.in_channels)
+        tensors = (TensorDesc * len(plan.tensors))()
+        for i, t in enumerate(plan.tensors):
+            tensors[i] = TensorDesc(t.h, t.w, cin_pad if i == 0 else t.c)
+        layers = (LayerDesc * len(plan.ops))()
+        chunks = []
+        off = 0
+        for i, op in enumerate(plan.ops):
+            d = LayerDesc(op=_OPS[op.kind], src=op.src, dst=op.dst, src_coff=op.src_coff, dst_coff=op.dst_coff,
+                          cin=op.cin, cout=op.cout, k=op.k, stride=op.stride, pad=op.pad, relu=int(op.relu),
+                          ceil_mode=1, w_off=0, b_off=0)
+            if op.kind == "conv":
+                W, b = fold_bn(weights[op.name], weights[op.bn] if op.bn else None, bn_eps)
+                cin_dev = cin_pad if op.src == 0 else op.cin
+                if W.shape != (op.cout, op.cin, op.k, op.k):
+                    raise ValueError("weights of %s have shape %s, expected %s" % (op.name, W.shape, (op.cout, op.cin, op.k, op.k)))
+                ohwi = np.zeros((op.cout, op.k, op.k, cin_dev), dtype=np.float32)
+                ohwi[..., :op.cin] = W.transpose(0, 2, 3, 1)                  # [Cout][kh][kw][Cin]
+                kdim = op.k * op.k * cin_dev
+                kp = (kdim + BK - 1) // BK * BK
+                packed = np.zeros((op.cout, kp), dtype=np.float32)
+                packed[:, :kdim] = ohwi.reshape(op.cout, kdim)
+                d.cin = cin_dev
+                d.w_off = off
+                chunks.append(packed.reshape(-1))
+                off += packed.size
+                d.b_off = off
+                bias = np.zeros(pad4(op.cout), dtype=np.float32)
+                bias[:op.cout] = b
+                chunks.append(bias)
+                off += bias.size
+            elif op.src == 0:
+                d.cin = d.cout = cin_pad
+            layers[i] = d
+        blob = np.ascontiguousarray(np.concatenate(chunks))
+        self._h = C.c_void_p()
+        call("vq_tsn_create", tensors, len(plan.tensors), layers, len(plan.ops), blob.ctypes.data_as(C.c_void_p), blob.size,
+             self.in_channels, plan.feature_slot, self.max_crops, device, C.byref(self._h))
+        self.feature_dim = plan.feature_dim
+        self.in_h, self.in_w = plan.tensors[0].h, plan.tensors[0].w
+        self._tensor_c = [cin_pad if i == 0 else t.c for i, t in enumerate(plan.tensors)]
+
+    # ------------------------------------------------------------------
+    def set_stream(self, hip_stream: int):
+        call("vq_tsn_set_stream", self._h, C.c_void_p(hip_stream))
+
+    def forward(self, crops: np.ndarray, T: int, mean: Sequence[float], want_per_snippet: bool = True):
+        """crops uint8 [B*T, H, W, C] (the T snippets of a clip contiguous) ->
+        (consensus [B, D] fp64, per-snippet global_pool [B*T, D] fp32)."""
+        x = np.ascontiguousarray(crops, dtype=np.uint8)
+        if x.ndim != 4 or x.shape[1:] != (self.in_h, self.in_w, self.in_channels):
+            raise ValueError("crops must be [n,%d,%d,%d] uint8" % (self.in_h, self.in_w, self.in_channels))
+        n = x.shape[0]
+        if n % T:
+            raise ValueError("number of crops must be a multiple of T")
+        m = np.ascontiguousarray(mean, dtype=np.float32)
+        if m.shape != (self.in_channels,):
+            raise ValueError("mean needs one entry per input channel")
+        feat = np.empty((n // T, self.feature_dim), dtype=np.float64)
+        ps = np.empty((n, self.feature_dim), dtype=np.float32) if want_per_snippet else None
+        call("vq_tsn_forward", self._h, x.ctypes.data_as(C.c_void_p), 0, n, T, m.ctypes.data_as(C.POINTER(C.c_float)),
+             feat.ctypes.data_as(C.c_void_p), ps.ctypes.data_as(C.c_void_p) if ps is not None else None)
+        return feat, ps
+
+    def forward_device(self, crops_dev_ptr: int, n: int, T: int, mean: Sequence[float]):
+        """Crops already in HBM (uint8 NHWC); results stay on the device (see feat_devptr)."""
+        m = np.ascontiguousarray(mean, dtype=np.float32)
+        call("vq_tsn_forward", self._h, C.c_void_p(crops_dev_ptr), 1, n, T, m.ctypes.data_as(C.POINTER(C.c_float)), None, None)
+
+    def feat_devptr(self):
+        f, p = C.c_void_p(), C.c_void_p()
+        call("vq_tsn_feat_devptr", self._h, C.byref(f), C.byref(p))
+        return f.value, p.value
+
+    def read_blob(self, name: str, n_crops: int) -> np.ndarray:
+        """Activation of blob `name` from the last forward, NHWC [n_crops, h, w, c] (per-layer parity)."""
+        slot, coff, c = self.plan.blob_loc[name]
+        t = self.plan.tensors[slot]
+        cs = self._tensor_c[slot]
+        buf = np.empty((n_crops, t.h, t.w, cs), dtype=np.float32)
+        call("vq_tsn_read_tensor", self._h, slot, n_crops, buf.ctypes.data_as(C.c_void_p))
+        return buf[..., coff:coff + c]
+
+    def flops_per_crop(self) -> float:
+        out = C.c_double()
+        call("vq_tsn_flops_per_crop", self._h, C.byref(out))
+        return out.value
+
+    def close(self):
+        if self._h:
+            _lib.load().vq_tsn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
