@@ -1,0 +1,260 @@
+"""Headline benchmark of the MI355X-native video-query hot path.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Primary line (BASELINE.json metric, first half): clips/sec of TSN feature extraction on configs[1] -- BN-Inception
+RGB stream, 224x224x3, T = 3 segments, B = 32 clips per GPU (96 crops per step), uint8 crops already resident
+in HBM, random-init weights, fp32 arithmetic on the fp32 matrix cores.  A step = one full forward of the batch
+(preprocess, 69 conv+BN+ReLU, 13 pools, global pool, segment consensus) and, for N > 1, the RCCL all-gather of
+the per-GPU [32,1024] fp64 feature blocks.  Weak scaling: every rank extracts its own 32 clips.
+
+Secondary object "similarity" (second half of the metric): queries/sec of the weighted similarity scan + score
+over a 1M-clip x (2 streams x 5 splits) x 1024 fp32 database (configs[3], 40.96 GB; row-sharded over the ranks,
+score slices all-gathered), HBM-bound.
+
+Both carry a `roofline` (HIP-event time of the dominant kernel inside the timed region vs the gfx950 peak) and a
+`cpu_baseline` (the oracle timed on the host cores, rank 0, N = 1 only, bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+import video_query_algorithms_amd as vqa
+from video_query_algorithms_amd._lib import call
+from video_query_algorithms_amd.shard import all_gather_rows, shard_range
+from video_query_algorithms_amd.tsn import bn_inception, net as tsn_net
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.29 TB/s measured achievable per the same guide)
+B_CLIPS, T_SEG, CH = 32, 3, 3     # configs[1]
+SIM_N, SIM_S, SIM_E, SIM_D = 1_000_000, 2, 5, 1024   # configs[3]
+
+
+class _DevArray:
+    """Zero-copy view of library-owned device memory as a torch tensor (for the RCCL all-gather)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def dev_tensor(ptr, shape, typestr, device):
+    return torch.as_tensor(_DevArray(ptr, shape, typestr), device=device)
+
+
+def bench_tsn(args, rank, world, device, stream):
+    g = bn_inception.bn_inception(CH)
+    weights = tsn_net.synthetic_weights(g, seed=2)
+    n_crops = B_CLIPS * T_SEG
+    model = tsn_net.TsnNet(g, weights, max_crops=n_crops, device=device.index)
+    model.set_stream(stream.cuda_stream)
+    gen = torch.Generator(device=device).manual_seed(1 + rank)
+    crops = torch.randint(0, 256, (n_crops, 224, 224, CH), dtype=torch.uint8, device=device, generator=gen)
+    feat_ptr, _ = model.feat_devptr()
+    feat = dev_tensor(feat_ptr, (B_CLIPS, model.feature_dim), "<f8", device)
+    import torch.distributed as dist
+
+    def step():
+        model.forward_device(crops.data_ptr(), n_crops, T_SEG, tsn_net.RGB_MEAN)
+        if world > 1:
+            all_gather_rows(feat, world * B_CLIPS)           # RCCL over xGMI: per-GPU feature blocks
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        model.set_profile(min(args.steps, 1024))     # HIP events around every layer launch, no host sync
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+    names, kinds, ms_layers, fl = model.layer_times()    # mean over the timed steps
+    ms_layers = ms_layers.astype(np.float64)
+    conv = np.array([k == "conv" for k in kinds])
+    conv_ms = float(ms_layers[conv].sum())
+    conv_flops = float(fl[conv].sum())
+    roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<BM,BN,...> (69 launches per step; fp32 v_mfma_f32_32x32x2)",
+            "achieved": conv_flops / conv_ms / 1e9, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": conv_flops / conv_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "launches_per_step": int(conv.sum()), "avg_launch_ms": conv_ms / int(conv.sum()),
+            "conv_ms_per_step": conv_ms, "other_kernels_ms_per_step": float(ms_layers[~conv].sum()),
+            "flops_per_step": conv_flops}
+    feats = feat.clone()
+    model.set_profile(0)
+    return dt, roof, model, crops, feats
+
+
+def cpu_baseline_tsn(crops_u8, weights_graph, seconds_target=15.0):
+    """The oracle (fp32 torch-CPU evaluation of the layer list, all host threads) on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import tsn_oracle as to
+    g, weights = weights_graph
+    threads = os.cpu_count() or 1
+    x = crops_u8[:T_SEG]
+    t0 = time.perf_counter()
+    to.features(g.layers, "data", weights, x, tsn_net.RGB_MEAN, T_SEG, dtype=np.float32, threads=threads)
+    one = time.perf_counter() - t0                       # includes first-touch; used to size the sample
+    n_clips = int(max(1, min(B_CLIPS, seconds_target / max(one, 1e-3))))
+    x = crops_u8[:n_clips * T_SEG]
+    t0 = time.perf_counter()
+    ps, _ = to.features(g.layers, "data", weights, x, tsn_net.RGB_MEAN, T_SEG, dtype=np.float32, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": n_clips / dt, "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": "%d clips (%d crops) of the same cfg2 batch, oracle/tsn_oracle.py fp32 torch-CPU, %d threads, %.1f s"
+                      % (n_clips, n_clips * T_SEG, threads, dt)}, ps
+
+
+def bench_sim(args, rank, world, device, stream):
+    import torch.distributed as dist
+    row0, rows = shard_range(SIM_N, world, rank)
+    db = vqa.FeatureDB.synthetic(rows, SIM_S, SIM_E, SIM_D, seed=17, scales=(4.0, 1.0), row0=row0, device=device.index)
+    db.set_stream(stream.cuda_stream)
+    # query = scaled features of global row 12345 (rank 0 holds it); broadcast t to every rank
+    t = torch.zeros((SIM_S, SIM_E, SIM_D), dtype=torch.float64, device=device)
+    if rank == 0:
+        t.copy_(torch.from_numpy(db.set_query_from_row(12345)))
+    if world > 1:
+        dist.broadcast(t, 0)
+    db.set_query(t.cpu().numpy())
+    w = [1.0, 1.5]
+    scores = dev_tensor(db.scores_devptr(), (rows,), "<f8", device)
+    tm = C.c_void_p()
+    call("vq_timer_create", C.byref(tm))
+    steps, warm = max(args.steps, 5), max(args.warmup, 2)
+    with torch.cuda.stream(stream):
+        for _ in range(warm):
+            db.scan(weights=w)
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        kern_ms = 0.0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            call("vq_timer_start", tm, C.c_void_p(stream.cuda_stream))
+            db.scan(weights=w)                               # one launch: dots, ensemble mean, weighted score
+            call("vq_timer_stop", tm, C.c_void_p(stream.cuda_stream))
+            if world > 1:
+                all_scores = all_gather_rows(scores, SIM_N)      # score slices -> every rank (N x 8 B, RCCL)
+            ms = C.c_float()
+            call("vq_timer_elapsed_ms", tm, C.byref(ms))
+            kern_ms += ms.value
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+    kern_ms /= steps
+    nbytes = rows * SIM_S * SIM_E * SIM_D * 4 + rows * 8
+    roof = {"bound": "hbm", "kernel": "scan_kernel<float,2,5,4>", "achieved": nbytes / kern_ms / 1e6, "peak": PEAK_HBM_GBS,
+            "unit": "GB/s", "frac": nbytes / kern_ms / 1e6 / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": kern_ms,
+            "bytes_per_launch": nbytes}
+    return dt, steps, roof, db, row0, rows
+
+
+def cpu_baseline_sim(db, row0):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sim_oracle as so
+    n = 20000
+    x = so.synth_features(17, row0, n, SIM_S, SIM_E, SIM_D, (4.0, 1.0))
+    t = np.stack([[so.scale_feature(x[7, s, e].astype(np.float64)) for e in range(SIM_E)] for s in range(SIM_S)])
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 10.0:
+        _, avg, _ = so.dense_similarities(x, t)
+        sc = so.dense_scores(avg, [1.0, 1.5])
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    qps_full = 1.0 / (dt * SIM_N / n)
+    return {"value": qps_full, "unit": "queries/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "sample": "%d of the 1M rows (same generator), oracle/sim_oracle.py numpy fp64 einsum (BLAS threads), %.3f s per "
+                      "pass, scaled by 1M/%d" % (n, dt, n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--skip-sim", action="store_true")
+    ap.add_argument("--skip-cpu", action="store_true")
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    stream = torch.cuda.Stream(device=device)
+
+    dt, roof, model, crops, feats = bench_tsn(args, rank, world, device, stream)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    value = world * B_CLIPS * args.steps / dt
+    out = {"metric": "clips/sec TSN feature-extract", "value": value, "unit": "clips/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "configs[1]: TSN BN-Inception RGB stream, 224x224x3 uint8 crops resident in HBM, "
+                                  "T=3 segments, B=32 clips per GPU (96 crops per step), random-init weights",
+                      "global_batch": world * B_CLIPS, "crops_per_step_per_gpu": B_CLIPS * T_SEG,
+                      "parallelism": "dp%d" % world, "collective": "all_gather feature blocks (RCCL)" if world > 1 else None},
+           "roofline": roof}
+    if rank == 0 and world == 1 and not args.skip_cpu:
+        base, ps_cpu = cpu_baseline_tsn(crops.cpu().numpy(), (model.graph, tsn_net.synthetic_weights(model.graph, seed=2)))
+        out["cpu_baseline"] = base
+        # the baseline run doubles as a live parity check of the timed path (first clips of the batch)
+        ncl = ps_cpu.shape[0] // T_SEG
+        ref = ps_cpu.astype(np.float64).reshape(ncl, T_SEG, -1).mean(axis=1)
+        got = feats[:ncl].cpu().numpy()
+        out["parity_vs_oracle_rel_err"] = float(np.abs(got - ref).max() / np.abs(ref).max())
+    model.close()
+    del crops
+
+    if not args.skip_sim:
+        sdt, ssteps, sroof, db, row0, rows = bench_sim(args, rank, world, device, stream)
+        tmax = torch.tensor([sdt], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        sdt = float(tmax.item())
+        sim = {"metric": "queries/sec similarity (1M x 1024)", "value": ssteps / sdt, "unit": "queries/s",
+               "ms_per_query": sdt / ssteps * 1e3, "steps": ssteps, "scaling": "strong", "dtype": "f64 accumulate over f32 features",
+               "config": {"workload": "configs[3]: 1 query x 1M clips x (2 streams x 5 splits) x 1024 fp32 = 40.96 GB, "
+                                      "row-sharded over %d GPU(s), weighted score fused, score slices all-gathered" % world,
+                          "rows_per_gpu": rows},
+               "roofline": sroof}
+        if rank == 0 and world == 1 and not args.skip_cpu:
+            sim["cpu_baseline"] = cpu_baseline_sim(db, row0)
+        out["similarity"] = sim
+        db.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

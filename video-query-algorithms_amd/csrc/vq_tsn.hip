@@ -315,9 +315,14 @@ struct vq_tsn {
     double* feat_dev = nullptr;           // [max_crops][D] (B <= max_crops)
     double flops_per_crop = 0;
     int last_crops = 0;
+    int profile_depth = 0;                // > 0: HIP events around every layer launch (bench roofline accounting)
+    int profile_count = 0;                // profiled forwards so far (ring of profile_depth event sets)
+    std::vector<hipEvent_t> events;       // profile_depth x (n_layers + 1)
 };
 
 static void tsn_free(vq_tsn* net) {
+    for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
+    net->events.clear();
     for (float* p : net->slots)
         if (p) (void)hipFree(p);
     if (net->blob) (void)hipFree(net->blob);
@@ -584,10 +589,17 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
     VQ_HIP(hipMemcpyAsync(net->mean_dev, mean_host, in_c * sizeof(float), hipMemcpyHostToDevice, net->stream));
     preprocess_kernel<<<cdiv(npix, 256), 256, 0, net->stream>>>(src, net->slots[0], npix, in_c, t0.c, net->mean_dev);
     VQ_CHECK_LAUNCH();
+    hipEvent_t* ev = nullptr;
+    if (net->profile_depth > 0) {
+        ev = net->events.data() + (size_t)(net->profile_count % net->profile_depth) * (net->layers.size() + 1);
+        VQ_HIP(hipEventRecord(ev[0], net->stream));
+    }
     for (int li = 0; li < (int)net->layers.size(); ++li) {
         const int rc = run_layer(net, li, n_crops);
         if (rc != VQ_OK) return rc;
+        if (ev) VQ_HIP(hipEventRecord(ev[li + 1], net->stream));
     }
+    if (ev) ++net->profile_count;
     const int B = n_crops / T;
     consensus_kernel<<<cdiv((int64_t)B * net->D, 256), 256, 0, net->stream>>>(net->slots[net->feature_slot], net->feat_dev, B, T,
                                                                               net->D, net->D);
@@ -619,6 +631,49 @@ int vq_tsn_read_tensor(vq_tsn* net, int32_t slot, int32_t n_crops, float* host) 
     VQ_HIP(hipMemcpyAsync(host, net->slots[slot], (size_t)n_crops * t.h * t.w * t.c * sizeof(float), hipMemcpyDeviceToHost,
                           net->stream));
     VQ_HIP(hipStreamSynchronize(net->stream));
+    return VQ_OK;
+}
+
+int vq_tsn_set_profile(vq_tsn* net, int32_t depth) {
+    VQ_REQUIRE(net, "net is NULL");
+    VQ_REQUIRE(depth >= 0 && depth <= 1024, "profile depth must be in [0,1024]");
+    std::lock_guard<std::mutex> lk(net->mu);
+    DeviceGuard g(net->device);
+    VQ_HIP(hipStreamSynchronize(net->stream));
+    for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
+    net->events.clear();
+    net->events.resize((size_t)depth * (net->layers.size() + 1));
+    for (hipEvent_t& e : net->events) VQ_HIP(hipEventCreate(&e));
+    net->profile_depth = depth;
+    net->profile_count = 0;
+    return VQ_OK;
+}
+
+int vq_tsn_layer_times(vq_tsn* net, float* ms, double* flops, int32_t n_layers) {
+    VQ_REQUIRE(net && ms, "NULL argument");
+    VQ_REQUIRE(n_layers == (int)net->layers.size(), "n_layers must be %d", (int)net->layers.size());
+    std::lock_guard<std::mutex> lk(net->mu);
+    if (net->profile_depth == 0 || net->profile_count == 0) return fail(VQ_E_STATE, "no profiled forward has run");
+    DeviceGuard g(net->device);
+    VQ_HIP(hipStreamSynchronize(net->stream));
+    const int sets = std::min(net->profile_count, net->profile_depth);
+    for (int i = 0; i < n_layers; ++i) ms[i] = 0.f;
+    for (int sidx = 0; sidx < sets; ++sidx) {
+        hipEvent_t* ev = net->events.data() + (size_t)sidx * (n_layers + 1);
+        for (int i = 0; i < n_layers; ++i) {
+            float t = 0.f;
+            VQ_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+            ms[i] += t / sets;                                   // mean over the profiled forwards
+        }
+    }
+    if (flops) {
+        for (int i = 0; i < n_layers; ++i) {
+            const vq_layer_desc& L = net->layers[i];
+            const vq_tensor_desc& td = net->tensors[L.dst];
+            flops[i] = L.op == VQ_OP_CONV ? 2.0 * net->last_crops * td.h * td.w * L.cout * (L.src == 0 ? net->in_channels : L.cin) * L.k * L.k
+                                          : 0.0;
+        }
+    }
     return VQ_OK;
 }
 

@@ -160,6 +160,18 @@ class TsnNet:
         call("vq_tsn_read_tensor", self._h, slot, n_crops, buf.ctypes.data_as(C.c_void_p))
         return buf[..., coff:coff + c]
 
+    def set_profile(self, depth: int):
+        """depth > 0: keep HIP-event timings of the last `depth` forwards (averaged by layer_times); 0 = off."""
+        call("vq_tsn_set_profile", self._h, int(depth))
+
+    def layer_times(self):
+        """(names, kinds, mean ms[n_layers] over the profiled forwards, flops[n_layers] of the last batch)."""
+        n = len(self.plan.ops)
+        ms = np.empty(n, dtype=np.float32)
+        fl = np.empty(n, dtype=np.float64)
+        call("vq_tsn_layer_times", self._h, ms.ctypes.data_as(C.c_void_p), fl.ctypes.data_as(C.c_void_p), n)
+        return [o.name for o in self.plan.ops], [o.kind for o in self.plan.ops], ms, fl
+
     def flops_per_crop(self) -> float:
         out = C.c_double()
         call("vq_tsn_flops_per_crop", self._h, C.byref(out))
