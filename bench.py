@@ -52,6 +52,19 @@ def dev_tensor(ptr, shape, typestr, device):
     return torch.as_tensor(_DevArray(ptr, shape, typestr), device=device)
 
 
+def host_cores():
+    """CPU cores this process may actually use (affinity mask, capped by the cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def bench_tsn(args, rank, world, device, stream):
     g = bn_inception.bn_inception(CH)
     weights = tsn_net.synthetic_weights(g, seed=2)
@@ -107,7 +120,7 @@ def cpu_baseline_tsn(crops_u8, weights_graph, seconds_target=15.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import tsn_oracle as to
     g, weights = weights_graph
-    threads = os.cpu_count() or 1
+    threads = host_cores()
     x = crops_u8[:T_SEG]
     t0 = time.perf_counter()
     to.features(g.layers, "data", weights, x, tsn_net.RGB_MEAN, T_SEG, dtype=np.float32, threads=threads)
@@ -182,8 +195,8 @@ def cpu_baseline_sim(db, row0):
         reps += 1
     dt = (time.perf_counter() - t0) / reps
     qps_full = 1.0 / (dt * SIM_N / n)
-    return {"value": qps_full, "unit": "queries/s", "cores": os.cpu_count() or 1, "kind": "port",
-            "sample": "%d of the 1M rows (same generator), oracle/sim_oracle.py numpy fp64 einsum (BLAS threads), %.3f s per "
+    return {"value": qps_full, "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": "%d of the 1M rows (same generator), oracle/sim_oracle.py numpy fp64 einsum (single thread), %.3f s per "
                       "pass, scaled by 1M/%d" % (n, dt, n)}
 
 

@@ -244,3 +244,37 @@ def test_errors_are_reported_not_swallowed(vqa):
         vqa.FeatureDB(8, 2, 3, 1022)
     with pytest.raises(vqa.VqError):
         db.scores()
+
+
+def test_library_memory_is_visible_to_rccl_collectives(vqa):
+    """The N > 1 path hands library-owned device memory to torch.distributed (backend nccl = RCCL) through a
+    zero-copy __cuda_array_interface__ view.  One GPU here, so a 1-rank RCCL group: the collective must read the
+    library's score buffer and reproduce it."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    sys_path_bench = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    sys.path.insert(0, sys_path_bench)
+    from bench import dev_tensor
+    db = vqa.FeatureDB.synthetic(4096, 2, 3, 1024, seed=3, scales=(4.0, 1.0))
+    db.set_query_from_row(5, want=False)
+    db.scan(weights=[1.0, 1.5])
+    want = db.scores()
+    dev = torch.device("cuda", 0)
+    view = dev_tensor(db.scores_devptr(), (4096,), "<f8", dev)
+    assert view.data_ptr() == db.scores_devptr()
+    assert (view.cpu().numpy() == want).all()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        out = torch.empty(4096, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(out, view)
+        torch.cuda.synchronize()
+        assert (out.cpu().numpy() == want).all()
+    finally:
+        dist.destroy_process_group()

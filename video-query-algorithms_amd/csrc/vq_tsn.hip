@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "vq_common.h"
@@ -20,6 +21,7 @@
 using namespace vq;
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // preprocess: uint8 NHWC crops -> fp32 NHWC (channels padded to a multiple of 4), minus mean
@@ -39,6 +41,7 @@ struct ConvArgs {
     float* out;
     const float* w;      // [Cout][Kp], k index = (kh*k + kw)*Cin + c, zero padded to Kp
     const float* bias;   // [Cout]
+    const float* zeros;  // >= 16 bytes of zeros: where masked-off lanes load from (no branches around loads)
     int H, W, Cs_in, coff_in, Cin;
     int Ho, Wo, Cs_out, coff_out, Cout;
     int k, stride, pad;
@@ -77,70 +80,75 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
     // ---- staging roles: thread -> (row lrow + 32 i, 16-byte column lcol)
     const int lrow = tid >> 3, lcol = tid & 7;
+    // Rows past M get an input row far outside the image, so the ordinary bounds test routes them to the
+    // zero page; every pointer below stays derived from a kernel argument (global address space -- a null
+    // alternative would demote the loads to flat_load, which also counts against lgkmcnt).
     const float* a_img[RA];
     int a_ih0[RA], a_iw0[RA];
     const int HoWo = a.Ho * a.Wo;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
         const int m = m0 + lrow + 32 * i;
-        if (m < a.M) {
-            const int n_img = m / HoWo, rem = m - n_img * HoWo;
-            const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-            a_img[i] = a.in + (size_t)n_img * a.H * a.W * a.Cs_in + a.coff_in;
-            a_ih0[i] = oh * a.stride - a.pad;
-            a_iw0[i] = ow * a.stride - a.pad;
-        } else {
-            a_img[i] = nullptr;
-            a_ih0[i] = a_iw0[i] = 0;
-        }
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        const int n_img = mm / HoWo, rem = mm - n_img * HoWo;
+        const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+        a_img[i] = a.in + (size_t)n_img * a.H * a.W * a.Cs_in + a.coff_in;
+        a_ih0[i] = ok ? oh * a.stride - a.pad : -(1 << 20);
+        a_iw0[i] = ow * a.stride - a.pad;
     }
     const float* b_row[RB];
+    bool b_ok[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         const int n = n0 + lrow + 32 * i;
-        b_row[i] = n < a.Cout ? a.w + (size_t)n * a.Kp + lcol * 4 : nullptr;
+        b_ok[i] = n < a.Cout;
+        b_row[i] = a.w + (size_t)(b_ok[i] ? n : 0) * a.Kp + lcol * 4;
     }
 
-    float4 ra[RA], rb[RB];
+    floatx4 ra[RA], rb[RB];   // ext-vector values (a HIP float4 struct copy becomes a memcpy the optimiser leaves in scratch)
     int kh = 0, kw = 0, c0 = 0;   // aligned mode: walk (tap, channel chunk) without divisions
-    auto load_tiles = [&](int kc) {
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (SMALL_CIN) {
-                const int kidx = (kc * 8 + lcol) * 4;
-                const int tap = kidx / a.Cin, c = kidx - tap * a.Cin;
-                const int th = tap / a.k, tw = tap - th * a.k;
-                const int ih = a_ih0[i] + th, iw = a_iw0[i] + tw;
-                if (a_img[i] && tap < a.k * a.k && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
-                    v = *reinterpret_cast<const float4*>(a_img[i] + ((size_t)ih * a.W + iw) * a.Cs_in + c);
-            } else {
-                const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-                if (a_img[i] && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
-                    v = *reinterpret_cast<const float4*>(a_img[i] + ((size_t)ih * a.W + iw) * a.Cs_in + c0 + lcol * 4);
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i)
-            rb[i] = b_row[i] ? *reinterpret_cast<const float4*>(b_row[i] + (size_t)kc * BK) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!SMALL_CIN) {
-            c0 += BK;
-            if (c0 >= a.Cin) {
-                c0 = 0;
-                if (++kw == a.k) {
-                    kw = 0;
-                    ++kh;
-                }
-            }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < RA; ++i) *reinterpret_cast<float4*>(&sm.a[buf][lrow + 32 * i][lcol * 4]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < RB; ++i) *reinterpret_cast<float4*>(&sm.b[buf][lrow + 32 * i][lcol * 4]) = rb[i];
-    };
+    // Every lane always issues its loads: lanes that fall into the zero padding (or past M / Cout) read the
+    // zero page instead, so there is no branch and no exec-mask juggling around the global loads.
+    // (Macros, not lambdas: by-reference captures of the staging arrays ended up in scratch memory.)
+#define VQ_LOAD_TILES(KC)                                                                                          \
+    {                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                                           \
+            const float* src = a.zeros;                                                                            \
+            if (SMALL_CIN) {                                                                                       \
+                const int kidx = ((KC) * 8 + lcol) * 4;                                                            \
+                const int tap = kidx / a.Cin, c = kidx - tap * a.Cin;                                              \
+                const int th = tap / a.k, tw = tap - th * a.k;                                                     \
+                const int ih = a_ih0[i] + th, iw = a_iw0[i] + tw;                                                  \
+                if (tap < a.k * a.k && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)   \
+                    src = a_img[i] + ((size_t)ih * a.W + iw) * a.Cs_in + c;                                        \
+            } else {                                                                                               \
+                const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;                                                  \
+                if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)                                  \
+                    src = a_img[i] + ((size_t)ih * a.W + iw) * a.Cs_in + c0 + lcol * 4;                            \
+            }                                                                                                      \
+            ra[i] = *reinterpret_cast<const floatx4*>(src);                                                        \
+        }                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i)                                                             \
+            rb[i] = *reinterpret_cast<const floatx4*>(b_ok[i] ? b_row[i] + (size_t)(KC) * BK : a.zeros);           \
+        if (!SMALL_CIN) {                                                                                          \
+            c0 += BK;                                                                                              \
+            if (c0 >= a.Cin) {                                                                                     \
+                c0 = 0;                                                                                            \
+                if (++kw == a.k) {                                                                                 \
+                    kw = 0;                                                                                        \
+                    ++kh;                                                                                          \
+                }                                                                                                  \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
+#define VQ_STORE_TILES(BUF)                                                                                        \
+    {                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i)                                                             \
+            *reinterpret_cast<floatx4*>(&sm.a[BUF][lrow + 32 * i][lcol * 4]) = ra[i];                              \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i)                                                             \
+            *reinterpret_cast<floatx4*>(&sm.b[BUF][lrow + 32 * i][lcol * 4]) = rb[i];                              \
+    }
 
     // ---- compute roles
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -154,24 +162,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // folded-BN bias of this lane's output columns: fetched now so that its latency (and its vmcnt wait)
+    // is long gone when the epilogue starts -- a load inside the store loop would serialise every store
+    float bias_v[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / WN) + 32 * j + l31;
+        bias_v[j] = a.bias[n < a.Cout ? n : 0];
+    }
+
     const int nk = a.Kp / BK;
-    load_tiles(0);
-    store_tiles(0);
+    VQ_LOAD_TILES(0)
+    VQ_STORE_TILES(0)
     __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
-        if (kc + 1 < nk) load_tiles(kc + 1);   // global loads in flight under the MFMAs below
+        if (kc + 1 < nk) VQ_LOAD_TILES(kc + 1)   // global loads in flight under the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             // lane (row r, half h) holds k = 8 kk + 4 h + j for MFMA step j: the two halves of a step cover a
             // k pair {8kk + j, 8kk + 4 + j}; A and B use the same assignment, so every k is summed once.
-            float af[TM][4], bf[TN][4];
+            floatx4 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                *reinterpret_cast<float4*>(af[i]) = *reinterpret_cast<const float4*>(&sm.a[buf][arow0 + 32 * i][kk * 8 + half * 4]);
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const floatx4*>(&sm.a[buf][arow0 + 32 * i][kk * 8 + half * 4]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                *reinterpret_cast<float4*>(bf[j]) = *reinterpret_cast<const float4*>(&sm.b[buf][brow0 + 32 * j][kk * 8 + half * 4]);
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const floatx4*>(&sm.b[buf][brow0 + 32 * j][kk * 8 + half * 4]);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -180,31 +195,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
-        if (kc + 1 < nk) store_tiles(buf ^ 1);
+        if (kc + 1 < nk) VQ_STORE_TILES(buf ^ 1)
         __syncthreads();
     }
 
     // ---- epilogue: + bias (folded BN), ReLU, store at the channel offset of the destination slot.
-    // C/D map of the 32x32 MFMA: column (N) = lane & 31, row (M) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / WN) + 32 * j + l31;
-        if (n >= a.Cout) continue;
-        const float bv = a.bias[n];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + wm * (BM / WM) + 32 * i + 4 * half;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                if (m < a.M) {
-                    float v = acc[i][j][r] + bv;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    a.out[(size_t)m * a.Cs_out + a.coff_out + n] = v;
-                }
-            }
-        }
+    // C/D map of the 32x32 MFMA: column (N) = lane & 31, row (M) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5):
+    // every store instruction writes two 128-byte runs (32 consecutive channels of two pixels).
+#define VQ_STORE_OUT(GUARD)                                                                          \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                 \
+        const int n = n0 + wn * (BN / WN) + 32 * j + l31;                                            \
+        if (n < a.Cout) {                                                                            \
+            const float bv = bias_v[j];                                                              \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                         \
+                const int mb = m0 + wm * (BM / WM) + 32 * i + 4 * half;                              \
+                float* o = a.out + (size_t)mb * a.Cs_out + a.coff_out + n;                           \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                     \
+                    const int dm = (r & 3) + 8 * (r >> 2);                                           \
+                    float v = acc[i][j][r] + bv;                                                     \
+                    if (a.relu) v = fmaxf(v, 0.f);                                                   \
+                    if (!(GUARD) || mb + dm < a.M) o[(size_t)dm * a.Cs_out] = v;                     \
+                }                                                                                    \
+            }                                                                                        \
+        }                                                                                            \
     }
+    if (m0 + BM <= a.M) {   // workgroup-uniform: only the last M tile needs row guards
+        VQ_STORE_OUT(false)
+    } else {
+        VQ_STORE_OUT(true)
+    }
+#undef VQ_LOAD_TILES
+#undef VQ_STORE_TILES
+#undef VQ_STORE_OUT
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -306,6 +328,7 @@ struct vq_tsn {
     std::vector<vq_layer_desc> layers;
     std::vector<ConvTile> tiles;          // per layer (conv only)
     std::vector<float*> slots;            // device activations, max_crops each
+    float* zeros = nullptr;               // 256 bytes of zeros (load target of masked lanes)
     float* blob = nullptr;                // weights + biases
     int64_t blob_floats = 0;
     int feature_slot = -1, D = 0;
@@ -326,6 +349,7 @@ static void tsn_free(vq_tsn* net) {
     for (float* p : net->slots)
         if (p) (void)hipFree(p);
     if (net->blob) (void)hipFree(net->blob);
+    if (net->zeros) (void)hipFree(net->zeros);
     if (net->crops_dev) (void)hipFree(net->crops_dev);
     if (net->mean_dev) (void)hipFree(net->mean_dev);
     if (net->feat_dev) (void)hipFree(net->feat_dev);
@@ -389,6 +413,7 @@ static int run_layer(vq_tsn* net, int li, int n_crops) {
         a.out = net->slots[L.dst];
         a.w = net->blob + L.w_off;
         a.bias = net->blob + L.b_off;
+        a.zeros = net->zeros;
         a.H = ts.h;
         a.W = ts.w;
         a.Cs_in = ts.c;
@@ -537,6 +562,10 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
     if (e != hipSuccess) return bail("hipMalloc(weights)", e);
     e = hipMemcpy(net->blob, blob_host, (size_t)blob_floats * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) return bail("hipMemcpy(weights)", e);
+    e = hipMalloc((void**)&net->zeros, 256);
+    if (e != hipSuccess) return bail("hipMalloc(zero page)", e);
+    e = hipMemset(net->zeros, 0, 256);
+    if (e != hipSuccess) return bail("hipMemset(zero page)", e);
     e = hipMalloc((void**)&net->mean_dev, (size_t)in_channels * sizeof(float));
     if (e != hipSuccess) return bail("hipMalloc(mean)", e);
     e = hipMalloc((void**)&net->feat_dev, (size_t)max_crops * net->D * sizeof(double));
