@@ -174,6 +174,10 @@ int vq_tsn_read_tensor(vq_tsn* net, int32_t slot, int32_t n_crops, float* host);
  * the un-padded channel counts; 0 for pooling).  depth = 0 switches profiling off. */
 int vq_tsn_set_profile(vq_tsn* net, int32_t depth);
 int vq_tsn_layer_times(vq_tsn* net, float* ms, double* flops, int32_t n_layers);
+/* The implicit-GEMM tiling (BM, BN, BK, pipelined?) each conv layer runs with at batch size n_crops: autotuned on the first
+ * forward of that batch size (every candidate yields the same bits), else the occupancy heuristic.
+ * tiles: int32 [n_layers][4], zeros for non-conv layers. */
+int vq_tsn_layer_tiles(vq_tsn* net, int32_t n_crops, int32_t* tiles, int32_t n_layers);
 /* Algorithmic FLOPs (2*MACs of the conv layers) of one crop, for roofline accounting. */
 int vq_tsn_flops_per_crop(vq_tsn* net, double* flops);
 

@@ -20,14 +20,16 @@ def main(channels=3, n_crops=96, T=3, reps=10):
     for _ in range(reps):
         m.forward_device(crops.data_ptr(), n_crops, T, mean)
     names, kinds, ms, fl = m.layer_times()
+    tiles = m.layer_tiles(n_crops)
     plan = m.plan
     tot = ms.sum()
-    print("%-34s %-8s %9s %5s %5s %8s %7s %6s" % ("layer", "kind", "M", "N", "K", "ms", "TF/s", "%time"))
-    for op, k, t, f in zip(plan.ops, kinds, ms, fl):
+    print("%-34s %-8s %9s %5s %5s %8s %7s %6s %s" % ("layer", "kind", "M", "N", "K", "ms", "TF/s", "%time", "tile"))
+    for op, k, t, f, tl in zip(plan.ops, kinds, ms, fl, tiles):
         td = plan.tensors[op.dst]
         M = n_crops * td.h * td.w
-        print("%-34s %-8s %9d %5d %5d %8.4f %7.1f %6.2f" % (op.name, k, M, op.cout, op.cin * op.k * op.k, t,
-                                                          f / t / 1e9 if t > 0 else 0, 100 * t / tot))
+        print("%-34s %-8s %9d %5d %5d %8.4f %7.1f %6.2f %s" % (op.name, k, M, op.cout, op.cin * op.k * op.k, t,
+                                                             f / t / 1e9 if t > 0 else 0, 100 * t / tot,
+                                                             "%dx%dx%d%s" % (tl[0], tl[1], tl[2], "p" if tl[3] else "") if tl[0] else ""))
     conv = np.array([k == "conv" for k in kinds])
     print("total %.3f ms; conv %.3f ms (%.1f TF/s = %.1f%% of 157.3); other %.3f ms" % (
         tot, ms[conv].sum(), fl[conv].sum() / ms[conv].sum() / 1e9, fl[conv].sum() / ms[conv].sum() / 1e9 / 1.573,

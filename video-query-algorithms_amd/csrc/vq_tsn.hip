@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <type_traits>
 #include <vector>
 
@@ -47,15 +48,18 @@ struct ConvArgs {
     int k, stride, pad;
     int M, Kp, relu;
     int tiles_m, tiles_n;
+    int dbg;             // timing experiments only: bit0 skip staging loads, bit1 skip LDS stores, bit2 skip barriers
+    int desync;          // 1: odd hardware wave slots run at raised priority (see desync_simd_partners)
 };
 
-constexpr int BK = 32;         // K elements staged per step
-constexpr int LDS_LD = BK + 4; // padded row: 16 consecutive rows hit 16 distinct 16-byte bank slots
+constexpr int KPAD = 32;       // weights are packed [Cout][Kp] with Kp a multiple of 32
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 struct ConvSmem {
-    float a[2][BM][LDS_LD];
-    float b[2][BN][LDS_LD];
+    // padded rows (BK + 4 floats): the 16 rows one ds_read_b128 lane group touches land on 16 distinct
+    // 16-byte bank slots for BK = 16 and BK = 32 alike
+    float a[2][BM][BK + 4];
+    float b[2][BN][BK + 4];
 };
 
 // XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2); give each XCD a contiguous run of
@@ -65,31 +69,83 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, int WM, int WN, bool SMALL_CIN>
+// Waves that share a SIMD run the same program and drift into lockstep: both are in their MFMA phase together
+// (each at half speed) and both in their staging / barrier phase together (matrix pipe idle).  Giving the waves
+// in odd hardware wave slots a higher issue priority breaks the symmetry, so one wave's staging phase overlaps
+// its neighbour's MFMA phase.  HW_REG_HW_ID (id 4) bits [3:0] = wave slot within the SIMD.
+__device__ __forceinline__ void desync_simd_partners() {
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+    if (slot & 1) __builtin_amdgcn_s_setprio(1);
+}
+
+// Epilogue shared by both kernels: + bias (folded BN), ReLU, store at the channel offset of the destination slot.
+// In the MFMA C/D layout a lane holds ONE channel of 16 pixels (column = lane & 31, row = (r & 3) + 8 (r >> 2) +
+// 4 (lane >> 5)), which would mean 16 four-byte stores per accumulator tile; the store tail of such a wave is
+// issue-bound and cost ~20 % of a K = 576 tile.  Each wave therefore transposes its 32x32 tile through a private
+// 4.5 KB LDS patch and writes 16 bytes per lane: 4 store instructions per tile, each 8 pixels x 128 bytes.
+#define VQ_EPILOGUE()                                                                                             \
+    {                                                                                                             \
+        __syncthreads(); /* every wave is done with the K-loop image of the LDS */                               \
+        float* patch = reinterpret_cast<float*>(smem_raw) + wave * (32 * 36);                                     \
+        const int prow = lane >> 3, pc4 = lane & 7;                                                               \
+        const bool full_m = m0 + BM <= a.M;                                                                       \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                          \
+            const int nb = n0 + wn * (BN / WN) + 32 * j;                                                          \
+            if (nb < a.Cout) {                                                                                    \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                  \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                \
+                        patch[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = acc[i][j][r];                     \
+                    const int mb = m0 + wm * (BM / WM) + 32 * i;                                                  \
+                    _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                            \
+                        const int row = prow + 8 * ps;                                                            \
+                        floatx4 v = *reinterpret_cast<const floatx4*>(&patch[row * 36 + pc4 * 4]);                \
+                        v += bias_v[j];                                                                           \
+                        if (a.relu) {                                                                             \
+                            v[0] = fmaxf(v[0], 0.f);                                                              \
+                            v[1] = fmaxf(v[1], 0.f);                                                              \
+                            v[2] = fmaxf(v[2], 0.f);                                                              \
+                            v[3] = fmaxf(v[3], 0.f);                                                              \
+                        }                                                                                         \
+                        if (full_m || mb + row < a.M)                                                             \
+                            *reinterpret_cast<floatx4*>(a.out + (size_t)(mb + row) * a.Cs_out + a.coff_out + nb + pc4 * 4) = v; \
+                    }                                                                                             \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+
+// One workgroup = 4 waves = one BM x BN output tile; K is walked in steps of BK through a double-buffered LDS
+// image that is filled through registers (global -> VGPR under the MFMAs of the current step -> LDS).
+template <int BM, int BN, int WM, int WN, int BK, bool SMALL_CIN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(BK == 16 || BK == 32, "BK is 16 or 32");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;   // 32x32 accumulator tiles per wave
-    constexpr int RA = BM / 32, RB = BN / 32;             // rows staged per thread
+    constexpr int CPR = BK / 4;                            // 16-byte chunks per staged row
+    constexpr int NA = (BM * CPR + 255) / 256, NB = (BN * CPR + 255) / 256;   // chunks staged per thread
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    ConvSmem<BM, BN>& sm = *reinterpret_cast<ConvSmem<BM, BN>*>(smem_raw);
+    ConvSmem<BM, BN, BK>& sm = *reinterpret_cast<ConvSmem<BM, BN, BK>*>(smem_raw);
 
+    if (a.desync) desync_simd_partners();
     const int tid = threadIdx.x;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / a.tiles_n) * BM;
     const int n0 = (tile % a.tiles_n) * BN;
 
-    // ---- staging roles: thread -> (row lrow + 32 i, 16-byte column lcol)
-    const int lrow = tid >> 3, lcol = tid & 7;
+    // ---- staging roles: chunk id = tid + 256 i -> (row, 16-byte column).
     // Rows past M get an input row far outside the image, so the ordinary bounds test routes them to the
     // zero page; every pointer below stays derived from a kernel argument (global address space -- a null
     // alternative would demote the loads to flat_load, which also counts against lgkmcnt).
-    const float* a_img[RA];
-    int a_ih0[RA], a_iw0[RA];
+    const float* a_img[NA];
+    int a_ih0[NA], a_iw0[NA], a_row[NA], a_col[NA];
     const int HoWo = a.Ho * a.Wo;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) {
-        const int m = m0 + lrow + 32 * i;
-        const bool ok = m < a.M;
+    for (int i = 0; i < NA; ++i) {
+        const int c = tid + 256 * i;
+        a_row[i] = c / CPR;
+        a_col[i] = c % CPR;
+        const int m = m0 + a_row[i];
+        const bool ok = m < a.M && a_row[i] < BM;
         const int mm = ok ? m : 0;
         const int n_img = mm / HoWo, rem = mm - n_img * HoWo;
         const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
@@ -97,40 +153,44 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         a_ih0[i] = ok ? oh * a.stride - a.pad : -(1 << 20);
         a_iw0[i] = ow * a.stride - a.pad;
     }
-    const float* b_row[RB];
-    bool b_ok[RB];
+    const float* b_ptr[NB];
+    bool b_ok[NB];
+    int b_row[NB], b_col[NB];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const int n = n0 + lrow + 32 * i;
-        b_ok[i] = n < a.Cout;
-        b_row[i] = a.w + (size_t)(b_ok[i] ? n : 0) * a.Kp + lcol * 4;
+    for (int i = 0; i < NB; ++i) {
+        const int c = tid + 256 * i;
+        b_row[i] = c / CPR;
+        b_col[i] = c % CPR;
+        const int n = n0 + b_row[i];
+        b_ok[i] = n < a.Cout && b_row[i] < BN;
+        b_ptr[i] = a.w + (size_t)(b_ok[i] ? n : 0) * a.Kp + b_col[i] * 4;
     }
 
-    floatx4 ra[RA], rb[RB];   // ext-vector values (a HIP float4 struct copy becomes a memcpy the optimiser leaves in scratch)
+    floatx4 ra[NA], rb[NB];   // ext-vector values (a HIP float4 struct copy becomes a memcpy the optimiser leaves in scratch)
     int kh = 0, kw = 0, c0 = 0;   // aligned mode: walk (tap, channel chunk) without divisions
     // Every lane always issues its loads: lanes that fall into the zero padding (or past M / Cout) read the
     // zero page instead, so there is no branch and no exec-mask juggling around the global loads.
     // (Macros, not lambdas: by-reference captures of the staging arrays ended up in scratch memory.)
 #define VQ_LOAD_TILES(KC)                                                                                          \
     {                                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                                           \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
             const float* src = a.zeros;                                                                            \
             if (SMALL_CIN) {                                                                                       \
-                const int kidx = ((KC) * 8 + lcol) * 4;                                                            \
+                const int kidx = ((KC) * CPR + a_col[i]) * 4;                                                      \
                 const int tap = kidx / a.Cin, c = kidx - tap * a.Cin;                                              \
                 const int th = tap / a.k, tw = tap - th * a.k;                                                     \
                 const int ih = a_ih0[i] + th, iw = a_iw0[i] + tw;                                                  \
-                if (tap < a.k * a.k && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)   \
+                if (tap < a.k * a.k && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)               \
                     src = a_img[i] + ((size_t)ih * a.W + iw) * a.Cs_in + c;                                        \
             } else {                                                                                               \
                 const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;                                                  \
                 if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)                                  \
-                    src = a_img[i] + ((size_t)ih * a.W + iw) * a.Cs_in + c0 + lcol * 4;                            \
+                    src = a_img[i] + ((size_t)ih * a.W + iw) * a.Cs_in + c0 + a_col[i] * 4;                        \
             }                                                                                                      \
             ra[i] = *reinterpret_cast<const floatx4*>(src);                                                        \
         }                                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < RB; ++i)                                                             \
-            rb[i] = *reinterpret_cast<const floatx4*>(b_ok[i] ? b_row[i] + (size_t)(KC) * BK : a.zeros);           \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                             \
+            rb[i] = *reinterpret_cast<const floatx4*>(b_ok[i] ? b_ptr[i] + (size_t)(KC) * BK : a.zeros);           \
         if (!SMALL_CIN) {                                                                                          \
             c0 += BK;                                                                                              \
             if (c0 >= a.Cin) {                                                                                     \
@@ -144,10 +204,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 #define VQ_STORE_TILES(BUF)                                                                                        \
     {                                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < RA; ++i)                                                             \
-            *reinterpret_cast<floatx4*>(&sm.a[BUF][lrow + 32 * i][lcol * 4]) = ra[i];                              \
-        _Pragma("unroll") for (int i = 0; i < RB; ++i)                                                             \
-            *reinterpret_cast<floatx4*>(&sm.b[BUF][lrow + 32 * i][lcol * 4]) = rb[i];                              \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                             \
+            if ((BM * CPR) % 256 == 0 || a_row[i] < BM)                                                            \
+                *reinterpret_cast<floatx4*>(&sm.a[BUF][a_row[i]][a_col[i] * 4]) = ra[i];                           \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                             \
+            if ((BN * CPR) % 256 == 0 || b_row[i] < BN)                                                            \
+                *reinterpret_cast<floatx4*>(&sm.b[BUF][b_row[i]][b_col[i] * 4]) = rb[i];                           \
     }
 
     // ---- compute roles
@@ -164,20 +226,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
     // folded-BN bias of this lane's output columns: fetched now so that its latency (and its vmcnt wait)
     // is long gone when the epilogue starts -- a load inside the store loop would serialise every store
-    float bias_v[TN];
+    floatx4 bias_v[TN];   // this lane's 4 output channels in the transposed store (see VQ_EPILOGUE)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / WN) + 32 * j + l31;
-        bias_v[j] = a.bias[n < a.Cout ? n : 0];
+        const int n = n0 + wn * (BN / WN) + 32 * j + (lane & 7) * 4;
+        bias_v[j] = *reinterpret_cast<const floatx4*>(a.bias + (n < a.Cout ? n : 0));
     }
 
-    const int nk = a.Kp / BK;
+    const int nk = (a.dbg & 8) ? 1 : ((a.dbg & 16) ? 2 * (a.Kp / BK) : a.Kp / BK);   // dbg: 1 K-step only / K doubled (timing only)
     VQ_LOAD_TILES(0)
     VQ_STORE_TILES(0)
     __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
-        if (kc + 1 < nk) VQ_LOAD_TILES(kc + 1)   // global loads in flight under the MFMAs below
+        if (kc + 1 < nk && !(a.dbg & 1)) VQ_LOAD_TILES(kc + 1)   // global loads in flight under the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             // lane (row r, half h) holds k = 8 kk + 4 h + j for MFMA step j: the two halves of a step cover a
@@ -195,38 +257,183 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
-        if (kc + 1 < nk) VQ_STORE_TILES(buf ^ 1)
-        __syncthreads();
+        if (kc + 1 < nk && !(a.dbg & 2)) VQ_STORE_TILES(buf ^ 1)
+        if (!(a.dbg & 4)) __syncthreads();
     }
 
-    // ---- epilogue: + bias (folded BN), ReLU, store at the channel offset of the destination slot.
-    // C/D map of the 32x32 MFMA: column (N) = lane & 31, row (M) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5):
-    // every store instruction writes two 128-byte runs (32 consecutive channels of two pixels).
-#define VQ_STORE_OUT(GUARD)                                                                          \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                 \
-        const int n = n0 + wn * (BN / WN) + 32 * j + l31;                                            \
-        if (n < a.Cout) {                                                                            \
-            const float bv = bias_v[j];                                                              \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                         \
-                const int mb = m0 + wm * (BM / WM) + 32 * i + 4 * half;                              \
-                float* o = a.out + (size_t)mb * a.Cs_out + a.coff_out + n;                           \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                     \
-                    const int dm = (r & 3) + 8 * (r >> 2);                                           \
-                    float v = acc[i][j][r] + bv;                                                     \
-                    if (a.relu) v = fmaxf(v, 0.f);                                                   \
-                    if (!(GUARD) || mb + dm < a.M) o[(size_t)dm * a.Cs_out] = v;                     \
-                }                                                                                    \
-            }                                                                                        \
-        }                                                                                            \
-    }
-    if (m0 + BM <= a.M) {   // workgroup-uniform: only the last M tile needs row guards
-        VQ_STORE_OUT(false)
-    } else {
-        VQ_STORE_OUT(true)
-    }
+    VQ_EPILOGUE()
 #undef VQ_LOAD_TILES
 #undef VQ_STORE_TILES
-#undef VQ_STORE_OUT
+}
+
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined variant (aligned Cin only).  Same tiles, same k order (bit-identical results), but the
+// instruction stream of a K-step is laid out by hand: every MFMA is followed by one small slice of the side
+// work -- a fragment prefetch for the next 8-wide k group, one global load (with its address arithmetic) of the
+// next tile, or one LDS store of it -- and a scheduling fence, so a wave keeps its SIMD's matrix pipe fed
+// while it stages (an in-order wave cannot overlap a BLOCK of vector work with more than one MFMA).
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int BK>
+__global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int CPR = BK / 4;
+    constexpr int NA = (BM * CPR + 255) / 256, NB = (BN * CPR + 255) / 256;
+    constexpr int NKK = BK / 8;              // 8-wide k groups per K-step
+    constexpr int MFK = 4 * TM * TN;         // MFMAs per k group
+    constexpr int NMF = NKK * MFK;           // MFMAs per K-step
+    constexpr int NFR = TM + TN;             // fragment reads per k group
+    constexpr int NG = NA + NB;              // global loads (= LDS stores) per K-step
+    constexpr int NFREE = NMF - (NKK - 1) * NFR;
+    static_assert(NFREE >= 2 * NG, "not enough MFMA gaps for the staging slices");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    ConvSmem<BM, BN, BK>& sm = *reinterpret_cast<ConvSmem<BM, BN, BK>*>(smem_raw);
+
+    if (a.desync) desync_simd_partners();
+    const int tid = threadIdx.x;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / a.tiles_n) * BM;
+    const int n0 = (tile % a.tiles_n) * BN;
+
+    const float* a_img[NA];
+    int a_ih0[NA], a_iw0[NA], a_row[NA], a_col[NA];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int c = tid + 256 * i;
+        a_row[i] = c / CPR;
+        a_col[i] = c % CPR;
+        const int m = m0 + a_row[i];
+        const bool ok = m < a.M && a_row[i] < BM;
+        const int mm = ok ? m : 0;
+        const int n_img = mm / HoWo, rem = mm - n_img * HoWo;
+        const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+        a_img[i] = a.in + (size_t)n_img * a.H * a.W * a.Cs_in + a.coff_in + a_col[i] * 4;
+        a_ih0[i] = ok ? oh * a.stride - a.pad : -(1 << 20);
+        a_iw0[i] = ow * a.stride - a.pad;
+    }
+    const float* b_ptr[NB];
+    bool b_ok[NB];
+    int b_row[NB], b_col[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int c = tid + 256 * i;
+        b_row[i] = c / CPR;
+        b_col[i] = c % CPR;
+        const int n = n0 + b_row[i];
+        b_ok[i] = n < a.Cout && b_row[i] < BN;
+        b_ptr[i] = b_ok[i] ? a.w + (size_t)n * a.Kp + b_col[i] * 4 : a.zeros;
+    }
+    const int b_step = BK;   // floats per K-step along a weight row (0 for rows parked on the zero page)
+
+    floatx4 ra[NA], rb[NB];
+    int kh = 0, kw = 0, c0 = 0;
+
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int arow0 = wm * (BM / WM) + l31, brow0 = wn * (BN / WN) + l31;
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    floatx4 bias_v[TN];   // this lane's 4 output channels in the transposed store (see VQ_EPILOGUE)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / WN) + 32 * j + (lane & 7) * 4;
+        bias_v[j] = *reinterpret_cast<const floatx4*>(a.bias + (n < a.Cout ? n : 0));
+    }
+
+#define VQ_G_LOAD(IDX, KC)                                                                                     \
+    {                                                                                                          \
+        if ((IDX) < NA) {                                                                                      \
+            const int ii = (IDX) < NA ? (IDX) : 0;                                                             \
+            const int ih = a_ih0[ii] + kh, iw = a_iw0[ii] + kw;                                                \
+            const float* src = a.zeros;                                                                        \
+            if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)                                  \
+                src = a_img[ii] + ((size_t)ih * a.W + iw) * a.Cs_in + c0;                                      \
+            ra[ii] = *reinterpret_cast<const floatx4*>(src);                                                   \
+        } else {                                                                                               \
+            const int ii = (IDX) >= NA ? (IDX) - NA : 0;                                                       \
+            rb[ii] = *reinterpret_cast<const floatx4*>(b_ptr[ii] + (b_ok[ii] ? (size_t)(KC) * b_step : 0));    \
+        }                                                                                                      \
+    }
+#define VQ_G_STORE(IDX, BUF)                                                                                   \
+    {                                                                                                          \
+        if ((IDX) < NA) {                                                                                      \
+            const int ii = (IDX) < NA ? (IDX) : 0;                                                             \
+            if ((BM * CPR) % 256 == 0 || a_row[ii] < BM)                                                       \
+                *reinterpret_cast<floatx4*>(&sm.a[BUF][a_row[ii]][a_col[ii] * 4]) = ra[ii];                    \
+        } else {                                                                                               \
+            const int ii = (IDX) >= NA ? (IDX) - NA : 0;                                                       \
+            if ((BN * CPR) % 256 == 0 || b_row[ii] < BN)                                                       \
+                *reinterpret_cast<floatx4*>(&sm.b[BUF][b_row[ii]][b_col[ii] * 4]) = rb[ii];                    \
+        }                                                                                                      \
+    }
+#define VQ_ADVANCE_TAP()            \
+    {                               \
+        c0 += BK;                   \
+        if (c0 >= a.Cin) {          \
+            c0 = 0;                 \
+            if (++kw == a.k) {      \
+                kw = 0;             \
+                ++kh;               \
+            }                       \
+        }                           \
+    }
+// One K-step on LDS buffer BUF.  HAS_NEXT: also stage tile KC+1 (global -> registers -> LDS buffer BUF^1).
+#define VQ_PIPE_STEP(BUF, KC, HAS_NEXT)                                                                        \
+    {                                                                                                          \
+        floatx4 fa[2][TM], fb[2][TN];                                                                          \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                         \
+            fa[0][i] = *reinterpret_cast<const floatx4*>(&sm.a[BUF][arow0 + 32 * i][half * 4]);                \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                         \
+            fb[0][j] = *reinterpret_cast<const floatx4*>(&sm.b[BUF][brow0 + 32 * j][half * 4]);                \
+        _Pragma("unroll") for (int q = 0; q < NMF; ++q) {                                                      \
+            const int kk = q / MFK, r = q % MFK, s_ = r / (TM * TN), i_ = (r / TN) % TM, j_ = r % TN;          \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i_][s_], fb[kk & 1][j_][s_], acc[i_][j_], 0, 0, 0); \
+            if (kk + 1 < NKK && r < NFR) {                                                                     \
+                if (r < TM)                                                                                    \
+                    fa[(kk + 1) & 1][r < TM ? r : 0] = *reinterpret_cast<const floatx4*>(                      \
+                        &sm.a[BUF][arow0 + 32 * (r < TM ? r : 0)][(kk + 1) * 8 + half * 4]);                   \
+                else                                                                                           \
+                    fb[(kk + 1) & 1][r >= TM ? r - TM : 0] = *reinterpret_cast<const floatx4*>(                \
+                        &sm.b[BUF][brow0 + 32 * (r >= TM ? r - TM : 0)][(kk + 1) * 8 + half * 4]);             \
+            } else if (HAS_NEXT) {                                                                             \
+                const int fidx = q - (kk + 1 < NKK ? (kk + 1) * NFR : (NKK - 1) * NFR);                        \
+                if (fidx < NG) VQ_G_LOAD(fidx, (KC) + 1)                                                       \
+                else if (fidx >= NFREE - NG) VQ_G_STORE(fidx - (NFREE - NG), (BUF) ^ 1)                        \
+            }                                                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+        }                                                                                                      \
+    }
+
+    const int nk = a.Kp / BK;
+    _Pragma("unroll") for (int i = 0; i < NG; ++i) VQ_G_LOAD(i, 0)
+    _Pragma("unroll") for (int i = 0; i < NG; ++i) VQ_G_STORE(i, 0)
+    __syncthreads();
+    for (int kc = 0; kc + 1 < nk; ++kc) {
+        VQ_ADVANCE_TAP()              // (kh, kw, c0) now address tile kc + 1
+        if (kc & 1) {
+            VQ_PIPE_STEP(1, kc, true)
+        } else {
+            VQ_PIPE_STEP(0, kc, true)
+        }
+        __syncthreads();
+    }
+    if ((nk - 1) & 1) {
+        VQ_PIPE_STEP(1, nk - 1, false)
+    } else {
+        VQ_PIPE_STEP(0, nk - 1, false)
+    }
+
+    VQ_EPILOGUE()
+#undef VQ_G_LOAD
+#undef VQ_G_STORE
+#undef VQ_ADVANCE_TAP
+#undef VQ_PIPE_STEP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -314,7 +521,8 @@ __global__ void consensus_kernel(const float* __restrict__ per_snippet, double* 
 // handle + executor
 // ------------------------------------------------------------------------------------------------
 struct ConvTile {
-    int bm, bn;
+    int bm, bn, bk;
+    int pipe;   // 1 = software-pipelined kernel (aligned Cin only)
 };
 
 struct vq_tsn {
@@ -326,7 +534,8 @@ struct vq_tsn {
     int in_channels = 0;
     std::vector<vq_tensor_desc> tensors;
     std::vector<vq_layer_desc> layers;
-    std::vector<ConvTile> tiles;          // per layer (conv only)
+    std::map<int, std::vector<int>> tuned;   // n_crops -> per-layer index into kTiles (autotuned)
+    bool autotune = true;
     std::vector<float*> slots;            // device activations, max_crops each
     float* zeros = nullptr;               // 256 bytes of zeros (load target of masked lanes)
     float* blob = nullptr;                // weights + biases
@@ -355,52 +564,164 @@ static void tsn_free(vq_tsn* net) {
     if (net->feat_dev) (void)hipFree(net->feat_dev);
 }
 
-template <int BM, int BN, int WM, int WN, bool SMALL>
+template <int BM, int BN, int WM, int WN, int BK, bool SMALL>
 static int launch_conv_t(vq_tsn* net, ConvArgs& a) {
     a.tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.Cout, BN);
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, SMALL>;
-    const size_t lds = sizeof(ConvSmem<BM, BN>);
-    VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, BK, SMALL>;
+    const size_t lds = sizeof(ConvSmem<BM, BN, BK>);
+    static bool attr_set = false;     // per instantiation
+    if (!attr_set) {
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
     kern<<<a.tiles_m * a.tiles_n, 256, lds, net->stream>>>(a);
     VQ_CHECK_LAUNCH();
     return VQ_OK;
 }
 
-// Candidate tilings (BM x BN, wave grid).  The chooser below scores them per layer.
-static const ConvTile kTiles[] = {{128, 128}, {128, 96}, {128, 64}, {128, 32}, {64, 64}, {64, 128}};
+// Candidate tilings (BM x BN x BK).  Every candidate sums each output element's K terms in the same order, so
+// the choice never changes a result bit; it is made per layer and batch size by timing (autotune) or, with
+// VQ_TSN_AUTOTUNE=0, by the occupancy heuristic below.
+static const ConvTile kTiles[] = {
+    {128, 128, 32, 0}, {128, 128, 16, 0}, {128, 96, 32, 0}, {128, 96, 16, 0}, {128, 64, 32, 0}, {128, 64, 16, 0},
+    {64, 128, 32, 0},  {64, 128, 16, 0},  {64, 64, 32, 0},  {64, 64, 16, 0},  {128, 32, 32, 0}, {128, 32, 16, 0},
+    {128, 128, 32, 1}, {128, 128, 16, 1}, {128, 96, 32, 1}, {128, 96, 16, 1}, {128, 64, 32, 1}, {128, 64, 16, 1},
+    {64, 128, 32, 1},  {64, 128, 16, 1},  {64, 64, 32, 1},  {64, 64, 16, 1},  {128, 32, 32, 1}, {128, 32, 16, 1}};
+constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 
-static double tile_score(const ConvTile& t, int M, int N, int cus) {
-    const long long tiles = (long long)cdiv(M, t.bm) * cdiv(N, t.bn);
-    const long long rounds = (tiles + cus - 1) / cus;          // MFMA-bound: a CU's tiles run back to back
-    const double useful = (double)M * N;
-    const double spent = (double)rounds * cus * t.bm * t.bn;
-    // larger tiles move fewer bytes per MAC and amortise the prologue/epilogue
-    const double intrinsic = t.bm * t.bn >= 128 * 128 ? 1.0 : t.bm * t.bn >= 128 * 96 ? 0.97 : t.bm * t.bn >= 128 * 64 ? 0.93 : 0.85;
-    return useful / spent * intrinsic;
+template <int BM, int BN, int WM, int WN, int BK>
+static int launch_conv_pipe_t(vq_tsn* net, ConvArgs& a) {
+    a.tiles_m = cdiv(a.M, BM);
+    a.tiles_n = cdiv(a.Cout, BN);
+    auto kern = conv_igemm_pipe_kernel<BM, BN, WM, WN, BK>;
+    const size_t lds = sizeof(ConvSmem<BM, BN, BK>);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    kern<<<a.tiles_m * a.tiles_n, 256, lds, net->stream>>>(a);
+    VQ_CHECK_LAUNCH();
+    return VQ_OK;
 }
 
-static ConvTile choose_tile(int M, int N, int cus) {
-    ConvTile best = kTiles[0];
+static int launch_conv_pipe(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
+#define P_(BM_, BN_, WM_, WN_, BK_) \
+    if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_) return launch_conv_pipe_t<BM_, BN_, WM_, WN_, BK_>(net, a);
+    P_(128, 128, 2, 2, 32) P_(128, 128, 2, 2, 16) P_(128, 96, 4, 1, 32) P_(128, 96, 4, 1, 16) P_(128, 64, 2, 2, 32)
+    P_(128, 64, 2, 2, 16) P_(64, 128, 2, 2, 32) P_(64, 128, 2, 2, 16) P_(64, 64, 2, 2, 32) P_(64, 64, 2, 2, 16)
+    P_(128, 32, 4, 1, 32) P_(128, 32, 4, 1, 16)
+#undef P_
+    return fail(VQ_E_INVALID, "no pipelined kernel for tile %dx%dx%d", t.bm, t.bn, t.bk);
+}
+
+template <bool SMALL>
+static int launch_conv(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
+#define T_(BM_, BN_, WM_, WN_, BK_) \
+    if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_) return launch_conv_t<BM_, BN_, WM_, WN_, BK_, SMALL>(net, a);
+    T_(128, 128, 2, 2, 32) T_(128, 128, 2, 2, 16) T_(128, 96, 4, 1, 32) T_(128, 96, 4, 1, 16) T_(128, 64, 2, 2, 32)
+    T_(128, 64, 2, 2, 16) T_(64, 128, 2, 2, 32) T_(64, 128, 2, 2, 16) T_(64, 64, 2, 2, 32) T_(64, 64, 2, 2, 16)
+    T_(128, 32, 4, 1, 32) T_(128, 32, 4, 1, 16)
+#undef T_
+    return fail(VQ_E_INVALID, "no kernel for tile %dx%dx%d", t.bm, t.bn, t.bk);
+}
+
+static int heuristic_tile(int M, int N, int cus) {
+    int best = 0;
     double bs = -1;
-    for (const ConvTile& t : kTiles) {
-        const double s = tile_score(t, M, N, cus);
-        if (s > bs) {
-            bs = s;
-            best = t;
+    for (int i = 0; i < kNumTiles; ++i) {
+        const ConvTile& t = kTiles[i];
+        if (t.bk != 32 || t.pipe) continue;
+        const long long tiles = (long long)cdiv(M, t.bm) * cdiv(N, t.bn);
+        const double per_cu = (double)tiles / cus;
+        const double balance = per_cu / std::ceil(per_cu);                      // tail quantisation
+        const double padding = ((double)M * N) / ((double)tiles * t.bm * t.bn); // ragged edges
+        const double area = (double)t.bm * t.bn;
+        const double intrinsic = area >= 128 * 128 ? 1.0 : area >= 128 * 96 ? 0.97 : area >= 128 * 64 ? 0.92 : area >= 64 * 64 ? 0.8 : 0.7;
+        const double sc = balance * padding * intrinsic;
+        if (sc > bs) {
+            bs = sc;
+            best = i;
         }
     }
     return best;
 }
 
-template <bool SMALL>
-static int launch_conv(vq_tsn* net, ConvArgs& a, ConvTile t) {
-    if (t.bm == 128 && t.bn == 128) return launch_conv_t<128, 128, 2, 2, SMALL>(net, a);
-    if (t.bm == 128 && t.bn == 96) return launch_conv_t<128, 96, 4, 1, SMALL>(net, a);
-    if (t.bm == 128 && t.bn == 64) return launch_conv_t<128, 64, 2, 2, SMALL>(net, a);
-    if (t.bm == 128 && t.bn == 32) return launch_conv_t<128, 32, 4, 1, SMALL>(net, a);
-    if (t.bm == 64 && t.bn == 128) return launch_conv_t<64, 128, 2, 2, SMALL>(net, a);
-    return launch_conv_t<64, 64, 2, 2, SMALL>(net, a);
+static void fill_conv_args(vq_tsn* net, int li, int n_crops, ConvArgs& a) {
+    const vq_layer_desc& L = net->layers[li];
+    const vq_tensor_desc& ts = net->tensors[L.src];
+    const vq_tensor_desc& td = net->tensors[L.dst];
+    a.in = net->slots[L.src];
+    a.out = net->slots[L.dst];
+    a.w = net->blob + L.w_off;
+    a.bias = net->blob + L.b_off;
+    a.zeros = net->zeros;
+    a.H = ts.h;
+    a.W = ts.w;
+    a.Cs_in = ts.c;
+    a.coff_in = L.src_coff;
+    a.Cin = L.cin;
+    a.Ho = td.h;
+    a.Wo = td.w;
+    a.Cs_out = td.c;
+    a.coff_out = L.dst_coff;
+    a.Cout = L.cout;
+    a.k = L.k;
+    a.stride = L.stride;
+    a.pad = L.pad;
+    a.M = n_crops * td.h * td.w;
+    a.Kp = (L.k * L.k * L.cin + KPAD - 1) / KPAD * KPAD;
+    a.relu = L.relu;
+    a.tiles_m = a.tiles_n = 0;
+    static const int desync = getenv("VQ_TSN_DESYNC") ? atoi(getenv("VQ_TSN_DESYNC")) : 1;
+    a.desync = desync;
+    static const int dbg = getenv("VQ_TSN_DBG") ? atoi(getenv("VQ_TSN_DBG")) : 0;
+    a.dbg = dbg;
+}
+
+static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
+    ConvArgs a;
+    fill_conv_args(net, li, n_crops, a);
+    const bool small = (net->layers[li].cin % KPAD) != 0;
+    if (kTiles[tile_idx].pipe && !small) return launch_conv_pipe(net, a, kTiles[tile_idx]);
+    return small ? launch_conv<true>(net, a, kTiles[tile_idx]) : launch_conv<false>(net, a, kTiles[tile_idx]);
+}
+
+// Time every candidate tiling of every conv layer at this batch size (activations hold whatever the slots
+// contain; only durations matter) and keep the fastest.
+static int autotune(vq_tsn* net, int n_crops) {
+    std::vector<int>& choice = net->tuned[n_crops];
+    choice.assign(net->layers.size(), 0);
+    hipEvent_t e0, e1;
+    VQ_HIP(hipEventCreate(&e0));
+    VQ_HIP(hipEventCreate(&e1));
+    for (int li = 0; li < (int)net->layers.size(); ++li) {
+        if (net->layers[li].op != VQ_OP_CONV) continue;
+        float best = 1e30f;
+        const bool small = (net->layers[li].cin % KPAD) != 0;
+        for (int t = 0; t < kNumTiles; ++t) {
+            if (small && kTiles[t].pipe) continue;
+            int rc = launch_conv_layer(net, li, n_crops, t);   // warm (also sets the LDS attribute)
+            if (rc != VQ_OK) return rc;
+            VQ_HIP(hipEventRecord(e0, net->stream));
+            for (int r = 0; r < 3; ++r) {
+                rc = launch_conv_layer(net, li, n_crops, t);
+                if (rc != VQ_OK) return rc;
+            }
+            VQ_HIP(hipEventRecord(e1, net->stream));
+            VQ_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            VQ_HIP(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) {
+                best = ms;
+                choice[li] = t;
+            }
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return VQ_OK;
 }
 
 static int run_layer(vq_tsn* net, int li, int n_crops) {
@@ -408,38 +729,18 @@ static int run_layer(vq_tsn* net, int li, int n_crops) {
     const vq_tensor_desc& ts = net->tensors[L.src];
     const vq_tensor_desc& td = net->tensors[L.dst];
     if (L.op == VQ_OP_CONV) {
-        ConvArgs a;
-        a.in = net->slots[L.src];
-        a.out = net->slots[L.dst];
-        a.w = net->blob + L.w_off;
-        a.bias = net->blob + L.b_off;
-        a.zeros = net->zeros;
-        a.H = ts.h;
-        a.W = ts.w;
-        a.Cs_in = ts.c;
-        a.coff_in = L.src_coff;
-        a.Cin = L.cin;
-        a.Ho = td.h;
-        a.Wo = td.w;
-        a.Cs_out = td.c;
-        a.coff_out = L.dst_coff;
-        a.Cout = L.cout;
-        a.k = L.k;
-        a.stride = L.stride;
-        a.pad = L.pad;
-        a.M = n_crops * td.h * td.w;
-        a.Kp = (L.k * L.k * L.cin + BK - 1) / BK * BK;
-        a.relu = L.relu;
-        const bool small = (L.cin % BK) != 0;
-        const char* force = getenv("VQ_TSN_TILE");   // tuning aid: "BMxBN"
-        ConvTile t = choose_tile(a.M, a.Cout, net->cus);
-        if (force) {
-            int bm = 0, bn = 0;
-            if (sscanf(force, "%dx%d", &bm, &bn) == 2)
-                for (const ConvTile& c : kTiles)
-                    if (c.bm == bm && c.bn == bn) t = c;
+        int t = -1;
+        if (const char* force = getenv("VQ_TSN_TILE")) {   // test / tuning aid: "BMxBN" or "BMxBNxBK"
+            int bm = 0, bn = 0, bk = 32, pipe = 0;   // "BMxBN", "BMxBNxBK" or "BMxBNxBKxP" (P = 1: pipelined kernel)
+            if (sscanf(force, "%dx%dx%dx%d", &bm, &bn, &bk, &pipe) >= 2)
+                for (int i = 0; i < kNumTiles; ++i)
+                    if (kTiles[i].bm == bm && kTiles[i].bn == bn && kTiles[i].bk == bk && kTiles[i].pipe == pipe) t = i;
         }
-        return small ? launch_conv<true>(net, a, t) : launch_conv<false>(net, a, t);
+        if (t < 0) {
+            auto it = net->tuned.find(n_crops);
+            t = it != net->tuned.end() ? it->second[li] : heuristic_tile(n_crops * td.h * td.w, L.cout, net->cus);
+        }
+        return launch_conv_layer(net, li, n_crops, t);
     }
     if (L.op == VQ_OP_MAXPOOL || L.op == VQ_OP_AVGPOOL) {
         PoolArgs a;
@@ -514,12 +815,12 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
         if (L.op == VQ_OP_CONV) {
             VQ_REQUIRE(td.h == (ts.h + 2 * L.pad - L.k) / L.stride + 1 && td.w == (ts.w + 2 * L.pad - L.k) / L.stride + 1,
                        "layer %d: conv output size mismatch", i);
-            const int64_t kp = (int64_t)(L.k * L.k * L.cin + BK - 1) / BK * BK;
+            const int64_t kp = (int64_t)(L.k * L.k * L.cin + KPAD - 1) / KPAD * KPAD;
             VQ_REQUIRE(L.w_off >= 0 && L.w_off % 4 == 0 && L.w_off + (int64_t)L.cout * kp <= blob_floats,
                        "layer %d: weights outside the blob", i);
             VQ_REQUIRE(L.b_off >= 0 && L.b_off + L.cout <= blob_floats, "layer %d: bias outside the blob", i);
-            VQ_REQUIRE(L.cin % BK == 0 || L.src_coff == 0, "layer %d: small-Cin convolution must read a whole slot", i);
-            VQ_REQUIRE(L.cin % BK == 0 || L.cin == ts.c, "layer %d: small-Cin convolution must read a whole slot", i);
+            VQ_REQUIRE(L.cin % KPAD == 0 || L.src_coff == 0, "layer %d: small-Cin convolution must read a whole slot", i);
+            VQ_REQUIRE(L.cin % KPAD == 0 || L.cin == ts.c, "layer %d: small-Cin convolution must read a whole slot", i);
             macs += (double)td.h * td.w * L.cout * (L.src == 0 ? in_channels : L.cin) * L.k * L.k;   // algorithmic, un-padded
         } else if (L.op == VQ_OP_MAXPOOL || L.op == VQ_OP_AVGPOOL) {
             VQ_REQUIRE(L.cin == L.cout, "layer %d: pooling keeps the channel count", i);
@@ -618,6 +919,13 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
     VQ_HIP(hipMemcpyAsync(net->mean_dev, mean_host, in_c * sizeof(float), hipMemcpyHostToDevice, net->stream));
     preprocess_kernel<<<cdiv(npix, 256), 256, 0, net->stream>>>(src, net->slots[0], npix, in_c, t0.c, net->mean_dev);
     VQ_CHECK_LAUNCH();
+    if (net->autotune && !getenv("VQ_TSN_TILE") && net->tuned.find(n_crops) == net->tuned.end()) {
+        const char* env = getenv("VQ_TSN_AUTOTUNE");
+        if (!env || atoi(env) != 0) {
+            const int rc = autotune(net, n_crops);
+            if (rc != VQ_OK) return rc;
+        }
+    }
     hipEvent_t* ev = nullptr;
     if (net->profile_depth > 0) {
         ev = net->events.data() + (size_t)(net->profile_count % net->profile_depth) * (net->layers.size() + 1);
@@ -702,6 +1010,24 @@ int vq_tsn_layer_times(vq_tsn* net, float* ms, double* flops, int32_t n_layers) 
             flops[i] = L.op == VQ_OP_CONV ? 2.0 * net->last_crops * td.h * td.w * L.cout * (L.src == 0 ? net->in_channels : L.cin) * L.k * L.k
                                           : 0.0;
         }
+    }
+    return VQ_OK;
+}
+
+int vq_tsn_layer_tiles(vq_tsn* net, int32_t n_crops, int32_t* tiles, int32_t n_layers) {
+    VQ_REQUIRE(net && tiles, "NULL argument");
+    VQ_REQUIRE(n_layers == (int)net->layers.size(), "n_layers must be %d", (int)net->layers.size());
+    std::lock_guard<std::mutex> lk(net->mu);
+    auto it = net->tuned.find(n_crops);
+    for (int i = 0; i < n_layers; ++i) {
+        tiles[4 * i] = tiles[4 * i + 1] = tiles[4 * i + 2] = tiles[4 * i + 3] = 0;
+        if (net->layers[i].op != VQ_OP_CONV) continue;
+        const vq_tensor_desc& td = net->tensors[net->layers[i].dst];
+        const int t = it != net->tuned.end() ? it->second[i] : heuristic_tile(n_crops * td.h * td.w, net->layers[i].cout, net->cus);
+        tiles[4 * i] = kTiles[t].bm;
+        tiles[4 * i + 1] = kTiles[t].bn;
+        tiles[4 * i + 2] = kTiles[t].bk;
+        tiles[4 * i + 3] = kTiles[t].pipe;
     }
     return VQ_OK;
 }

@@ -172,6 +172,13 @@ class TsnNet:
         call("vq_tsn_layer_times", self._h, ms.ctypes.data_as(C.c_void_p), fl.ctypes.data_as(C.c_void_p), n)
         return [o.name for o in self.plan.ops], [o.kind for o in self.plan.ops], ms, fl
 
+    def layer_tiles(self, n_crops: int) -> np.ndarray:
+        """[n_layers, 4] (BM, BN, BK, pipelined) implicit-GEMM tiling per conv layer at this batch size."""
+        n = len(self.plan.ops)
+        out = np.zeros((n, 4), dtype=np.int32)
+        call("vq_tsn_layer_tiles", self._h, int(n_crops), out.ctypes.data_as(C.c_void_p), n)
+        return out
+
     def flops_per_crop(self) -> float:
         out = C.c_double()
         call("vq_tsn_flops_per_crop", self._h, C.byref(out))
