@@ -1,0 +1,84 @@
+"""CPU: the feature-file layout (writer = calcSig_wOF.py:116-134, reader = api_load_records.py:41-58) and the
+frame-ingest helpers."""
+import os
+
+import numpy as np
+import pytest
+
+import tsn_oracle as to
+from video_query_algorithms_amd.tsn import feature_csv, frames
+
+REF_CSV = ("/root/reference/data/features/stock-video-clips_features/DowntownBrooklynDrive_480p/UCF101_split1/"
+           "rgb_global_pool_features.csv")
+
+
+def test_writer_layout_and_number_format(tmp_path):
+    feat = {"rgb": np.array([[0.1, 1.0 / 3.0, 2.5e-7, 77.5], [0.0, 1e22, 3.0, 4.000000000000001]]),
+            "warped_optical_flow": np.ones((2, 4))}
+    files = feature_csv.write_features(str(tmp_path), "vid", "/frames/vid/", "UCF101_split2", "global_pool",
+                                       ["clip_0003", "clip_0012"], feat, {"rgb": "w_rgb.caffemodel",
+                                                                          "warped_optical_flow": "w_flow.caffemodel"})
+    assert [os.path.relpath(f, tmp_path) for f in files] == ["vid/UCF101_split2/rgb_global_pool_features.csv",
+                                                             "vid/UCF101_split2/warped_optical_flow_global_pool_features.csv"]
+    raw = open(files[0], "rb").read()
+    assert b"\r" not in raw and raw.endswith(b"\n")
+    lines = raw.decode().split("\n")
+    assert lines[0] == "video =vid, video url =/frames/vid/, CNN stream =rgb, feature blob =global_pool, caffe model =w_rgb.caffemodel"
+    assert lines[1] == "3,0.1,0.3333333333333333,2.5e-07,77.5"
+    assert lines[2] == "12,0.0,1e+22,3.0,4.000000000000001"
+    meta, clips, back = feature_csv.read_features(files[0])
+    assert meta == {"video": "vid", "dnn_stream": "rgb", "feature_name": "global_pool", "dnn_weights_file_uri": "w_rgb.caffemodel"}
+    assert clips.tolist() == [3, 12] and (back == feat["rgb"]).all()          # exact round trip
+    nsplit, streams = feature_csv.read_split_dir(os.path.dirname(files[0]))
+    assert nsplit == 2 and set(streams) == {"rgb", "warped_optical_flow"}
+
+
+def test_writer_reproduces_a_shipped_reference_file_byte_for_byte(tmp_path):
+    if not os.path.exists(REF_CSV):
+        pytest.skip("reference checkout not present (GPU box)")
+    meta, clips, feats = feature_csv.read_features(REF_CSV)
+    raw = open(REF_CSV, "rb").read()
+    header = raw.split(b"\n", 1)[0].decode()
+    fields = [h.split("=")[-1] for h in header.split(", ")]
+    files = feature_csv.write_features(str(tmp_path), fields[0], fields[1], "UCF101_split1", fields[3],
+                                       ["clip_%04d" % c for c in clips], {"rgb": feats}, {"rgb": fields[4]})
+    assert open(files[0], "rb").read() == raw
+
+
+def test_ticks_and_stacks_match_the_oracle():
+    for cnt in (150, 151, 60, 10, 5, 26):
+        for T in (25, 7, 3, 2):
+            for depth in (1, 5):
+                assert frames.frame_ticks(cnt, T, depth) == to.frame_ticks(cnt, T, depth)
+    assert frames.flow_stack_indices(148, 150, 5) == to.flow_stack_indices(148, 150, 5)
+
+
+def test_parse_directory_and_image_io(tmp_path):
+    rng = np.random.default_rng(0)
+    for clip, n in (("clip_0002", 4), ("clip_0010", 3)):
+        d = tmp_path / "video" / clip
+        d.mkdir(parents=True)
+        for i in range(1, n + 1):
+            frames.write_pnm(str(d / ("img_%05d.ppm" % i)), rng.integers(0, 256, (20, 30, 3), dtype=np.uint8))
+            frames.write_pnm(str(d / ("flow_x_%05d.pgm" % i)), rng.integers(0, 256, (20, 30), dtype=np.uint8))
+            frames.write_pnm(str(d / ("flow_y_%05d.pgm" % i)), rng.integers(0, 256, (20, 30), dtype=np.uint8))
+    dirs, rgb, flow = frames.parse_directory(str(tmp_path / "video"))
+    assert rgb == {"clip_0002": 4, "clip_0010": 3} and flow == rgb and set(dirs) == set(rgb)
+    img = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    frames.write_pnm(str(tmp_path / "a.ppm"), img)
+    assert (frames.imread(str(tmp_path / "a.ppm"), True) == img).all()        # BGR in, BGR out
+    (tmp_path / "video" / "clip_0002" / "flow_y_00004.pgm").unlink()
+    with pytest.raises(ValueError):
+        frames.parse_directory(str(tmp_path / "video"))
+
+
+def test_resize_and_crop0():
+    img = np.arange(256 * 340 * 3, dtype=np.uint32).reshape(256, 340, 3).astype(np.uint8)
+    assert frames.resize_bilinear(img, (340, 256)) is img                      # already 340x256: untouched
+    c = frames.crop0(img)
+    assert c.shape == (224, 224, 3) and (c == img[:224, :224]).all()           # crop 0 = top-left, un-mirrored
+    flat = np.full((100, 120), 37, dtype=np.uint8)
+    assert (frames.resize_bilinear(flat, (340, 256)) == 37).all()
+    ramp = np.tile(np.arange(0, 200, 2, dtype=np.uint8)[None, :], (50, 1))     # horizontal ramp stays monotone
+    r = frames.resize_bilinear(ramp, (340, 256))
+    assert r.shape == (256, 340) and (np.diff(r[0].astype(int)) >= 0).all() and r[0, 0] == 0 and r[0, -1] == 198

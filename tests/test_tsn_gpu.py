@@ -199,3 +199,81 @@ def test_bad_shapes_are_rejected_before_launch(tsn):
     with pytest.raises(ValueError):
         net.TsnNet(g, bad, max_crops=2, feature_blob="gp")
     m.close()
+
+
+def test_calcsig_command_line_end_to_end(tsn, tmp_path):
+    """The drop-in CLI on a synthetic frame tree: two clips of one video, T = 3, both streams; the CSVs it writes
+    must parse with load_db's rules and carry the oracle's features; the reference's own per-snippet loop run on the
+    CaffeNet-shaped adapter must give the same numbers."""
+    bi, net = tsn
+    from video_query_algorithms_amd import calcSig_wOF
+    from video_query_algorithms_amd.tsn import caffe_net, feature_csv, frames
+    rng = np.random.default_rng(7)
+    root = tmp_path / "frames"
+    counts = {"clip_0001": 7, "clip_0002": 9}
+    for clip, n in counts.items():
+        d = root / "myvideo" / clip
+        d.mkdir(parents=True)
+        for i in range(1, n + 1):
+            frames.write_pnm(str(d / ("img_%05d.ppm" % i)), rng.integers(0, 256, (256, 340, 3), dtype=np.uint8))
+            # grayscale (P5) content; the reader goes by the magic number, so one extension serves both
+            frames.write_pnm(str(d / ("flow_x_%05d.ppm" % i)), rng.integers(0, 256, (256, 340), dtype=np.uint8))
+            frames.write_pnm(str(d / ("flow_y_%05d.ppm" % i)), rng.integers(0, 256, (256, 340), dtype=np.uint8))
+    protos = {}
+    for name, c in (("rgb", 3), ("flow", 10)):
+        g = bi.bn_inception(c)
+        lines = ['name: "BN-Inception"', 'input: "data"', "input_dim: 1", "input_dim: %d" % c, "input_dim: 224", "input_dim: 224"]
+        for l in g.layers:
+            body = 'layer { name: "%s" type: "%s" %s %s' % (l.name, l.type, " ".join('bottom: "%s"' % b for b in l.bottoms),
+                                                            " ".join('top: "%s"' % t for t in l.tops))
+            if l.type == "Convolution":
+                body += " convolution_param { num_output: %d pad: %d kernel_size: %d stride: %d }" % (l.num_output, l.pad, l.kernel, l.stride)
+            elif l.type == "Pooling":
+                body += " pooling_param { pool: %s kernel_size: %d stride: %d pad: %d }" % (l.pool, l.kernel, l.stride, l.pad)
+            elif l.type == "InnerProduct":
+                body += " inner_product_param { num_output: %d }" % l.num_output
+            lines.append(body + " }")
+        protos[name] = str(tmp_path / ("%s.prototxt" % name))
+        open(protos[name], "w").write("\n".join(lines))
+        assert bi.load_prototxt(protos[name]).layers == g.layers
+    wfile = {}
+    weights = {}
+    for name, c, seed in (("rgb", 3, 2), ("flow", 10, 5)):
+        weights[name] = net.synthetic_weights(bi.bn_inception(c), seed=seed)
+        wfile[name] = str(tmp_path / ("ucf101_split1_tsn_%s_bn.npz" % name))
+        caffe_net.save_weights(wfile[name], weights[name])
+    out_dir = tmp_path / "features"
+    rc = calcSig_wOF.main([str(root), protos["rgb"], wfile["rgb"], protos["flow"], wfile["flow"], "--num_frame_per_video", "3",
+                           "--outFeatures_dir", str(out_dir), "--modelname", "UCF101_split1", "--frame_ext", ".ppm",
+                           "--batch_clips", "2"])
+    assert rc == 0
+    nsplit, streams = feature_csv.read_split_dir(str(out_dir / "myvideo" / "UCF101_split1"))
+    assert nsplit == 1 and set(streams) == {"rgb", "warped_optical_flow"}
+    for mode, name, c, mean in (("rgb", "rgb", 3, net.RGB_MEAN), ("warped_optical_flow", "flow", 10, net.FLOW_MEAN)):
+        clips, feats, meta = streams[mode]
+        assert clips.tolist() == [1, 2] and feats.shape == (2, 1024) and meta["video"] == "myvideo"
+        assert meta["dnn_weights_file_uri"] == wfile[name]
+        g = bi.bn_inception(c)
+        crops = []
+        for clip, n in counts.items():
+            d = str(root / "myvideo" / clip)
+            ticks = to.frame_ticks(n, 3, 1 if c == 3 else 5)
+            if c == 3:
+                crops.append(frames.load_rgb_snippets(d, ticks, ext=".ppm"))
+            else:
+                crops.append(frames.load_flow_snippets(d, ticks, n, ext=".ppm"))
+        crops = np.concatenate(crops)
+        ps, cons = to.features(g.layers, "data", weights[name], crops, mean, 3)
+        assert np.abs(feats - cons).max() <= 2e-4 * np.abs(cons).max()
+        if c == 3:
+            # the reference's own loop (calcSig_wOF.py:88-96) on the CaffeNet-shaped adapter
+            cn = caffe_net.CaffeNet(protos["rgb"], wfile["rgb"], 0, max_crops=4)
+            d = str(root / "myvideo" / "clip_0001")
+            frame_features = []
+            for tick in to.frame_ticks(7, 3, 1):
+                frame = frames.imread(os.path.join(d, "img_%05d.ppm" % tick), True)
+                cn.predict_single_frame([frame, ], "fc-action", frame_size=(340, 256))
+                frame_features.append(cn._net.blobs["global_pool"].data[0].reshape(1, -1).tolist())
+            v_avg_feature = np.array(frame_features).mean(axis=0)[0]
+            assert (v_avg_feature == feats[0]).all()          # batched path == per-snippet path, bit for bit
+            cn.close()

@@ -1,0 +1,134 @@
+"""Drop-in for the reference's ``src/features_GPU_compute/calcSig_wOF.py`` command line.
+
+Same positional arguments, flags and defaults (calcSig_wOF.py:156-176), same clip order (:200), same snippet
+sampling (:67-72), same consensus (:82), same output tree and CSV bytes (:116-134).  Differences, all internal:
+one network per stream is built once (not per video, :205-210), all B*T crops of a batch of clips go through the
+network in one pass instead of one 10-crop forward per snippet (only crop 0 was ever kept, :95), and with
+``torchrun`` the clips of a video are sharded over the ranks (one process per GPU) and the per-GPU feature blocks
+are all-gathered over RCCL; rank 0 writes the files.  ``--num_worker`` is accepted and ignored.
+
+    python calcSig_wOF.py frames/ rgb.prototxt rgb_weights.npz flow.prototxt flow_weights.npz \
+        --outFeatures_dir features/ --modelname UCF101_split1 [--num_frame_per_video 25] [--gpus 0]
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import os
+import sys
+
+import numpy as np
+
+if __package__ in (None, ""):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import video_query_algorithms_amd  # noqa: F401
+    from video_query_algorithms_amd.tsn import frames
+    from video_query_algorithms_amd.tsn.caffe_net import CaffeNet
+    from video_query_algorithms_amd.tsn.feature_csv import write_features
+    from video_query_algorithms_amd.shard import all_gather_rows, shard_range
+else:
+    from .tsn import frames
+    from .tsn.caffe_net import CaffeNet
+    from .tsn.feature_csv import write_features
+    from .shard import all_gather_rows, shard_range
+
+
+def build_parser():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('frame_path', type=str, help="root directory holding the frames")
+    parser.add_argument('net_proto_rgb', type=str)
+    parser.add_argument('net_weights_rgb', type=str)
+    parser.add_argument('net_proto_flow', type=str)
+    parser.add_argument('net_weights_flow', type=str)
+    parser.add_argument('--rgb_prefix', type=str, help="prefix of RGB frames", default='img_')
+    parser.add_argument('--flow_x_prefix', type=str, help="prefix of x direction flow images", default='flow_x_')
+    parser.add_argument('--flow_y_prefix', type=str, help="prefix of y direction flow images", default='flow_y_')
+    parser.add_argument('--num_frame_per_video', type=int, default=25, help="number of frames to evaluate in each video")
+    parser.add_argument('--num_worker', type=int, default=1, help="accepted for compatibility; batching replaces workers")
+    parser.add_argument("--gpus", type=int, nargs='+', default=None, help='GPU ids; one process per GPU under torchrun')
+    parser.add_argument('--outFeatures_dir', type=str, default=None, help='Specify directory to write out feature files')
+    parser.add_argument('--delimiter', type=str, default=',', help='delimiter used in feature files')
+    parser.add_argument('--modelname', type=str, default=None)
+    parser.add_argument('--featureBlob', type=str, default='global_pool', help='name of blob to extract as a feature')
+    parser.add_argument('--featureBlob_size', type=int, default=1024, help='expected size of the feature blob')
+    # additions (not in the reference)
+    parser.add_argument('--frame_ext', type=str, default='.jpg', help='frame file extension (.jpg needs cv2 or PIL)')
+    parser.add_argument('--batch_clips', type=int, default=32, help='clips per forward pass')
+    return parser
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist
+    except ImportError:
+        pass
+    return None
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.modelname is None:                                                         # calcSig_wOF.py:179-180
+        args.modelname = args.net_weights_rgb.split('/')[-1][:-11] + '_' + args.net_weights_flow.split('/')[-1][:-11]
+    T = args.num_frame_per_video
+    rank, world = 0, 1
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch
+        import torch.distributed as dist
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        if not dist.is_initialized():
+            dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    gpu_list = args.gpus
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = gpu_list[local % len(gpu_list)] if gpu_list else local                    # calcSig_wOF.py:50-55
+    frame_path = args.frame_path if args.frame_path[-1] == '/' else args.frame_path + '/'
+    streamCNN = [{'modality': 'rgb', 'mode': 'rgb', 'net_proto': args.net_proto_rgb, 'net_weights': args.net_weights_rgb,
+                  'cnt_indexer': 1, 'stack_depth': 1},
+                 {'modality': 'flow', 'mode': 'warped_optical_flow', 'net_proto': args.net_proto_flow,
+                  'net_weights': args.net_weights_flow, 'cnt_indexer': 2, 'stack_depth': 5}]   # calcSig_wOF.py:185-189
+    nets = {}
+    for video_path in sorted(glob.glob(frame_path + '*/')):                            # calcSig_wOF.py:193-195
+        f_info = frames.parse_directory(video_path, args.rgb_prefix, args.flow_x_prefix, args.flow_y_prefix)
+        clip_list = sorted(list(f_info[0]), key=lambda clip: int(clip[-4:]))           # calcSig_wOF.py:199-200
+        first, count = shard_range(len(clip_list), world, rank)
+        features = {}
+        for s in streamCNN:
+            if s['modality'] not in nets:
+                nets[s['modality']] = CaffeNet(s['net_proto'], s['net_weights'], device,
+                                               max_crops=args.batch_clips * T, feature_blob=args.featureBlob)
+            net = nets[s['modality']]
+            mine = []
+            for b0 in range(first, first + count, args.batch_clips):
+                crops = []
+                for vid in clip_list[b0:min(b0 + args.batch_clips, first + count)]:
+                    frame_cnt = f_info[s['cnt_indexer']][vid]
+                    ticks = frames.frame_ticks(frame_cnt, T, s['stack_depth'])
+                    if s['modality'] == 'rgb':
+                        crops.append(frames.load_rgb_snippets(f_info[0][vid], ticks, args.rgb_prefix, args.frame_ext))
+                    else:
+                        crops.append(frames.load_flow_snippets(f_info[0][vid], ticks, frame_cnt, s['stack_depth'],
+                                                               args.flow_x_prefix, args.flow_y_prefix, args.frame_ext))
+                    print('video {} for {} modality done'.format(vid, s['modality']))
+                if crops:
+                    mine.append(net.extract_clips(np.concatenate(crops, axis=0), T))
+            local_feat = np.concatenate(mine, axis=0) if mine else np.zeros((0, net.feature_dim))
+            if world > 1:
+                import torch
+                dev = "cuda:%d" % device if torch.cuda.is_available() else "cpu"
+                gathered = all_gather_rows(torch.from_numpy(local_feat).to(dev), len(clip_list))
+                local_feat = gathered.cpu().numpy()
+            features[s['mode']] = local_feat
+        numFeatures = features['rgb'].shape[1] if len(clip_list) else args.featureBlob_size
+        assert numFeatures == args.featureBlob_size                                      # calcSig_wOF.py:219-220
+        if rank == 0 and clip_list:
+            video = video_path.split('/')[-2]
+            write_features(args.outFeatures_dir, video, video_path, args.modelname, args.featureBlob, clip_list, features,
+                           {'rgb': args.net_weights_rgb, 'warped_optical_flow': args.net_weights_flow})
+    for n in nets.values():
+        n.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,90 @@
+"""``CaffeNet``-shaped front door for the MI355X TSN extractor.
+
+The reference touches exactly four things of ``pyActionRecog.action_caffe.CaffeNet``:
+``CaffeNet(net_proto, net_weights, device_id)`` (calcSig_wOF.py:52,55), ``predict_single_frame([frame], score_name,
+frame_size=(340,256))`` (:94), ``predict_single_flow_stack(flow_stack, score_name, frame_size=(340,256))`` (:111) and
+``net._net.blobs[blob].data[0]`` (:95,112).  This class offers the same four, so the reference's per-snippet loop runs
+unchanged on top of it, plus ``extract_clips`` -- the batched path (all B*T crops in one forward) the drop-in
+command line uses.
+
+Weights: ``.npz`` with ``<layer>/W``, ``<layer>/b`` for convolutions and ``<layer>/scale|shift|mean|var`` for the
+frozen BN layers, or ``synthetic:<seed>`` (random init of the right architecture).  A ``.caffemodel`` importer is the
+"next" row 8(f)-2 and is not built yet: passing one raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import bn_inception, frames
+from .net import FLOW_MEAN, RGB_MEAN, TsnNet, synthetic_weights
+
+
+def load_weights(graph, spec: str):
+    if spec.startswith("synthetic:"):
+        return synthetic_weights(graph, seed=int(spec.split(":", 1)[1]))
+    if spec.endswith(".npz"):
+        z = np.load(spec, allow_pickle=False)
+        out = {}
+        for key in z.files:
+            layer, field = key.rsplit("/", 1)
+            out.setdefault(layer, {})[field] = z[key]
+        return out
+    raise NotImplementedError("weights file %r: only .npz and synthetic:<seed> are supported so far (the .caffemodel "
+                              "importer is not built yet)" % spec)
+
+
+def save_weights(path: str, weights):
+    np.savez(path, **{"%s/%s" % (layer, f): a for layer, d in weights.items() for f, a in d.items()})
+
+
+class _Blob:
+    def __init__(self, data):
+        self.data = data
+
+
+class _NetView:
+    def __init__(self):
+        self.blobs = {}
+
+
+class CaffeNet:
+    def __init__(self, net_proto, net_weights, device_id=0, max_crops=96, feature_blob="global_pool"):
+        self._graph = bn_inception.load_prototxt(net_proto) if isinstance(net_proto, str) else net_proto
+        self._weights = load_weights(self._graph, net_weights) if isinstance(net_weights, str) else net_weights
+        self._blob = feature_blob
+        self._channels = self._graph.input_shape[0]
+        self._mean = RGB_MEAN if self._channels == 3 else tuple([128.0] * self._channels)
+        self._model = TsnNet(self._graph, self._weights, max_crops=max_crops, device=device_id, feature_blob=feature_blob)
+        self._net = _NetView()
+
+    # -- the reference's per-snippet interface ------------------------------------------------------------
+    def predict_single_frame(self, frame, score_name=None, over_sample=True, frame_size=(340, 256)):
+        crop = frames.crop0(frame[0], frame_size)[None]                     # crop 0 of the 10-crop over-sample
+        _, ps = self._model.forward(crop, 1, self._mean)
+        self._net.blobs[self._blob] = _Blob(ps.reshape(1, -1, 1, 1))        # .data[0] is what calcSig reads
+        return None
+
+    def predict_single_flow_stack(self, frame, score_name=None, over_sample=True, frame_size=(340, 256)):
+        crop = np.stack([frames.crop0(f, frame_size) for f in frame], axis=-1)[None]
+        _, ps = self._model.forward(crop, 1, self._mean)
+        self._net.blobs[self._blob] = _Blob(ps.reshape(1, -1, 1, 1))
+        return None
+
+    # -- the batched path ------------------------------------------------------------------------------------
+    def extract_clips(self, crops: np.ndarray, T: int):
+        """crops uint8 [B*T, 224, 224, C] -> consensus features [B, D] float64 (calcSig_wOF.py:82)."""
+        out = []
+        per = (self._model.max_crops // T) * T
+        if per == 0:
+            raise ValueError("max_crops (%d) is smaller than T (%d)" % (self._model.max_crops, T))
+        for i in range(0, crops.shape[0], per):
+            feat, _ = self._model.forward(crops[i:i + per], T, self._mean, want_per_snippet=False)
+            out.append(feat)
+        return np.concatenate(out, axis=0)
+
+    @property
+    def feature_dim(self):
+        return self._model.feature_dim
+
+    def close(self):
+        self._model.close()

@@ -1,0 +1,66 @@
+"""The on-disk feature layout both sides of the reference agree on.
+
+Writer: byte-for-byte what ``writeFeatures`` produces (src/features_GPU_compute/calcSig_wOF.py:116-134) --
+``<out>/<video>/<modelname>/<stream>_<blob>_features.csv``, one header line
+``video =<v>, video url =<path>, CNN stream =<mode>, feature blob =<blob>, caffe model =<weights>`` and one row
+per clip: ``int(clip_dir[-4:])`` then the 1024 values printed with ``str(float64)`` (shortest round-trip repr),
+LF line ends, trailing newline.  Reader: the parsing rules of ``load_db`` (src/api/api_load_records.py:41-58).
+"""
+from __future__ import annotations
+
+import csv
+import os
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+STREAM_MODES = ("rgb", "warped_optical_flow")          # calcSig_wOF.py:120
+
+
+def write_features(out_dir: str, video: str, video_path: str, modelname: str, blob: str, clip_names: Sequence[str],
+                   features: Dict[str, np.ndarray], weights_files: Dict[str, str]) -> List[str]:
+    """features[mode] is [n_clips, D] float64 in clip order; returns the files written."""
+    f_output_dir = os.path.join(out_dir, video, modelname)
+    os.makedirs(f_output_dir, exist_ok=True)
+    written = []
+    for mode in STREAM_MODES:
+        if mode not in features:
+            continue
+        header_txt = 'video =' + video + ', video url =' + video_path + ', CNN stream =' + mode \
+                     + ', feature blob =' + blob + ', caffe model =' + weights_files[mode]
+        outfile = os.path.join(f_output_dir, mode + "_" + blob + "_features.csv")
+        feat = np.asarray(features[mode], dtype=np.float64)
+        with open(outfile, mode='w', newline='\n') as fout:
+            fout.write(header_txt + "\n")
+            for i, vid in enumerate(clip_names):
+                clip_no = int(vid[-4:])
+                fout.write(str(clip_no) + "," + ",".join(map(repr, feat[i].tolist())) + "\n")
+        written.append(outfile)
+    return written
+
+
+def read_features(csv_path: str) -> Tuple[dict, np.ndarray, np.ndarray]:
+    """api_load_records.py:45-58: header fields via ``split('=')[-1]``; rows ``clip, f0, f1, ...``.
+    Returns (header dict, clip numbers [n], features [n, D] float64)."""
+    with open(csv_path, 'r') as f:
+        reader = csv.reader(f)
+        header = next(reader)
+        meta = {"video": header[0].split('=')[-1], "dnn_stream": header[2].split('=')[-1],
+                "feature_name": header[3].split('=')[-1], "dnn_weights_file_uri": header[4].split('=')[-1]}
+        clips, rows = [], []
+        for row in reader:
+            clips.append(int(row[0]))
+            rows.append([float(x) for x in row[1:]])
+    return meta, np.asarray(clips, dtype=np.int64), np.asarray(rows, dtype=np.float64)
+
+
+def read_split_dir(split_path: str):
+    """One ``<video>/<split>`` directory -> (split number, {stream: (clips, features)}); the split number is the
+    LAST CHARACTER of the directory name (api_load_records.py:43)."""
+    nsplit = int(split_path.rstrip("/")[-1])
+    out = {}
+    for entry in sorted(os.scandir(split_path), key=lambda e: e.name):
+        if entry.is_file() and entry.name.endswith('.csv') and not entry.name.startswith('.'):
+            meta, clips, feats = read_features(entry.path)
+            out[meta["dnn_stream"]] = (clips, feats, meta)
+    return nsplit, out

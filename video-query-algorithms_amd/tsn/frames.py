@@ -1,0 +1,154 @@
+"""Frame ingest for the TSN feature extractor: what sits between the frame directories and the network input.
+
+Restated from the reference's driver (src/features_GPU_compute/calcSig_wOF.py) and, where the reference hands
+over to the un-vendored ``pyActionRecog`` package, from that package's documented behaviour (SURVEY.md
+Appendix B -- those parts are "parity unpinned"):
+  * ``parse_directory``      -> {clip: path}, {clip: #rgb}, {clip: #flow}           (calcSig_wOF.py:198)
+  * ``frame_ticks``          -> the T sampled frame numbers of a clip               (calcSig_wOF.py:67-72)
+  * ``flow_stack_indices``   -> the 5 flow frames of a snippet                       (calcSig_wOF.py:104)
+  * ``crop0``                -> resize to 340x256 and keep the top-left 224x224 crop: the only one of the 10
+                                over-sampled crops whose feature the reference keeps (calcSig_wOF.py:94-95)
+Image decoding uses cv2 when present, else PIL, else the built-in PPM/PGM/NPY reader (this image has neither).
+"""
+from __future__ import annotations
+
+import glob
+import os
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+
+def parse_directory(path: str, rgb_prefix='img_', flow_x_prefix='flow_x_', flow_y_prefix='flow_y_'):
+    """Sub-directories of `path` are clips; count frames by prefix; x/y flow counts must agree."""
+    dir_dict, rgb_counts, flow_counts = {}, {}, {}
+    for d in sorted(glob.glob(os.path.join(path, '*'))):
+        if not os.path.isdir(d):
+            continue
+        names = os.listdir(d)
+        k = os.path.basename(d)
+        nr = sum(1 for n in names if n.startswith(rgb_prefix))
+        nx = sum(1 for n in names if n.startswith(flow_x_prefix))
+        ny = sum(1 for n in names if n.startswith(flow_y_prefix))
+        if nx != ny:
+            raise ValueError('x and y direction have different number of flow images. video: ' + d)
+        dir_dict[k], rgb_counts[k], flow_counts[k] = d, nr, nx
+    return dir_dict, rgb_counts, flow_counts
+
+
+def frame_ticks(frame_cnt: int, num_frame_per_video: int, stack_depth: int) -> List[int]:
+    """calcSig_wOF.py:67-72 under Python-2 integer division (``T == 1`` raises ZeroDivisionError there too)."""
+    step = (frame_cnt - stack_depth) // (num_frame_per_video - 1)
+    if step > 0:
+        frame_ticks_ = list(range(1, min((2 + step * (num_frame_per_video - 1)), frame_cnt + 1), step))
+    else:
+        frame_ticks_ = [1] * num_frame_per_video
+    assert (len(frame_ticks_) == num_frame_per_video)
+    return frame_ticks_
+
+
+def flow_stack_indices(tick: int, frame_cnt: int, stk_depth: int) -> List[int]:
+    return [min(frame_cnt, tick + offset) for offset in range(stk_depth)]
+
+
+# ------------------------------------------------------------------------------------------------ decoding
+def _read_pnm(path: str) -> np.ndarray:
+    with open(path, 'rb') as f:
+        data = f.read()
+    parts, pos = [], 0
+    while len(parts) < 4:
+        while data[pos:pos + 1].isspace():
+            pos += 1
+        if data[pos:pos + 1] == b'#':
+            pos = data.index(b'\n', pos) + 1
+            continue
+        end = pos
+        while not data[end:end + 1].isspace():
+            end += 1
+        parts.append(data[pos:end])
+        pos = end
+    magic, w, h = parts[0], int(parts[1]), int(parts[2])
+    pos += 1
+    if magic == b'P6':
+        return np.frombuffer(data, dtype=np.uint8, count=w * h * 3, offset=pos).reshape(h, w, 3)[:, :, ::-1].copy()   # -> BGR
+    if magic == b'P5':
+        return np.frombuffer(data, dtype=np.uint8, count=w * h, offset=pos).reshape(h, w).copy()
+    raise ValueError("unsupported PNM file " + path)
+
+
+def imread(path: str, color: bool) -> np.ndarray:
+    """BGR uint8 [H,W,3] (cv2.IMREAD_COLOR order) or grayscale uint8 [H,W]."""
+    ext = os.path.splitext(path)[1].lower()
+    if ext == '.npy':
+        return np.load(path, allow_pickle=False)
+    if ext in ('.ppm', '.pgm', '.pnm'):
+        return _read_pnm(path)
+    try:
+        import cv2
+        img = cv2.imread(path, cv2.IMREAD_COLOR if color else cv2.IMREAD_GRAYSCALE)
+        if img is None:
+            raise IOError("cannot read " + path)
+        return img
+    except ImportError:
+        pass
+    try:
+        from PIL import Image
+        im = Image.open(path)
+        return np.asarray(im.convert('RGB'))[:, :, ::-1].copy() if color else np.asarray(im.convert('L'))
+    except ImportError:
+        raise ImportError("no JPEG decoder in this environment (cv2 / PIL missing); use .ppm/.pgm/.npy frames "
+                          "(--frame_ext) or install one")
+
+
+def write_pnm(path: str, img: np.ndarray):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    with open(path, 'wb') as f:
+        if img.ndim == 3:
+            f.write(b'P6\n%d %d\n255\n' % (img.shape[1], img.shape[0]))
+            f.write(img[:, :, ::-1].tobytes())
+        else:
+            f.write(b'P5\n%d %d\n255\n' % (img.shape[1], img.shape[0]))
+            f.write(img.tobytes())
+
+
+def resize_bilinear(img: np.ndarray, size_wh: Tuple[int, int]) -> np.ndarray:
+    """Bilinear resize with half-pixel centres (the sampling grid of cv2.resize INTER_LINEAR; cv2 itself uses
+    11-bit fixed-point coefficients for uint8, so single values can differ by one grey level)."""
+    w, h = size_wh
+    ih, iw = img.shape[:2]
+    if (ih, iw) == (h, w):
+        return img
+    ys = np.clip((np.arange(h) + 0.5) * ih / h - 0.5, 0, ih - 1)
+    xs = np.clip((np.arange(w) + 0.5) * iw / w - 0.5, 0, iw - 1)
+    y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+    y1, x1 = np.minimum(y0 + 1, ih - 1), np.minimum(x0 + 1, iw - 1)
+    wy, wx = (ys - y0)[:, None], (xs - x0)[None, :]
+    a = img.astype(np.float64)
+    if a.ndim == 3:
+        wy, wx = wy[..., None], wx[..., None]
+    out = (a[y0][:, x0] * (1 - wy) * (1 - wx) + a[y0][:, x1] * (1 - wy) * wx
+           + a[y1][:, x0] * wy * (1 - wx) + a[y1][:, x1] * wy * wx)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+def crop0(img: np.ndarray, frame_size=(340, 256), crop=224) -> np.ndarray:
+    """Resize to frame_size (w, h) and keep over-sample crop 0 = top-left, un-mirrored."""
+    return resize_bilinear(img, frame_size)[:crop, :crop]
+
+
+def load_rgb_snippets(clip_dir: str, ticks: List[int], rgb_prefix='img_', ext='.jpg') -> np.ndarray:
+    """[T, 224, 224, 3] uint8 BGR (calcSig_wOF.py:88-96)."""
+    return np.stack([crop0(imread(os.path.join(clip_dir, '{}{:05d}{}'.format(rgb_prefix, t, ext)), True)) for t in ticks])
+
+
+def load_flow_snippets(clip_dir: str, ticks: List[int], frame_cnt: int, stk_depth=5, flow_x_prefix='flow_x_',
+                       flow_y_prefix='flow_y_', ext='.jpg') -> np.ndarray:
+    """[T, 224, 224, 10] uint8: x/y of 5 consecutive flow frames interleaved (calcSig_wOF.py:99-113)."""
+    out = []
+    for tick in ticks:
+        stack = []
+        for idx in flow_stack_indices(tick, frame_cnt, stk_depth):
+            stack.append(crop0(imread(os.path.join(clip_dir, '{}{:05d}{}'.format(flow_x_prefix, idx, ext)), False)))
+            stack.append(crop0(imread(os.path.join(clip_dir, '{}{:05d}{}'.format(flow_y_prefix, idx, ext)), False)))
+        out.append(np.stack(stack, axis=-1))
+    return np.stack(out)
