@@ -71,6 +71,9 @@ def bench_tsn(args, rank, world, device, stream):
     n_crops = B_CLIPS * T_SEG
     model = tsn_net.TsnNet(g, weights, max_crops=n_crops, device=device.index)
     model.set_stream(stream.cuda_stream)
+    if args.tiles and os.path.exists(args.tiles):          # tiling table of an earlier run: skip the autotune launches
+        with open(args.tiles) as f:
+            model.set_layer_tiles(n_crops, np.array(json.load(f)["tiles"], dtype=np.int32))
     gen = torch.Generator(device=device).manual_seed(1 + rank)
     crops = torch.randint(0, 256, (n_crops, 224, 224, CH), dtype=torch.uint8, device=device, generator=gen)
     feat_ptr, _ = model.feat_devptr()
@@ -112,6 +115,10 @@ def bench_tsn(args, rank, world, device, stream):
             "flops_per_step": conv_flops}
     feats = feat.clone()
     model.set_profile(0)
+    if args.tiles and rank == 0 and not os.path.exists(args.tiles):
+        os.makedirs(os.path.dirname(os.path.abspath(args.tiles)), exist_ok=True)
+        with open(args.tiles, "w") as f:
+            json.dump({"n_crops": n_crops, "tiles": model.layer_tiles(n_crops).tolist()}, f)
     return dt, roof, model, crops, feats
 
 
@@ -128,11 +135,14 @@ def cpu_baseline_tsn(crops_u8, weights_graph, seconds_target=15.0):
     n_clips = int(max(1, min(B_CLIPS, seconds_target / max(one, 1e-3))))
     x = crops_u8[:n_clips * T_SEG]
     t0 = time.perf_counter()
-    ps, _ = to.features(g.layers, "data", weights, x, tsn_net.RGB_MEAN, T_SEG, dtype=np.float32, threads=threads)
+    reps = 0
+    while reps == 0 or time.perf_counter() - t0 < 10.0:
+        ps, _ = to.features(g.layers, "data", weights, x, tsn_net.RGB_MEAN, T_SEG, dtype=np.float32, threads=threads)
+        reps += 1
     dt = time.perf_counter() - t0
-    return {"value": n_clips / dt, "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": "%d clips (%d crops) of the same cfg2 batch, oracle/tsn_oracle.py fp32 torch-CPU, %d threads, %.1f s"
-                      % (n_clips, n_clips * T_SEG, threads, dt)}, ps
+    return {"value": n_clips * reps / dt, "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": "%d x %d clips (%d crops) of the same cfg2 batch, oracle/tsn_oracle.py fp32 torch-CPU, %d threads, %.1f s"
+                      % (reps, n_clips, n_clips * T_SEG, threads, dt)}, ps
 
 
 def bench_sim(args, rank, world, device, stream):
@@ -207,6 +217,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--skip-sim", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--tiles", default=None, help="JSON file: load the conv tiling table if it exists, else write it")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

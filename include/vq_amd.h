@@ -178,6 +178,8 @@ int vq_tsn_layer_times(vq_tsn* net, float* ms, double* flops, int32_t n_layers);
  * forward of that batch size (every candidate yields the same bits), else the occupancy heuristic.
  * tiles: int32 [n_layers][4], zeros for non-conv layers. */
 int vq_tsn_layer_tiles(vq_tsn* net, int32_t n_crops, int32_t* tiles, int32_t n_layers);
+/* Install a tiling table (as returned by vq_tsn_layer_tiles) for batch size n_crops instead of autotuning. */
+int vq_tsn_set_layer_tiles(vq_tsn* net, int32_t n_crops, const int32_t* tiles, int32_t n_layers);
 /* Algorithmic FLOPs (2*MACs of the conv layers) of one crop, for roofline accounting. */
 int vq_tsn_flops_per_crop(vq_tsn* net, double* flops);
 

@@ -62,7 +62,7 @@ SIGNATURES = {
     "vq_tsn_forward": [_P, _P, _I32, _I32, _I32, _pF32, _P, _P],
     "vq_tsn_feat_devptr": [_P, _PP, _PP], "vq_tsn_read_tensor": [_P, _I32, _I32, _P],
     "vq_tsn_flops_per_crop": [_P, _pF64],
-    "vq_tsn_layer_tiles": [_P, _I32, _P, _I32],
+    "vq_tsn_layer_tiles": [_P, _I32, _P, _I32], "vq_tsn_set_layer_tiles": [_P, _I32, _P, _I32],
     "vq_tsn_set_profile": [_P, _I32], "vq_tsn_layer_times": [_P, _P, _P, _I32],
 }
 _SPECIAL = {"vq_last_error": ([], C.c_char_p), "vq_abi_version": ([], C.c_int)}

@@ -1032,6 +1032,28 @@ int vq_tsn_layer_tiles(vq_tsn* net, int32_t n_crops, int32_t* tiles, int32_t n_l
     return VQ_OK;
 }
 
+int vq_tsn_set_layer_tiles(vq_tsn* net, int32_t n_crops, const int32_t* tiles, int32_t n_layers) {
+    VQ_REQUIRE(net && tiles, "NULL argument");
+    VQ_REQUIRE(n_layers == (int)net->layers.size(), "n_layers must be %d", (int)net->layers.size());
+    VQ_REQUIRE(n_crops > 0 && n_crops <= net->max_crops, "n_crops out of range");
+    std::vector<int> choice(net->layers.size(), 0);
+    for (int i = 0; i < n_layers; ++i) {
+        if (net->layers[i].op != VQ_OP_CONV) continue;
+        int found = -1;
+        for (int t = 0; t < kNumTiles; ++t)
+            if (kTiles[t].bm == tiles[4 * i] && kTiles[t].bn == tiles[4 * i + 1] && kTiles[t].bk == tiles[4 * i + 2] &&
+                kTiles[t].pipe == tiles[4 * i + 3])
+                found = t;
+        VQ_REQUIRE(found >= 0, "layer %d: no kernel for tile %dx%dx%d pipe=%d", i, tiles[4 * i], tiles[4 * i + 1], tiles[4 * i + 2],
+                   tiles[4 * i + 3]);
+        VQ_REQUIRE(!(kTiles[found].pipe && net->layers[i].cin % KPAD != 0), "layer %d: pipelined kernel needs Cin %% 32 == 0", i);
+        choice[i] = found;
+    }
+    std::lock_guard<std::mutex> lk(net->mu);
+    net->tuned[n_crops] = choice;
+    return VQ_OK;
+}
+
 int vq_tsn_flops_per_crop(vq_tsn* net, double* flops) {
     VQ_REQUIRE(net && flops, "NULL argument");
     *flops = net->flops_per_crop;

@@ -179,6 +179,11 @@ class TsnNet:
         call("vq_tsn_layer_tiles", self._h, int(n_crops), out.ctypes.data_as(C.c_void_p), n)
         return out
 
+    def set_layer_tiles(self, n_crops: int, tiles: np.ndarray):
+        """Install a tiling table (from layer_tiles, e.g. of an earlier process) instead of autotuning."""
+        t = np.ascontiguousarray(tiles, dtype=np.int32)
+        call("vq_tsn_set_layer_tiles", self._h, int(n_crops), t.ctypes.data_as(C.c_void_p), t.shape[0])
+
     def flops_per_crop(self) -> float:
         out = C.c_double()
         call("vq_tsn_flops_per_crop", self._h, C.byref(out))
