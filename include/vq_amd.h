@@ -136,9 +136,20 @@ typedef struct vq_layer_desc {
     int32_t k, stride, pad;
     int32_t relu;
     int32_t ceil_mode;           /* pooling output size: Caffe ceil rule                     */
+    int32_t has_bias;            /* AVGPOOL: add bias[b_off..] after the division, then ReLU if relu (finishes a
+                                    1x1 projection that was commuted with the pool); conv: always biased     */
+    int32_t seg_first, seg_count;/* conv with seg_count > 0: its cout columns are split over seg_count
+                                    destinations (segments[seg_first ..]); dst/dst_coff/relu are then ignored */
     int64_t w_off;               /* floats into the blob: weights [cout][k][k][cin] (OHWI)   */
     int64_t b_off;               /* floats into the blob: bias [cout]                        */
 } vq_layer_desc;
+
+/* One destination of a multi-destination convolution: `cout` consecutive output columns (a multiple of 32) go to
+ * tensor slot `dst` at channel offset `dst_coff`.  Sibling 1x1 convolutions of an inception block that read the same
+ * tensor are executed as one GEMM this way. */
+typedef struct vq_conv_segment {
+    int32_t cout, dst, dst_coff, relu;
+} vq_conv_segment;
 
 typedef struct vq_tensor_desc {
     int32_t h, w, c;             /* NHWC activations, fp32                                    */
@@ -151,8 +162,9 @@ typedef struct vq_tensor_desc {
  * calcSig_wOF.py:95,112,174-175).  Replaces CaffeNet(proto, weights, device) at
  * calcSig_wOF.py:52,55. */
 int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_layer_desc* layers,
-                  int32_t n_layers, const float* blob_host, int64_t blob_floats, int32_t in_channels,
-                  int32_t feature_slot, int32_t max_crops, int32_t device, vq_tsn** out);
+                  int32_t n_layers, const vq_conv_segment* segments, int32_t n_segments, const float* blob_host,
+                  int64_t blob_floats, int32_t in_channels, int32_t feature_slot, int32_t max_crops, int32_t device,
+                  vq_tsn** out);
 int vq_tsn_destroy(vq_tsn* net);
 int vq_tsn_set_stream(vq_tsn* net, void* hip_stream);
 /* crops: uint8 NHWC [n_crops][h][w][c] (host, or device if crops_on_device), n_crops = B*T with the

@@ -66,7 +66,8 @@ CONV_CASES = [
 @pytest.mark.parametrize("tile", [None, "128x128", "128x96", "128x64", "128x32", "64x64", "64x128",
                                   "128x128x16", "128x96x16", "128x64x16", "128x32x16", "64x64x16", "64x128x16",
                                   "128x128x32x1", "128x96x32x1", "128x64x32x1", "128x32x32x1", "64x64x32x1", "64x128x32x1",
-                                  "128x128x16x1", "128x96x16x1", "128x64x16x1", "128x32x16x1", "64x64x16x1", "64x128x16x1"])
+                                  "128x128x16x1", "128x96x16x1", "128x64x16x1", "128x32x16x1", "64x64x16x1", "64x128x16x1",
+                                  "128x128x3x2", "128x128x4x2", "128x64x3x2", "128x64x4x2", "64x128x3x2", "64x64x3x2", "64x64x4x2"])
 def test_conv_bn_relu_layer(tsn, monkeypatch, cin, h, cout, k, s, p, n, tile):
     bi, net = tsn
     if tile:
@@ -147,6 +148,27 @@ def test_bn_inception_rgb_layerwise_and_features(tsn, rgb_case):
     feat1, ps1 = m.forward(crops[[2, 0]], 1, net.RGB_MEAN)
     assert (ps1[0] == ps[2]).all() and (ps1[1] == ps[0]).all()
     m.close()
+
+
+def test_fused_and_unfused_graphs_agree(tsn, rgb_case):
+    """Merging sibling 1x1 convolutions never changes a bit (same k order per output element); commuting the average
+    pool with its projection changes only that branch, at rounding level."""
+    bi, net = tsn
+    g, w, crops, keep, want = rgb_case
+    m0 = net.TsnNet(g, w, max_crops=4, fuse=False)
+    m1 = net.TsnNet(g, w, max_crops=4, fuse=True)
+    f0, p0 = m0.forward(crops, 2, net.RGB_MEAN)
+    f1, p1 = m1.forward(crops, 2, net.RGB_MEAN)
+    for name in ("inception_3a/3x3_reduce_bn", "inception_3a/double_3x3_reduce_bn"):   # same input bits (pool2)
+        assert (m0.read_blob(name, 4) == m1.read_blob(name, 4)).all(), name
+    a0, a1 = m0.read_blob("inception_3a/output", 4), m1.read_blob("inception_3a/output", 4)
+    assert (a0[..., :224] == a1[..., :224]).all()                      # 1x1 | 3x3 | double 3x3 branches: identical bits
+    assert np.abs(a0[..., 224:] - a1[..., 224:]).max() <= 1e-5 * np.abs(a0).max()   # pool_proj branch: rounding only
+    assert np.abs(p0 - p1).max() <= 2e-5 * np.abs(p0).max()
+    ref = want["global_pool"].reshape(4, -1)
+    assert np.abs(p1 - ref).max() <= 2e-4 * np.abs(ref).max()
+    m0.close()
+    m1.close()
 
 
 def test_bn_inception_flow_features(tsn):

@@ -76,9 +76,9 @@ def test_builtin_graph_equals_reference_prototxt():
 
 def test_plan_matches_survey_appendix_a():
     from video_query_algorithms_amd.tsn import bn_inception as bi
-    p = bi.bn_inception(3).plan()
+    p = bi.bn_inception(3).plan(fuse=False)
     assert p.macs_per_crop() == 2_031_576_064                 # SURVEY Appendix A (fc-action excluded)
-    assert bi.bn_inception(10).plan().macs_per_crop() == 2_306_941_952
+    assert bi.bn_inception(10).plan(fuse=False).macs_per_crop() == 2_306_941_952
     kinds = [o.kind for o in p.ops]
     assert kinds.count("conv") == 69 and kinds.count("avgpool") == 7 and kinds.count("maxpool") == 5
     assert kinds.count("gavgpool") == 1 and p.feature_dim == 1024
@@ -91,6 +91,35 @@ def test_plan_matches_survey_appendix_a():
     # reduction block 3c: max-pool passes through un-projected at offset 160+96
     s3c = loc["inception_3c/output"][0]
     assert loc["inception_3c/pool"] == (s3c, 256, 320) and p.tensors[s3c].c == 576
+
+
+def test_fused_plan_keeps_the_work_and_the_destinations():
+    """Graph-level rewrites (sibling 1x1 merge, avg-pool / projection commute) change no MAC and no destination."""
+    from video_query_algorithms_amd.tsn import bn_inception as bi
+    for c, macs in ((3, 2_031_576_064), (10, 2_306_941_952)):
+        g = bi.bn_inception(c)
+        p0, p = g.plan(fuse=False), g.plan()
+        assert p.macs_per_crop() == macs == p0.macs_per_crop()
+        kinds = [o.kind for o in p.ops]
+        assert kinds.count("conv") == 44 and kinds.count("avgpool") == 7 and kinds.count("maxpool") == 5
+        plain = {o.name: o for o in p0.ops if o.kind == "conv"}
+        seen = set()
+        for o in p.ops:
+            if o.kind != "conv":
+                continue
+            for sg in (o.segments or [bi.Segment(o.name, o.bn, o.cout, o.dst, o.dst_coff, o.relu, o.bias)]):
+                ref = plain[sg.name]
+                seen.add(sg.name)
+                assert sg.cout == ref.cout and o.cin == ref.cin and o.k == ref.k
+                if sg.bias:                       # un-commuted: same destination, same activation
+                    assert (sg.dst, sg.dst_coff, sg.relu) == (ref.dst, ref.dst_coff, ref.relu)
+                else:                             # commuted projection: raw output to a temp, finished by the pool
+                    fin = [q for q in p.ops if q.kind == "avgpool" and q.bias_from and q.bias_from[0] == sg.name]
+                    assert len(fin) == 1 and (fin[0].dst, fin[0].dst_coff, fin[0].relu) == (ref.dst, ref.dst_coff, ref.relu)
+                    assert fin[0].src == sg.dst and not sg.relu
+        assert seen == set(plain)
+        # 5b keeps its max pool in front of the projection (max does not commute with a linear map)
+        assert any(o.kind == "maxpool" and o.name == "inception_5b/pool" for o in p.ops)
 
 
 def test_prototxt_parser_handles_comments_and_nesting():

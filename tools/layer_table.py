@@ -25,9 +25,9 @@ def main(channels=3, n_crops=96, T=3, reps=10):
     tot = ms.sum()
     print("%-34s %-8s %9s %5s %5s %8s %7s %6s %s" % ("layer", "kind", "M", "N", "K", "ms", "TF/s", "%time", "tile"))
     for op, k, t, f, tl in zip(plan.ops, kinds, ms, fl, tiles):
-        td = plan.tensors[op.dst]
+        td = plan.tensors[op.segments[0].dst if getattr(op, "segments", None) else op.dst]
         M = n_crops * td.h * td.w
-        print("%-34s %-8s %9d %5d %5d %8.4f %7.1f %6.2f %s" % (op.name, k, M, op.cout, op.cin * op.k * op.k, t,
+        print("%-34s %-8s %9d %5d %5d %8.4f %7.1f %6.2f %s" % (op.name[:34], k, M, op.cout, op.cin * op.k * op.k, t,
                                                              f / t / 1e9 if t > 0 else 0, 100 * t / tot,
                                                              "%dx%dx%d%s" % (tl[0], tl[1], tl[2], "p" if tl[3] else "") if tl[0] else ""))
     conv = np.array([k == "conv" for k in kinds])

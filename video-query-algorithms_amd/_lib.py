@@ -28,7 +28,12 @@ class LayerDesc(C.Structure):
     _fields_ = [("op", C.c_int32), ("src", C.c_int32), ("dst", C.c_int32), ("src_coff", C.c_int32),
                 ("dst_coff", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("k", C.c_int32),
                 ("stride", C.c_int32), ("pad", C.c_int32), ("relu", C.c_int32), ("ceil_mode", C.c_int32),
+                ("has_bias", C.c_int32), ("seg_first", C.c_int32), ("seg_count", C.c_int32),
                 ("w_off", C.c_int64), ("b_off", C.c_int64)]
+
+
+class ConvSegment(C.Structure):
+    _fields_ = [("cout", C.c_int32), ("dst", C.c_int32), ("dst_coff", C.c_int32), ("relu", C.c_int32)]
 
 
 class TensorDesc(C.Structure):
@@ -57,7 +62,8 @@ SIGNATURES = {
     "vq_db_scores_grid": [_P, _P, _I32, _P, _I32, _P],
     "vq_db_select": [_P, _F64, _F64, _pI64, _pI64, _pI64], "vq_db_select_fetch": [_P, _P, _I64, _P, _I64],
     "vq_db_topk": [_P, _I64, _P, _P, _pI64], "vq_db_min_score": [_P, _P, _I32, _pF64],
-    "vq_tsn_create": [C.POINTER(TensorDesc), _I32, C.POINTER(LayerDesc), _I32, _P, _I64, _I32, _I32, _I32, _I32, _PP],
+    "vq_tsn_create": [C.POINTER(TensorDesc), _I32, C.POINTER(LayerDesc), _I32, C.POINTER(ConvSegment), _I32, _P, _I64, _I32, _I32,
+                      _I32, _I32, _PP],
     "vq_tsn_destroy": [_P], "vq_tsn_set_stream": [_P, _P],
     "vq_tsn_forward": [_P, _P, _I32, _I32, _I32, _pF32, _P, _P],
     "vq_tsn_feat_devptr": [_P, _PP, _PP], "vq_tsn_read_tensor": [_P, _I32, _I32, _P],

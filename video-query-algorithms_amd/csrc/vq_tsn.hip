@@ -37,8 +37,17 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ src, float* __rest
 // ------------------------------------------------------------------------------------------------
 // convolution (+ folded BN + ReLU) as implicit GEMM on v_mfma_f32_32x32x2_f32
 // ------------------------------------------------------------------------------------------------
+// Where a group of 32 output columns of a convolution goes.  One convolution may feed several tensors (sibling 1x1
+// convolutions of an inception block merged into one GEMM): the table has one entry per 32-column group.
+struct ConvSeg {
+    float* out_base;     // destination slot + its channel offset - first column of the segment: index with the GEMM column
+    int Cs;              // channel stride of the destination slot
+    int relu;
+};
+
 struct ConvArgs {
     const float* in;
+    const ConvSeg* segs; // [ceil(Cout / 32)]
     float* out;
     const float* w;      // [Cout][Kp], k index = (kh*k + kw)*Cin + c, zero padded to Kp
     const float* bias;   // [Cout]
@@ -48,6 +57,7 @@ struct ConvArgs {
     int k, stride, pad;
     int M, Kp, relu;
     int tiles_m, tiles_n;
+    unsigned in_bytes, w_bytes;   // extents for the buffer descriptors (out-of-range offsets read as zero)
     int dbg;             // timing experiments only: bit0 skip staging loads, bit1 skip LDS stores, bit2 skip barriers
     int desync;          // 1: odd hardware wave slots run at raised priority (see desync_simd_partners)
 };
@@ -92,6 +102,7 @@ __device__ __forceinline__ void desync_simd_partners() {
         _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                          \
             const int nb = n0 + wn * (BN / WN) + 32 * j;                                                          \
             if (nb < a.Cout) {                                                                                    \
+                const ConvSeg sg = seg_v[j];                                                                      \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                  \
                     _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                \
                         patch[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = acc[i][j][r];                     \
@@ -100,14 +111,14 @@ __device__ __forceinline__ void desync_simd_partners() {
                         const int row = prow + 8 * ps;                                                            \
                         floatx4 v = *reinterpret_cast<const floatx4*>(&patch[row * 36 + pc4 * 4]);                \
                         v += bias_v[j];                                                                           \
-                        if (a.relu) {                                                                             \
+                        if (sg.relu) {                                                                            \
                             v[0] = fmaxf(v[0], 0.f);                                                              \
                             v[1] = fmaxf(v[1], 0.f);                                                              \
                             v[2] = fmaxf(v[2], 0.f);                                                              \
                             v[3] = fmaxf(v[3], 0.f);                                                              \
                         }                                                                                         \
-                        if (full_m || mb + row < a.M)                                                             \
-                            *reinterpret_cast<floatx4*>(a.out + (size_t)(mb + row) * a.Cs_out + a.coff_out + nb + pc4 * 4) = v; \
+                        if ((full_m || mb + row < a.M) && nb + pc4 * 4 < a.Cout)                                  \
+                            *reinterpret_cast<floatx4*>(sg.out_base + (size_t)(mb + row) * sg.Cs + nb + pc4 * 4) = v; \
                     }                                                                                             \
                 }                                                                                                 \
             }                                                                                                     \
@@ -227,10 +238,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     // folded-BN bias of this lane's output columns: fetched now so that its latency (and its vmcnt wait)
     // is long gone when the epilogue starts -- a load inside the store loop would serialise every store
     floatx4 bias_v[TN];   // this lane's 4 output channels in the transposed store (see VQ_EPILOGUE)
+    ConvSeg seg_v[TN];    // where each 32-column group of this wave goes (wave-uniform)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / WN) + 32 * j + (lane & 7) * 4;
+        const int nb_ = n0 + wn * (BN / WN) + 32 * j;
+        const int n = nb_ + (lane & 7) * 4;
         bias_v[j] = *reinterpret_cast<const floatx4*>(a.bias + (n < a.Cout ? n : 0));
+        seg_v[j] = a.segs[nb_ < a.Cout ? nb_ >> 5 : 0];
     }
 
     const int nk = (a.dbg & 8) ? 1 : ((a.dbg & 16) ? 2 * (a.Kp / BK) : a.Kp / BK);   // dbg: 1 K-step only / K doubled (timing only)
@@ -295,8 +309,16 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     const int m0 = (tile / a.tiles_n) * BM;
     const int n0 = (tile % a.tiles_n) * BN;
 
-    const float* a_img[NA];
-    int a_ih0[NA], a_iw0[NA], a_row[NA], a_col[NA];
+    // Staging addresses are 32-bit byte offsets into two buffer descriptors (activation slot, weights).  A lane
+    // whose tap falls into the zero padding (or whose row is past M / Cout) uses offset 0xFFFFFFFF: the
+    // hardware range check of buffer_load returns zeros, so a load costs one add and one select -- no 64-bit
+    // address arithmetic, no branches, no zero page.  Which of the k*k taps are inside the image is a per-pixel
+    // bit mask computed once per tile.
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+    int a_off[NA];            // byte offset of (pixel, tap (0,0), channel chunk) -- may be "negative" in the padding
+    unsigned a_mask[NA];      // bit kh*k+kw set: that tap reads inside the image
+    int a_row[NA], a_col[NA];
     const int HoWo = a.Ho * a.Wo;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -308,12 +330,15 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         const int mm = ok ? m : 0;
         const int n_img = mm / HoWo, rem = mm - n_img * HoWo;
         const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-        a_img[i] = a.in + (size_t)n_img * a.H * a.W * a.Cs_in + a.coff_in + a_col[i] * 4;
-        a_ih0[i] = ok ? oh * a.stride - a.pad : -(1 << 20);
-        a_iw0[i] = ow * a.stride - a.pad;
+        const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
+        a_off[i] = (((n_img * a.H + ih0) * a.W + iw0) * a.Cs_in + a.coff_in + a_col[i] * 4) * 4;
+        unsigned mask = 0;
+        for (int th = 0; th < a.k; ++th)
+            for (int tw = 0; tw < a.k; ++tw)
+                if (ok && (unsigned)(ih0 + th) < (unsigned)a.H && (unsigned)(iw0 + tw) < (unsigned)a.W) mask |= 1u << (th * a.k + tw);
+        a_mask[i] = mask;
     }
-    const float* b_ptr[NB];
-    bool b_ok[NB];
+    unsigned b_off[NB];
     int b_row[NB], b_col[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -321,13 +346,11 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         b_row[i] = c / CPR;
         b_col[i] = c % CPR;
         const int n = n0 + b_row[i];
-        b_ok[i] = n < a.Cout && b_row[i] < BN;
-        b_ptr[i] = b_ok[i] ? a.w + (size_t)n * a.Kp + b_col[i] * 4 : a.zeros;
+        b_off[i] = (n < a.Cout && b_row[i] < BN) ? (unsigned)((n * a.Kp + b_col[i] * 4) * 4) : 0xFFFFFFFFu;
     }
-    const int b_step = BK;   // floats per K-step along a weight row (0 for rows parked on the zero page)
 
     floatx4 ra[NA], rb[NB];
-    int kh = 0, kw = 0, c0 = 0;
+    int kh = 0, kw = 0, c0 = 0, tap = 0, tap_off = 0;   // tap_off: byte offset of (kh, kw, c0) relative to tap (0,0)
 
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
@@ -340,24 +363,25 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     floatx4 bias_v[TN];   // this lane's 4 output channels in the transposed store (see VQ_EPILOGUE)
+    ConvSeg seg_v[TN];    // where each 32-column group of this wave goes (wave-uniform)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / WN) + 32 * j + (lane & 7) * 4;
+        const int nb_ = n0 + wn * (BN / WN) + 32 * j;
+        const int n = nb_ + (lane & 7) * 4;
         bias_v[j] = *reinterpret_cast<const floatx4*>(a.bias + (n < a.Cout ? n : 0));
+        seg_v[j] = a.segs[nb_ < a.Cout ? nb_ >> 5 : 0];
     }
 
 #define VQ_G_LOAD(IDX, KC)                                                                                     \
     {                                                                                                          \
         if ((IDX) < NA) {                                                                                      \
             const int ii = (IDX) < NA ? (IDX) : 0;                                                             \
-            const int ih = a_ih0[ii] + kh, iw = a_iw0[ii] + kw;                                                \
-            const float* src = a.zeros;                                                                        \
-            if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)                                  \
-                src = a_img[ii] + ((size_t)ih * a.W + iw) * a.Cs_in + c0;                                      \
-            ra[ii] = *reinterpret_cast<const floatx4*>(src);                                                   \
+            const unsigned off = ((a_mask[ii] >> tap) & 1u) ? (unsigned)(a_off[ii] + tap_off) : 0xFFFFFFFFu;   \
+            ra[ii] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0));   \
         } else {                                                                                               \
             const int ii = (IDX) >= NA ? (IDX) - NA : 0;                                                       \
-            rb[ii] = *reinterpret_cast<const floatx4*>(b_ptr[ii] + (b_ok[ii] ? (size_t)(KC) * b_step : 0));    \
+            const unsigned off = b_off[ii] == 0xFFFFFFFFu ? 0xFFFFFFFFu : b_off[ii] + (unsigned)(KC) * (BK * 4); \
+            rb[ii] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, off, 0, 0));    \
         }                                                                                                      \
     }
 #define VQ_G_STORE(IDX, BUF)                                                                                   \
@@ -372,16 +396,18 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
                 *reinterpret_cast<floatx4*>(&sm.b[BUF][b_row[ii]][b_col[ii] * 4]) = rb[ii];                    \
         }                                                                                                      \
     }
-#define VQ_ADVANCE_TAP()            \
-    {                               \
-        c0 += BK;                   \
-        if (c0 >= a.Cin) {          \
-            c0 = 0;                 \
-            if (++kw == a.k) {      \
-                kw = 0;             \
-                ++kh;               \
-            }                       \
-        }                           \
+#define VQ_ADVANCE_TAP()                                        \
+    {                                                           \
+        c0 += BK;                                               \
+        if (c0 >= a.Cin) {                                      \
+            c0 = 0;                                             \
+            ++tap;                                              \
+            if (++kw == a.k) {                                  \
+                kw = 0;                                         \
+                ++kh;                                           \
+            }                                                   \
+        }                                                       \
+        tap_off = ((kh * a.W + kw) * a.Cs_in + c0) * 4;         \
     }
 // One K-step on LDS buffer BUF.  HAS_NEXT: also stage tile KC+1 (global -> registers -> LDS buffer BUF^1).
 #define VQ_PIPE_STEP(BUF, KC, HAS_NEXT)                                                                        \
@@ -437,6 +463,232 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Ring variant (aligned Cin only): loader / consumer wave specialisation.
+//
+// The ablations (profiles/README.md) show that what keeps the two kernels above at ~73 % of the matrix peak is
+// not bandwidth but ISSUE: an in-order wave that has to issue global loads, LDS stores and waits cannot also
+// keep its SIMD's matrix pipe fed.  Here a workgroup has 8 waves: waves 0-3 ("consumers", one per SIMD) issue
+// nothing but LDS fragment reads and MFMAs; waves 4-7 ("loaders", one per SIMD) stream the im2col tiles
+// global -> LDS with LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write) into a ring of NS stages,
+// NS-1 K-steps ahead, and never touch the matrix pipe.  One s_barrier per K-step hands a landed stage to the
+// consumers and a drained one back to the loaders.  Workgroups are persistent: each walks its tiles
+// (blockIdx, blockIdx + grid, ...) as one flat sequence of K-steps, so the loaders already fill the ring for
+// the next tile while the consumers store the current one.
+//
+// LDS image of a stage: BM + BN rows of 32 floats (128 B), A rows first, rows linear (one DMA instruction
+// = 8 rows = 1 KiB), the 16-byte chunk c of row r stored at chunk slot c ^ ((r >> 1) & 7): the 16 rows a
+// ds_read_b128 lane group touches then fall on 16 distinct bank slots.  The DMA destination is lane-linear,
+// so the swizzle is applied on the per-lane SOURCE address and again on the read address.
+// Same k order as the other kernels: results are bit-identical.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(512) void conv_ring_kernel(ConvArgs a) {
+    static_assert(WM * WN == 4, "4 consumer waves");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    constexpr int NI = (BM + BN) / 8;      // DMA instructions per stage (8 rows of 128 B each)
+    constexpr int NIL = NI / 4;            // per loader wave
+    static_assert(NI % 4 == 0 && NS >= 3, "tile rows must split over 4 loader waves");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ntiles = a.tiles_m * a.tiles_n;
+    const int nk = a.Kp / 32;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int G = my_tiles * nk;           // K-steps this workgroup walks; every wave passes exactly G barriers
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ loaders
+        const int L = wave - 4;
+        const int lrow = lane >> 3, lslot = lane & 7;
+        const float* src_base[NIL];        // A: image base (+ channel chunk); B: weight row (+ chunk)
+        int ih0[NIL], iw0[NIL];            // A only; B rows park ih0 at a flag value
+        int ti = 0, kc = 0, kh = 0, kw = 0, c0 = 0;
+        const int HoWo = a.Ho * a.Wo;
+        auto setup_tile = [&](int t_index) __attribute__((always_inline)) {
+            const int tile = xcd_remap((int)blockIdx.x + t_index * (int)gridDim.x, ntiles);
+            const int m0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
+#pragma unroll
+            for (int t = 0; t < NIL; ++t) {
+                const int q = L + 4 * t;
+                if (q < BM / 8) {
+                    const int row = 8 * q + lrow;
+                    const int chunk = lslot ^ ((row >> 1) & 7);
+                    const int m = m0 + row;
+                    const bool ok = m < a.M;
+                    const int mm = ok ? m : 0;
+                    const int n_img = mm / HoWo, rem = mm - n_img * HoWo;
+                    const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+                    src_base[t] = a.in + (size_t)n_img * a.H * a.W * a.Cs_in + a.coff_in + chunk * 4;
+                    ih0[t] = ok ? oh * a.stride - a.pad : -(1 << 20);
+                    iw0[t] = ow * a.stride - a.pad;
+                } else {
+                    const int row = 8 * (q - BM / 8) + lrow;
+                    const int chunk = lslot ^ ((row >> 1) & 7);
+                    const int n = n0 + row;
+                    src_base[t] = n < a.Cout ? a.w + (size_t)n * a.Kp + chunk * 4 : a.zeros;
+                    ih0[t] = n < a.Cout ? 0 : -(1 << 20);
+                    iw0[t] = 0;
+                }
+            }
+        };
+        auto issue = [&](int g) __attribute__((always_inline)) {
+            char* stage = smem_raw + (g % NS) * STAGE_BYTES;
+#pragma unroll
+            for (int t = 0; t < NIL; ++t) {
+                const int q = L + 4 * t;
+                const float* src = a.zeros;
+                if (q < BM / 8) {
+                    const int ih = ih0[t] + kh, iw = iw0[t] + kw;
+                    if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+                        src = src_base[t] + ((size_t)ih * a.W + iw) * a.Cs_in + c0;
+                } else {
+                    if (ih0[t] == 0) src = src_base[t] + (size_t)kc * 32;
+                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(stage + q * 1024), 16, 0, 0);
+            }
+            // advance the issue position: next K-step of this tile, or the first of the next tile
+            ++kc;
+            c0 += 32;
+            if (c0 >= a.Cin) {
+                c0 = 0;
+                if (++kw == a.k) {
+                    kw = 0;
+                    ++kh;
+                }
+            }
+            if (kc == nk) {
+                kc = kh = kw = c0 = 0;
+                ++ti;
+                if (ti < my_tiles) setup_tile(ti);
+            }
+        };
+        if (G > 0) setup_tile(0);
+        for (int g = 0; g < NS - 1 && g < G; ++g) issue(g);
+        for (int g = 0; g < G; ++g) {
+            // stage g has landed once at most the (NS-2) newer stages' DMAs are outstanding
+            if (g + NS - 2 < G)
+                wait_vmcnt<(NS - 2) * NIL>();
+            else
+                wait_vmcnt<0>();
+            if (!(a.dbg & 4)) wg_barrier();                 // consumers may read stage g; stage g-1 is drained
+            if (g + NS - 1 < G && !(a.dbg & 1)) issue(g + NS - 1);   // refill the stage the consumers just left
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    int a_off[TM], a_swz[TM], b_off[TN], b_swz[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * (BM / WM) + 32 * i + l31;
+        a_off[i] = r * 128;
+        a_swz[i] = (r >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = wn * (BN / WN) + 32 * j + l31;
+        b_off[j] = BM * 128 + r * 128;
+        b_swz[j] = (r >> 1) & 7;
+    }
+    float* patch = reinterpret_cast<float*>(smem_raw + NS * STAGE_BYTES) + wave * (32 * 36);
+    const int prow = lane >> 3, pc4 = lane & 7;
+    int g = 0;
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        const int tile = xcd_remap((int)blockIdx.x + ti * (int)gridDim.x, ntiles);
+        const int m0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
+        floatx16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        floatx4 bias_v[TN];
+        ConvSeg seg_v[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nb_ = n0 + wn * (BN / WN) + 32 * j;
+            const int n = nb_ + pc4 * 4;
+            bias_v[j] = *reinterpret_cast<const floatx4*>(a.bias + (n < a.Cout ? n : 0));
+            seg_v[j] = a.segs[nb_ < a.Cout ? nb_ >> 5 : 0];
+        }
+        for (int kc = 0; kc < nk; ++kc, ++g) {
+            if (!(a.dbg & 4)) wg_barrier();                 // stage g % NS has landed
+            const char* stage = smem_raw + (g % NS) * STAGE_BYTES;
+            floatx4 fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const floatx4*>(stage + a_off[i] + ((half ^ a_swz[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const floatx4*>(stage + b_off[j] + ((half ^ b_swz[j]) << 4));
+            // 16 TM TN MFMAs per K-step; the fragment reads of the next 8-wide k group are issued one per MFMA
+            // right behind the first MFMAs of the current group and pinned there (the scheduler would otherwise
+            // sink them to their first use and expose the LDS latency four times per K-step)
+            constexpr int MFK = 4 * TM * TN, NFR = TM + TN;
+#pragma unroll
+            for (int q = 0; q < 4 * MFK; ++q) {
+                const int kk = q / MFK, r = q % MFK, s_ = r / (TM * TN), i_ = (r / TN) % TM, j_ = r % TN;
+                acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i_][s_], fb[kk & 1][j_][s_], acc[i_][j_], 0, 0, 0);
+                if (kk + 1 < 4 && r < NFR) {
+                    const int c = (kk + 1) * 2 + half;
+                    if (r < TM)
+                        fa[(kk + 1) & 1][r < TM ? r : 0] =
+                            *reinterpret_cast<const floatx4*>(stage + a_off[r < TM ? r : 0] + ((c ^ a_swz[r < TM ? r : 0]) << 4));
+                    else
+                        fb[(kk + 1) & 1][r >= TM ? r - TM : 0] =
+                            *reinterpret_cast<const floatx4*>(stage + b_off[r >= TM ? r - TM : 0] + ((c ^ b_swz[r >= TM ? r - TM : 0]) << 4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // epilogue: + bias, ReLU, transposed 16-byte stores through this wave's private LDS patch (no barrier: the
+        // loaders keep filling the ring for the next tile meanwhile)
+        const bool full_m = m0 + BM <= a.M;
+        if (a.dbg & 32) continue;   // timing experiments: skip the epilogue
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nb = n0 + wn * (BN / WN) + 32 * j;
+            if (nb < a.Cout) {
+                const ConvSeg sg = seg_v[j];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = acc[i][j][r];
+                    const int mb = m0 + wm * (BM / WM) + 32 * i;
+#pragma unroll
+                    for (int ps = 0; ps < 4; ++ps) {
+                        const int row = prow + 8 * ps;
+                        floatx4 v = *reinterpret_cast<const floatx4*>(&patch[row * 36 + pc4 * 4]);
+                        v += bias_v[j];
+                        if (sg.relu) {
+                            v[0] = fmaxf(v[0], 0.f);
+                            v[1] = fmaxf(v[1], 0.f);
+                            v[2] = fmaxf(v[2], 0.f);
+                            v[3] = fmaxf(v[3], 0.f);
+                        }
+                        if ((full_m || mb + row < a.M) && nb + pc4 * 4 < a.Cout)
+                            *reinterpret_cast<floatx4*>(sg.out_base + (size_t)(mb + row) * sg.Cs + nb + pc4 * 4) = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // pooling (Caffe semantics: ceil-mode output size; MAX ignores padding; AVE divides by the window
 // clipped to the padded extent and accumulates h-major in fp32)
 // ------------------------------------------------------------------------------------------------
@@ -447,6 +699,8 @@ struct PoolArgs {
     int Ho, Wo, Cs_out, coff_out;
     int k, stride, pad;
     int64_t total;   // n * Ho * Wo * C/4
+    const float* bias;   // AVE only: added after the division (finishes a commuted 1x1 projection), may be null
+    int relu;
 };
 
 template <bool IS_MAX>
@@ -489,6 +743,19 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
         acc.y /= pool_size;
         acc.z /= pool_size;
         acc.w /= pool_size;
+        if (a.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(a.bias + c4 * 4);
+            acc.x += b.x;
+            acc.y += b.y;
+            acc.z += b.z;
+            acc.w += b.w;
+        }
+        if (a.relu) {
+            acc.x = fmaxf(acc.x, 0.f);
+            acc.y = fmaxf(acc.y, 0.f);
+            acc.z = fmaxf(acc.z, 0.f);
+            acc.w = fmaxf(acc.w, 0.f);
+        }
     }
     float* o = a.out + (((size_t)n * a.Ho + ph) * a.Wo + pw) * a.Cs_out + a.coff_out + c4 * 4;
     *reinterpret_cast<float4*>(o) = acc;
@@ -538,6 +805,8 @@ struct vq_tsn {
     bool autotune = true;
     std::vector<float*> slots;            // device activations, max_crops each
     float* zeros = nullptr;               // 256 bytes of zeros (load target of masked lanes)
+    ConvSeg* seg_table = nullptr;         // destination tables of all conv layers, back to back
+    std::vector<int> seg_table_off;       // per layer: first entry
     float* blob = nullptr;                // weights + biases
     int64_t blob_floats = 0;
     int feature_slot = -1, D = 0;
@@ -559,6 +828,7 @@ static void tsn_free(vq_tsn* net) {
         if (p) (void)hipFree(p);
     if (net->blob) (void)hipFree(net->blob);
     if (net->zeros) (void)hipFree(net->zeros);
+    if (net->seg_table) (void)hipFree(net->seg_table);
     if (net->crops_dev) (void)hipFree(net->crops_dev);
     if (net->mean_dev) (void)hipFree(net->mean_dev);
     if (net->feat_dev) (void)hipFree(net->feat_dev);
@@ -587,7 +857,10 @@ static const ConvTile kTiles[] = {
     {128, 128, 32, 0}, {128, 128, 16, 0}, {128, 96, 32, 0}, {128, 96, 16, 0}, {128, 64, 32, 0}, {128, 64, 16, 0},
     {64, 128, 32, 0},  {64, 128, 16, 0},  {64, 64, 32, 0},  {64, 64, 16, 0},  {128, 32, 32, 0}, {128, 32, 16, 0},
     {128, 128, 32, 1}, {128, 128, 16, 1}, {128, 96, 32, 1}, {128, 96, 16, 1}, {128, 64, 32, 1}, {128, 64, 16, 1},
-    {64, 128, 32, 1},  {64, 128, 16, 1},  {64, 64, 32, 1},  {64, 64, 16, 1},  {128, 32, 32, 1}, {128, 32, 16, 1}};
+    {64, 128, 32, 1},  {64, 128, 16, 1},  {64, 64, 32, 1},  {64, 64, 16, 1},  {128, 32, 32, 1}, {128, 32, 16, 1},
+    // pipe = 2: ring kernel (loader/consumer waves, LDS-DMA, persistent); bk field = number of ring stages
+    {128, 128, 3, 2},  {128, 128, 4, 2},  {128, 64, 3, 2},   {128, 64, 4, 2},  {64, 128, 3, 2},  {64, 64, 3, 2},
+    {64, 64, 4, 2}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 
 template <int BM, int BN, int WM, int WN, int BK>
@@ -604,6 +877,35 @@ static int launch_conv_pipe_t(vq_tsn* net, ConvArgs& a) {
     kern<<<a.tiles_m * a.tiles_n, 256, lds, net->stream>>>(a);
     VQ_CHECK_LAUNCH();
     return VQ_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int NS>
+static int launch_conv_ring_t(vq_tsn* net, ConvArgs& a) {
+    a.tiles_m = cdiv(a.M, BM);
+    a.tiles_n = cdiv(a.Cout, BN);
+    auto kern = conv_ring_kernel<BM, BN, WM, WN, NS>;
+    const size_t lds = (size_t)NS * (BM + BN) * 128 + 4 * 32 * 36 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds)));   // 8-wave workgroups: at most 2 per CU
+    const int ntiles = a.tiles_m * a.tiles_n;
+    int grid = std::min(ntiles, net->cus * per_cu);
+    if (grid >= 8) grid &= ~7;                                                // keep block b on the XCD of b % 8 across its tiles
+    kern<<<grid, 512, lds, net->stream>>>(a);
+    VQ_CHECK_LAUNCH();
+    return VQ_OK;
+}
+
+static int launch_conv_ring(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
+#define R_(BM_, BN_, WM_, WN_, NS_) \
+    if (t.bm == BM_ && t.bn == BN_ && t.bk == NS_) return launch_conv_ring_t<BM_, BN_, WM_, WN_, NS_>(net, a);
+    R_(128, 128, 2, 2, 3) R_(128, 128, 2, 2, 4) R_(128, 64, 2, 2, 3) R_(128, 64, 2, 2, 4) R_(64, 128, 2, 2, 3)
+    R_(64, 64, 2, 2, 3) R_(64, 64, 2, 2, 4)
+#undef R_
+    return fail(VQ_E_INVALID, "no ring kernel for tile %dx%d with %d stages", t.bm, t.bn, t.bk);
 }
 
 static int launch_conv_pipe(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
@@ -657,6 +959,7 @@ static void fill_conv_args(vq_tsn* net, int li, int n_crops, ConvArgs& a) {
     a.w = net->blob + L.w_off;
     a.bias = net->blob + L.b_off;
     a.zeros = net->zeros;
+    a.segs = net->seg_table + net->seg_table_off[li];
     a.H = ts.h;
     a.W = ts.w;
     a.Cs_in = ts.c;
@@ -674,6 +977,8 @@ static void fill_conv_args(vq_tsn* net, int li, int n_crops, ConvArgs& a) {
     a.Kp = (L.k * L.k * L.cin + KPAD - 1) / KPAD * KPAD;
     a.relu = L.relu;
     a.tiles_m = a.tiles_n = 0;
+    a.in_bytes = (unsigned)std::min<size_t>((size_t)n_crops * ts.h * ts.w * ts.c * sizeof(float), 0xFFFFFFF0u);
+    a.w_bytes = (unsigned)((size_t)L.cout * a.Kp * sizeof(float));
     static const int desync = getenv("VQ_TSN_DESYNC") ? atoi(getenv("VQ_TSN_DESYNC")) : 1;
     a.desync = desync;
     static const int dbg = getenv("VQ_TSN_DBG") ? atoi(getenv("VQ_TSN_DBG")) : 0;
@@ -684,7 +989,10 @@ static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
     ConvArgs a;
     fill_conv_args(net, li, n_crops, a);
     const bool small = (net->layers[li].cin % KPAD) != 0;
-    if (kTiles[tile_idx].pipe && !small) return launch_conv_pipe(net, a, kTiles[tile_idx]);
+    if (small && kTiles[tile_idx].pipe) tile_idx = heuristic_tile(a.M, a.Cout, net->cus);   // small-Cin stem: plain kernel only
+    if (kTiles[tile_idx].pipe == 1 && a.in_bytes >= 0x7FFFFFF0u) tile_idx = heuristic_tile(a.M, a.Cout, net->cus);   // 32-bit offsets
+    if (kTiles[tile_idx].pipe == 2 && !small) return launch_conv_ring(net, a, kTiles[tile_idx]);
+    if (kTiles[tile_idx].pipe == 1 && !small) return launch_conv_pipe(net, a, kTiles[tile_idx]);
     return small ? launch_conv<true>(net, a, kTiles[tile_idx]) : launch_conv<false>(net, a, kTiles[tile_idx]);
 }
 
@@ -759,6 +1067,8 @@ static int run_layer(vq_tsn* net, int li, int n_crops) {
         a.stride = L.stride;
         a.pad = L.pad;
         a.total = (int64_t)n_crops * td.h * td.w * (L.cin / 4);
+        a.bias = (L.op == VQ_OP_AVGPOOL && L.has_bias) ? net->blob + L.b_off : nullptr;
+        a.relu = (L.op == VQ_OP_AVGPOOL) ? L.relu : 0;
         const int64_t blocks = (a.total + 255) / 256;
         if (L.op == VQ_OP_MAXPOOL)
             pool_kernel<true><<<(unsigned)blocks, 256, 0, net->stream>>>(a);
@@ -785,12 +1095,13 @@ static int pool_out_size(int size, int k, int s, int p) {
 extern "C" {
 
 int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_layer_desc* layers, int32_t n_layers,
-                  const float* blob_host, int64_t blob_floats, int32_t in_channels, int32_t feature_slot, int32_t max_crops,
-                  int32_t device, vq_tsn** out) {
+                  const vq_conv_segment* segments, int32_t n_segments, const float* blob_host, int64_t blob_floats,
+                  int32_t in_channels, int32_t feature_slot, int32_t max_crops, int32_t device, vq_tsn** out) {
     VQ_REQUIRE(out, "out is NULL");
     *out = nullptr;
     VQ_REQUIRE(tensors && layers && blob_host, "NULL argument");
     VQ_REQUIRE(n_tensors > 0 && n_layers > 0 && blob_floats > 0 && max_crops > 0, "sizes must be positive");
+    VQ_REQUIRE(n_segments >= 0 && (n_segments == 0 || segments), "bad segment table");
     VQ_REQUIRE(feature_slot > 0 && feature_slot < n_tensors, "feature_slot out of range");
     VQ_REQUIRE(tensors[feature_slot].h == 1 && tensors[feature_slot].w == 1, "feature slot must be 1x1xD");
     VQ_REQUIRE(tensors[0].c % 4 == 0, "input slot channels must be padded to a multiple of 4 (got %d)", tensors[0].c);
@@ -801,16 +1112,32 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
     double macs = 0;
     for (int i = 0; i < n_layers; ++i) {
         const vq_layer_desc& L = layers[i];
+        const bool multi = L.op == VQ_OP_CONV && L.seg_count > 0;
         VQ_REQUIRE(L.src >= 0 && L.src < n_tensors && L.dst > 0 && L.dst < n_tensors && L.src != L.dst,
                    "layer %d: bad tensor slots %d -> %d", i, L.src, L.dst);
         const vq_tensor_desc& ts = tensors[L.src];
         const vq_tensor_desc& td = tensors[L.dst];
         VQ_REQUIRE(L.src_coff >= 0 && L.cin > 0 && L.src_coff + L.cin <= ts.c, "layer %d: reads channels [%d,%d) of a %d-channel slot",
                    i, L.src_coff, L.src_coff + L.cin, ts.c);
-        VQ_REQUIRE(L.dst_coff >= 0 && L.cout > 0 && L.dst_coff + L.cout <= td.c, "layer %d: writes channels [%d,%d) of a %d-channel slot",
-                   i, L.dst_coff, L.dst_coff + L.cout, td.c);
+        VQ_REQUIRE(multi || (L.dst_coff >= 0 && L.cout > 0 && L.dst_coff + L.cout <= td.c),
+                   "layer %d: writes channels [%d,%d) of a %d-channel slot", i, L.dst_coff, L.dst_coff + L.cout, td.c);
+        if (multi) {
+            VQ_REQUIRE(L.seg_first >= 0 && L.seg_first + L.seg_count <= n_segments, "layer %d: segments outside the table", i);
+            int sum = 0;
+            for (int q = 0; q < L.seg_count; ++q) {
+                const vq_conv_segment& sg = segments[L.seg_first + q];
+                VQ_REQUIRE(sg.dst > 0 && sg.dst < n_tensors && sg.dst != L.src, "layer %d segment %d: bad slot", i, q);
+                const vq_tensor_desc& t2 = tensors[sg.dst];
+                VQ_REQUIRE(sg.cout > 0 && sg.cout % 32 == 0 && sg.dst_coff >= 0 && sg.dst_coff % 4 == 0 && sg.dst_coff + sg.cout <= t2.c,
+                           "layer %d segment %d: channels [%d,%d) do not fit a %d-channel slot (cout must be a multiple of 32)", i, q,
+                           sg.dst_coff, sg.dst_coff + sg.cout, t2.c);
+                VQ_REQUIRE(t2.h == td.h && t2.w == td.w && t2.c % 4 == 0, "layer %d segment %d: spatial size differs", i, q);
+                sum += sg.cout;
+            }
+            VQ_REQUIRE(sum == L.cout, "layer %d: segments cover %d of %d output channels", i, sum, L.cout);
+        }
         VQ_REQUIRE(L.k >= 1 && L.stride >= 1 && L.pad >= 0 && L.pad < L.k, "layer %d: bad kernel/stride/pad", i);
-        VQ_REQUIRE(ts.c % 4 == 0 && td.c % 4 == 0 && L.src_coff % 4 == 0 && L.dst_coff % 4 == 0 && L.cin % 4 == 0,
+        VQ_REQUIRE(ts.c % 4 == 0 && td.c % 4 == 0 && L.src_coff % 4 == 0 && L.dst_coff % 4 == 0 && L.cin % 4 == 0 && L.cout % 4 == 0,
                    "layer %d: channel counts and offsets must be multiples of 4", i);
         if (L.op == VQ_OP_CONV) {
             VQ_REQUIRE(td.h == (ts.h + 2 * L.pad - L.k) / L.stride + 1 && td.w == (ts.w + 2 * L.pad - L.k) / L.stride + 1,
@@ -824,6 +1151,8 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
             macs += (double)td.h * td.w * L.cout * (L.src == 0 ? in_channels : L.cin) * L.k * L.k;   // algorithmic, un-padded
         } else if (L.op == VQ_OP_MAXPOOL || L.op == VQ_OP_AVGPOOL) {
             VQ_REQUIRE(L.cin == L.cout, "layer %d: pooling keeps the channel count", i);
+            VQ_REQUIRE(!(L.op == VQ_OP_AVGPOOL && L.has_bias) || (L.b_off >= 0 && L.b_off % 4 == 0 && L.b_off + L.cout <= blob_floats),
+                       "layer %d: pooling bias outside the blob", i);
             VQ_REQUIRE(td.h == pool_out_size(ts.h, L.k, L.stride, L.pad) && td.w == pool_out_size(ts.w, L.k, L.stride, L.pad),
                        "layer %d: pooling output size mismatch (Caffe ceil rule)", i);
         } else if (L.op == VQ_OP_GLOBAL_AVGPOOL) {
@@ -863,6 +1192,31 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
     if (e != hipSuccess) return bail("hipMalloc(weights)", e);
     e = hipMemcpy(net->blob, blob_host, (size_t)blob_floats * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) return bail("hipMemcpy(weights)", e);
+    {   // destination tables: one entry per 32 output columns of every convolution
+        std::vector<ConvSeg> table;
+        net->seg_table_off.assign(n_layers, 0);
+        for (int i = 0; i < n_layers; ++i) {
+            const vq_layer_desc& L = layers[i];
+            if (L.op != VQ_OP_CONV) continue;
+            net->seg_table_off[i] = (int)table.size();
+            if (L.seg_count > 0) {
+                int col0 = 0;
+                for (int q = 0; q < L.seg_count; ++q) {
+                    const vq_conv_segment& sg = segments[L.seg_first + q];
+                    for (int b = 0; b < sg.cout / 32; ++b)
+                        table.push_back(ConvSeg{net->slots[sg.dst] + sg.dst_coff - col0, tensors[sg.dst].c, sg.relu});
+                    col0 += sg.cout;
+                }
+            } else {
+                for (int b = 0; b < (L.cout + 31) / 32; ++b)
+                    table.push_back(ConvSeg{net->slots[L.dst] + L.dst_coff, tensors[L.dst].c, L.relu});
+            }
+        }
+        e = hipMalloc((void**)&net->seg_table, std::max<size_t>(table.size(), 1) * sizeof(ConvSeg));
+        if (e != hipSuccess) return bail("hipMalloc(destination tables)", e);
+        e = hipMemcpy(net->seg_table, table.data(), table.size() * sizeof(ConvSeg), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return bail("hipMemcpy(destination tables)", e);
+    }
     e = hipMalloc((void**)&net->zeros, 256);
     if (e != hipSuccess) return bail("hipMalloc(zero page)", e);
     e = hipMemset(net->zeros, 0, 256);

@@ -47,8 +47,9 @@ class Graph:
     def conv_layers(self) -> List[Layer]:
         return [l for l in self.layers if l.type == "Convolution"]
 
-    def plan(self, feature_blob: str = "global_pool") -> "Plan":
-        return _lower(self, feature_blob)
+    def plan(self, feature_blob: str = "global_pool", fuse: bool = True) -> "Plan":
+        p = _lower(self, feature_blob)
+        return _fuse(p) if fuse else p
 
 
 @dataclass
@@ -75,6 +76,20 @@ class Op:
     relu: bool = False
     bn: Optional[str] = None       # name of the folded BN layer
     out_blob: str = ""
+    bias: bool = True              # conv: add the (folded) bias in the epilogue
+    segments: Optional[List["Segment"]] = None   # merged sibling 1x1 convs: one GEMM, several destinations
+    bias_from: Optional[Tuple[str, Optional[str]]] = None   # avgpool that finishes a commuted pool_proj: (conv, bn)
+
+
+@dataclass
+class Segment:
+    name: str                      # conv layer whose weights fill these output columns
+    bn: Optional[str]
+    cout: int
+    dst: int
+    dst_coff: int
+    relu: bool
+    bias: bool
 
 
 @dataclass
@@ -89,7 +104,7 @@ class Plan:
         total = 0
         for op in self.ops:
             if op.kind == "conv":
-                t = self.tensors[op.dst]
+                t = self.tensors[op.segments[0].dst if op.segments else op.dst]
                 total += t.h * t.w * op.cout * op.cin * op.k * op.k
         return total
 
@@ -214,6 +229,66 @@ def _lower(g: Graph, feature_blob: str) -> Plan:
     if fs[1] != 0 or tensors[fs[0]].h != 1 or tensors[fs[0]].w != 1:
         raise ValueError("feature blob must be a 1x1 tensor of its own")
     return Plan(tensors, keep, fs[0], fs[2], dict(loc))
+
+
+def _fuse(plan: Plan) -> Plan:
+    """Two graph-level rewrites that change no layer's mathematics:
+
+    * ``pool_proj(avgpool(x))`` -> ``avgpool(pool_proj_linear(x)) + bias, ReLU``: a 3x3/1 average pool and a 1x1
+      convolution are both linear and commute (zero padding counted in the divisor either way), so the pool runs
+      on the 32..128 projected channels instead of the 192..1056 input channels, and the projection becomes one
+      more sibling of the block's other 1x1 convolutions;
+    * sibling 1x1/1 convolutions that read the same tensor (3-4 per inception block) become ONE implicit GEMM
+      with concatenated output columns; each 32-column group is stored to its own destination.
+    """
+    ops = list(plan.ops)
+    tensors = list(plan.tensors)
+    loc = dict(plan.blob_loc)
+    # --- commute average pool and projection
+    out: List[Op] = []
+    i = 0
+    consumed_by: Dict[Tuple[int, int], List[Op]] = {}
+    for op in ops:
+        consumed_by.setdefault((op.src, op.src_coff), []).append(op)
+    skip = set()
+    for op in ops:
+        if id(op) in skip:
+            continue
+        if op.kind == "avgpool" and op.k == 3 and op.stride == 1 and op.pad == 1:
+            users = consumed_by.get((op.dst, op.dst_coff), [])
+            if len(users) == 1 and users[0].kind == "conv" and users[0].k == 1 and users[0].stride == 1 and users[0].pad == 0 \
+                    and users[0].cin == op.cout:
+                conv = users[0]
+                t = tensors[conv.dst]
+                tensors.append(Tensor(t.h, t.w, conv.cout, conv.name + "/linear"))
+                tmp = len(tensors) - 1
+                out.append(Op("conv", conv.name, op.src, tmp, op.src_coff, 0, conv.cin, conv.cout, 1, 1, 0, relu=False,
+                              bn=conv.bn, out_blob=conv.name + "/linear", bias=False))
+                out.append(Op("avgpool", op.name, tmp, conv.dst, 0, conv.dst_coff, conv.cout, conv.cout, 3, 1, 1,
+                              relu=conv.relu, out_blob=conv.out_blob, bias_from=(conv.name, conv.bn)))
+                loc.pop(op.out_blob, None)
+                loc[conv.name + "/linear"] = (tmp, 0, conv.cout)
+                skip.add(id(conv))
+                continue
+        out.append(op)
+    # --- merge sibling 1x1 convolutions
+    merged: List[Op] = []
+    done = set()
+    for idx, op in enumerate(out):
+        if id(op) in done:
+            continue
+        if op.kind == "conv" and op.k == 1 and op.stride == 1 and op.pad == 0:
+            sibs = [o for o in out[idx:] if o.kind == "conv" and o.k == 1 and o.stride == 1 and o.pad == 0
+                    and (o.src, o.src_coff, o.cin) == (op.src, op.src_coff, op.cin) and id(o) not in done]
+            if len(sibs) > 1:
+                segs = [Segment(o.name, o.bn, o.cout, o.dst, o.dst_coff, o.relu, o.bias) for o in sibs]
+                m = Op("conv", "+".join(o.name for o in sibs), op.src, sibs[0].dst, op.src_coff, sibs[0].dst_coff, op.cin,
+                       sum(o.cout for o in sibs), 1, 1, 0, relu=False, out_blob=sibs[0].out_blob, segments=segs)
+                merged.append(m)
+                done.update(id(o) for o in sibs)
+                continue
+        merged.append(op)
+    return Plan(tensors, merged, plan.feature_slot, plan.feature_dim, loc)
 
 
 # ------------------------------------------------------------------------------------------------

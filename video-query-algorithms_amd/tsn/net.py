@@ -13,7 +13,7 @@ from typing import Dict, Sequence
 import numpy as np
 
 from .. import _lib
-from .._lib import LayerDesc, TensorDesc, call
+from .._lib import ConvSegment, LayerDesc, TensorDesc, call
 from .bn_inception import Graph, Plan
 
 BK = 32                      # K granularity of the implicit-GEMM kernel (csrc/vq_tsn.hip)
@@ -70,9 +70,9 @@ def pad4(c: int) -> int:
 
 class TsnNet:
     def __init__(self, graph: Graph, weights: Dict[str, Dict[str, np.ndarray]], max_crops: int = 96, device: int = 0,
-                 feature_blob: str = "global_pool", bn_eps: float = 1e-5):
+                 feature_blob: str = "global_pool", bn_eps: float = 1e-5, fuse: bool = True):
         self.graph = graph
-        self.plan: Plan = graph.plan(feature_blob)
+        self.plan: Plan = graph.plan(feature_blob, fuse=fuse)
         self.in_channels = graph.input_shape[0]
         self.max_crops = int(max_crops)
         self.device = device
@@ -82,23 +82,37 @@ class TsnNet:
         for i, t in enumerate(plan.tensors):
             tensors[i] = TensorDesc(t.h, t.w, cin_pad if i == 0 else t.c)
         layers = (LayerDesc * len(plan.ops))()
+        seg_list = []
         chunks = []
         off = 0
+
+        def packed_conv(name, bn, cin, cout, k, cin_dev, with_bias=True):
+            W, b = fold_bn(weights[name], weights[bn] if bn else None, bn_eps)
+            if W.shape != (cout, cin, k, k):
+                raise ValueError("weights of %s have shape %s, expected %s" % (name, W.shape, (cout, cin, k, k)))
+            ohwi = np.zeros((cout, k, k, cin_dev), dtype=np.float32)
+            ohwi[..., :cin] = W.transpose(0, 2, 3, 1)                      # [Cout][kh][kw][Cin]
+            kdim = k * k * cin_dev
+            kp = (kdim + BK - 1) // BK * BK
+            packed = np.zeros((cout, kp), dtype=np.float32)
+            packed[:, :kdim] = ohwi.reshape(cout, kdim)
+            return packed, (b if with_bias else np.zeros_like(b))
+
         for i, op in enumerate(plan.ops):
             d = LayerDesc(op=_OPS[op.kind], src=op.src, dst=op.dst, src_coff=op.src_coff, dst_coff=op.dst_coff,
                           cin=op.cin, cout=op.cout, k=op.k, stride=op.stride, pad=op.pad, relu=int(op.relu),
-                          ceil_mode=1, w_off=0, b_off=0)
+                          ceil_mode=1, has_bias=0, seg_first=0, seg_count=0, w_off=0, b_off=0)
             if op.kind == "conv":
-                W, b = fold_bn(weights[op.name], weights[op.bn] if op.bn else None, bn_eps)
                 cin_dev = cin_pad if op.src == 0 else op.cin
-                if W.shape != (op.cout, op.cin, op.k, op.k):
-                    raise ValueError("weights of %s have shape %s, expected %s" % (op.name, W.shape, (op.cout, op.cin, op.k, op.k)))
-                ohwi = np.zeros((op.cout, op.k, op.k, cin_dev), dtype=np.float32)
-                ohwi[..., :op.cin] = W.transpose(0, 2, 3, 1)                  # [Cout][kh][kw][Cin]
-                kdim = op.k * op.k * cin_dev
-                kp = (kdim + BK - 1) // BK * BK
-                packed = np.zeros((op.cout, kp), dtype=np.float32)
-                packed[:, :kdim] = ohwi.reshape(op.cout, kdim)
+                if op.segments:                                            # sibling 1x1 convolutions: one GEMM
+                    parts = [packed_conv(sg.name, sg.bn, op.cin, sg.cout, 1, cin_dev, sg.bias) for sg in op.segments]
+                    packed = np.concatenate([q[0] for q in parts], axis=0)
+                    b = np.concatenate([q[1] for q in parts])
+                    d.seg_first, d.seg_count = len(seg_list), len(op.segments)
+                    for sg in op.segments:
+                        seg_list.append(ConvSegment(sg.cout, sg.dst, sg.dst_coff, int(sg.relu)))
+                else:
+                    packed, b = packed_conv(op.name, op.bn, op.cin, op.cout, op.k, cin_dev, op.bias)
                 d.cin = cin_dev
                 d.w_off = off
                 chunks.append(packed.reshape(-1))
@@ -108,13 +122,23 @@ class TsnNet:
                 bias[:op.cout] = b
                 chunks.append(bias)
                 off += bias.size
+            elif op.kind == "avgpool" and op.bias_from is not None:       # finishes a commuted projection
+                _, b = fold_bn(weights[op.bias_from[0]], weights[op.bias_from[1]] if op.bias_from[1] else None, bn_eps)
+                d.has_bias = 1
+                d.b_off = off
+                bias = np.zeros(pad4(op.cout), dtype=np.float32)
+                bias[:op.cout] = b
+                chunks.append(bias)
+                off += bias.size
             elif op.src == 0:
                 d.cin = d.cout = cin_pad
             layers[i] = d
+        segs = (ConvSegment * max(len(seg_list), 1))(*seg_list)
         blob = np.ascontiguousarray(np.concatenate(chunks))
         self._h = C.c_void_p()
-        call("vq_tsn_create", tensors, len(plan.tensors), layers, len(plan.ops), blob.ctypes.data_as(C.c_void_p), blob.size,
-             self.in_channels, plan.feature_slot, self.max_crops, device, C.byref(self._h))
+        call("vq_tsn_create", tensors, len(plan.tensors), layers, len(plan.ops), segs, len(seg_list),
+             blob.ctypes.data_as(C.c_void_p), blob.size, self.in_channels, plan.feature_slot, self.max_crops, device,
+             C.byref(self._h))
         self.feature_dim = plan.feature_dim
         self.in_h, self.in_w = plan.tensors[0].h, plan.tensors[0].w
         self._tensor_c = [cin_pad if i == 0 else t.c for i, t in enumerate(plan.tensors)]
