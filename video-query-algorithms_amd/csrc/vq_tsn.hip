@@ -125,6 +125,16 @@ __device__ __forceinline__ void desync_simd_partners() {
         }                                                                                                         \
     }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // One workgroup = 4 waves = one BM x BN output tile; K is walked in steps of BK through a double-buffered LDS
 // image that is filled through registers (global -> VGPR under the MFMAs of the current step -> LDS).
 template <int BM, int BN, int WM, int WN, int BK, bool SMALL_CIN>
@@ -463,6 +473,187 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the software-pipelined kernel (aligned Cin, BK = 32): the staging stream is
+// global_load_lds_dwordx4 straight into the other LDS buffer -- no staging VGPRs, no ds_write, half the side
+// slices per K-step.  LDS rows are unpadded (an LDS-DMA instruction writes 64 x 16 contiguous bytes = 8 rows),
+// bank conflicts are avoided by storing chunk c of row r at chunk slot c ^ ((r >> 1) & 7): applied on the
+// per-lane SOURCE address of the DMA and on the fragment read address.  Same k order: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+struct ConvSmemLinear {
+    float a[2][BM][32];
+    float b[2][BN][32];
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs a) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int NI = (BM + BN) / 8;        // DMA instructions per K-step (8 rows of 128 B each)
+    constexpr int NG = NI / 4;               // per wave
+    constexpr int MFK = 4 * TM * TN, NMF = 4 * MFK, NFR = TM + TN;
+    constexpr int NFREE = NMF - 3 * NFR;
+    static_assert(NI % 4 == 0 && NFREE >= NG, "tile rows must split over 4 waves and fit the MFMA gaps");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    ConvSmemLinear<BM, BN>& sm = *reinterpret_cast<ConvSmemLinear<BM, BN>*>(smem_raw);
+
+    if (a.desync) desync_simd_partners();
+    const int tid = threadIdx.x;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / a.tiles_n) * BM;
+    const int n0 = (tile % a.tiles_n) * BN;
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+
+    // ---- staging roles: wave w issues DMA instructions q = w + 4 t; lane -> (row 8 q + lane / 8, slot lane % 8)
+    const char* src_base[NG];     // A: activation slot base (bytes); B: weight row + chunk (bytes) or the zero page
+    int s_off[NG];                // A: byte offset of (pixel, tap (0,0), chunk);  B: 0
+    unsigned s_mask[NG];          // A: taps inside the image;  B: all ones when the row exists, 0 otherwise
+    const int HoWo = a.Ho * a.Wo;
+    const int lrow = lane >> 3, lslot = lane & 7;
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+        const int q = wave + 4 * t;
+        if (q < BM / 8) {
+            const int row = 8 * q + lrow;
+            const int chunk = lslot ^ ((row >> 1) & 7);
+            const int m = m0 + row;
+            const bool ok = m < a.M;
+            const int mm = ok ? m : 0;
+            const int n_img = mm / HoWo, rem = mm - n_img * HoWo;
+            const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+            const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
+            src_base[t] = reinterpret_cast<const char*>(a.in);
+            s_off[t] = (((n_img * a.H + ih0) * a.W + iw0) * a.Cs_in + a.coff_in + chunk * 4) * 4;
+            unsigned mask = 0;
+            for (int th = 0; th < a.k; ++th)
+                for (int tw = 0; tw < a.k; ++tw)
+                    if (ok && (unsigned)(ih0 + th) < (unsigned)a.H && (unsigned)(iw0 + tw) < (unsigned)a.W) mask |= 1u << (th * a.k + tw);
+            s_mask[t] = mask;
+        } else {
+            const int row = 8 * (q - BM / 8) + lrow;
+            const int chunk = lslot ^ ((row >> 1) & 7);
+            const int n = n0 + row;
+            src_base[t] = reinterpret_cast<const char*>(a.w + (size_t)(n < a.Cout ? n : 0) * a.Kp + chunk * 4);
+            s_off[t] = 0;
+            s_mask[t] = n < a.Cout ? 0xFFFFFFFFu : 0u;
+        }
+    }
+    int kh = 0, kw = 0, c0 = 0, tap = 0, tap_off = 0, w_off = 0;   // byte offsets of the K-step being staged
+
+    // ---- compute roles
+    const int wm = wave / WN, wn = wave % WN;
+    int fa_off[TM], fa_swz[TM], fb_off[TN], fb_swz[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * (BM / WM) + 32 * i + l31;
+        fa_off[i] = r * 128;
+        fa_swz[i] = (r >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = wn * (BN / WN) + 32 * j + l31;
+        fb_off[j] = r * 128;
+        fb_swz[j] = (r >> 1) & 7;
+    }
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    floatx4 bias_v[TN];   // this lane's 4 output channels in the transposed store (see VQ_EPILOGUE)
+    ConvSeg seg_v[TN];    // where each 32-column group of this wave goes (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nb_ = n0 + wn * (BN / WN) + 32 * j;
+        const int n = nb_ + (lane & 7) * 4;
+        bias_v[j] = *reinterpret_cast<const floatx4*>(a.bias + (n < a.Cout ? n : 0));
+        seg_v[j] = a.segs[nb_ < a.Cout ? nb_ >> 5 : 0];
+    }
+
+// one DMA instruction of the staging stream: (A rows) pixel + tap offset, or (B rows) weight row + K offset
+#define VQ_DMA(T_, BUF)                                                                                              \
+    {                                                                                                                \
+        const int q_ = wave + 4 * (T_);                                                                              \
+        const bool is_a = q_ < BM / 8;                                                                               \
+        const bool ok_ = is_a ? ((s_mask[T_] >> tap) & 1u) != 0 : s_mask[T_] != 0;                                   \
+        const char* src_ = ok_ ? src_base[T_] + (is_a ? (unsigned)(s_off[T_] + tap_off) : (unsigned)w_off)           \
+                               : reinterpret_cast<const char*>(a.zeros);                                             \
+        char* dst_ = is_a ? reinterpret_cast<char*>(&sm.a[BUF][0][0]) + q_ * 1024                                     \
+                          : reinterpret_cast<char*>(&sm.b[BUF][0][0]) + (q_ - BM / 8) * 1024;                         \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                        \
+                                         (__attribute__((address_space(3))) void*)dst_, 16, 0, 0);                   \
+    }
+#define VQ_DMA_ADVANCE()                                        \
+    {                                                           \
+        c0 += 32;                                               \
+        w_off += 128;                                           \
+        if (c0 >= a.Cin) {                                      \
+            c0 = 0;                                             \
+            ++tap;                                              \
+            if (++kw == a.k) {                                  \
+                kw = 0;                                         \
+                ++kh;                                           \
+            }                                                   \
+        }                                                       \
+        tap_off = ((kh * a.W + kw) * a.Cs_in + c0) * 4;         \
+    }
+#define VQ_DMA_STEP(BUF, HAS_NEXT)                                                                                    \
+    {                                                                                                                \
+        const char* sa = reinterpret_cast<const char*>(&sm.a[BUF][0][0]);                                             \
+        const char* sb = reinterpret_cast<const char*>(&sm.b[BUF][0][0]);                                             \
+        floatx4 fa[2][TM], fb[2][TN];                                                                                \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
+            fa[0][i] = *reinterpret_cast<const floatx4*>(sa + fa_off[i] + ((half ^ fa_swz[i]) << 4));                 \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                               \
+            fb[0][j] = *reinterpret_cast<const floatx4*>(sb + fb_off[j] + ((half ^ fb_swz[j]) << 4));                 \
+        _Pragma("unroll") for (int q = 0; q < NMF; ++q) {                                                            \
+            const int kk = q / MFK, r = q % MFK, s_ = r / (TM * TN), i_ = (r / TN) % TM, j_ = r % TN;                \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i_][s_], fb[kk & 1][j_][s_], acc[i_][j_], 0, 0, 0); \
+            if (kk + 1 < 4 && r < NFR) {                                                                             \
+                const int c_ = (kk + 1) * 2 + half;                                                                  \
+                if (r < TM)                                                                                          \
+                    fa[(kk + 1) & 1][r < TM ? r : 0] = *reinterpret_cast<const floatx4*>(                            \
+                        sa + fa_off[r < TM ? r : 0] + ((c_ ^ fa_swz[r < TM ? r : 0]) << 4));                          \
+                else                                                                                                 \
+                    fb[(kk + 1) & 1][r >= TM ? r - TM : 0] = *reinterpret_cast<const floatx4*>(                      \
+                        sb + fb_off[r >= TM ? r - TM : 0] + ((c_ ^ fb_swz[r >= TM ? r - TM : 0]) << 4));              \
+            } else if (HAS_NEXT) {                                                                                   \
+                const int fidx = q - (kk + 1 < 4 ? (kk + 1) * NFR : 3 * NFR);                                        \
+                if (fidx < NG) VQ_DMA(fidx < NG ? fidx : 0, (BUF) ^ 1)                                               \
+            }                                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                            \
+    }
+
+    const int nk = a.Kp / 32;
+#pragma unroll
+    for (int t = 0; t < NG; ++t) VQ_DMA(t, 0)
+    wait_vmcnt<0>();
+    __syncthreads();
+    for (int kc = 0; kc + 1 < nk; ++kc) {
+        VQ_DMA_ADVANCE()              // (tap, c0) now address K-step kc + 1
+        if (kc & 1) {
+            VQ_DMA_STEP(1, true)
+        } else {
+            VQ_DMA_STEP(0, true)
+        }
+        wait_vmcnt<0>();              // this wave's pieces of K-step kc + 1 have landed ...
+        __syncthreads();              // ... and so have everybody else's
+    }
+    if ((nk - 1) & 1) {
+        VQ_DMA_STEP(1, false)
+    } else {
+        VQ_DMA_STEP(0, false)
+    }
+    VQ_EPILOGUE()
+#undef VQ_DMA
+#undef VQ_DMA_ADVANCE
+#undef VQ_DMA_STEP
+}
+
+// ------------------------------------------------------------------------------------------------
 // Ring variant (aligned Cin only): loader / consumer wave specialisation.
 //
 // The ablations (profiles/README.md) show that what keeps the two kernels above at ~73 % of the matrix peak is
@@ -481,16 +672,6 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
 // so the swizzle is applied on the per-lane SOURCE address and again on the read address.
 // Same k order as the other kernels: results are bit-identical.
 // ------------------------------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void wg_barrier() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
 template <int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(512) void conv_ring_kernel(ConvArgs a) {
     static_assert(WM * WN == 4, "4 consumer waves");
@@ -860,7 +1041,9 @@ static const ConvTile kTiles[] = {
     {64, 128, 32, 1},  {64, 128, 16, 1},  {64, 64, 32, 1},  {64, 64, 16, 1},  {128, 32, 32, 1}, {128, 32, 16, 1},
     // pipe = 2: ring kernel (loader/consumer waves, LDS-DMA, persistent); bk field = number of ring stages
     {128, 128, 3, 2},  {128, 128, 4, 2},  {128, 64, 3, 2},   {128, 64, 4, 2},  {64, 128, 3, 2},  {64, 64, 3, 2},
-    {64, 64, 4, 2}};
+    {64, 64, 4, 2},
+    // pipe = 3: software-pipelined kernel with LDS-DMA staging (BK = 32)
+    {128, 128, 32, 3}, {128, 96, 32, 3},  {128, 64, 32, 3},  {64, 128, 32, 3}, {64, 64, 32, 3},  {128, 32, 32, 3}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 
 template <int BM, int BN, int WM, int WN, int BK>
@@ -906,6 +1089,30 @@ static int launch_conv_ring(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
     R_(64, 64, 2, 2, 3) R_(64, 64, 2, 2, 4)
 #undef R_
     return fail(VQ_E_INVALID, "no ring kernel for tile %dx%d with %d stages", t.bm, t.bn, t.bk);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_conv_dma_t(vq_tsn* net, ConvArgs& a) {
+    a.tiles_m = cdiv(a.M, BM);
+    a.tiles_n = cdiv(a.Cout, BN);
+    auto kern = conv_igemm_dma_kernel<BM, BN, WM, WN>;
+    const size_t lds = std::max(sizeof(ConvSmemLinear<BM, BN>), (size_t)4 * 32 * 36 * sizeof(float));
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    kern<<<a.tiles_m * a.tiles_n, 256, lds, net->stream>>>(a);
+    VQ_CHECK_LAUNCH();
+    return VQ_OK;
+}
+
+static int launch_conv_dma(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
+#define D_(BM_, BN_, WM_, WN_) \
+    if (t.bm == BM_ && t.bn == BN_) return launch_conv_dma_t<BM_, BN_, WM_, WN_>(net, a);
+    D_(128, 128, 2, 2) D_(128, 96, 4, 1) D_(128, 64, 2, 2) D_(64, 128, 2, 2) D_(64, 64, 2, 2) D_(128, 32, 4, 1)
+#undef D_
+    return fail(VQ_E_INVALID, "no LDS-DMA kernel for tile %dx%d", t.bm, t.bn);
 }
 
 static int launch_conv_pipe(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
@@ -990,7 +1197,8 @@ static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
     fill_conv_args(net, li, n_crops, a);
     const bool small = (net->layers[li].cin % KPAD) != 0;
     if (small && kTiles[tile_idx].pipe) tile_idx = heuristic_tile(a.M, a.Cout, net->cus);   // small-Cin stem: plain kernel only
-    if (kTiles[tile_idx].pipe == 1 && a.in_bytes >= 0x7FFFFFF0u) tile_idx = heuristic_tile(a.M, a.Cout, net->cus);   // 32-bit offsets
+    if ((kTiles[tile_idx].pipe == 1 || kTiles[tile_idx].pipe == 3) && a.in_bytes >= 0x7FFFFFF0u) tile_idx = heuristic_tile(a.M, a.Cout, net->cus);   // 32-bit offsets
+    if (kTiles[tile_idx].pipe == 3 && !small) return launch_conv_dma(net, a, kTiles[tile_idx]);
     if (kTiles[tile_idx].pipe == 2 && !small) return launch_conv_ring(net, a, kTiles[tile_idx]);
     if (kTiles[tile_idx].pipe == 1 && !small) return launch_conv_pipe(net, a, kTiles[tile_idx]);
     return small ? launch_conv<true>(net, a, kTiles[tile_idx]) : launch_conv<false>(net, a, kTiles[tile_idx]);
