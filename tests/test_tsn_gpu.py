@@ -66,9 +66,7 @@ CONV_CASES = [
 @pytest.mark.parametrize("tile", [None, "128x128", "128x96", "128x64", "128x32", "64x64", "64x128",
                                   "128x128x16", "128x96x16", "128x64x16", "128x32x16", "64x64x16", "64x128x16",
                                   "128x128x32x1", "128x96x32x1", "128x64x32x1", "128x32x32x1", "64x64x32x1", "64x128x32x1",
-                                  "128x128x16x1", "128x96x16x1", "128x64x16x1", "128x32x16x1", "64x64x16x1", "64x128x16x1",
-                                  "128x128x3x2", "128x128x4x2", "128x64x3x2", "128x64x4x2", "64x128x3x2", "64x64x3x2", "64x64x4x2",
-                                  "128x128x32x3", "128x96x32x3", "128x64x32x3", "64x128x32x3", "64x64x32x3", "128x32x32x3"])
+                                  "128x128x16x1", "128x96x16x1", "128x64x16x1", "128x32x16x1", "64x64x16x1", "64x128x16x1"])
 def test_conv_bn_relu_layer(tsn, monkeypatch, cin, h, cout, k, s, p, n, tile):
     bi, net = tsn
     if tile:

@@ -125,16 +125,6 @@ __device__ __forceinline__ void desync_simd_partners() {
         }                                                                                                         \
     }
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void wg_barrier() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
 // One workgroup = 4 waves = one BM x BN output tile; K is walked in steps of BK through a double-buffered LDS
 // image that is filled through registers (global -> VGPR under the MFMAs of the current step -> LDS).
 template <int BM, int BN, int WM, int WN, int BK, bool SMALL_CIN>
@@ -300,9 +290,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 template <int BM, int BN, int WM, int WN, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int NT = 256;                    // threads per workgroup
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int CPR = BK / 4;
-    constexpr int NA = (BM * CPR + 255) / 256, NB = (BN * CPR + 255) / 256;
+    constexpr int NA = (BM * CPR + NT - 1) / NT, NB = (BN * CPR + NT - 1) / NT;
     constexpr int NKK = BK / 8;              // 8-wide k groups per K-step
     constexpr int MFK = 4 * TM * TN;         // MFMAs per k group
     constexpr int NMF = NKK * MFK;           // MFMAs per K-step
@@ -332,7 +323,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     const int HoWo = a.Ho * a.Wo;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int c = tid + 256 * i;
+        const int c = tid + NT * i;
         a_row[i] = c / CPR;
         a_col[i] = c % CPR;
         const int m = m0 + a_row[i];
@@ -352,7 +343,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     int b_row[NB], b_col[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int c = tid + 256 * i;
+        const int c = tid + NT * i;
         b_row[i] = c / CPR;
         b_col[i] = c % CPR;
         const int n = n0 + b_row[i];
@@ -398,11 +389,11 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     {                                                                                                          \
         if ((IDX) < NA) {                                                                                      \
             const int ii = (IDX) < NA ? (IDX) : 0;                                                             \
-            if ((BM * CPR) % 256 == 0 || a_row[ii] < BM)                                                       \
+            if ((BM * CPR) % NT == 0 || a_row[ii] < BM)                                                       \
                 *reinterpret_cast<floatx4*>(&sm.a[BUF][a_row[ii]][a_col[ii] * 4]) = ra[ii];                    \
         } else {                                                                                               \
             const int ii = (IDX) >= NA ? (IDX) - NA : 0;                                                       \
-            if ((BN * CPR) % 256 == 0 || b_row[ii] < BN)                                                       \
+            if ((BN * CPR) % NT == 0 || b_row[ii] < BN)                                                       \
                 *reinterpret_cast<floatx4*>(&sm.b[BUF][b_row[ii]][b_col[ii] * 4]) = rb[ii];                    \
         }                                                                                                      \
     }
@@ -470,403 +461,6 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
 #undef VQ_G_STORE
 #undef VQ_ADVANCE_TAP
 #undef VQ_PIPE_STEP
-}
-
-// ------------------------------------------------------------------------------------------------
-// LDS-DMA variant of the software-pipelined kernel (aligned Cin, BK = 32): the staging stream is
-// global_load_lds_dwordx4 straight into the other LDS buffer -- no staging VGPRs, no ds_write, half the side
-// slices per K-step.  LDS rows are unpadded (an LDS-DMA instruction writes 64 x 16 contiguous bytes = 8 rows),
-// bank conflicts are avoided by storing chunk c of row r at chunk slot c ^ ((r >> 1) & 7): applied on the
-// per-lane SOURCE address of the DMA and on the fragment read address.  Same k order: bit-identical results.
-// ------------------------------------------------------------------------------------------------
-template <int BM, int BN>
-struct ConvSmemLinear {
-    float a[2][BM][32];
-    float b[2][BN][32];
-};
-
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs a) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int NI = (BM + BN) / 8;        // DMA instructions per K-step (8 rows of 128 B each)
-    constexpr int NG = NI / 4;               // per wave
-    constexpr int MFK = 4 * TM * TN, NMF = 4 * MFK, NFR = TM + TN;
-    constexpr int NFREE = NMF - 3 * NFR;
-    static_assert(NI % 4 == 0 && NFREE >= NG, "tile rows must split over 4 waves and fit the MFMA gaps");
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    ConvSmemLinear<BM, BN>& sm = *reinterpret_cast<ConvSmemLinear<BM, BN>*>(smem_raw);
-
-    if (a.desync) desync_simd_partners();
-    const int tid = threadIdx.x;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / a.tiles_n) * BM;
-    const int n0 = (tile % a.tiles_n) * BN;
-    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
-
-    // ---- staging roles: wave w issues DMA instructions q = w + 4 t; lane -> (row 8 q + lane / 8, slot lane % 8)
-    const char* src_base[NG];     // A: activation slot base (bytes); B: weight row + chunk (bytes) or the zero page
-    int s_off[NG];                // A: byte offset of (pixel, tap (0,0), chunk);  B: 0
-    unsigned s_mask[NG];          // A: taps inside the image;  B: all ones when the row exists, 0 otherwise
-    const int HoWo = a.Ho * a.Wo;
-    const int lrow = lane >> 3, lslot = lane & 7;
-#pragma unroll
-    for (int t = 0; t < NG; ++t) {
-        const int q = wave + 4 * t;
-        if (q < BM / 8) {
-            const int row = 8 * q + lrow;
-            const int chunk = lslot ^ ((row >> 1) & 7);
-            const int m = m0 + row;
-            const bool ok = m < a.M;
-            const int mm = ok ? m : 0;
-            const int n_img = mm / HoWo, rem = mm - n_img * HoWo;
-            const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-            const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
-            src_base[t] = reinterpret_cast<const char*>(a.in);
-            s_off[t] = (((n_img * a.H + ih0) * a.W + iw0) * a.Cs_in + a.coff_in + chunk * 4) * 4;
-            unsigned mask = 0;
-            for (int th = 0; th < a.k; ++th)
-                for (int tw = 0; tw < a.k; ++tw)
-                    if (ok && (unsigned)(ih0 + th) < (unsigned)a.H && (unsigned)(iw0 + tw) < (unsigned)a.W) mask |= 1u << (th * a.k + tw);
-            s_mask[t] = mask;
-        } else {
-            const int row = 8 * (q - BM / 8) + lrow;
-            const int chunk = lslot ^ ((row >> 1) & 7);
-            const int n = n0 + row;
-            src_base[t] = reinterpret_cast<const char*>(a.w + (size_t)(n < a.Cout ? n : 0) * a.Kp + chunk * 4);
-            s_off[t] = 0;
-            s_mask[t] = n < a.Cout ? 0xFFFFFFFFu : 0u;
-        }
-    }
-    int kh = 0, kw = 0, c0 = 0, tap = 0, tap_off = 0, w_off = 0;   // byte offsets of the K-step being staged
-
-    // ---- compute roles
-    const int wm = wave / WN, wn = wave % WN;
-    int fa_off[TM], fa_swz[TM], fb_off[TN], fb_swz[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int r = wm * (BM / WM) + 32 * i + l31;
-        fa_off[i] = r * 128;
-        fa_swz[i] = (r >> 1) & 7;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int r = wn * (BN / WN) + 32 * j + l31;
-        fb_off[j] = r * 128;
-        fb_swz[j] = (r >> 1) & 7;
-    }
-    floatx16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    floatx4 bias_v[TN];   // this lane's 4 output channels in the transposed store (see VQ_EPILOGUE)
-    ConvSeg seg_v[TN];    // where each 32-column group of this wave goes (wave-uniform)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int nb_ = n0 + wn * (BN / WN) + 32 * j;
-        const int n = nb_ + (lane & 7) * 4;
-        bias_v[j] = *reinterpret_cast<const floatx4*>(a.bias + (n < a.Cout ? n : 0));
-        seg_v[j] = a.segs[nb_ < a.Cout ? nb_ >> 5 : 0];
-    }
-
-// one DMA instruction of the staging stream: (A rows) pixel + tap offset, or (B rows) weight row + K offset
-#define VQ_DMA(T_, BUF)                                                                                              \
-    {                                                                                                                \
-        const int q_ = wave + 4 * (T_);                                                                              \
-        const bool is_a = q_ < BM / 8;                                                                               \
-        const bool ok_ = is_a ? ((s_mask[T_] >> tap) & 1u) != 0 : s_mask[T_] != 0;                                   \
-        const char* src_ = ok_ ? src_base[T_] + (is_a ? (unsigned)(s_off[T_] + tap_off) : (unsigned)w_off)           \
-                               : reinterpret_cast<const char*>(a.zeros);                                             \
-        char* dst_ = is_a ? reinterpret_cast<char*>(&sm.a[BUF][0][0]) + q_ * 1024                                     \
-                          : reinterpret_cast<char*>(&sm.b[BUF][0][0]) + (q_ - BM / 8) * 1024;                         \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                        \
-                                         (__attribute__((address_space(3))) void*)dst_, 16, 0, 0);                   \
-    }
-#define VQ_DMA_ADVANCE()                                        \
-    {                                                           \
-        c0 += 32;                                               \
-        w_off += 128;                                           \
-        if (c0 >= a.Cin) {                                      \
-            c0 = 0;                                             \
-            ++tap;                                              \
-            if (++kw == a.k) {                                  \
-                kw = 0;                                         \
-                ++kh;                                           \
-            }                                                   \
-        }                                                       \
-        tap_off = ((kh * a.W + kw) * a.Cs_in + c0) * 4;         \
-    }
-#define VQ_DMA_STEP(BUF, HAS_NEXT)                                                                                    \
-    {                                                                                                                \
-        const char* sa = reinterpret_cast<const char*>(&sm.a[BUF][0][0]);                                             \
-        const char* sb = reinterpret_cast<const char*>(&sm.b[BUF][0][0]);                                             \
-        floatx4 fa[2][TM], fb[2][TN];                                                                                \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
-            fa[0][i] = *reinterpret_cast<const floatx4*>(sa + fa_off[i] + ((half ^ fa_swz[i]) << 4));                 \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                               \
-            fb[0][j] = *reinterpret_cast<const floatx4*>(sb + fb_off[j] + ((half ^ fb_swz[j]) << 4));                 \
-        _Pragma("unroll") for (int q = 0; q < NMF; ++q) {                                                            \
-            const int kk = q / MFK, r = q % MFK, s_ = r / (TM * TN), i_ = (r / TN) % TM, j_ = r % TN;                \
-            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i_][s_], fb[kk & 1][j_][s_], acc[i_][j_], 0, 0, 0); \
-            if (kk + 1 < 4 && r < NFR) {                                                                             \
-                const int c_ = (kk + 1) * 2 + half;                                                                  \
-                if (r < TM)                                                                                          \
-                    fa[(kk + 1) & 1][r < TM ? r : 0] = *reinterpret_cast<const floatx4*>(                            \
-                        sa + fa_off[r < TM ? r : 0] + ((c_ ^ fa_swz[r < TM ? r : 0]) << 4));                          \
-                else                                                                                                 \
-                    fb[(kk + 1) & 1][r >= TM ? r - TM : 0] = *reinterpret_cast<const floatx4*>(                      \
-                        sb + fb_off[r >= TM ? r - TM : 0] + ((c_ ^ fb_swz[r >= TM ? r - TM : 0]) << 4));              \
-            } else if (HAS_NEXT) {                                                                                   \
-                const int fidx = q - (kk + 1 < 4 ? (kk + 1) * NFR : 3 * NFR);                                        \
-                if (fidx < NG) VQ_DMA(fidx < NG ? fidx : 0, (BUF) ^ 1)                                               \
-            }                                                                                                        \
-            __builtin_amdgcn_sched_barrier(0);                                                                       \
-        }                                                                                                            \
-    }
-
-    const int nk = a.Kp / 32;
-#pragma unroll
-    for (int t = 0; t < NG; ++t) VQ_DMA(t, 0)
-    wait_vmcnt<0>();
-    __syncthreads();
-    for (int kc = 0; kc + 1 < nk; ++kc) {
-        VQ_DMA_ADVANCE()              // (tap, c0) now address K-step kc + 1
-        if (kc & 1) {
-            VQ_DMA_STEP(1, true)
-        } else {
-            VQ_DMA_STEP(0, true)
-        }
-        wait_vmcnt<0>();              // this wave's pieces of K-step kc + 1 have landed ...
-        __syncthreads();              // ... and so have everybody else's
-    }
-    if ((nk - 1) & 1) {
-        VQ_DMA_STEP(1, false)
-    } else {
-        VQ_DMA_STEP(0, false)
-    }
-    VQ_EPILOGUE()
-#undef VQ_DMA
-#undef VQ_DMA_ADVANCE
-#undef VQ_DMA_STEP
-}
-
-// ------------------------------------------------------------------------------------------------
-// Ring variant (aligned Cin only): loader / consumer wave specialisation.
-//
-// The ablations (profiles/README.md) show that what keeps the two kernels above at ~73 % of the matrix peak is
-// not bandwidth but ISSUE: an in-order wave that has to issue global loads, LDS stores and waits cannot also
-// keep its SIMD's matrix pipe fed.  Here a workgroup has 8 waves: waves 0-3 ("consumers", one per SIMD) issue
-// nothing but LDS fragment reads and MFMAs; waves 4-7 ("loaders", one per SIMD) stream the im2col tiles
-// global -> LDS with LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write) into a ring of NS stages,
-// NS-1 K-steps ahead, and never touch the matrix pipe.  One s_barrier per K-step hands a landed stage to the
-// consumers and a drained one back to the loaders.  Workgroups are persistent: each walks its tiles
-// (blockIdx, blockIdx + grid, ...) as one flat sequence of K-steps, so the loaders already fill the ring for
-// the next tile while the consumers store the current one.
-//
-// LDS image of a stage: BM + BN rows of 32 floats (128 B), A rows first, rows linear (one DMA instruction
-// = 8 rows = 1 KiB), the 16-byte chunk c of row r stored at chunk slot c ^ ((r >> 1) & 7): the 16 rows a
-// ds_read_b128 lane group touches then fall on 16 distinct bank slots.  The DMA destination is lane-linear,
-// so the swizzle is applied on the per-lane SOURCE address and again on the read address.
-// Same k order as the other kernels: results are bit-identical.
-// ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NS>
-__global__ __launch_bounds__(512) void conv_ring_kernel(ConvArgs a) {
-    static_assert(WM * WN == 4, "4 consumer waves");
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int STAGE_BYTES = (BM + BN) * 128;
-    constexpr int NI = (BM + BN) / 8;      // DMA instructions per stage (8 rows of 128 B each)
-    constexpr int NIL = NI / 4;            // per loader wave
-    static_assert(NI % 4 == 0 && NS >= 3, "tile rows must split over 4 loader waves");
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int ntiles = a.tiles_m * a.tiles_n;
-    const int nk = a.Kp / 32;
-    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int G = my_tiles * nk;           // K-steps this workgroup walks; every wave passes exactly G barriers
-
-    if (wave >= 4) {
-        // ------------------------------------------------------------------ loaders
-        const int L = wave - 4;
-        const int lrow = lane >> 3, lslot = lane & 7;
-        const float* src_base[NIL];        // A: image base (+ channel chunk); B: weight row (+ chunk)
-        int ih0[NIL], iw0[NIL];            // A only; B rows park ih0 at a flag value
-        int ti = 0, kc = 0, kh = 0, kw = 0, c0 = 0;
-        const int HoWo = a.Ho * a.Wo;
-        auto setup_tile = [&](int t_index) __attribute__((always_inline)) {
-            const int tile = xcd_remap((int)blockIdx.x + t_index * (int)gridDim.x, ntiles);
-            const int m0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
-#pragma unroll
-            for (int t = 0; t < NIL; ++t) {
-                const int q = L + 4 * t;
-                if (q < BM / 8) {
-                    const int row = 8 * q + lrow;
-                    const int chunk = lslot ^ ((row >> 1) & 7);
-                    const int m = m0 + row;
-                    const bool ok = m < a.M;
-                    const int mm = ok ? m : 0;
-                    const int n_img = mm / HoWo, rem = mm - n_img * HoWo;
-                    const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-                    src_base[t] = a.in + (size_t)n_img * a.H * a.W * a.Cs_in + a.coff_in + chunk * 4;
-                    ih0[t] = ok ? oh * a.stride - a.pad : -(1 << 20);
-                    iw0[t] = ow * a.stride - a.pad;
-                } else {
-                    const int row = 8 * (q - BM / 8) + lrow;
-                    const int chunk = lslot ^ ((row >> 1) & 7);
-                    const int n = n0 + row;
-                    src_base[t] = n < a.Cout ? a.w + (size_t)n * a.Kp + chunk * 4 : a.zeros;
-                    ih0[t] = n < a.Cout ? 0 : -(1 << 20);
-                    iw0[t] = 0;
-                }
-            }
-        };
-        auto issue = [&](int g) __attribute__((always_inline)) {
-            char* stage = smem_raw + (g % NS) * STAGE_BYTES;
-#pragma unroll
-            for (int t = 0; t < NIL; ++t) {
-                const int q = L + 4 * t;
-                const float* src = a.zeros;
-                if (q < BM / 8) {
-                    const int ih = ih0[t] + kh, iw = iw0[t] + kw;
-                    if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
-                        src = src_base[t] + ((size_t)ih * a.W + iw) * a.Cs_in + c0;
-                } else {
-                    if (ih0[t] == 0) src = src_base[t] + (size_t)kc * 32;
-                }
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(stage + q * 1024), 16, 0, 0);
-            }
-            // advance the issue position: next K-step of this tile, or the first of the next tile
-            ++kc;
-            c0 += 32;
-            if (c0 >= a.Cin) {
-                c0 = 0;
-                if (++kw == a.k) {
-                    kw = 0;
-                    ++kh;
-                }
-            }
-            if (kc == nk) {
-                kc = kh = kw = c0 = 0;
-                ++ti;
-                if (ti < my_tiles) setup_tile(ti);
-            }
-        };
-        if (G > 0) setup_tile(0);
-        for (int g = 0; g < NS - 1 && g < G; ++g) issue(g);
-        for (int g = 0; g < G; ++g) {
-            // stage g has landed once at most the (NS-2) newer stages' DMAs are outstanding
-            if (g + NS - 2 < G)
-                wait_vmcnt<(NS - 2) * NIL>();
-            else
-                wait_vmcnt<0>();
-            if (!(a.dbg & 4)) wg_barrier();                 // consumers may read stage g; stage g-1 is drained
-            if (g + NS - 1 < G && !(a.dbg & 1)) issue(g + NS - 1);   // refill the stage the consumers just left
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------- consumers
-    const int l31 = lane & 31, half = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-    int a_off[TM], a_swz[TM], b_off[TN], b_swz[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int r = wm * (BM / WM) + 32 * i + l31;
-        a_off[i] = r * 128;
-        a_swz[i] = (r >> 1) & 7;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int r = wn * (BN / WN) + 32 * j + l31;
-        b_off[j] = BM * 128 + r * 128;
-        b_swz[j] = (r >> 1) & 7;
-    }
-    float* patch = reinterpret_cast<float*>(smem_raw + NS * STAGE_BYTES) + wave * (32 * 36);
-    const int prow = lane >> 3, pc4 = lane & 7;
-    int g = 0;
-    for (int ti = 0; ti < my_tiles; ++ti) {
-        const int tile = xcd_remap((int)blockIdx.x + ti * (int)gridDim.x, ntiles);
-        const int m0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
-        floatx16 acc[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        floatx4 bias_v[TN];
-        ConvSeg seg_v[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nb_ = n0 + wn * (BN / WN) + 32 * j;
-            const int n = nb_ + pc4 * 4;
-            bias_v[j] = *reinterpret_cast<const floatx4*>(a.bias + (n < a.Cout ? n : 0));
-            seg_v[j] = a.segs[nb_ < a.Cout ? nb_ >> 5 : 0];
-        }
-        for (int kc = 0; kc < nk; ++kc, ++g) {
-            if (!(a.dbg & 4)) wg_barrier();                 // stage g % NS has landed
-            const char* stage = smem_raw + (g % NS) * STAGE_BYTES;
-            floatx4 fa[2][TM], fb[2][TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const floatx4*>(stage + a_off[i] + ((half ^ a_swz[i]) << 4));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const floatx4*>(stage + b_off[j] + ((half ^ b_swz[j]) << 4));
-            // 16 TM TN MFMAs per K-step; the fragment reads of the next 8-wide k group are issued one per MFMA
-            // right behind the first MFMAs of the current group and pinned there (the scheduler would otherwise
-            // sink them to their first use and expose the LDS latency four times per K-step)
-            constexpr int MFK = 4 * TM * TN, NFR = TM + TN;
-#pragma unroll
-            for (int q = 0; q < 4 * MFK; ++q) {
-                const int kk = q / MFK, r = q % MFK, s_ = r / (TM * TN), i_ = (r / TN) % TM, j_ = r % TN;
-                acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i_][s_], fb[kk & 1][j_][s_], acc[i_][j_], 0, 0, 0);
-                if (kk + 1 < 4 && r < NFR) {
-                    const int c = (kk + 1) * 2 + half;
-                    if (r < TM)
-                        fa[(kk + 1) & 1][r < TM ? r : 0] =
-                            *reinterpret_cast<const floatx4*>(stage + a_off[r < TM ? r : 0] + ((c ^ a_swz[r < TM ? r : 0]) << 4));
-                    else
-                        fb[(kk + 1) & 1][r >= TM ? r - TM : 0] =
-                            *reinterpret_cast<const floatx4*>(stage + b_off[r >= TM ? r - TM : 0] + ((c ^ b_swz[r >= TM ? r - TM : 0]) << 4));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // epilogue: + bias, ReLU, transposed 16-byte stores through this wave's private LDS patch (no barrier: the
-        // loaders keep filling the ring for the next tile meanwhile)
-        const bool full_m = m0 + BM <= a.M;
-        if (a.dbg & 32) continue;   // timing experiments: skip the epilogue
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nb = n0 + wn * (BN / WN) + 32 * j;
-            if (nb < a.Cout) {
-                const ConvSeg sg = seg_v[j];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = acc[i][j][r];
-                    const int mb = m0 + wm * (BM / WM) + 32 * i;
-#pragma unroll
-                    for (int ps = 0; ps < 4; ++ps) {
-                        const int row = prow + 8 * ps;
-                        floatx4 v = *reinterpret_cast<const floatx4*>(&patch[row * 36 + pc4 * 4]);
-                        v += bias_v[j];
-                        if (sg.relu) {
-                            v[0] = fmaxf(v[0], 0.f);
-                            v[1] = fmaxf(v[1], 0.f);
-                            v[2] = fmaxf(v[2], 0.f);
-                            v[3] = fmaxf(v[3], 0.f);
-                        }
-                        if ((full_m || mb + row < a.M) && nb + pc4 * 4 < a.Cout)
-                            *reinterpret_cast<floatx4*>(sg.out_base + (size_t)(mb + row) * sg.Cs + nb + pc4 * 4) = v;
-                    }
-                }
-            }
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1038,12 +632,7 @@ static const ConvTile kTiles[] = {
     {128, 128, 32, 0}, {128, 128, 16, 0}, {128, 96, 32, 0}, {128, 96, 16, 0}, {128, 64, 32, 0}, {128, 64, 16, 0},
     {64, 128, 32, 0},  {64, 128, 16, 0},  {64, 64, 32, 0},  {64, 64, 16, 0},  {128, 32, 32, 0}, {128, 32, 16, 0},
     {128, 128, 32, 1}, {128, 128, 16, 1}, {128, 96, 32, 1}, {128, 96, 16, 1}, {128, 64, 32, 1}, {128, 64, 16, 1},
-    {64, 128, 32, 1},  {64, 128, 16, 1},  {64, 64, 32, 1},  {64, 64, 16, 1},  {128, 32, 32, 1}, {128, 32, 16, 1},
-    // pipe = 2: ring kernel (loader/consumer waves, LDS-DMA, persistent); bk field = number of ring stages
-    {128, 128, 3, 2},  {128, 128, 4, 2},  {128, 64, 3, 2},   {128, 64, 4, 2},  {64, 128, 3, 2},  {64, 64, 3, 2},
-    {64, 64, 4, 2},
-    // pipe = 3: software-pipelined kernel with LDS-DMA staging (BK = 32)
-    {128, 128, 32, 3}, {128, 96, 32, 3},  {128, 64, 32, 3},  {64, 128, 32, 3}, {64, 64, 32, 3},  {128, 32, 32, 3}};
+    {64, 128, 32, 1},  {64, 128, 16, 1},  {64, 64, 32, 1},  {64, 64, 16, 1},  {128, 32, 32, 1}, {128, 32, 16, 1}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 
 template <int BM, int BN, int WM, int WN, int BK>
@@ -1060,59 +649,6 @@ static int launch_conv_pipe_t(vq_tsn* net, ConvArgs& a) {
     kern<<<a.tiles_m * a.tiles_n, 256, lds, net->stream>>>(a);
     VQ_CHECK_LAUNCH();
     return VQ_OK;
-}
-
-template <int BM, int BN, int WM, int WN, int NS>
-static int launch_conv_ring_t(vq_tsn* net, ConvArgs& a) {
-    a.tiles_m = cdiv(a.M, BM);
-    a.tiles_n = cdiv(a.Cout, BN);
-    auto kern = conv_ring_kernel<BM, BN, WM, WN, NS>;
-    const size_t lds = (size_t)NS * (BM + BN) * 128 + 4 * 32 * 36 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    const int per_cu = std::max(1, std::min(2, (int)((160 * 1024) / lds)));   // 8-wave workgroups: at most 2 per CU
-    const int ntiles = a.tiles_m * a.tiles_n;
-    int grid = std::min(ntiles, net->cus * per_cu);
-    if (grid >= 8) grid &= ~7;                                                // keep block b on the XCD of b % 8 across its tiles
-    kern<<<grid, 512, lds, net->stream>>>(a);
-    VQ_CHECK_LAUNCH();
-    return VQ_OK;
-}
-
-static int launch_conv_ring(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
-#define R_(BM_, BN_, WM_, WN_, NS_) \
-    if (t.bm == BM_ && t.bn == BN_ && t.bk == NS_) return launch_conv_ring_t<BM_, BN_, WM_, WN_, NS_>(net, a);
-    R_(128, 128, 2, 2, 3) R_(128, 128, 2, 2, 4) R_(128, 64, 2, 2, 3) R_(128, 64, 2, 2, 4) R_(64, 128, 2, 2, 3)
-    R_(64, 64, 2, 2, 3) R_(64, 64, 2, 2, 4)
-#undef R_
-    return fail(VQ_E_INVALID, "no ring kernel for tile %dx%d with %d stages", t.bm, t.bn, t.bk);
-}
-
-template <int BM, int BN, int WM, int WN>
-static int launch_conv_dma_t(vq_tsn* net, ConvArgs& a) {
-    a.tiles_m = cdiv(a.M, BM);
-    a.tiles_n = cdiv(a.Cout, BN);
-    auto kern = conv_igemm_dma_kernel<BM, BN, WM, WN>;
-    const size_t lds = std::max(sizeof(ConvSmemLinear<BM, BN>), (size_t)4 * 32 * 36 * sizeof(float));
-    static bool attr_set = false;
-    if (!attr_set) {
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    kern<<<a.tiles_m * a.tiles_n, 256, lds, net->stream>>>(a);
-    VQ_CHECK_LAUNCH();
-    return VQ_OK;
-}
-
-static int launch_conv_dma(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
-#define D_(BM_, BN_, WM_, WN_) \
-    if (t.bm == BM_ && t.bn == BN_) return launch_conv_dma_t<BM_, BN_, WM_, WN_>(net, a);
-    D_(128, 128, 2, 2) D_(128, 96, 4, 1) D_(128, 64, 2, 2) D_(64, 128, 2, 2) D_(64, 64, 2, 2) D_(128, 32, 4, 1)
-#undef D_
-    return fail(VQ_E_INVALID, "no LDS-DMA kernel for tile %dx%d", t.bm, t.bn);
 }
 
 static int launch_conv_pipe(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
@@ -1186,7 +722,7 @@ static void fill_conv_args(vq_tsn* net, int li, int n_crops, ConvArgs& a) {
     a.tiles_m = a.tiles_n = 0;
     a.in_bytes = (unsigned)std::min<size_t>((size_t)n_crops * ts.h * ts.w * ts.c * sizeof(float), 0xFFFFFFF0u);
     a.w_bytes = (unsigned)((size_t)L.cout * a.Kp * sizeof(float));
-    static const int desync = getenv("VQ_TSN_DESYNC") ? atoi(getenv("VQ_TSN_DESYNC")) : 1;
+    static const int desync = getenv("VQ_TSN_DESYNC") ? atoi(getenv("VQ_TSN_DESYNC")) : 0;   // experiment knob; no measured gain
     a.desync = desync;
     static const int dbg = getenv("VQ_TSN_DBG") ? atoi(getenv("VQ_TSN_DBG")) : 0;
     a.dbg = dbg;
@@ -1197,9 +733,7 @@ static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
     fill_conv_args(net, li, n_crops, a);
     const bool small = (net->layers[li].cin % KPAD) != 0;
     if (small && kTiles[tile_idx].pipe) tile_idx = heuristic_tile(a.M, a.Cout, net->cus);   // small-Cin stem: plain kernel only
-    if ((kTiles[tile_idx].pipe == 1 || kTiles[tile_idx].pipe == 3) && a.in_bytes >= 0x7FFFFFF0u) tile_idx = heuristic_tile(a.M, a.Cout, net->cus);   // 32-bit offsets
-    if (kTiles[tile_idx].pipe == 3 && !small) return launch_conv_dma(net, a, kTiles[tile_idx]);
-    if (kTiles[tile_idx].pipe == 2 && !small) return launch_conv_ring(net, a, kTiles[tile_idx]);
+    if (kTiles[tile_idx].pipe && a.in_bytes >= 0x7FFFFFF0u) tile_idx = heuristic_tile(a.M, a.Cout, net->cus);   // 32-bit offsets
     if (kTiles[tile_idx].pipe == 1 && !small) return launch_conv_pipe(net, a, kTiles[tile_idx]);
     return small ? launch_conv<true>(net, a, kTiles[tile_idx]) : launch_conv<false>(net, a, kTiles[tile_idx]);
 }
