@@ -188,6 +188,14 @@ def bench_sim(args, rank, world, device, stream):
     roof = {"bound": "hbm", "kernel": "scan_kernel<float,2,5,4>", "achieved": nbytes / kern_ms / 1e6, "peak": PEAK_HBM_GBS,
             "unit": "GB/s", "frac": nbytes / kern_ms / 1e6 / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": kern_ms,
             "bytes_per_launch": nbytes}
+    # HBM bytes per launch from the PMC counters (collected off-line by tools/pmc_sim.sh on the full 1M-row launch and
+    # committed; FETCH_SIZE doubled as the microarchitecture guide prescribes for gfx950); scaled to this rank's rows
+    tpath = os.path.join(ROOT, "profiles", "r01_scan_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        roof["traffic"] = tj["hbm_bytes_per_launch"] * rows / SIM_N
+        roof["traffic_source"] = "profiles/r01_scan_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
     return dt, steps, roof, db, row0, rows
 
 
