@@ -82,3 +82,36 @@ def test_resize_and_crop0():
     ramp = np.tile(np.arange(0, 200, 2, dtype=np.uint8)[None, :], (50, 1))     # horizontal ramp stays monotone
     r = frames.resize_bilinear(ramp, (340, 256))
     assert r.shape == (256, 340) and (np.diff(r[0].astype(int)) >= 0).all() and r[0, 0] == 0 and r[0, -1] == 198
+
+
+def test_caffemodel_round_trip(tmp_path):
+    """The schema-less .caffemodel reader against files written by our own encoder (no .caffemodel ships with the
+    reference: blob ORDER of the BN layer is unpinned, the container format is what is tested here)."""
+    from video_query_algorithms_amd.tsn import bn_inception as bi, caffemodel
+    from video_query_algorithms_amd.tsn.net import synthetic_weights
+    g = bi.bn_inception(10)
+    w = synthetic_weights(g, seed=9)
+    path = str(tmp_path / "flow.caffemodel")
+    caffemodel.write_caffemodel(path, g, w)
+    raw = caffemodel.read_caffemodel(path)
+    assert raw["conv1/7x7_s2"]["type"] == "Convolution" and raw["conv1/7x7_s2"]["blobs"][0].shape == (64, 10, 7, 7)
+    assert raw["conv1/7x7_s2_bn"]["type"] == "BN" and len(raw["conv1/7x7_s2_bn"]["blobs"]) == 4
+    back = caffemodel.weights_from_caffemodel(path, g)
+    assert set(back) == set(w)
+    for layer, d in w.items():
+        for k, a in d.items():
+            assert back[layer][k].dtype == np.float32 and (back[layer][k] == a).all(), (layer, k)
+    # legacy 4-d shape fields + V1 'layers' container
+    legacy = (caffemodel._enc_varint(1 << 3) + caffemodel._enc_varint(2) + caffemodel._enc_varint(2 << 3) + caffemodel._enc_varint(3)
+              + caffemodel._enc_varint(3 << 3) + caffemodel._enc_varint(1) + caffemodel._enc_varint(4 << 3) + caffemodel._enc_varint(1)
+              + caffemodel._enc_ld(5, np.arange(6, dtype="<f4").tobytes()))
+    v1 = caffemodel._enc_ld(2, caffemodel._enc_ld(4, b"ip") + caffemodel._enc_varint(5 << 3) + caffemodel._enc_varint(14)
+                            + caffemodel._enc_ld(6, legacy))
+    (tmp_path / "v1.caffemodel").write_bytes(v1)
+    r = caffemodel.read_caffemodel(str(tmp_path / "v1.caffemodel"))
+    assert r["ip"]["type"] == 14 and r["ip"]["blobs"][0].shape == (2, 3, 1, 1) and r["ip"]["blobs"][0].ravel().tolist() == [0, 1, 2, 3, 4, 5]
+    bad = dict(w)
+    del bad["conv2/3x3_bn"]
+    caffemodel.write_caffemodel(str(tmp_path / "bad.caffemodel"), g, bad)
+    with pytest.raises(KeyError):
+        caffemodel.weights_from_caffemodel(str(tmp_path / "bad.caffemodel"), g)

@@ -261,8 +261,13 @@ def test_calcsig_command_line_end_to_end(tsn, tmp_path):
     weights = {}
     for name, c, seed in (("rgb", 3, 2), ("flow", 10, 5)):
         weights[name] = net.synthetic_weights(bi.bn_inception(c), seed=seed)
-        wfile[name] = str(tmp_path / ("ucf101_split1_tsn_%s_bn.npz" % name))
-        caffe_net.save_weights(wfile[name], weights[name])
+        if name == "rgb":                                  # one stream from a .caffemodel (what the reference passes) ...
+            from video_query_algorithms_amd.tsn import caffemodel
+            wfile[name] = str(tmp_path / "ucf101_split1_tsn_rgb_bn_inception.caffemodel")
+            caffemodel.write_caffemodel(wfile[name], bi.bn_inception(c), weights[name])
+        else:                                              # ... the other from the .npz layout
+            wfile[name] = str(tmp_path / ("ucf101_split1_tsn_%s_bn.npz" % name))
+            caffe_net.save_weights(wfile[name], weights[name])
     out_dir = tmp_path / "features"
     rc = calcSig_wOF.main([str(root), protos["rgb"], wfile["rgb"], protos["flow"], wfile["flow"], "--num_frame_per_video", "3",
                            "--outFeatures_dir", str(out_dir), "--modelname", "UCF101_split1", "--frame_ext", ".ppm",

@@ -7,9 +7,10 @@ frame_size=(340,256))`` (:94), ``predict_single_flow_stack(flow_stack, score_nam
 unchanged on top of it, plus ``extract_clips`` -- the batched path (all B*T crops in one forward) the drop-in
 command line uses.
 
-Weights: ``.npz`` with ``<layer>/W``, ``<layer>/b`` for convolutions and ``<layer>/scale|shift|mean|var`` for the
-frozen BN layers, or ``synthetic:<seed>`` (random init of the right architecture).  A ``.caffemodel`` importer is the
-"next" row 8(f)-2 and is not built yet: passing one raises.
+Weights: a ``.caffemodel`` (decoded by ``tsn/caffemodel.py`` without Caffe or a protobuf schema; the BN blob order is
+"parity unpinned", see there), an ``.npz`` with ``<layer>/W``, ``<layer>/b`` for convolutions and
+``<layer>/scale|shift|mean|var`` for the frozen BN layers, or ``synthetic:<seed>`` (random init of the right
+architecture).
 """
 from __future__ import annotations
 
@@ -29,8 +30,10 @@ def load_weights(graph, spec: str):
             layer, field = key.rsplit("/", 1)
             out.setdefault(layer, {})[field] = z[key]
         return out
-    raise NotImplementedError("weights file %r: only .npz and synthetic:<seed> are supported so far (the .caffemodel "
-                              "importer is not built yet)" % spec)
+    if spec.endswith(".caffemodel"):
+        from .caffemodel import weights_from_caffemodel
+        return weights_from_caffemodel(spec, graph)
+    raise ValueError("weights file %r: expected .caffemodel, .npz or synthetic:<seed>" % spec)
 
 
 def save_weights(path: str, weights):
