@@ -67,3 +67,42 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.delenv("VQ_AMD_LIB")
     monkeypatch.setattr(vqa._lib, "_lib", None)
     vqa._lib.load()
+
+
+def test_install_patches_exactly_the_hot_path_methods():
+    """install() swaps the four Ticket methods and optimize_weights on the classes it is given -- checked on the
+    reference's own classes when the checkout is present (build container), on look-alikes otherwise."""
+    import sys
+    import types
+    import video_query_algorithms_amd as vqa
+    ref_src = "/root/reference/src"
+    if os.path.isdir(ref_src):
+        sys.dont_write_bytecode = True
+        stub = types.ModuleType("coreapi")
+        stub.Client = object
+        stub.auth = types.SimpleNamespace(TokenAuthentication=object)
+        sys.modules.setdefault("coreapi", stub)
+        os.environ.setdefault("COMPUTE_EPS", "0.000003")
+        sys.path.insert(0, ref_src)
+        try:
+            from models import Hyperparameter as RefHp, Ticket as RefTicket
+        finally:
+            sys.path.remove(ref_src)
+        Ticket = type("Ticket", (RefTicket,), {})              # patch subclasses: leave the imported module pristine
+        Hp = type("Hyperparameter", (RefHp,), {})
+        untouched = ["add_matches_to_database", "catch_errors", "change_process_state", "create_final_report",
+                     "create_query_result", "_get_candidate_features", "_request"]
+    else:
+        Ticket = type("Ticket", (), {n: (lambda self: None) for n in ("compute_similarities", "compute_scores",
+                                                                       "select_clips_to_review", "lowest_scoring_user_match",
+                                                                       "create_query_result")})
+        Hp = type("Hyperparameter", (), {"optimize_weights": lambda self, t: None})
+        untouched = ["create_query_result"]
+    before = {n: getattr(Ticket, n) for n in untouched}
+    vqa.install(Ticket, Hp)
+    for n in ("compute_similarities", "compute_scores", "select_clips_to_review", "lowest_scoring_user_match"):
+        assert getattr(Ticket, n) is getattr(vqa.TicketScoring, n)
+    assert Hp.optimize_weights is vqa.Hyperparameter.optimize_weights
+    for n in untouched:
+        assert getattr(Ticket, n) is before[n]
+    assert Ticket.feature_db is None
