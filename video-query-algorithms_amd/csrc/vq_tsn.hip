@@ -441,19 +441,18 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     _Pragma("unroll") for (int i = 0; i < NG; ++i) VQ_G_LOAD(i, 0)
     _Pragma("unroll") for (int i = 0; i < NG; ++i) VQ_G_STORE(i, 0)
     __syncthreads();
+    // (one instantiation of the step with a run-time buffer index: duplicating the body per buffer made the
+    // register allocator keep the accumulators in VGPRs across the merge and copy all of them into AGPRs -- 16
+    // v_accvgpr_write per tile and K-step -- in front of every body)
     for (int kc = 0; kc + 1 < nk; ++kc) {
         VQ_ADVANCE_TAP()              // (kh, kw, c0) now address tile kc + 1
-        if (kc & 1) {
-            VQ_PIPE_STEP(1, kc, true)
-        } else {
-            VQ_PIPE_STEP(0, kc, true)
-        }
+        const int buf = kc & 1;
+        VQ_PIPE_STEP(buf, kc, true)
         __syncthreads();
     }
-    if ((nk - 1) & 1) {
-        VQ_PIPE_STEP(1, nk - 1, false)
-    } else {
-        VQ_PIPE_STEP(0, nk - 1, false)
+    {
+        const int buf = (nk - 1) & 1;
+        VQ_PIPE_STEP(buf, nk - 1, false)
     }
 
     VQ_EPILOGUE()
