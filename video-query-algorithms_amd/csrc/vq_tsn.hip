@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         b_off[i] = (n < a.Cout && b_row[i] < BN) ? (unsigned)((n * a.Kp + b_col[i] * 4) * 4) : 0xFFFFFFFFu;
     }
 
-    floatx4 ra[NA], rb[NB];
+    floatx4 ra[2][NA], rb[2][NB];   // two staging sets: tile kc+1 waits in one while tile kc+2 is fetched into the other
     int kh = 0, kw = 0, c0 = 0, tap = 0, tap_off = 0;   // tap_off: byte offset of (kh, kw, c0) relative to tap (0,0)
 
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -373,28 +373,28 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         seg_v[j] = a.segs[nb_ < a.Cout ? nb_ >> 5 : 0];
     }
 
-#define VQ_G_LOAD(IDX, KC)                                                                                     \
+#define VQ_G_LOAD(IDX, KC, SET)                                                                                \
     {                                                                                                          \
         if ((IDX) < NA) {                                                                                      \
             const int ii = (IDX) < NA ? (IDX) : 0;                                                             \
             const unsigned off = ((a_mask[ii] >> tap) & 1u) ? (unsigned)(a_off[ii] + tap_off) : 0xFFFFFFFFu;   \
-            ra[ii] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0));   \
+            ra[SET][ii] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0)); \
         } else {                                                                                               \
             const int ii = (IDX) >= NA ? (IDX) - NA : 0;                                                       \
             const unsigned off = b_off[ii] == 0xFFFFFFFFu ? 0xFFFFFFFFu : b_off[ii] + (unsigned)(KC) * (BK * 4); \
-            rb[ii] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, off, 0, 0));    \
+            rb[SET][ii] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, off, 0, 0)); \
         }                                                                                                      \
     }
-#define VQ_G_STORE(IDX, BUF)                                                                                   \
+#define VQ_G_STORE(IDX, BUF, SET)                                                                              \
     {                                                                                                          \
         if ((IDX) < NA) {                                                                                      \
             const int ii = (IDX) < NA ? (IDX) : 0;                                                             \
-            if ((BM * CPR) % NT == 0 || a_row[ii] < BM)                                                       \
-                *reinterpret_cast<floatx4*>(&sm.a[BUF][a_row[ii]][a_col[ii] * 4]) = ra[ii];                    \
+            if ((BM * CPR) % NT == 0 || a_row[ii] < BM)                                                        \
+                *reinterpret_cast<floatx4*>(&sm.a[BUF][a_row[ii]][a_col[ii] * 4]) = ra[SET][ii];               \
         } else {                                                                                               \
             const int ii = (IDX) >= NA ? (IDX) - NA : 0;                                                       \
-            if ((BN * CPR) % NT == 0 || b_row[ii] < BN)                                                       \
-                *reinterpret_cast<floatx4*>(&sm.b[BUF][b_row[ii]][b_col[ii] * 4]) = rb[ii];                    \
+            if ((BN * CPR) % NT == 0 || b_row[ii] < BN)                                                        \
+                *reinterpret_cast<floatx4*>(&sm.b[BUF][b_row[ii]][b_col[ii] * 4]) = rb[SET][ii];               \
         }                                                                                                      \
     }
 #define VQ_ADVANCE_TAP()                                        \
@@ -410,8 +410,10 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         }                                                       \
         tap_off = ((kh * a.W + kw) * a.Cs_in + c0) * 4;         \
     }
-// One K-step on LDS buffer BUF.  HAS_NEXT: also stage tile KC+1 (global -> registers -> LDS buffer BUF^1).
-#define VQ_PIPE_STEP(BUF, KC, HAS_NEXT)                                                                        \
+// One K-step on LDS buffer BUF (compute on tile KC).  DO_STORE: tile KC+1, fetched during the previous step into
+// staging set SS, goes to LDS buffer BUF^1 behind the first MFMAs (a whole K-step after its loads were issued, so the
+// vmcnt wait in front of the LDS store does not stall).  DO_LOAD: tile KC+2 is fetched into staging set SL.
+#define VQ_PIPE_STEP(BUF, KC, DO_STORE, DO_LOAD, SS, SL)                                                       \
     {                                                                                                          \
         floatx4 fa[2][TM], fb[2][TN];                                                                          \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                         \
@@ -428,33 +430,57 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
                 else                                                                                           \
                     fb[(kk + 1) & 1][r >= TM ? r - TM : 0] = *reinterpret_cast<const floatx4*>(                \
                         &sm.b[BUF][brow0 + 32 * (r >= TM ? r - TM : 0)][(kk + 1) * 8 + half * 4]);             \
-            } else if (HAS_NEXT) {                                                                             \
+            } else {                                                                                           \
                 const int fidx = q - (kk + 1 < NKK ? (kk + 1) * NFR : (NKK - 1) * NFR);                        \
-                if (fidx < NG) VQ_G_LOAD(fidx, (KC) + 1)                                                       \
-                else if (fidx >= NFREE - NG) VQ_G_STORE(fidx - (NFREE - NG), (BUF) ^ 1)                        \
+                if ((DO_STORE) && fidx < NG) VQ_G_STORE(fidx < NG ? fidx : 0, (BUF) ^ 1, SS)                   \
+                else if ((DO_LOAD) && fidx >= NG && fidx < 2 * NG) VQ_G_LOAD(fidx - NG < NG ? fidx - NG : 0, (KC) + 2, SL) \
             }                                                                                                  \
             __builtin_amdgcn_sched_barrier(0);                                                                 \
         }                                                                                                      \
     }
 
     const int nk = a.Kp / BK;
-    _Pragma("unroll") for (int i = 0; i < NG; ++i) VQ_G_LOAD(i, 0)
-    _Pragma("unroll") for (int i = 0; i < NG; ++i) VQ_G_STORE(i, 0)
+    _Pragma("unroll") for (int i = 0; i < NG; ++i) VQ_G_LOAD(i, 0, 0)
+    _Pragma("unroll") for (int i = 0; i < NG; ++i) VQ_G_STORE(i, 0, 0)
+    if (nk > 1) {
+        VQ_ADVANCE_TAP()              // (tap, c0) now address tile 1
+        _Pragma("unroll") for (int i = 0; i < NG; ++i) VQ_G_LOAD(i, 1, 1)
+    }
     __syncthreads();
-    // (one instantiation of the step with a run-time buffer index: duplicating the body per buffer made the
-    // register allocator keep the accumulators in VGPRs across the merge and copy all of them into AGPRs -- 16
-    // v_accvgpr_write per tile and K-step -- in front of every body)
-    for (int kc = 0; kc + 1 < nk; ++kc) {
-        VQ_ADVANCE_TAP()              // (kh, kw, c0) now address tile kc + 1
-        const int buf = kc & 1;
-        VQ_PIPE_STEP(buf, kc, true)
+    // Steady state (steps 0 .. nk-3: store tile kc+1, fetch tile kc+2), unrolled by two so that the staging sets have
+    // static names, as a straight-line pair with no exit in the middle (a mid-loop exit made the register allocator
+    // shuttle the accumulators between VGPRs and AGPRs on every trip).
+    const int n_steady = nk > 2 ? nk - 2 : 0;
+    int kc = 0;
+    for (; kc + 1 < n_steady; kc += 2) {
+        VQ_ADVANCE_TAP()              // tile kc + 2
+        VQ_PIPE_STEP(0, kc, true, true, 1, 0)
+        __syncthreads();
+        VQ_ADVANCE_TAP()              // tile kc + 3
+        VQ_PIPE_STEP(1, kc + 1, true, true, 0, 1)
         __syncthreads();
     }
-    {
-        const int buf = (nk - 1) & 1;
-        VQ_PIPE_STEP(buf, nk - 1, false)
+    if (kc < n_steady) {              // odd number of steady steps: one more even-indexed step
+        VQ_ADVANCE_TAP()
+        VQ_PIPE_STEP(0, kc, true, true, 1, 0)
+        __syncthreads();
+        ++kc;
     }
-
+    // tail: the step that still has a successor to store (nothing left to fetch), then the last step
+    if (kc + 1 < nk) {
+        if (kc & 1) {
+            VQ_PIPE_STEP(1, kc, true, false, 0, 0)
+        } else {
+            VQ_PIPE_STEP(0, kc, true, false, 1, 1)
+        }
+        __syncthreads();
+        ++kc;
+    }
+    if (kc & 1) {
+        VQ_PIPE_STEP(1, kc, false, false, 0, 0)
+    } else {
+        VQ_PIPE_STEP(0, kc, false, false, 0, 0)
+    }
     VQ_EPILOGUE()
 #undef VQ_G_LOAD
 #undef VQ_G_STORE
