@@ -301,6 +301,10 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     constexpr int NG = NA + NB;              // global loads (= LDS stores) per K-step
     constexpr int NFREE = NMF - (NKK - 1) * NFR;
     static_assert(NFREE >= 2 * NG, "not enough MFMA gaps for the staging slices");
+    // EARLY: the LDS stores of tile kc+1 are all issued before the last k group of step kc, so a barrier right behind
+    // them lets that last group's gaps prefetch the first fragments of step kc+1: no LDS latency is exposed at the
+    // start of a step.
+    constexpr bool EARLY = (NKK - 1) * (MFK - NFR) >= NG && NFREE - NFR >= 2 * NG;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     ConvSmem<BM, BN, BK>& sm = *reinterpret_cast<ConvSmem<BM, BN, BK>*>(smem_raw);
 
@@ -410,16 +414,19 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         }                                                       \
         tap_off = ((kh * a.W + kw) * a.Cs_in + c0) * 4;         \
     }
-// One K-step on LDS buffer BUF (compute on tile KC).  DO_STORE: tile KC+1, fetched during the previous step into
-// staging set SS, goes to LDS buffer BUF^1 behind the first MFMAs (a whole K-step after its loads were issued, so the
-// vmcnt wait in front of the LDS store does not stall).  DO_LOAD: tile KC+2 is fetched into staging set SL.
+// One K-step on LDS buffer BUF (compute on tile KC); its first fragments are already in fa[0] / fb[0].
+// DO_STORE: tile KC+1, fetched during the previous step into staging set SS, goes to LDS buffer BUF^1 behind the first
+// MFMAs (a whole K-step after its loads were issued, so the vmcnt wait in front of the LDS store does not stall); with
+// EARLY a barrier follows the last of these stores and the last k group prefetches the first fragments of step KC+1.
+// DO_LOAD: tile KC+2 is fetched into staging set SL.
 #define VQ_PIPE_STEP(BUF, KC, DO_STORE, DO_LOAD, SS, SL)                                                       \
     {                                                                                                          \
-        floatx4 fa[2][TM], fb[2][TN];                                                                          \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                         \
-            fa[0][i] = *reinterpret_cast<const floatx4*>(&sm.a[BUF][arow0 + 32 * i][half * 4]);                \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                         \
-            fb[0][j] = *reinterpret_cast<const floatx4*>(&sm.b[BUF][brow0 + 32 * j][half * 4]);                \
+        if (!EARLY) {                                                                                          \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                     \
+                fa[0][i] = *reinterpret_cast<const floatx4*>(&sm.a[BUF][arow0 + 32 * i][half * 4]);            \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
+                fb[0][j] = *reinterpret_cast<const floatx4*>(&sm.b[BUF][brow0 + 32 * j][half * 4]);            \
+        }                                                                                                      \
         _Pragma("unroll") for (int q = 0; q < NMF; ++q) {                                                      \
             const int kk = q / MFK, r = q % MFK, s_ = r / (TM * TN), i_ = (r / TN) % TM, j_ = r % TN;          \
             acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i_][s_], fb[kk & 1][j_][s_], acc[i_][j_], 0, 0, 0); \
@@ -430,10 +437,20 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
                 else                                                                                           \
                     fb[(kk + 1) & 1][r >= TM ? r - TM : 0] = *reinterpret_cast<const floatx4*>(                \
                         &sm.b[BUF][brow0 + 32 * (r >= TM ? r - TM : 0)][(kk + 1) * 8 + half * 4]);             \
+            } else if (EARLY && (DO_STORE) && kk + 1 == NKK && r < NFR) {                                      \
+                if (r < TM)                                                                                    \
+                    fa[0][r < TM ? r : 0] = *reinterpret_cast<const floatx4*>(                                 \
+                        &sm.a[(BUF) ^ 1][arow0 + 32 * (r < TM ? r : 0)][half * 4]);                            \
+                else                                                                                           \
+                    fb[0][r >= TM ? r - TM : 0] = *reinterpret_cast<const floatx4*>(                           \
+                        &sm.b[(BUF) ^ 1][brow0 + 32 * (r >= TM ? r - TM : 0)][half * 4]);                      \
             } else {                                                                                           \
-                const int fidx = q - (kk + 1 < NKK ? (kk + 1) * NFR : (NKK - 1) * NFR);                        \
-                if ((DO_STORE) && fidx < NG) VQ_G_STORE(fidx < NG ? fidx : 0, (BUF) ^ 1, SS)                   \
-                else if ((DO_LOAD) && fidx >= NG && fidx < 2 * NG) VQ_G_LOAD(fidx - NG < NG ? fidx - NG : 0, (KC) + 2, SL) \
+                const int fidx = q - (kk + 1 < NKK ? (kk + 1) * NFR : (NKK - 1) * NFR + (EARLY && (DO_STORE) ? NFR : 0)); \
+                if ((DO_STORE) && fidx < NG) {                                                                 \
+                    VQ_G_STORE(fidx < NG ? fidx : 0, (BUF) ^ 1, SS)                                            \
+                    if (EARLY && fidx == NG - 1) __syncthreads(); /* tile KC+1 is complete in LDS */           \
+                } else if ((DO_LOAD) && fidx >= NG && fidx < 2 * NG)                                           \
+                    VQ_G_LOAD(fidx - NG < NG ? fidx - NG : 0, (KC) + 2, SL)                                    \
             }                                                                                                  \
             __builtin_amdgcn_sched_barrier(0);                                                                 \
         }                                                                                                      \
@@ -447,23 +464,44 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         _Pragma("unroll") for (int i = 0; i < NG; ++i) VQ_G_LOAD(i, 1, 1)
     }
     __syncthreads();
+    floatx4 fa[2][TM], fb[2][TN];     // MFMA operand fragments, double-buffered over the 8-wide k groups
+    if (EARLY) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const floatx4*>(&sm.a[0][arow0 + 32 * i][half * 4]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const floatx4*>(&sm.b[0][brow0 + 32 * j][half * 4]);
+    }
     // Steady state (steps 0 .. nk-3: store tile kc+1, fetch tile kc+2), unrolled by two so that the staging sets have
     // static names, as a straight-line pair with no exit in the middle (a mid-loop exit made the register allocator
     // shuttle the accumulators between VGPRs and AGPRs on every trip).
+    // End-of-step barrier: every wave is done READING buffer b before anybody stores tile kc+2 into it.  With EARLY
+    // the only LDS operations still in flight are the NFR fragment prefetches of the next step (from the other
+    // buffer), so the wait is counted and the barrier raw -- a full __syncthreads() would wait for those prefetches
+    // and put the LDS latency right back in front of the next step's first MFMA.
+#define VQ_END_BARRIER()                                                     \
+    {                                                                        \
+        if (EARLY) {                                                         \
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NFR) : "memory");     \
+            __builtin_amdgcn_s_barrier();                                    \
+            asm volatile("" ::: "memory");                                   \
+        } else {                                                             \
+            __syncthreads();                                                 \
+        }                                                                    \
+    }
     const int n_steady = nk > 2 ? nk - 2 : 0;
     int kc = 0;
     for (; kc + 1 < n_steady; kc += 2) {
         VQ_ADVANCE_TAP()              // tile kc + 2
         VQ_PIPE_STEP(0, kc, true, true, 1, 0)
-        __syncthreads();
+        VQ_END_BARRIER()
         VQ_ADVANCE_TAP()              // tile kc + 3
         VQ_PIPE_STEP(1, kc + 1, true, true, 0, 1)
-        __syncthreads();
+        VQ_END_BARRIER()
     }
     if (kc < n_steady) {              // odd number of steady steps: one more even-indexed step
         VQ_ADVANCE_TAP()
         VQ_PIPE_STEP(0, kc, true, true, 1, 0)
-        __syncthreads();
+        VQ_END_BARRIER()
         ++kc;
     }
     // tail: the step that still has a successor to store (nothing left to fetch), then the last step
@@ -473,7 +511,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         } else {
             VQ_PIPE_STEP(0, kc, true, false, 1, 1)
         }
-        __syncthreads();
+        VQ_END_BARRIER()
         ++kc;
     }
     if (kc & 1) {
@@ -486,6 +524,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
 #undef VQ_G_STORE
 #undef VQ_ADVANCE_TAP
 #undef VQ_PIPE_STEP
+#undef VQ_END_BARRIER
 }
 
 // ------------------------------------------------------------------------------------------------
