@@ -122,7 +122,16 @@ int vq_db_min_score(vq_db* db, const int64_t* rows_host, int32_t L, double* min_
  * ------------------------------------------------------------------------------------------ */
 typedef struct vq_tsn vq_tsn;
 
-enum { VQ_OP_CONV = 1, VQ_OP_MAXPOOL = 2, VQ_OP_AVGPOOL = 3, VQ_OP_GLOBAL_AVGPOOL = 4 };
+enum {
+    VQ_OP_CONV = 1,
+    VQ_OP_MAXPOOL = 2,
+    VQ_OP_AVGPOOL = 3,
+    VQ_OP_GLOBAL_AVGPOOL = 4,
+    /* 3x3 / stride 1 / pad 1 convolution evaluated as Winograd F(2x2,3x3): same result up to fp32 rounding
+     * (2.25x fewer multiplies).  w_off then addresses the host-transformed filters U = G g G^T laid out
+     * [cin/8][16][cout][8] (position 4 i + j of the 4x4 transform, 8 consecutive input channels innermost). */
+    VQ_OP_CONV_WINOGRAD = 5
+};
 
 /* One executed layer of the frozen network
  * (src/features_GPU_compute/models/ucf101/tsn_bn_inception_{rgb,flow}_deploy.prototxt).
@@ -192,6 +201,10 @@ int vq_tsn_layer_times(vq_tsn* net, float* ms, double* flops, int32_t n_layers);
 int vq_tsn_layer_tiles(vq_tsn* net, int32_t n_crops, int32_t* tiles, int32_t n_layers);
 /* Install a tiling table (as returned by vq_tsn_layer_tiles) for batch size n_crops instead of autotuning. */
 int vq_tsn_set_layer_tiles(vq_tsn* net, int32_t n_crops, const int32_t* tiles, int32_t n_layers);
+/* The fixed schedule: the lane (HIP stream) of every layer.  Independent arms of the graph run on different lanes
+ * (lane 0 is the stream of vq_tsn_set_stream; VQ_TSN_LANES, default 1 = one stream, read at creation).
+ * Results do not depend on the lane count. */
+int vq_tsn_layer_lanes(vq_tsn* net, int32_t* lanes, int32_t n_layers);
 /* Algorithmic FLOPs (2*MACs of the conv layers) of one crop, for roofline accounting. */
 int vq_tsn_flops_per_crop(vq_tsn* net, double* flops);
 

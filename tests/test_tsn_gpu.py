@@ -90,6 +90,53 @@ def test_conv_bn_relu_layer(tsn, monkeypatch, cin, h, cout, k, s, p, n, tile):
     m.close()
 
 
+WINO_CASES = [
+    # (cin, h, cout, n_crops)      3x3 / stride 1 / pad 1 layers: Winograd F(2x2,3x3) form (csrc/vq_wino.hip)
+    (64, 28, 96, 2),               # 3a/double_3x3_1: 392 tiles, Cout = 96 (ragged second 64-block)
+    (64, 56, 192, 1),              # conv2/3x3
+    (96, 14, 128, 3),              # 14x14: 147 tiles (ragged tile block)
+    (160, 7, 224, 5),              # 7x7: odd size, 4x4 tiles cover 8x8
+    (8, 5, 32, 1),                 # minimum: one K step, 9 tiles
+    (256, 9, 320, 2),              # 32 K steps, odd size
+]
+
+
+@pytest.mark.parametrize("cin,h,cout,n", WINO_CASES)
+def test_winograd_conv_layer(tsn, monkeypatch, cin, h, cout, n):
+    """Both workgroup shapes of the Winograd kernel against the fp64 oracle (same tolerance as the direct kernel),
+    bit-identical to each other, and within the stated tolerance of the direct kernel."""
+    bi, net = tsn
+    monkeypatch.delenv("VQ_TSN_TILE", raising=False)
+    g = _mini(bi, cin, h, h, cout, 3, 1, 1)
+    w = net.synthetic_weights(g, seed=cin + cout)
+    crops = np.random.default_rng(cin * h).integers(0, 256, (n, h, h, cin), dtype=np.uint8)
+    mean = np.linspace(100.0, 130.0, cin).astype(np.float32)
+    want = to.forward(g.layers, "data", w, to.preprocess(crops, mean), keep=("c_bn", "gp"))
+    tol = 2e-5 * np.abs(want["c_bn"]).max()
+    outs = []
+    for bn in (32, 64):
+        m = net.TsnNet(g, w, max_crops=n, feature_blob="gp", winograd=True)
+        tiles = m.layer_tiles(n)
+        assert tiles[0].tolist()[2:] == [8, 2]                       # the conv layer is in Winograd form
+        tiles[0] = (128, bn, 8, 2)
+        m.set_layer_tiles(n, tiles)
+        feat, ps = m.forward(crops, 1, mean)
+        got = _nchw(m.read_blob("c_bn", n))
+        assert m.layer_tiles(n)[0].tolist() == [128, bn, 8, 2]
+        assert np.abs(got - want["c_bn"]).max() <= tol
+        assert (got >= 0).all()
+        assert np.abs(ps - want["gp"].reshape(n, -1)).max() <= tol
+        outs.append(got)
+        m.close()
+    assert (outs[0] == outs[1]).all()
+    m = net.TsnNet(g, w, max_crops=n, feature_blob="gp", winograd=False)
+    assert m.layer_tiles(n)[0, 3] != 2
+    m.forward(crops, 1, mean)
+    direct = _nchw(m.read_blob("c_bn", n))
+    m.close()
+    assert np.abs(direct - outs[0]).max() <= tol
+
+
 @pytest.mark.parametrize("kind,k,s,p,h,c", [("MAX", 3, 2, 0, 28, 64), ("MAX", 3, 2, 0, 14, 96), ("AVE", 3, 1, 1, 14, 64),
                                           ("MAX", 3, 1, 1, 7, 128), ("AVE", 3, 1, 1, 7, 32), ("MAX", 3, 2, 0, 9, 32)])
 def test_pooling_is_bit_exact(tsn, kind, k, s, p, h, c):

@@ -137,3 +137,31 @@ def test_prototxt_parser_handles_comments_and_nesting():
     p = g.plan("gp")
     assert [o.kind for o in p.ops] == ["conv", "gavgpool"] and p.ops[0].relu and p.ops[0].bn == "c_bn"
     assert p.feature_dim == 32
+
+
+def test_winograd_filter_transform_and_layout():
+    """net.winograd_filters: U = G g G^T in the device layout [Cin/8][16][Cout][8].  Evaluating F(2x2,3x3) with it
+    (numpy, fp64) reproduces the direct 3x3 / pad 1 correlation of the oracle."""
+    import video_query_algorithms_amd  # noqa: F401
+    from video_query_algorithms_amd.tsn import net
+    rng = np.random.default_rng(5)
+    cin, cout, h = 16, 32, 7
+    W = rng.standard_normal((cout, cin, 3, 3))
+    x = rng.standard_normal((2, cin, h, h))
+    U = net.winograd_filters(W)
+    assert U.shape == (cin // 8, 16, cout, 8) and U.dtype == np.float32
+    Uf = U.astype(np.float64).transpose(2, 0, 3, 1).reshape(cout, cin, 4, 4)          # [o][c][i][j]
+    Bt = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=np.float64)
+    At = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float64)
+    th = (h + 1) // 2
+    xp = np.zeros((2, cin, 2 * th + 2, 2 * th + 2))
+    xp[:, :, 1:h + 1, 1:h + 1] = x
+    y = np.zeros((2, cout, 2 * th, 2 * th))
+    for ty in range(th):
+        for tx in range(th):
+            d = xp[:, :, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4]
+            V = np.einsum("ir,ncrs,js->ncij", Bt, d, Bt)
+            M = np.einsum("ncij,ocij->noij", V, Uf)
+            y[:, :, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = np.einsum("ai,noij,bj->noab", At, M, At)
+    want = to.conv_direct(x, W, np.zeros(cout), 1, 1)
+    assert np.abs(y[:, :, :h, :h] - want).max() <= 1e-6 * np.abs(want).max()     # U is rounded to fp32

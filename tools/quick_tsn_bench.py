@@ -19,6 +19,9 @@ def bench(channels, n_crops, T, reps=5):
     mean = net.RGB_MEAN if channels == 3 else net.FLOW_MEAN
     torch.cuda.synchronize()
     m.forward_device(crops.data_ptr(), n_crops, T, mean)
+    if os.environ.get("VQ_SHOW_LANES"):
+        for o, l in zip(m.plan.ops, m.layer_lanes()):
+            print("  lane %d  %s" % (l, o.name))
     tm = C.c_void_p()
     call("vq_timer_create", C.byref(tm))
     times = []
@@ -37,6 +40,11 @@ def bench(channels, n_crops, T, reps=5):
 
 
 if __name__ == "__main__":
-    bench(3, 96, 3)
-    bench(3, 448, 7)
-    bench(10, 448, 7)
+    if len(sys.argv) > 1:      # quick_tsn_bench.py C:crops:T ...
+        for spec in sys.argv[1:]:
+            c, n, t = (int(v) for v in spec.split(":"))
+            bench(c, n, t, reps=15)
+    else:
+        bench(3, 96, 3)
+        bench(3, 448, 7)
+        bench(10, 448, 7)

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvqamd.so")
 
 VQ_F32, VQ_F64 = 0, 1
-VQ_OP_CONV, VQ_OP_MAXPOOL, VQ_OP_AVGPOOL, VQ_OP_GLOBAL_AVGPOOL = 1, 2, 3, 4
+VQ_OP_CONV, VQ_OP_MAXPOOL, VQ_OP_AVGPOOL, VQ_OP_GLOBAL_AVGPOOL, VQ_OP_CONV_WINOGRAD = 1, 2, 3, 4, 5
 
 _ERR_NAMES = {-1: "VQ_E_INVALID", -2: "VQ_E_HIP", -3: "VQ_E_NOMEM", -4: "VQ_E_STATE", -5: "VQ_E_UNSUPPORTED"}
 
@@ -67,7 +67,7 @@ SIGNATURES = {
     "vq_tsn_destroy": [_P], "vq_tsn_set_stream": [_P, _P],
     "vq_tsn_forward": [_P, _P, _I32, _I32, _I32, _pF32, _P, _P],
     "vq_tsn_feat_devptr": [_P, _PP, _PP], "vq_tsn_read_tensor": [_P, _I32, _I32, _P],
-    "vq_tsn_flops_per_crop": [_P, _pF64],
+    "vq_tsn_flops_per_crop": [_P, _pF64], "vq_tsn_layer_lanes": [_P, _P, _I32],
     "vq_tsn_layer_tiles": [_P, _I32, _P, _I32], "vq_tsn_set_layer_tiles": [_P, _I32, _P, _I32],
     "vq_tsn_set_profile": [_P, _I32], "vq_tsn_layer_times": [_P, _P, _P, _I32],
 }

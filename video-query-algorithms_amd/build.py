@@ -8,8 +8,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = ["csrc/vq_sim.hip", "csrc/vq_tsn.hip"]
-HEADERS = ["csrc/vq_common.h", "../include/vq_amd.h"]
+SOURCES = ["csrc/vq_sim.hip", "csrc/vq_tsn.hip", "csrc/vq_wino.hip"]
+HEADERS = ["csrc/vq_common.h", "csrc/vq_tsn_kernels.h", "../include/vq_amd.h"]
 OUT = os.path.join(HERE, "libvqamd.so")
 # -ffp-contract=off: score arithmetic must round like the reference's numpy scalars; FMAs are explicit
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-result",

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "vq_common.h"
+#include "vq_tsn_kernels.h"
 
 using namespace vq;
 
@@ -71,13 +72,6 @@ struct ConvSmem {
     float a[2][BM][BK + 4];
     float b[2][BN][BK + 4];
 };
-
-// XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2); give each XCD a contiguous run of
-// tiles, with the N tiles of one M tile adjacent, so the gathered activation tile is re-read from L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
 
 // Waves that share a SIMD run the same program and drift into lockstep: both are in their MFMA phase together
 // (each at half speed) and both in their staging / barrier phase together (matrix pipe idle).  Giving the waves
@@ -287,7 +281,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 // next tile, or one LDS store of it -- and a scheduling fence, so a wave keeps its SIMD's matrix pipe fed
 // while it stages (an in-order wave cannot overlap a BLOCK of vector work with more than one MFMA).
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int BK>
+template <int BM, int BN, int WM, int WN, int BK, bool SMALL_CIN>
 __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int NT = 256;                    // threads per workgroup
@@ -322,7 +316,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
     int a_off[NA];            // byte offset of (pixel, tap (0,0), channel chunk) -- may be "negative" in the padding
-    unsigned a_mask[NA];      // bit kh*k+kw set: that tap reads inside the image
+    unsigned long long a_mask[NA];   // bit kh*k+kw set: that tap reads inside the image (k*k <= 64)
     int a_row[NA], a_col[NA];
     const int HoWo = a.Ho * a.Wo;
 #pragma unroll
@@ -336,11 +330,12 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         const int n_img = mm / HoWo, rem = mm - n_img * HoWo;
         const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
         const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
-        a_off[i] = (((n_img * a.H + ih0) * a.W + iw0) * a.Cs_in + a.coff_in + a_col[i] * 4) * 4;
-        unsigned mask = 0;
+        // aligned mode: the chunk column is a channel offset inside the tap; small-Cin mode: it selects the tap itself
+        a_off[i] = (((n_img * a.H + ih0) * a.W + iw0) * a.Cs_in + a.coff_in + (SMALL_CIN ? 0 : a_col[i] * 4)) * 4;
+        unsigned long long mask = 0;
         for (int th = 0; th < a.k; ++th)
             for (int tw = 0; tw < a.k; ++tw)
-                if (ok && (unsigned)(ih0 + th) < (unsigned)a.H && (unsigned)(iw0 + tw) < (unsigned)a.W) mask |= 1u << (th * a.k + tw);
+                if (ok && (unsigned)(ih0 + th) < (unsigned)a.H && (unsigned)(iw0 + tw) < (unsigned)a.W) mask |= 1ull << (th * a.k + tw);
         a_mask[i] = mask;
     }
     unsigned b_off[NB];
@@ -356,6 +351,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
 
     floatx4 ra[2][NA], rb[2][NB];   // two staging sets: tile kc+1 waits in one while tile kc+2 is fetched into the other
     int kh = 0, kw = 0, c0 = 0, tap = 0, tap_off = 0;   // tap_off: byte offset of (kh, kw, c0) relative to tap (0,0)
+    const unsigned cpt = (unsigned)a.Cin >> 2, inv_cpt = 65536u / cpt + 1u, inv_k = 65536u / (unsigned)a.k + 1u;   // small-Cin decode
 
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
@@ -377,11 +373,23 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         seg_v[j] = a.segs[nb_ < a.Cout ? nb_ >> 5 : 0];
     }
 
+// Small-Cin mode (the 7x7 stem: Cin padded to 4 or 12): a 32-wide K-step spans several taps, so every staged
+// 16-byte chunk decodes its own tap from its K index -- g = KC * CPR + column, tap = g / (Cin/4), (th, tw) = tap / k,
+// tap % k -- with multiply-shift divisions (exact for the < 2^10 values that occur).
 #define VQ_G_LOAD(IDX, KC, SET)                                                                                \
     {                                                                                                          \
         if ((IDX) < NA) {                                                                                      \
             const int ii = (IDX) < NA ? (IDX) : 0;                                                             \
-            const unsigned off = ((a_mask[ii] >> tap) & 1u) ? (unsigned)(a_off[ii] + tap_off) : 0xFFFFFFFFu;   \
+            unsigned off;                                                                                      \
+            if (SMALL_CIN) {                                                                                   \
+                const unsigned g_ = (unsigned)(KC) * CPR + a_col[ii];                                          \
+                const unsigned tap_ = (g_ * inv_cpt) >> 16, c4_ = g_ - tap_ * cpt;                             \
+                const unsigned th_ = (tap_ * inv_k) >> 16, tw_ = tap_ - th_ * a.k;                             \
+                const unsigned ok_ = (unsigned)(a_mask[ii] >> (tap_ & 63u)) & (tap_ < 64u ? 1u : 0u);          \
+                off = ok_ ? (unsigned)(a_off[ii] + (int)(((th_ * a.W + tw_) * a.Cs_in + c4_ * 4) * 4)) : 0xFFFFFFFFu; \
+            } else {                                                                                           \
+                off = ((a_mask[ii] >> tap) & 1ull) ? (unsigned)(a_off[ii] + tap_off) : 0xFFFFFFFFu;            \
+            }                                                                                                  \
             ra[SET][ii] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0)); \
         } else {                                                                                               \
             const int ii = (IDX) >= NA ? (IDX) - NA : 0;                                                       \
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         }                                                                                                      \
     }
 #define VQ_ADVANCE_TAP()                                        \
-    {                                                           \
+    if (!SMALL_CIN) {                                           \
         c0 += BK;                                               \
         if (c0 >= a.Cin) {                                      \
             c0 = 0;                                             \
@@ -626,6 +634,8 @@ __global__ void consensus_kernel(const float* __restrict__ per_snippet, double* 
 // ------------------------------------------------------------------------------------------------
 // handle + executor
 // ------------------------------------------------------------------------------------------------
+static inline bool is_conv(int op) { return op == VQ_OP_CONV || op == VQ_OP_CONV_WINOGRAD; }
+
 struct ConvTile {
     int bm, bn, bk;
     int pipe;   // 1 = software-pipelined kernel (aligned Cin only)
@@ -658,11 +668,30 @@ struct vq_tsn {
     int profile_depth = 0;                // > 0: HIP events around every layer launch (bench roofline accounting)
     int profile_count = 0;                // profiled forwards so far (ring of profile_depth event sets)
     std::vector<hipEvent_t> events;       // profile_depth x (n_layers + 1)
+    // Lanes: independent branches of the graph (the 3x3 / double-3x3 / pooling arms of an inception module) run on
+    // separate HIP streams so that a layer too small to fill 256 CUs shares the chip with its siblings.  Lane 0 is
+    // the caller's stream; the others are owned.  The schedule is fixed at creation from the slot read/write sets.
+    hipStream_t ls = nullptr;             // stream the next launch goes to
+    int n_lanes = 1;
+    std::vector<hipStream_t> lane_streams;        // [n_lanes]; entry 0 unused (caller's stream)
+    std::vector<int> lane;                        // per layer
+    std::vector<std::vector<int>> xdeps;          // per layer: latest producer/hazard on each *other* lane
+    std::vector<char> needs_event;                // per layer: some later layer on another lane waits for it
+    std::vector<hipEvent_t> done;                 // per layer (created only where needs_event)
+    hipEvent_t fork_ev = nullptr;
+    std::vector<hipEvent_t> join_ev;              // per aux lane
 };
 
 static void tsn_free(vq_tsn* net) {
     for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
     net->events.clear();
+    for (hipEvent_t e : net->done)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : net->join_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (net->fork_ev) (void)hipEventDestroy(net->fork_ev);
+    for (hipStream_t st : net->lane_streams)
+        if (st) (void)hipStreamDestroy(st);
     for (float* p : net->slots)
         if (p) (void)hipFree(p);
     if (net->blob) (void)hipFree(net->blob);
@@ -684,7 +713,7 @@ static int launch_conv_t(vq_tsn* net, ConvArgs& a) {
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    kern<<<a.tiles_m * a.tiles_n, 256, lds, net->stream>>>(a);
+    kern<<<a.tiles_m * a.tiles_n, 256, lds, net->ls>>>(a);
     VQ_CHECK_LAUNCH();
     return VQ_OK;
 }
@@ -699,25 +728,26 @@ static const ConvTile kTiles[] = {
     {64, 128, 32, 1},  {64, 128, 16, 1},  {64, 64, 32, 1},  {64, 64, 16, 1},  {128, 32, 32, 1}, {128, 32, 16, 1}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 
-template <int BM, int BN, int WM, int WN, int BK>
+template <int BM, int BN, int WM, int WN, int BK, bool SMALL>
 static int launch_conv_pipe_t(vq_tsn* net, ConvArgs& a) {
     a.tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.Cout, BN);
-    auto kern = conv_igemm_pipe_kernel<BM, BN, WM, WN, BK>;
+    auto kern = conv_igemm_pipe_kernel<BM, BN, WM, WN, BK, SMALL>;
     const size_t lds = sizeof(ConvSmem<BM, BN, BK>);
     static bool attr_set = false;
     if (!attr_set) {
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    kern<<<a.tiles_m * a.tiles_n, 256, lds, net->stream>>>(a);
+    kern<<<a.tiles_m * a.tiles_n, 256, lds, net->ls>>>(a);
     VQ_CHECK_LAUNCH();
     return VQ_OK;
 }
 
+template <bool SMALL>
 static int launch_conv_pipe(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
 #define P_(BM_, BN_, WM_, WN_, BK_) \
-    if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_) return launch_conv_pipe_t<BM_, BN_, WM_, WN_, BK_>(net, a);
+    if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_) return launch_conv_pipe_t<BM_, BN_, WM_, WN_, BK_, SMALL>(net, a);
     P_(128, 128, 2, 2, 32) P_(128, 128, 2, 2, 16) P_(128, 96, 4, 1, 32) P_(128, 96, 4, 1, 16) P_(128, 64, 2, 2, 32)
     P_(128, 64, 2, 2, 16) P_(64, 128, 2, 2, 32) P_(64, 128, 2, 2, 16) P_(64, 64, 2, 2, 32) P_(64, 64, 2, 2, 16)
     P_(128, 32, 4, 1, 32) P_(128, 32, 4, 1, 16)
@@ -796,10 +826,36 @@ static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
     ConvArgs a;
     fill_conv_args(net, li, n_crops, a);
     const bool small = (net->layers[li].cin % KPAD) != 0;
-    if (small && kTiles[tile_idx].pipe) tile_idx = heuristic_tile(a.M, a.Cout, net->cus);   // small-Cin stem: plain kernel only
     if (kTiles[tile_idx].pipe && a.in_bytes >= 0x7FFFFFF0u) tile_idx = heuristic_tile(a.M, a.Cout, net->cus);   // 32-bit offsets
-    if (kTiles[tile_idx].pipe == 1 && !small) return launch_conv_pipe(net, a, kTiles[tile_idx]);
+    if (kTiles[tile_idx].pipe == 1) return small ? launch_conv_pipe<true>(net, a, kTiles[tile_idx]) : launch_conv_pipe<false>(net, a, kTiles[tile_idx]);
     return small ? launch_conv<true>(net, a, kTiles[tile_idx]) : launch_conv<false>(net, a, kTiles[tile_idx]);
+}
+
+static int launch_wino_layer(vq_tsn* net, int li, int n_crops, int variant) {
+    const vq_layer_desc& L = net->layers[li];
+    const vq_tensor_desc& ts = net->tensors[L.src];
+    const vq_tensor_desc& td = net->tensors[L.dst];
+    WinoArgs a;
+    a.in = net->slots[L.src];
+    a.u = net->blob + L.w_off;
+    a.bias = net->blob + L.b_off;
+    a.out = net->slots[L.dst];
+    a.H = ts.h;
+    a.W = ts.w;
+    a.Cs_in = ts.c;
+    a.coff_in = L.src_coff;
+    a.Cin = L.cin;
+    a.Cs_out = td.c;
+    a.coff_out = L.dst_coff;
+    a.Cout = L.cout;
+    a.th = (ts.h + 1) / 2;
+    a.tw = (ts.w + 1) / 2;
+    a.P = n_crops * a.th * a.tw;
+    a.relu = L.relu;
+    a.tiles_m = a.tiles_n = 0;
+    a.in_bytes = (unsigned)std::min<size_t>((size_t)n_crops * ts.h * ts.w * ts.c * sizeof(float), 0xFFFFFFF0u);
+    a.u_bytes = (unsigned)((size_t)16 * L.cout * L.cin * sizeof(float));
+    return launch_wino(a, variant, net->ls);
 }
 
 // Time every candidate tiling of every conv layer at this batch size (activations hold whatever the slots
@@ -807,20 +863,20 @@ static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
 static int autotune(vq_tsn* net, int n_crops) {
     std::vector<int>& choice = net->tuned[n_crops];
     choice.assign(net->layers.size(), 0);
+    net->ls = net->stream;
     hipEvent_t e0, e1;
     VQ_HIP(hipEventCreate(&e0));
     VQ_HIP(hipEventCreate(&e1));
     for (int li = 0; li < (int)net->layers.size(); ++li) {
-        if (net->layers[li].op != VQ_OP_CONV) continue;
+        if (!is_conv(net->layers[li].op)) continue;
+        const bool wino = net->layers[li].op == VQ_OP_CONV_WINOGRAD;
         float best = 1e30f;
-        const bool small = (net->layers[li].cin % KPAD) != 0;
-        for (int t = 0; t < kNumTiles; ++t) {
-            if (small && kTiles[t].pipe) continue;
-            int rc = launch_conv_layer(net, li, n_crops, t);   // warm (also sets the LDS attribute)
+        for (int t = 0; t < (wino ? kWinoVariants : kNumTiles); ++t) {
+            int rc = wino ? launch_wino_layer(net, li, n_crops, t) : launch_conv_layer(net, li, n_crops, t);   // warm
             if (rc != VQ_OK) return rc;
             VQ_HIP(hipEventRecord(e0, net->stream));
             for (int r = 0; r < 3; ++r) {
-                rc = launch_conv_layer(net, li, n_crops, t);
+                rc = wino ? launch_wino_layer(net, li, n_crops, t) : launch_conv_layer(net, li, n_crops, t);
                 if (rc != VQ_OK) return rc;
             }
             VQ_HIP(hipEventRecord(e1, net->stream));
@@ -856,6 +912,10 @@ static int run_layer(vq_tsn* net, int li, int n_crops) {
         }
         return launch_conv_layer(net, li, n_crops, t);
     }
+    if (L.op == VQ_OP_CONV_WINOGRAD) {
+        auto it = net->tuned.find(n_crops);
+        return launch_wino_layer(net, li, n_crops, it != net->tuned.end() ? it->second[li] : 0);
+    }
     if (L.op == VQ_OP_MAXPOOL || L.op == VQ_OP_AVGPOOL) {
         PoolArgs a;
         a.in = net->slots[L.src];
@@ -877,14 +937,14 @@ static int run_layer(vq_tsn* net, int li, int n_crops) {
         a.relu = (L.op == VQ_OP_AVGPOOL) ? L.relu : 0;
         const int64_t blocks = (a.total + 255) / 256;
         if (L.op == VQ_OP_MAXPOOL)
-            pool_kernel<true><<<(unsigned)blocks, 256, 0, net->stream>>>(a);
+            pool_kernel<true><<<(unsigned)blocks, 256, 0, net->ls>>>(a);
         else
-            pool_kernel<false><<<(unsigned)blocks, 256, 0, net->stream>>>(a);
+            pool_kernel<false><<<(unsigned)blocks, 256, 0, net->ls>>>(a);
         VQ_CHECK_LAUNCH();
         return VQ_OK;
     }
     if (L.op == VQ_OP_GLOBAL_AVGPOOL) {
-        gavgpool_kernel<<<cdiv((int64_t)n_crops * L.cin, 256), 256, 0, net->stream>>>(
+        gavgpool_kernel<<<cdiv((int64_t)n_crops * L.cin, 256), 256, 0, net->ls>>>(
             net->slots[L.src], net->slots[L.dst], n_crops, ts.h * ts.w, ts.c, L.src_coff, L.cin, td.c, L.dst_coff);
         VQ_CHECK_LAUNCH();
         return VQ_OK;
@@ -896,6 +956,66 @@ static int pool_out_size(int size, int k, int s, int p) {
     int out = (size + 2 * p - k + s - 1) / s + 1;
     if (p > 0 && (out - 1) * s >= size + p) --out;
     return out;
+}
+
+// Channel range of one slot that a layer reads or writes.
+struct SlotRange {
+    int slot, c0, c1;
+};
+static bool overlaps(const std::vector<SlotRange>& x, const std::vector<SlotRange>& y) {
+    for (const SlotRange& p : x)
+        for (const SlotRange& q : y)
+            if (p.slot == q.slot && p.c0 < q.c1 && q.c0 < p.c1) return true;
+    return false;
+}
+
+// Assign every layer to a lane and list the cross-lane waits.  Layer i depends on an earlier layer j when i reads
+// what j wrote, overwrites what j read, or writes the same channels; slots are never recycled, so in a valid plan
+// only the first kind occurs, but all three are honoured.  A layer continues the lane of a producer whose lane
+// has not moved on since (a chain stays on one stream and needs no event); otherwise it takes the lane that has
+// been idle longest.
+static void build_schedule(vq_tsn* net, const vq_conv_segment* segments) {
+    const int n = (int)net->layers.size();
+    std::vector<std::vector<SlotRange>> rd(n), wr(n);
+    for (int i = 0; i < n; ++i) {
+        const vq_layer_desc& L = net->layers[i];
+        const bool whole = L.op == VQ_OP_CONV && L.cin % KPAD != 0;
+        rd[i].push_back(whole ? SlotRange{L.src, 0, net->tensors[L.src].c} : SlotRange{L.src, L.src_coff, L.src_coff + L.cin});
+        if (L.op == VQ_OP_CONV && L.seg_count > 0)
+            for (int q = 0; q < L.seg_count; ++q) {
+                const vq_conv_segment& sg = segments[L.seg_first + q];
+                wr[i].push_back(SlotRange{sg.dst, sg.dst_coff, sg.dst_coff + sg.cout});
+            }
+        else
+            wr[i].push_back(SlotRange{L.dst, L.dst_coff, L.dst_coff + L.cout});
+    }
+    net->lane.assign(n, 0);
+    net->xdeps.assign(n, {});
+    net->needs_event.assign(n, 0);
+    std::vector<int> tail(net->n_lanes, -1);   // last layer put on each lane
+    for (int i = 0; i < n; ++i) {
+        std::vector<int> deps;
+        for (int j = 0; j < i; ++j)
+            if (overlaps(wr[j], rd[i]) || overlaps(rd[j], wr[i]) || overlaps(wr[j], wr[i])) deps.push_back(j);
+        int pick = -1;
+        for (int d : deps)
+            if (tail[net->lane[d]] == d && (pick < 0 || d > tail[pick])) pick = net->lane[d];
+        if (pick < 0) {
+            pick = 0;
+            for (int l = 1; l < net->n_lanes; ++l)
+                if (tail[l] < tail[pick]) pick = l;
+        }
+        net->lane[i] = pick;
+        tail[pick] = i;
+        std::vector<int> latest(net->n_lanes, -1);
+        for (int d : deps)
+            if (net->lane[d] != pick) latest[net->lane[d]] = std::max(latest[net->lane[d]], d);
+        for (int l = 0; l < net->n_lanes; ++l)
+            if (latest[l] >= 0) {
+                net->xdeps[i].push_back(latest[l]);
+                net->needs_event[latest[l]] = 1;
+            }
+    }
 }
 
 extern "C" {
@@ -946,6 +1066,7 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
         VQ_REQUIRE(ts.c % 4 == 0 && td.c % 4 == 0 && L.src_coff % 4 == 0 && L.dst_coff % 4 == 0 && L.cin % 4 == 0 && L.cout % 4 == 0,
                    "layer %d: channel counts and offsets must be multiples of 4", i);
         if (L.op == VQ_OP_CONV) {
+            VQ_REQUIRE(L.k <= 8, "layer %d: conv kernels up to 8x8 (the tap mask is 64 bits)", i);
             VQ_REQUIRE(td.h == (ts.h + 2 * L.pad - L.k) / L.stride + 1 && td.w == (ts.w + 2 * L.pad - L.k) / L.stride + 1,
                        "layer %d: conv output size mismatch", i);
             const int64_t kp = (int64_t)(L.k * L.k * L.cin + KPAD - 1) / KPAD * KPAD;
@@ -955,6 +1076,14 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
             VQ_REQUIRE(L.cin % KPAD == 0 || L.src_coff == 0, "layer %d: small-Cin convolution must read a whole slot", i);
             VQ_REQUIRE(L.cin % KPAD == 0 || L.cin == ts.c, "layer %d: small-Cin convolution must read a whole slot", i);
             macs += (double)td.h * td.w * L.cout * (L.src == 0 ? in_channels : L.cin) * L.k * L.k;   // algorithmic, un-padded
+        } else if (L.op == VQ_OP_CONV_WINOGRAD) {
+            VQ_REQUIRE(L.k == 3 && L.stride == 1 && L.pad == 1 && L.seg_count == 0, "layer %d: Winograd form is 3x3 / stride 1 / pad 1, one destination", i);
+            VQ_REQUIRE(L.cin % 8 == 0 && L.cout % 32 == 0, "layer %d: Winograd form needs Cin %% 8 == 0 and Cout %% 32 == 0", i);
+            VQ_REQUIRE(td.h == ts.h && td.w == ts.w, "layer %d: conv output size mismatch", i);
+            VQ_REQUIRE(L.w_off >= 0 && L.w_off % 4 == 0 && L.w_off + (int64_t)16 * L.cout * L.cin <= blob_floats,
+                       "layer %d: transformed filters outside the blob", i);
+            VQ_REQUIRE(L.b_off >= 0 && L.b_off % 4 == 0 && L.b_off + L.cout <= blob_floats, "layer %d: bias outside the blob", i);
+            macs += (double)td.h * td.w * L.cout * L.cin * 9;   // algorithmic (direct-form) count
         } else if (L.op == VQ_OP_MAXPOOL || L.op == VQ_OP_AVGPOOL) {
             VQ_REQUIRE(L.cin == L.cout, "layer %d: pooling keeps the channel count", i);
             VQ_REQUIRE(!(L.op == VQ_OP_AVGPOOL && L.has_bias) || (L.b_off >= 0 && L.b_off % 4 == 0 && L.b_off + L.cout <= blob_floats),
@@ -1022,6 +1151,27 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
         if (e != hipSuccess) return bail("hipMalloc(destination tables)", e);
         e = hipMemcpy(net->seg_table, table.data(), table.size() * sizeof(ConvSeg), hipMemcpyHostToDevice);
         if (e != hipSuccess) return bail("hipMemcpy(destination tables)", e);
+    }
+    {
+        const char* env = getenv("VQ_TSN_LANES");
+        net->n_lanes = std::min(std::max(env ? atoi(env) : 1, 1), 8);
+        build_schedule(net, segments);
+        net->lane_streams.assign(net->n_lanes, nullptr);
+        net->join_ev.assign(net->n_lanes, nullptr);
+        net->done.assign(n_layers, nullptr);
+        for (int l = 1; l < net->n_lanes; ++l) {
+            e = hipStreamCreateWithFlags(&net->lane_streams[l], hipStreamNonBlocking);
+            if (e != hipSuccess) return bail("hipStreamCreate(lane)", e);
+            e = hipEventCreateWithFlags(&net->join_ev[l], hipEventDisableTiming);
+            if (e != hipSuccess) return bail("hipEventCreate(lane join)", e);
+        }
+        e = hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming);
+        if (e != hipSuccess) return bail("hipEventCreate(lane fork)", e);
+        for (int i = 0; i < n_layers; ++i)
+            if (net->needs_event[i]) {
+                e = hipEventCreateWithFlags(&net->done[i], hipEventDisableTiming);
+                if (e != hipSuccess) return bail("hipEventCreate(layer)", e);
+            }
     }
     e = hipMalloc((void**)&net->zeros, 256);
     if (e != hipSuccess) return bail("hipMalloc(zero page)", e);
@@ -1091,11 +1241,27 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
         ev = net->events.data() + (size_t)(net->profile_count % net->profile_depth) * (net->layers.size() + 1);
         VQ_HIP(hipEventRecord(ev[0], net->stream));
     }
+    // Per-layer profiling serialises the graph on the caller's stream (each duration is then the layer alone).
+    const bool lanes_on = net->n_lanes > 1 && !ev;
+    if (lanes_on) {
+        VQ_HIP(hipEventRecord(net->fork_ev, net->stream));
+        for (int l = 1; l < net->n_lanes; ++l) VQ_HIP(hipStreamWaitEvent(net->lane_streams[l], net->fork_ev, 0));
+    }
     for (int li = 0; li < (int)net->layers.size(); ++li) {
+        net->ls = lanes_on && net->lane[li] > 0 ? net->lane_streams[net->lane[li]] : net->stream;
+        if (lanes_on)
+            for (int d : net->xdeps[li]) VQ_HIP(hipStreamWaitEvent(net->ls, net->done[d], 0));
         const int rc = run_layer(net, li, n_crops);
         if (rc != VQ_OK) return rc;
+        if (lanes_on && net->needs_event[li]) VQ_HIP(hipEventRecord(net->done[li], net->ls));
         if (ev) VQ_HIP(hipEventRecord(ev[li + 1], net->stream));
     }
+    net->ls = net->stream;
+    if (lanes_on)
+        for (int l = 1; l < net->n_lanes; ++l) {
+            VQ_HIP(hipEventRecord(net->join_ev[l], net->lane_streams[l]));
+            VQ_HIP(hipStreamWaitEvent(net->stream, net->join_ev[l], 0));
+        }
     if (ev) ++net->profile_count;
     const int B = n_crops / T;
     consensus_kernel<<<cdiv((int64_t)B * net->D, 256), 256, 0, net->stream>>>(net->slots[net->feature_slot], net->feat_dev, B, T,
@@ -1167,7 +1333,7 @@ int vq_tsn_layer_times(vq_tsn* net, float* ms, double* flops, int32_t n_layers) 
         for (int i = 0; i < n_layers; ++i) {
             const vq_layer_desc& L = net->layers[i];
             const vq_tensor_desc& td = net->tensors[L.dst];
-            flops[i] = L.op == VQ_OP_CONV ? 2.0 * net->last_crops * td.h * td.w * L.cout * (L.src == 0 ? net->in_channels : L.cin) * L.k * L.k
+            flops[i] = is_conv(L.op) ? 2.0 * net->last_crops * td.h * td.w * L.cout * (L.src == 0 ? net->in_channels : L.cin) * L.k * L.k
                                           : 0.0;
         }
     }
@@ -1181,6 +1347,14 @@ int vq_tsn_layer_tiles(vq_tsn* net, int32_t n_crops, int32_t* tiles, int32_t n_l
     auto it = net->tuned.find(n_crops);
     for (int i = 0; i < n_layers; ++i) {
         tiles[4 * i] = tiles[4 * i + 1] = tiles[4 * i + 2] = tiles[4 * i + 3] = 0;
+        if (net->layers[i].op == VQ_OP_CONV_WINOGRAD) {   // 32 tiles (128 pixels) x 32 (v+1) channels, 8 channels per step
+            const int v = it != net->tuned.end() ? it->second[i] : 0;
+            tiles[4 * i] = 128;
+            tiles[4 * i + 1] = 32 * (v + 1);
+            tiles[4 * i + 2] = 8;
+            tiles[4 * i + 3] = 2;
+            continue;
+        }
         if (net->layers[i].op != VQ_OP_CONV) continue;
         const vq_tensor_desc& td = net->tensors[net->layers[i].dst];
         const int t = it != net->tuned.end() ? it->second[i] : heuristic_tile(n_crops * td.h * td.w, net->layers[i].cout, net->cus);
@@ -1198,6 +1372,12 @@ int vq_tsn_set_layer_tiles(vq_tsn* net, int32_t n_crops, const int32_t* tiles, i
     VQ_REQUIRE(n_crops > 0 && n_crops <= net->max_crops, "n_crops out of range");
     std::vector<int> choice(net->layers.size(), 0);
     for (int i = 0; i < n_layers; ++i) {
+        if (net->layers[i].op == VQ_OP_CONV_WINOGRAD) {
+            VQ_REQUIRE(tiles[4 * i + 3] == 2 && tiles[4 * i + 1] >= 32 && tiles[4 * i + 1] <= 32 * kWinoVariants && tiles[4 * i + 1] % 32 == 0,
+                       "layer %d: no Winograd variant for tile %dx%d", i, tiles[4 * i], tiles[4 * i + 1]);
+            choice[i] = tiles[4 * i + 1] / 32 - 1;
+            continue;
+        }
         if (net->layers[i].op != VQ_OP_CONV) continue;
         int found = -1;
         for (int t = 0; t < kNumTiles; ++t)
@@ -1206,11 +1386,17 @@ int vq_tsn_set_layer_tiles(vq_tsn* net, int32_t n_crops, const int32_t* tiles, i
                 found = t;
         VQ_REQUIRE(found >= 0, "layer %d: no kernel for tile %dx%dx%d pipe=%d", i, tiles[4 * i], tiles[4 * i + 1], tiles[4 * i + 2],
                    tiles[4 * i + 3]);
-        VQ_REQUIRE(!(kTiles[found].pipe && net->layers[i].cin % KPAD != 0), "layer %d: pipelined kernel needs Cin %% 32 == 0", i);
         choice[i] = found;
     }
     std::lock_guard<std::mutex> lk(net->mu);
     net->tuned[n_crops] = choice;
+    return VQ_OK;
+}
+
+int vq_tsn_layer_lanes(vq_tsn* net, int32_t* lanes, int32_t n_layers) {
+    VQ_REQUIRE(net && lanes, "NULL argument");
+    VQ_REQUIRE(n_layers == (int)net->layers.size(), "n_layers must be %d", (int)net->layers.size());
+    for (int i = 0; i < n_layers; ++i) lanes[i] = net->lane[i];
     return VQ_OK;
 }
 

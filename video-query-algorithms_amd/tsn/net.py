@@ -8,6 +8,7 @@ fp64 segment consensus (calcSig_wOF.py:82).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Sequence
 
 import numpy as np
@@ -53,7 +54,7 @@ def synthetic_weights(graph: Graph, seed: int = 2) -> Dict[str, Dict[str, np.nda
     return w
 
 
-def fold_bn(conv: Dict[str, np.ndarray], bn: Dict[str, np.ndarray] | None, eps: float = 1e-5):
+def fold_bn(conv: Dict[str, np.ndarray], bn: Dict[str, np.ndarray] | None, eps: float = 1e-5, keep64: bool = False):
     """Frozen BN is a per-channel affine; fold it into the convolution: W' = a W, b' = a (b - mean) + shift."""
     W = conv["W"].astype(np.float64)
     b = conv["b"].astype(np.float64)
@@ -61,7 +62,25 @@ def fold_bn(conv: Dict[str, np.ndarray], bn: Dict[str, np.ndarray] | None, eps: 
         a = bn["scale"].astype(np.float64) / np.sqrt(bn["var"].astype(np.float64) + eps)
         W = W * a[:, None, None, None]
         b = a * (b - bn["mean"].astype(np.float64)) + bn["shift"].astype(np.float64)
-    return W.astype(np.float32), b.astype(np.float32)
+    return (W if keep64 else W.astype(np.float32)), b.astype(np.float32)
+
+
+# Winograd F(2x2, 3x3) filter transform (Lavin & Gray): U = G g G^T, 4x4 per (cout, cin)
+_WINO_G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+
+
+def winograd_filters(W: np.ndarray) -> np.ndarray:
+    """[Cout][Cin][3][3] (fp64, BN folded) -> device layout [Cin/8][16][Cout][8] fp32 (csrc/vq_wino.hip): transformed
+    in fp64 and rounded once."""
+    cout, cin = W.shape[:2]
+    U = np.einsum("ia,ocab,jb->ocij", _WINO_G, W.astype(np.float64), _WINO_G)          # [o][c][i][j]
+    U = U.reshape(cout, cin // 8, 8, 16).transpose(1, 3, 0, 2)                           # [c/8][xi][o][c%8]
+    return np.ascontiguousarray(U, dtype=np.float32)
+
+
+def winograd_default() -> bool:
+    """3x3 stride-1 convolutions run in Winograd form unless VQ_TSN_WINOGRAD=0."""
+    return os.environ.get("VQ_TSN_WINOGRAD", "1") != "0"
 
 
 def pad4(c: int) -> int:
@@ -70,12 +89,14 @@ def pad4(c: int) -> int:
 
 class TsnNet:
     def __init__(self, graph: Graph, weights: Dict[str, Dict[str, np.ndarray]], max_crops: int = 96, device: int = 0,
-                 feature_blob: str = "global_pool", bn_eps: float = 1e-5, fuse: bool = True):
+                 feature_blob: str = "global_pool", bn_eps: float = 1e-5, fuse: bool = True,
+                 winograd: bool | None = None):
         self.graph = graph
         self.plan: Plan = graph.plan(feature_blob, fuse=fuse)
         self.in_channels = graph.input_shape[0]
         self.max_crops = int(max_crops)
         self.device = device
+        self.winograd = winograd_default() if winograd is None else bool(winograd)
         plan = self.plan
         cin_pad = pad4(self.in_channels)
         tensors = (TensorDesc * len(plan.tensors))()
@@ -111,6 +132,15 @@ class TsnNet:
                     d.seg_first, d.seg_count = len(seg_list), len(op.segments)
                     for sg in op.segments:
                         seg_list.append(ConvSegment(sg.cout, sg.dst, sg.dst_coff, int(sg.relu)))
+                elif (self.winograd and op.k == 3 and op.stride == 1 and op.pad == 1
+                      and op.cin % 8 == 0 and op.cout % 32 == 0):
+                    W64, b = fold_bn(weights[op.name], weights[op.bn] if op.bn else None, bn_eps, keep64=True)
+                    if W64.shape != (op.cout, op.cin, 3, 3):
+                        raise ValueError("weights of %s have shape %s" % (op.name, W64.shape))
+                    packed = winograd_filters(W64)
+                    if not op.bias:
+                        b = np.zeros_like(b)
+                    d.op = _lib.VQ_OP_CONV_WINOGRAD
                 else:
                     packed, b = packed_conv(op.name, op.bn, op.cin, op.cout, op.k, cin_dev, op.bias)
                 d.cin = cin_dev
@@ -201,6 +231,13 @@ class TsnNet:
         n = len(self.plan.ops)
         out = np.zeros((n, 4), dtype=np.int32)
         call("vq_tsn_layer_tiles", self._h, int(n_crops), out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def layer_lanes(self) -> np.ndarray:
+        """Lane (HIP stream) of every layer in the fixed schedule; independent arms of a module differ."""
+        n = len(self.plan.ops)
+        out = np.zeros(n, dtype=np.int32)
+        call("vq_tsn_layer_lanes", self._h, out.ctypes.data_as(C.c_void_p), n)
         return out
 
     def set_layer_tiles(self, n_crops: int, tiles: np.ndarray):
