@@ -107,12 +107,32 @@ def bench_tsn(args, rank, world, device, stream):
     conv = np.array([k == "conv" for k in kinds])
     conv_ms = float(ms_layers[conv].sum())
     conv_flops = float(fl[conv].sum())
-    roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<BM,BN,...> (69 launches per step; fp32 v_mfma_f32_32x32x2)",
+    # MFMA work actually issued: the direct kernels run K padded to 32 (the 7x7 stem: 147 -> 224); the Winograd
+    # kernel runs 16 multiplies per 2x2 output tile instead of 36 (tiles padded to whole 2x2 blocks)
+    tiles = model.layer_tiles(n_crops)
+    issued = 0.0
+    for i, op in enumerate(model.plan.ops):
+        if op.kind != "conv":
+            continue
+        t = model.plan.tensors[op.segments[0].dst if op.segments else op.dst]
+        if tiles[i, 3] == 2:
+            issued += 2.0 * n_crops * ((t.h + 1) // 2) * ((t.w + 1) // 2) * 16 * op.cin * op.cout
+        else:
+            cin_dev = (op.cin + 3) // 4 * 4
+            issued += 2.0 * n_crops * t.h * t.w * op.cout * ((op.k * op.k * cin_dev + 31) // 32 * 32)
+    n_wino = int((tiles[:, 3] == 2).sum())
+    roof = {"bound": "mfma",
+            "kernel": "all %d convolution launches of a step: conv_igemm_pipe_kernel / conv_igemm_kernel (direct implicit GEMM, %d) + "
+                      "wino_f2x2_3x3_kernel (Winograd F(2x2,3x3), %d); fp32 v_mfma_f32_32x32x2" % (int(conv.sum()), int(conv.sum()) - n_wino, n_wino),
             "achieved": conv_flops / conv_ms / 1e9, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": conv_flops / conv_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
             "launches_per_step": int(conv.sum()), "avg_launch_ms": conv_ms / int(conv.sum()),
             "conv_ms_per_step": conv_ms, "other_kernels_ms_per_step": float(ms_layers[~conv].sum()),
-            "flops_per_step": conv_flops}
+            "flops_per_step": conv_flops,
+            "mfma_issued_flops_per_step": issued, "mfma_issued_tflops": issued / conv_ms / 1e9,
+            "mfma_issued_frac": issued / conv_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS,
+            "note": "achieved/frac use ALGORITHMIC direct-convolution FLOPs (SURVEY 8(d): 2 x MACs of Appendix A); the "
+                    "Winograd layers issue 2.25x fewer multiplies, so mfma_issued_* is what the matrix pipe really ran"}
     feats = feat.clone()
     model.set_profile(0)
     if args.tiles and rank == 0 and not os.path.exists(args.tiles):

@@ -7,7 +7,7 @@ stats, bench_json, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
 fam = {}
 for r in csv.DictReader(open(stats)):
     name = r["Name"]
-    key = ("conv_igemm (all tilings)" if "conv_igemm" in name else "scan_kernel" if "scan_kernel" in name
+    key = ("conv (conv_igemm* + wino_f2x2_3x3)" if ("conv_igemm" in name or "wino_f2x2" in name) else "scan_kernel" if "scan_kernel" in name
            else "pool/gavgpool/preprocess/consensus" if any(k in name for k in ("pool_kernel", "gavgpool", "preprocess", "consensus"))
            else "other")
     f = fam.setdefault(key, [0, 0.0])
@@ -17,9 +17,9 @@ b = json.load(open(bench_json))
 print("family, calls, total_ms, avg_us")
 for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
     print("%s, %d, %.3f, %.2f" % (k, c, t / 1e6, t / c / 1e3))
-c, t = fam["conv_igemm (all tilings)"]
+c, t = fam["conv (conv_igemm* + wino_f2x2_3x3)"]
 print("conv: rocprof avg launch %.4f ms over %d launches (%d per forward); bench.py HIP-event avg launch %.4f ms"
-      % (t / c / 1e6, c, 69, b["roofline"]["avg_launch_ms"]))
+      % (t / c / 1e6, c, b["roofline"]["launches_per_step"], b["roofline"]["avg_launch_ms"]))
 if "scan_kernel" in fam:
     c, t = fam["scan_kernel"]
     print("scan: rocprof avg launch %.4f ms over %d launches; bench.py HIP-event avg launch %.4f ms"

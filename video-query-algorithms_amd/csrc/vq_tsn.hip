@@ -855,6 +855,8 @@ static int launch_wino_layer(vq_tsn* net, int li, int n_crops, int variant) {
     a.tiles_m = a.tiles_n = 0;
     a.in_bytes = (unsigned)std::min<size_t>((size_t)n_crops * ts.h * ts.w * ts.c * sizeof(float), 0xFFFFFFF0u);
     a.u_bytes = (unsigned)((size_t)16 * L.cout * L.cin * sizeof(float));
+    static const int dbg = getenv("VQ_TSN_DBG") ? atoi(getenv("VQ_TSN_DBG")) : 0;
+    a.dbg = dbg;
     return launch_wino(a, variant, net->ls);
 }
 

@@ -31,15 +31,30 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+#ifdef VQ_WINO_PHASES   // tools/ubench/wino_phases.hip: where a workgroup's time goes
+#define VQ_PHASE(K)                                                                                               \
+    if (threadIdx.x == 0) {                                                                                       \
+        a.phases[(size_t)blockIdx.x * 6 + (K)] = (long long)__builtin_readcyclecounter();                         \
+        if ((K) == 0) {                                                                                           \
+            a.phases[(size_t)blockIdx.x * 6 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  /* HW_ID */         \
+            a.phases[(size_t)blockIdx.x * 6 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20); /* XCC_ID */       \
+        }                                                                                                         \
+    }
+#else
+#define VQ_PHASE(K)
+#endif
+
 constexpr int BP = 32;    // tiles per workgroup
 constexpr int KC = 8;     // channels per step
 constexpr int HS_STAGE = 4 * 4 * BP * KC;   // floats: h[r][j][tile][k]
 
 template <int NB>
-__global__ __launch_bounds__(256) void wino_f2x2_3x3_kernel(WinoArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 4 : 2, NB == 1 ? 4 : 2)))
+void wino_f2x2_3x3_kernel(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* hs = reinterpret_cast<float*>(smem_raw);        // [2][4][4][32][8] (K loop); [4][2][32][32] (epilogue)
 
+    VQ_PHASE(0)
     const int tid = threadIdx.x;
     const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -65,7 +80,7 @@ __global__ __launch_bounds__(256) void wino_f2x2_3x3_kernel(WinoArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int x = x0 + c;
-            poff[c] = (row_ok && (unsigned)x < (unsigned)a.W)
+            poff[c] = (row_ok && (unsigned)x < (unsigned)a.W && !(a.dbg & 1))
                           ? (unsigned)((((n_img * a.H + y) * a.W + x) * a.Cs_in + a.coff_in + c4 * 4) * 4)
                           : 0xFFFFFFFFu;
         }
@@ -81,7 +96,7 @@ __global__ __launch_bounds__(256) void wino_f2x2_3x3_kernel(WinoArgs a) {
     const int fb_off = rb * 4 * BP * KC + l31 * KC + half * 4;
     unsigned uvoff[NB];                                    // lane part of the filter fragment address
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) uvoff[nb] = (n0 + 32 * nb < a.Cout) ? (unsigned)((l31 * 8 + half * 4) * 4) : 0xFFFFFFFFu;
+    for (int nb = 0; nb < NB; ++nb) uvoff[nb] = (n0 + 32 * nb < a.Cout && !(a.dbg & 2)) ? (unsigned)((l31 * 8 + half * 4) * 4) : 0xFFFFFFFFu;
     const unsigned u_step = (unsigned)(16 * a.Cout * 8 * 4);          // bytes between consecutive 8-channel groups
     const unsigned u_wave = (unsigned)(((wave * 4) * a.Cout + n0) * 8 * 4);
     const unsigned u_pos = (unsigned)(a.Cout * 8 * 4);                  // bytes between positions
@@ -94,6 +109,7 @@ __global__ __launch_bounds__(256) void wino_f2x2_3x3_kernel(WinoArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.f;
 
+    constexpr int G = NB == 1 ? 2 : 1, NGRP = 4 / G;   // positions per MFMA group, groups per step
     floatx4 d[4];          // patch row in flight (next step)
     floatx4 bq[4][NB];     // filter fragments of the current step; reloaded for the next step right after use
 
@@ -113,18 +129,34 @@ __global__ __launch_bounds__(256) void wino_f2x2_3x3_kernel(WinoArgs a) {
         *reinterpret_cast<floatx4*>(dst + 2 * BP * KC) = d[2] - d[1];                                           \
         *reinterpret_cast<floatx4*>(dst + 3 * BP * KC) = d[1] - d[3];                                           \
     }
-// One step on LDS stage ST: 4 positions x 4 k-pairs x NB MFMAs; with NEXT, position j's filter registers are
-// refilled for step KSTEP+1 as soon as its MFMAs are issued (the loads then have a whole step to land).
+// One step on LDS stage ST: 4 positions x 4 k-pairs x NB MFMAs, in groups of G positions chosen so that two
+// accumulators alternate (consecutive MFMAs never chain on one accumulator).  The A fragments of group g+1 are read
+// under the MFMAs of group g; with NEXT, a group's filter registers are refilled for step KSTEP+1 as soon as its
+// MFMAs are issued (the loads then have a whole step to land).  sched_barrier pins that order: left alone, the
+// compiler sinks every global load to the end of the step and waits for it on the spot.
+#define VQ_W_READ_A(ST, GRP, SET)                                                                               \
+    _Pragma("unroll") for (int q = 0; q < G; ++q) {                                                             \
+        a0[SET][q] = *reinterpret_cast<const floatx4*>(hs + (ST) * HS_STAGE + fa_off + (G * (GRP) + q) * BP * KC); \
+        a1[SET][q] = *reinterpret_cast<const floatx4*>(hs + (ST) * HS_STAGE + fb_off + (G * (GRP) + q) * BP * KC); \
+    }
 #define VQ_W_STEP(ST, KSTEP, NEXT)                                                                              \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                             \
-        const floatx4 a0 = *reinterpret_cast<const floatx4*>(hs + (ST) * HS_STAGE + fa_off + j * BP * KC);      \
-        const floatx4 a1 = *reinterpret_cast<const floatx4*>(hs + (ST) * HS_STAGE + fb_off + j * BP * KC);      \
-        floatx4 av;                                                                                             \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) av[e] = __builtin_fmaf(a1[e], sgn, a0[e]);                \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                           \
-            _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                   \
-                acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bq[j][nb][e], acc[j][nb], 0, 0, 0);    \
-        if (NEXT) VQ_W_LOAD_U((KSTEP) + 1, j)                                                                   \
+    {                                                                                                           \
+        floatx4 a0[2][G], a1[2][G];                                                                             \
+        VQ_W_READ_A(ST, 0, 0)                                                                                   \
+        _Pragma("unroll") for (int g = 0; g < NGRP; ++g) {                                                      \
+            if (g + 1 < NGRP) VQ_W_READ_A(ST, g + 1, (g + 1) & 1)                                               \
+            floatx4 av[G];                                                                                      \
+            _Pragma("unroll") for (int q = 0; q < G; ++q)                                                       \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) av[q][e] = __builtin_fmaf(a1[g & 1][q][e], sgn, a0[g & 1][q][e]); \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                       \
+                _Pragma("unroll") for (int q = 0; q < G; ++q)                                                   \
+                    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                           \
+                        acc[G * g + q][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][e], bq[G * g + q][nb][e], acc[G * g + q][nb], 0, 0, 0); \
+            if (NEXT) {                                                                                         \
+                _Pragma("unroll") for (int q = 0; q < G; ++q) VQ_W_LOAD_U((KSTEP) + 1, G * g + q)               \
+            }                                                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+        }                                                                                                       \
     }
 
     const int nk = a.Cin / KC;
@@ -133,19 +165,23 @@ __global__ __launch_bounds__(256) void wino_f2x2_3x3_kernel(WinoArgs a) {
     for (int j = 0; j < 4; ++j) VQ_W_LOAD_U(0, j)
     VQ_W_STORE_H(0)
     __syncthreads();
+    VQ_PHASE(1)
     int kc = 0;
     for (; kc + 1 < nk; ++kc) {
         const int st = kc & 1;
         VQ_W_LOAD_PATCH(kc + 1)
+        __builtin_amdgcn_sched_barrier(0);
         VQ_W_STEP(st, kc, true)
-        VQ_W_STORE_H(st ^ 1)
-        __syncthreads();        // stage st^1 complete; everybody is done reading stage st
+        if (!(a.dbg & 8)) VQ_W_STORE_H(st ^ 1)
+        if (!(a.dbg & 4)) __syncthreads();        // stage st^1 complete; everybody is done reading stage st
     }
     VQ_W_STEP(kc & 1, kc, false)
+    VQ_PHASE(2)
 #undef VQ_W_LOAD_PATCH
 #undef VQ_W_LOAD_U
 #undef VQ_W_STORE_H
 #undef VQ_W_STEP
+#undef VQ_W_READ_A
 
     // ---- epilogue: Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]] ---------------------------------------------------
     // This thread finishes output pixel (a_, b_) of tile p0 + (tid >> 3), channels (tid & 7)*4 .. +4 of each block.
@@ -200,6 +236,7 @@ __global__ __launch_bounds__(256) void wino_f2x2_3x3_kernel(WinoArgs a) {
         }
         if (nb + 1 < NB) __syncthreads();
     }
+    VQ_PHASE(3)
 }
 
 template <int NB>
