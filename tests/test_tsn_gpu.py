@@ -350,3 +350,26 @@ def test_calcsig_command_line_end_to_end(tsn, tmp_path):
             v_avg_feature = np.array(frame_features).mean(axis=0)[0]
             assert (v_avg_feature == feats[0]).all()          # batched path == per-snippet path, bit for bit
             cn.close()
+
+
+@pytest.mark.parametrize("split", ["1", "2", "3", "2,1"])
+def test_batch_split_streams_do_not_change_a_bit(tsn, monkeypatch, split):
+    """VQ_TSN_SPLIT: sub-batches of one forward on separate HIP streams (default 2).  Every crop is independent and
+    every tiling sums in the same order, so the features must be bit-identical to the single-stream run."""
+    bi, net = tsn
+    g = bi.bn_inception(3)
+    w = net.synthetic_weights(g, seed=2)
+    crops = np.random.default_rng(9).integers(0, 256, (6, 224, 224, 3), dtype=np.uint8)
+    monkeypatch.setenv("VQ_TSN_SPLIT", "1")
+    m = net.TsnNet(g, w, max_crops=6)
+    f1, p1 = m.forward(crops, 3, net.RGB_MEAN)
+    b1 = m.read_blob("inception_4c/output", 6)
+    m.close()
+    monkeypatch.setenv("VQ_TSN_SPLIT", split)
+    m = net.TsnNet(g, w, max_crops=6)
+    f2, p2 = m.forward(crops, 3, net.RGB_MEAN)
+    b2 = m.read_blob("inception_4c/output", 6)
+    f3, p3 = m.forward(crops[:3], 3, net.RGB_MEAN)          # a size the split does not divide falls back to one stream
+    m.close()
+    assert (p1 == p2).all() and (f1 == f2).all() and (b1 == b2).all()
+    assert (p3 == p1[:3]).all() and (f3 == f1[:1]).all()

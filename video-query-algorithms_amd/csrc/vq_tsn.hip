@@ -57,6 +57,7 @@ struct ConvArgs {
     int Ho, Wo, Cs_out, coff_out, Cout;
     int k, stride, pad;
     int M, Kp, relu;
+    int out_row0;        // first output row (pixel) of this launch inside the destination slots (sub-batch launches)
     int tiles_m, tiles_n;
     unsigned in_bytes, w_bytes;   // extents for the buffer descriptors (out-of-range offsets read as zero)
     int dbg;             // timing experiments only: bit0 skip staging loads, bit1 skip LDS stores, bit2 skip barriers
@@ -112,7 +113,7 @@ __device__ __forceinline__ void desync_simd_partners() {
                             v[3] = fmaxf(v[3], 0.f);                                                              \
                         }                                                                                         \
                         if ((full_m || mb + row < a.M) && nb + pc4 * 4 < a.Cout)                                  \
-                            *reinterpret_cast<floatx4*>(sg.out_base + (size_t)(mb + row) * sg.Cs + nb + pc4 * 4) = v; \
+                            *reinterpret_cast<floatx4*>(sg.out_base + (size_t)(a.out_row0 + mb + row) * sg.Cs + nb + pc4 * 4) = v; \
                     }                                                                                             \
                 }                                                                                                 \
             }                                                                                                     \
@@ -671,6 +672,9 @@ struct vq_tsn {
     // Lanes: independent branches of the graph (the 3x3 / double-3x3 / pooling arms of an inception module) run on
     // separate HIP streams so that a layer too small to fill 256 CUs shares the chip with its siblings.  Lane 0 is
     // the caller's stream; the others are owned.  The schedule is fixed at creation from the slot read/write sets.
+    int crop_off = 0;                     // first crop of the sub-batch the next launch works on (batch split)
+    int n_split = 1;                      // VQ_TSN_SPLIT: sub-batches of one forward run on separate streams
+    std::vector<int> split_parts;         // VQ_TSN_SPLIT=a,b,..: relative sizes of the sub-batches (default equal)
     hipStream_t ls = nullptr;             // stream the next launch goes to
     int n_lanes = 1;
     std::vector<hipStream_t> lane_streams;        // [n_lanes]; entry 0 unused (caller's stream)
@@ -791,8 +795,9 @@ static void fill_conv_args(vq_tsn* net, int li, int n_crops, ConvArgs& a) {
     const vq_layer_desc& L = net->layers[li];
     const vq_tensor_desc& ts = net->tensors[L.src];
     const vq_tensor_desc& td = net->tensors[L.dst];
-    a.in = net->slots[L.src];
+    a.in = net->slots[L.src] + (size_t)net->crop_off * ts.h * ts.w * ts.c;
     a.out = net->slots[L.dst];
+    a.out_row0 = net->crop_off * td.h * td.w;
     a.w = net->blob + L.w_off;
     a.bias = net->blob + L.b_off;
     a.zeros = net->zeros;
@@ -836,10 +841,10 @@ static int launch_wino_layer(vq_tsn* net, int li, int n_crops, int variant) {
     const vq_tensor_desc& ts = net->tensors[L.src];
     const vq_tensor_desc& td = net->tensors[L.dst];
     WinoArgs a;
-    a.in = net->slots[L.src];
+    a.in = net->slots[L.src] + (size_t)net->crop_off * ts.h * ts.w * ts.c;
     a.u = net->blob + L.w_off;
     a.bias = net->blob + L.b_off;
-    a.out = net->slots[L.dst];
+    a.out = net->slots[L.dst] + (size_t)net->crop_off * td.h * td.w * td.c;
     a.H = ts.h;
     a.W = ts.w;
     a.Cs_in = ts.c;
@@ -866,6 +871,7 @@ static int autotune(vq_tsn* net, int n_crops) {
     std::vector<int>& choice = net->tuned[n_crops];
     choice.assign(net->layers.size(), 0);
     net->ls = net->stream;
+    net->crop_off = 0;
     hipEvent_t e0, e1;
     VQ_HIP(hipEventCreate(&e0));
     VQ_HIP(hipEventCreate(&e1));
@@ -920,8 +926,8 @@ static int run_layer(vq_tsn* net, int li, int n_crops) {
     }
     if (L.op == VQ_OP_MAXPOOL || L.op == VQ_OP_AVGPOOL) {
         PoolArgs a;
-        a.in = net->slots[L.src];
-        a.out = net->slots[L.dst];
+        a.in = net->slots[L.src] + (size_t)net->crop_off * ts.h * ts.w * ts.c;
+        a.out = net->slots[L.dst] + (size_t)net->crop_off * td.h * td.w * td.c;
         a.H = ts.h;
         a.W = ts.w;
         a.Cs_in = ts.c;
@@ -947,7 +953,8 @@ static int run_layer(vq_tsn* net, int li, int n_crops) {
     }
     if (L.op == VQ_OP_GLOBAL_AVGPOOL) {
         gavgpool_kernel<<<cdiv((int64_t)n_crops * L.cin, 256), 256, 0, net->ls>>>(
-            net->slots[L.src], net->slots[L.dst], n_crops, ts.h * ts.w, ts.c, L.src_coff, L.cin, td.c, L.dst_coff);
+            net->slots[L.src] + (size_t)net->crop_off * ts.h * ts.w * ts.c, net->slots[L.dst] + (size_t)net->crop_off * td.c, n_crops,
+            ts.h * ts.w, ts.c, L.src_coff, L.cin, td.c, L.dst_coff);
         VQ_CHECK_LAUNCH();
         return VQ_OK;
     }
@@ -1157,11 +1164,27 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
     {
         const char* env = getenv("VQ_TSN_LANES");
         net->n_lanes = std::min(std::max(env ? atoi(env) : 1, 1), 8);
+        const char* sp = getenv("VQ_TSN_SPLIT");
+        if (sp && strchr(sp, ',')) {                   // "2,1": sub-batches of 2/3 and 1/3 of the crops
+            for (const char* q = sp; *q;) {
+                net->split_parts.push_back(std::max(atoi(q), 1));
+                q = strchr(q, ',');
+                if (!q) break;
+                ++q;
+            }
+            net->n_split = std::min<int>((int)net->split_parts.size(), 8);
+            net->split_parts.resize(net->n_split);
+        } else {
+            net->n_split = std::min(std::max(sp ? atoi(sp) : 2, 1), 8);
+            net->split_parts.assign(net->n_split, 1);
+        }
+        if (net->n_split > 1) net->n_lanes = 1;   // one or the other
         build_schedule(net, segments);
-        net->lane_streams.assign(net->n_lanes, nullptr);
-        net->join_ev.assign(net->n_lanes, nullptr);
+        const int n_streams = std::max(net->n_lanes, net->n_split);
+        net->lane_streams.assign(n_streams, nullptr);
+        net->join_ev.assign(n_streams, nullptr);
         net->done.assign(n_layers, nullptr);
-        for (int l = 1; l < net->n_lanes; ++l) {
+        for (int l = 1; l < n_streams; ++l) {
             e = hipStreamCreateWithFlags(&net->lane_streams[l], hipStreamNonBlocking);
             if (e != hipSuccess) return bail("hipStreamCreate(lane)", e);
             e = hipEventCreateWithFlags(&net->join_ev[l], hipEventDisableTiming);
@@ -1245,22 +1268,56 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
     }
     // Per-layer profiling serialises the graph on the caller's stream (each duration is then the layer alone).
     const bool lanes_on = net->n_lanes > 1 && !ev;
-    if (lanes_on) {
+    int parts_sum = 0;
+    for (int v : net->split_parts) parts_sum += v;
+    const int n_split = (!ev && net->n_split > 1 && n_crops % parts_sum == 0) ? net->n_split : 1;
+    std::vector<int> sub(n_split, n_crops), sub_off(n_split, 0);
+    if (n_split > 1)
+        for (int sb = 0, o = 0; sb < n_split; ++sb) {
+            sub[sb] = n_crops / parts_sum * net->split_parts[sb];
+            sub_off[sb] = o;
+            o += sub[sb];
+        }
+    for (int sb = 0; sb < n_split && n_split > 1; ++sb)
+        if (net->autotune && !getenv("VQ_TSN_TILE") && net->tuned.find(sub[sb]) == net->tuned.end()) {
+            const char* env = getenv("VQ_TSN_AUTOTUNE");
+            if (!env || atoi(env) != 0) {
+                const int rc = autotune(net, sub[sb]);
+                if (rc != VQ_OK) return rc;
+            }
+        }
+    if (lanes_on || n_split > 1) {
         VQ_HIP(hipEventRecord(net->fork_ev, net->stream));
-        for (int l = 1; l < net->n_lanes; ++l) VQ_HIP(hipStreamWaitEvent(net->lane_streams[l], net->fork_ev, 0));
+        for (int l = 1; l < std::max(net->n_lanes, n_split); ++l) VQ_HIP(hipStreamWaitEvent(net->lane_streams[l], net->fork_ev, 0));
     }
-    for (int li = 0; li < (int)net->layers.size(); ++li) {
-        net->ls = lanes_on && net->lane[li] > 0 ? net->lane_streams[net->lane[li]] : net->stream;
-        if (lanes_on)
-            for (int d : net->xdeps[li]) VQ_HIP(hipStreamWaitEvent(net->ls, net->done[d], 0));
-        const int rc = run_layer(net, li, n_crops);
-        if (rc != VQ_OK) return rc;
-        if (lanes_on && net->needs_event[li]) VQ_HIP(hipEventRecord(net->done[li], net->ls));
-        if (ev) VQ_HIP(hipEventRecord(ev[li + 1], net->stream));
+    if (n_split > 1) {
+        // Batch split: the sub-batches are independent, so each runs the whole layer list on its own stream with no
+        // synchronisation in between; one sub-batch's launch ramp and tail overlap the other's steady state.
+        for (int li = 0; li < (int)net->layers.size(); ++li)
+            for (int sb = 0; sb < n_split; ++sb) {
+                net->ls = sb > 0 ? net->lane_streams[sb] : net->stream;
+                net->crop_off = sub_off[sb];
+                const int rc = run_layer(net, li, sub[sb]);
+                if (rc != VQ_OK) {
+                    net->crop_off = 0;
+                    return rc;
+                }
+            }
+        net->crop_off = 0;
+    } else {
+        for (int li = 0; li < (int)net->layers.size(); ++li) {
+            net->ls = lanes_on && net->lane[li] > 0 ? net->lane_streams[net->lane[li]] : net->stream;
+            if (lanes_on)
+                for (int d : net->xdeps[li]) VQ_HIP(hipStreamWaitEvent(net->ls, net->done[d], 0));
+            const int rc = run_layer(net, li, n_crops);
+            if (rc != VQ_OK) return rc;
+            if (lanes_on && net->needs_event[li]) VQ_HIP(hipEventRecord(net->done[li], net->ls));
+            if (ev) VQ_HIP(hipEventRecord(ev[li + 1], net->stream));
+        }
     }
     net->ls = net->stream;
-    if (lanes_on)
-        for (int l = 1; l < net->n_lanes; ++l) {
+    if (lanes_on || n_split > 1)
+        for (int l = 1; l < std::max(net->n_lanes, n_split); ++l) {
             VQ_HIP(hipEventRecord(net->join_ev[l], net->lane_streams[l]));
             VQ_HIP(hipStreamWaitEvent(net->stream, net->join_ev[l], 0));
         }
