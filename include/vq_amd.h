@@ -82,6 +82,24 @@ int vq_db_set_query(vq_db* db, const double* t_host);
  * t[s][e] = r / (r . r) with r = row `row` (fp64 arithmetic).  t_out_host may be NULL. */
 int vq_db_set_query_from_row(vq_db* db, int64_t row, double* t_out_host);
 
+/* Target bootstrapping ("dynamic target adjustment", src/models/target_clip.py:161-261): the closed-form new query
+ * vector of one (stream, split) from its user-validated clips.  With X = the n_valid validated matches and Y = the
+ * n_invalid validated non-matches (rows of `dim` values):
+ *   n_invalid == 0 (or mu == 0):  w = X^T (X X^T)^-1 1                         (_bootstrap_valid_matches, :192-197)
+ *   otherwise:                    the minimiser built at :245-260 from M = I + (mu / tr(Y Y^T)) Y^T Y
+ *                                 (_bootstrap_valid_plus_invalid).
+ * Computed on the device in fp64 from the Gram matrix of the rows (Woodbury form: two solves of size <= n_valid +
+ * n_invalid instead of the reference's dim x dim inverses).  n_valid + n_invalid <= 256 per problem.
+ * rows_host: the problems back to back, each its valid rows then its invalid rows, dtype VQ_F32 / VQ_F64.
+ * targets_host: [n_problems][dim] fp64.  VQ_E_INVALID if a system is singular (numpy.linalg.inv raises there). */
+int vq_bootstrap_targets(const void* rows_host, int32_t dtype, int32_t n_problems, const int32_t* n_valid,
+                         const int32_t* n_invalid, int32_t dim, double mu, int32_t device, double* targets_host);
+/* Same for clips that live in the DB: problem (s, e) uses rows valid_rows / invalid_rows of stream s, split e (every
+ * listed clip must hold every stream and split).  targets_host [S][E][D] may be NULL; set_query != 0 installs the
+ * targets as the query vectors (as vq_db_set_query would). */
+int vq_db_bootstrap_target(vq_db* db, const int64_t* valid_rows, int32_t n_valid, const int64_t* invalid_rows,
+                           int32_t n_invalid, double mu, double* targets_host, int32_t set_query);
+
 /* One pass over the DB: sim[c][s][e] = t[s][e] . x[c][s][e]; avg[c][s] = sum_e sim / n_e;
  * if w != NULL also score[c] = 1 - sqrt(sum_s (w_s (1 - avg))^2 / sum_s w_s^2).
  * Replaces Ticket.compute_similarities (ticket.py:120-163) + compute_scores (ticket.py:165-180).

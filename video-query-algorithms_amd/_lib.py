@@ -56,6 +56,8 @@ SIGNATURES = {
     "vq_db_upload": [_P, _I64, _I64, _P], "vq_db_adopt_device": [_P, _P], "vq_db_set_present": [_P, _P],
     "vq_db_generate": [_P, _U64, _I64, _pF32], "vq_db_feats_devptr": [_P, _PP],
     "vq_db_set_query": [_P, _P], "vq_db_set_query_from_row": [_P, _I64, _P],
+    "vq_bootstrap_targets": [_P, _I32, _I32, _P, _P, _I32, _F64, _I32, _P],
+    "vq_db_bootstrap_target": [_P, _P, _I32, _P, _I32, _F64, _P, _I32],
     "vq_db_scan": [_P, _P, _I32], "vq_db_rescore": [_P, _P],
     "vq_db_read_similarities": [_P, _P, _P, _P], "vq_db_read_scores": [_P, _P],
     "vq_db_scores_devptr": [_P, _PP], "vq_db_avg_devptr": [_P, _PP], "vq_db_write_avg": [_P, _P, _P],

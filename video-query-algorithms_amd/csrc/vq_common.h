@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "vq_amd.h"
 
@@ -57,5 +58,11 @@ struct DeviceGuard {
 };
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// csrc/vq_boot.hip: closed-form target bootstrapping on rows that already live on the device.  row_off [P][stride]
+// element offsets into base_dev (the n_valid[p] validated matches first, then the n_invalid[p] non-matches).
+int bootstrap_from_device_rows(const void* base_dev, int dtype, const std::vector<int64_t>& row_off, int stride, const int32_t* n_valid,
+                               const int32_t* n_invalid, int P, int D, double mu, hipStream_t stream, double* targets_host,
+                               double* targets_dev_copy);
 
 }  // namespace vq

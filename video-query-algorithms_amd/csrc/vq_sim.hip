@@ -749,6 +749,35 @@ int vq_db_set_query(vq_db* db, const double* t_host) {
     return VQ_OK;
 }
 
+int vq_db_bootstrap_target(vq_db* db, const int64_t* valid_rows, int32_t n_valid, const int64_t* invalid_rows, int32_t n_invalid,
+                           double mu, double* targets_host, int32_t set_query) {
+    VQ_REQUIRE(db && valid_rows, "NULL argument");
+    VQ_REQUIRE(n_valid >= 1 && n_invalid >= 0 && (n_invalid == 0 || invalid_rows), "need >= 1 validated match (and invalid_rows if n_invalid > 0)");
+    for (int k = 0; k < n_valid; ++k)
+        VQ_REQUIRE(valid_rows[k] >= 0 && valid_rows[k] < db->n, "valid row %lld outside [0,%lld)", (long long)valid_rows[k], (long long)db->n);
+    for (int k = 0; k < n_invalid; ++k)
+        VQ_REQUIRE(invalid_rows[k] >= 0 && invalid_rows[k] < db->n, "invalid row %lld outside [0,%lld)", (long long)invalid_rows[k],
+                   (long long)db->n);
+    std::lock_guard<std::mutex> lk(db->mu);
+    DeviceGuard g(db->device);
+    const int P = db->S * db->E, stride = n_valid + n_invalid;
+    std::vector<int64_t> off((size_t)P * stride);
+    std::vector<int32_t> nv(P, n_valid), ni(P, n_invalid);
+    for (int p = 0; p < P; ++p)
+        for (int k = 0; k < stride; ++k) {
+            const int64_t row = k < n_valid ? valid_rows[k] : invalid_rows[k - n_valid];
+            off[(size_t)p * stride + k] = (row * P + p) * db->D;      // [N][S][E][D], p = s * E + e
+        }
+    const int rc = bootstrap_from_device_rows(db->feats, db->dtype, off, stride, nv.data(), ni.data(), P, db->D, mu, db->stream, targets_host,
+                                              set_query ? db->t : nullptr);
+    if (rc != VQ_OK) return rc;
+    if (set_query) {
+        db->have_query = true;
+        db->have_avg = db->have_scores = db->have_sims = false;
+    }
+    return VQ_OK;
+}
+
 int vq_db_set_query_from_row(vq_db* db, int64_t row, double* t_out_host) {
     VQ_REQUIRE(db, "db is NULL");
     VQ_REQUIRE(row >= 0 && row < db->n, "row %lld outside [0,%lld)", (long long)row, (long long)db->n);

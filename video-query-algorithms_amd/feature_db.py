@@ -178,6 +178,17 @@ class FeatureDB:
         call("vq_db_set_query_from_row", self._h, int(row), _np_ptr(out) if want else None)
         return out
 
+    def bootstrap_target(self, valid_rows: Sequence[int], invalid_rows: Sequence[int] = (), mu: float = 0.0,
+                         set_query: bool = True) -> np.ndarray:
+        """New query vectors [S,E,D] from user-validated resident clips (target_clip.py:161-261, closed forms on the
+        device; see csrc/vq_boot.hip).  With ``set_query`` they become the query of the next scan."""
+        v = np.ascontiguousarray(valid_rows, dtype=np.int64)
+        iv = np.ascontiguousarray(invalid_rows, dtype=np.int64)
+        out = np.empty((self.S, self.E, self.D), dtype=np.float64)
+        call("vq_db_bootstrap_target", self._h, _np_ptr(v), int(v.size), _np_ptr(iv) if iv.size else None, int(iv.size), float(mu),
+             _np_ptr(out), 1 if set_query else 0)
+        return out
+
     def scan(self, weights: Sequence[float] | None = None, keep_sims: bool = False):
         """One pass over the DB (ticket.py:120-163 [+ 165-180 when weights are given])."""
         w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)

@@ -202,17 +202,31 @@ class Ticket(TicketScoring):
         self.feature_db = feature_db
         self.device = device
         self._records = records if records is not None else []
+        # matches of the latest query result ({"video_clip": id, "user_match": True/False/None}), served in pages like
+        # the API endpoint ["matches", "list"] that target bootstrapping reads (target_clip.py:114-121)
+        self._match_list = update_object.get("match_list", [])
+        self._match_page = int(update_object.get("match_page_size", 100))
 
     def _request(self, action, params):
         if action == ["search-sets", "features"]:
             return self._records
         if action == ["video-clips", "features"]:
             return [r for r in self._records if r["video_clip_id"] == params["id"]]
+        if action == ["matches", "list"]:
+            page = int(params.get("page", 1))
+            chunk = self._match_list[(page - 1) * self._match_page:page * self._match_page]
+            nxt = page + 1 if page * self._match_page < len(self._match_list) else None
+            return {"results": chunk, "pagination": {"nextPage": nxt}}
         raise KeyError("offline Ticket has no endpoint %r" % (action,))
 
 
-def install(ticket_cls, hyperparameter_cls=None):
+def install(ticket_cls, hyperparameter_cls=None, target_clip_cls=None):
     """Patch the reference's classes in place so broker.py / compute_matches.py see a drop-in."""
+    if target_clip_cls is not None:                       # dynamic target adjustment: matrix formulas on the GPU
+        from .target_clip import TargetClip as _TC
+        for name in ("get_target_features", "avg_new_old_targets", "_previous", "dynamic_target_adjustment", "target_by_bagging",
+                     "_draw", "_solve", "_stack"):
+            setattr(target_clip_cls, name, getattr(_TC, name))
     for name in ("compute_similarities", "compute_scores", "lowest_scoring_user_match", "select_clips_to_review"):
         setattr(ticket_cls, name, getattr(TicketScoring, name))
     for name in ("feature_db", "feature_db_dtype", "device"):
