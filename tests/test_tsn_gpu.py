@@ -373,3 +373,19 @@ def test_batch_split_streams_do_not_change_a_bit(tsn, monkeypatch, split):
     m.close()
     assert (p1 == p2).all() and (f1 == f2).all() and (b1 == b2).all()
     assert (p3 == p1[:3]).all() and (f3 == f1[:1]).all()
+
+
+def test_cfg5_pipeline_small(tsn, tmp_path, capsys):
+    """BASELINE configs[4] at toy size: features of both streams x 3 weight seeds written into the resident DB on the
+    device, the CSV tree round trip, then query rounds through the Ticket / Hyperparameter drop-ins."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import e2e_cfg5
+    rc = e2e_cfg5.main(["--clips", "24", "--segments", "3", "--batch-clips", "8", "--rounds", "3", "--labels", "8", "--csv-clips", "5",
+                        "--out", str(tmp_path)])
+    assert rc == 0
+    out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert out["clips"] == 24 and out["rounds"] == 3 and out["csv_clips"] == 5
+    assert 0 < out["final_matches"] <= 21 and 0.5 <= out["final_weights"]["warped_optical_flow"] <= 2.5
+    assert os.path.exists(os.path.join(str(tmp_path), "synthetic_video", "UCF101_split2", "warped_optical_flow_global_pool_features.csv"))
