@@ -206,8 +206,10 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
 int vq_tsn_feat_devptr(vq_tsn* net, void** feat_dev /* double [B][D] */, void** per_snippet_dev);
 /* Copy an activation slot of the last forward to the host ([n_crops][h][w][c] fp32): per-layer parity. */
 int vq_tsn_read_tensor(vq_tsn* net, int32_t slot, int32_t n_crops, float* host);
-/* Roofline accounting: with depth > 0 every forward records HIP events around each layer launch on the
- * handle's stream into a ring of `depth` event sets (no host synchronisation inside the forward);
+/* Roofline accounting: with depth > 0 every layer launch of a forward carries a start and a stop HIP event
+ * (hipExtLaunchKernelGGL: the dispatch packet's own begin / end timestamps, i.e. the kernel alone, as rocprofv3
+ * reports it) from a ring of `depth` event sets -- no host synchronisation and no extra packets inside the forward;
+ * profiled forwards run on the handle's stream only (no batch split).
  * vq_tsn_layer_times returns the per-layer device time averaged over the profiled forwards since
  * vq_tsn_set_profile and (optionally) each layer's algorithmic FLOPs for the last batch size (2*MACs with
  * the un-padded channel counts; 0 for pooling).  depth = 0 switches profiling off. */

@@ -45,10 +45,10 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int w = 0; w < 3; ++w) vq::launch_wino(a, variant, nullptr);
+    for (int w = 0; w < 3; ++w) vq::launch_wino(a, variant, nullptr, nullptr, nullptr);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    if (vq::launch_wino(a, variant, nullptr) != 0) {
+    if (vq::launch_wino(a, variant, nullptr, nullptr, nullptr) != 0) {
         printf("launch failed: %s\n", vq::last_error_ref().c_str());
         return 1;
     }

@@ -668,7 +668,7 @@ struct vq_tsn {
     int last_crops = 0;
     int profile_depth = 0;                // > 0: HIP events around every layer launch (bench roofline accounting)
     int profile_count = 0;                // profiled forwards so far (ring of profile_depth event sets)
-    std::vector<hipEvent_t> events;       // profile_depth x (n_layers + 1)
+    std::vector<hipEvent_t> events;       // profile_depth x n_layers x {start, stop}
     // Lanes: independent branches of the graph (the 3x3 / double-3x3 / pooling arms of an inception module) run on
     // separate HIP streams so that a layer too small to fill 256 CUs shares the chip with its siblings.  Lane 0 is
     // the caller's stream; the others are owned.  The schedule is fixed at creation from the slot read/write sets.
@@ -676,6 +676,7 @@ struct vq_tsn {
     int n_split = 1;                      // VQ_TSN_SPLIT: sub-batches of one forward run on separate streams
     std::vector<int> split_parts;         // VQ_TSN_SPLIT=a,b,..: relative sizes of the sub-batches (default equal)
     hipStream_t ls = nullptr;             // stream the next launch goes to
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // per-layer profiling: events of the next launch
     int n_lanes = 1;
     std::vector<hipStream_t> lane_streams;        // [n_lanes]; entry 0 unused (caller's stream)
     std::vector<int> lane;                        // per layer
@@ -717,7 +718,7 @@ static int launch_conv_t(vq_tsn* net, ConvArgs& a) {
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    kern<<<a.tiles_m * a.tiles_n, 256, lds, net->ls>>>(a);
+    VQ_LAUNCH(kern, a.tiles_m * a.tiles_n, 256, lds, net->ls, net->ev_start, net->ev_stop, a);
     VQ_CHECK_LAUNCH();
     return VQ_OK;
 }
@@ -743,7 +744,7 @@ static int launch_conv_pipe_t(vq_tsn* net, ConvArgs& a) {
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    kern<<<a.tiles_m * a.tiles_n, 256, lds, net->ls>>>(a);
+    VQ_LAUNCH(kern, a.tiles_m * a.tiles_n, 256, lds, net->ls, net->ev_start, net->ev_stop, a);
     VQ_CHECK_LAUNCH();
     return VQ_OK;
 }
@@ -862,7 +863,7 @@ static int launch_wino_layer(vq_tsn* net, int li, int n_crops, int variant) {
     a.u_bytes = (unsigned)((size_t)16 * L.cout * L.cin * sizeof(float));
     static const int dbg = getenv("VQ_TSN_DBG") ? atoi(getenv("VQ_TSN_DBG")) : 0;
     a.dbg = dbg;
-    return launch_wino(a, variant, net->ls);
+    return launch_wino(a, variant, net->ls, net->ev_start, net->ev_stop);
 }
 
 // Time every candidate tiling of every conv layer at this batch size (activations hold whatever the slots
@@ -945,16 +946,17 @@ static int run_layer(vq_tsn* net, int li, int n_crops) {
         a.relu = (L.op == VQ_OP_AVGPOOL) ? L.relu : 0;
         const int64_t blocks = (a.total + 255) / 256;
         if (L.op == VQ_OP_MAXPOOL)
-            pool_kernel<true><<<(unsigned)blocks, 256, 0, net->ls>>>(a);
+            VQ_LAUNCH(pool_kernel<true>, (unsigned)blocks, 256, 0, net->ls, net->ev_start, net->ev_stop, a);
         else
-            pool_kernel<false><<<(unsigned)blocks, 256, 0, net->ls>>>(a);
+            VQ_LAUNCH(pool_kernel<false>, (unsigned)blocks, 256, 0, net->ls, net->ev_start, net->ev_stop, a);
         VQ_CHECK_LAUNCH();
         return VQ_OK;
     }
     if (L.op == VQ_OP_GLOBAL_AVGPOOL) {
-        gavgpool_kernel<<<cdiv((int64_t)n_crops * L.cin, 256), 256, 0, net->ls>>>(
-            net->slots[L.src] + (size_t)net->crop_off * ts.h * ts.w * ts.c, net->slots[L.dst] + (size_t)net->crop_off * td.c, n_crops,
-            ts.h * ts.w, ts.c, L.src_coff, L.cin, td.c, L.dst_coff);
+        const float* gin = net->slots[L.src] + (size_t)net->crop_off * ts.h * ts.w * ts.c;
+        float* gout = net->slots[L.dst] + (size_t)net->crop_off * td.c;
+        VQ_LAUNCH(gavgpool_kernel, cdiv((int64_t)n_crops * L.cin, 256), 256, 0, net->ls, net->ev_start, net->ev_stop, gin, gout, n_crops,
+                  ts.h * ts.w, ts.c, L.src_coff, L.cin, td.c, L.dst_coff);
         VQ_CHECK_LAUNCH();
         return VQ_OK;
     }
@@ -1263,8 +1265,7 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
     }
     hipEvent_t* ev = nullptr;
     if (net->profile_depth > 0) {
-        ev = net->events.data() + (size_t)(net->profile_count % net->profile_depth) * (net->layers.size() + 1);
-        VQ_HIP(hipEventRecord(ev[0], net->stream));
+        ev = net->events.data() + (size_t)(net->profile_count % net->profile_depth) * (2 * net->layers.size());
     }
     // Per-layer profiling serialises the graph on the caller's stream (each duration is then the layer alone).
     const bool lanes_on = net->n_lanes > 1 && !ev;
@@ -1309,10 +1310,14 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
             net->ls = lanes_on && net->lane[li] > 0 ? net->lane_streams[net->lane[li]] : net->stream;
             if (lanes_on)
                 for (int d : net->xdeps[li]) VQ_HIP(hipStreamWaitEvent(net->ls, net->done[d], 0));
+            if (ev) {
+                net->ev_start = ev[2 * li];
+                net->ev_stop = ev[2 * li + 1];
+            }
             const int rc = run_layer(net, li, n_crops);
+            net->ev_start = net->ev_stop = nullptr;
             if (rc != VQ_OK) return rc;
             if (lanes_on && net->needs_event[li]) VQ_HIP(hipEventRecord(net->done[li], net->ls));
-            if (ev) VQ_HIP(hipEventRecord(ev[li + 1], net->stream));
         }
     }
     net->ls = net->stream;
@@ -1364,7 +1369,7 @@ int vq_tsn_set_profile(vq_tsn* net, int32_t depth) {
     VQ_HIP(hipStreamSynchronize(net->stream));
     for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
     net->events.clear();
-    net->events.resize((size_t)depth * (net->layers.size() + 1));
+    net->events.resize((size_t)depth * 2 * net->layers.size());
     for (hipEvent_t& e : net->events) VQ_HIP(hipEventCreate(&e));
     net->profile_depth = depth;
     net->profile_count = 0;
@@ -1381,10 +1386,10 @@ int vq_tsn_layer_times(vq_tsn* net, float* ms, double* flops, int32_t n_layers) 
     const int sets = std::min(net->profile_count, net->profile_depth);
     for (int i = 0; i < n_layers; ++i) ms[i] = 0.f;
     for (int sidx = 0; sidx < sets; ++sidx) {
-        hipEvent_t* ev = net->events.data() + (size_t)sidx * (n_layers + 1);
+        hipEvent_t* ev = net->events.data() + (size_t)sidx * (2 * n_layers);
         for (int i = 0; i < n_layers; ++i) {
             float t = 0.f;
-            VQ_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+            VQ_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
             ms[i] += t / sets;                                   // mean over the profiled forwards
         }
     }

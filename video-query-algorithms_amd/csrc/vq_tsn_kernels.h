@@ -1,6 +1,7 @@
 // Kernel entry points shared between the TSN executor (vq_tsn.hip) and separately compiled kernel files.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 namespace vq {
 
@@ -31,7 +32,19 @@ struct WinoArgs {
 
 constexpr int kWinoVariants = 2;   // output-channel blocks of 32 per workgroup: variant v -> v + 1
 
-// Launch on `stream`; variant in [0, kWinoVariants).  Returns a VQ_* status.
-int launch_wino(const WinoArgs& a, int variant, hipStream_t stream);
+// Launch on `stream`; variant in [0, kWinoVariants).  ev_start / ev_stop (both or neither): events that receive the
+// kernel's own begin / end timestamps (hipExtLaunchKernelGGL) for per-layer profiling.  Returns a VQ_* status.
+int launch_wino(const WinoArgs& a, int variant, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
+
+// A launch whose begin / end timestamps land in two events when they are given: the timestamps come from the
+// dispatch packet itself, so the measured interval is the kernel alone (what rocprofv3 reports) and no extra
+// marker packets sit between consecutive layers.
+#define VQ_LAUNCH(KERN, GRID, BLOCK, LDS, STREAM, EV_START, EV_STOP, ...)                                     \
+    do {                                                                                                      \
+        if (EV_START)                                                                                         \
+            hipExtLaunchKernelGGL(KERN, dim3(GRID), dim3(BLOCK), (std::uint32_t)(LDS), STREAM, EV_START, EV_STOP, 0, __VA_ARGS__); \
+        else                                                                                                  \
+            KERN<<<GRID, BLOCK, LDS, STREAM>>>(__VA_ARGS__);                                                  \
+    } while (0)
 
 }  // namespace vq

@@ -240,13 +240,13 @@ void wino_f2x2_3x3_kernel(WinoArgs a) {
 }
 
 template <int NB>
-int launch_t(const WinoArgs& a0, hipStream_t stream) {
+int launch_t(const WinoArgs& a0, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     WinoArgs a = a0;
     a.tiles_m = cdiv(a.P, BP);
     a.tiles_n = cdiv(a.Cout, 32 * NB);
     auto kern = wino_f2x2_3x3_kernel<NB>;
     const size_t lds = 2 * HS_STAGE * sizeof(float);
-    kern<<<a.tiles_m * a.tiles_n, 256, lds, stream>>>(a);
+    VQ_LAUNCH(kern, a.tiles_m * a.tiles_n, 256, lds, stream, ev_start, ev_stop, a);
     VQ_CHECK_LAUNCH();
     return VQ_OK;
 }
@@ -255,11 +255,11 @@ int launch_t(const WinoArgs& a0, hipStream_t stream) {
 
 namespace vq {
 
-int launch_wino(const WinoArgs& a, int variant, hipStream_t stream) {
+int launch_wino(const WinoArgs& a, int variant, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     VQ_REQUIRE(a.Cin % KC == 0 && a.Cout % 32 == 0 && a.Cs_out % 4 == 0 && a.coff_out % 4 == 0 && a.Cs_in % 4 == 0 && a.coff_in % 4 == 0,
                "Winograd convolution needs Cin %% 8 == 0, Cout %% 32 == 0 and 16-byte aligned channel offsets");
-    if (variant == 0) return launch_t<1>(a, stream);
-    if (variant == 1) return launch_t<2>(a, stream);
+    if (variant == 0) return launch_t<1>(a, stream, ev_start, ev_stop);
+    if (variant == 1) return launch_t<2>(a, stream, ev_start, ev_stop);
     return fail(VQ_E_INVALID, "no Winograd kernel variant %d", variant);
 }
 
