@@ -1,5 +1,6 @@
 """CPU: the feature-file layout (writer = calcSig_wOF.py:116-134, reader = api_load_records.py:41-58) and the
 frame-ingest helpers."""
+import json
 import os
 
 import numpy as np
@@ -115,3 +116,50 @@ def test_caffemodel_round_trip(tmp_path):
     caffemodel.write_caffemodel(str(tmp_path / "bad.caffemodel"), g, bad)
     with pytest.raises(KeyError):
         caffemodel.weights_from_caffemodel(str(tmp_path / "bad.caffemodel"), g)
+
+
+def test_feature_store_round_trip_and_csv_tree_import(tmp_path):
+    """feature_store: the [N,S,E,D] block + ids + presence mask on disk; import of a data/features CSV tree with a
+    missing file (one stream of one split of one video) and clips that only some files hold."""
+    import video_query_algorithms_amd  # noqa: F401
+    from video_query_algorithms_amd import feature_store as fs
+    from video_query_algorithms_amd.tsn import feature_csv
+    rng = np.random.default_rng(3)
+    tree = tmp_path / "features"
+    vids = {"video_b": [1, 2, 3, 5], "video_a": [1, 2]}
+    vals = {}
+    for video, clips in vids.items():
+        for split in (1, 2, 3):
+            feats = {}
+            for st in feature_csv.STREAM_MODES:
+                if video == "video_a" and split == 2 and st == "rgb":
+                    continue                                               # a missing file
+                use = [c for c in clips if not (video == "video_b" and c == 5 and split == 3)]   # a clip missing in one split
+                f = np.abs(rng.standard_normal((len(use), 1024))).astype(np.float32).astype(np.float64)
+                for c, row in zip(use, f):
+                    vals[(video, c, st, split)] = row
+                feats[st] = (use, f)
+            for st, (use, f) in feats.items():
+                feature_csv.write_features(str(tree), video, "/v/", "UCF101_split%d" % split, "global_pool",
+                                           ["clip_%04d" % c for c in use], {st: f}, {st: "w"})
+    out = fs.store_from_csv_tree(str(tree), str(tmp_path / "store"))
+    meta, feats, ids, present = fs.open_store(out)
+    assert meta["streams"] == list(feature_csv.STREAM_MODES) and meta["splits"] == [1, 2, 3] and feats.shape == (6, 2, 3, 1024)
+    assert ids.tolist() == [1, 2, 3, 4, 5, 6]                              # video_a (2 clips) first, then video_b
+    clips = json.load(open(os.path.join(out, "clips.json")))
+    assert [(c["video"], c["clip"]) for c in clips] == [("video_a", 1), ("video_a", 2), ("video_b", 1), ("video_b", 2),
+                                                        ("video_b", 3), ("video_b", 5)]
+    for row, c in enumerate(clips):
+        for si, st in enumerate(feature_csv.STREAM_MODES):
+            for ei, sp in enumerate((1, 2, 3)):
+                key = (c["video"], c["clip"], st, sp)
+                assert bool(present[row, si, ei]) == (key in vals)
+                if key in vals:
+                    assert (feats[row, si, ei] == vals[key].astype(np.float32)).all()
+    # plain round trip, dense: no presence file is written
+    x = rng.standard_normal((5, 2, 3, 8)).astype(np.float32)
+    p2 = fs.save_store(str(tmp_path / "s2"), x, [9, 4, 7, 1, 3], ("rgb", "warped_optical_flow"), (1, 2, 3))
+    m2, f2, i2, pr2 = fs.open_store(p2)
+    assert (np.asarray(f2) == x).all() and i2.tolist() == [9, 4, 7, 1, 3] and pr2 is None and m2["dim"] == 8
+    with pytest.raises(ValueError):
+        fs.save_store(str(tmp_path / "s3"), x, [1, 1, 2, 3, 4], ("rgb", "warped_optical_flow"), (1, 2, 3))

@@ -278,3 +278,37 @@ def test_library_memory_is_visible_to_rccl_collectives(vqa):
         assert (out.cpu().numpy() == want).all()
     finally:
         dist.destroy_process_group()
+
+
+def test_db_from_binary_store_and_row_shards(vqa, tmp_path):
+    """FeatureDB.from_store: chunked upload from the memory-mapped store, whole and as two row shards; scores equal the
+    in-memory database bit for bit."""
+    from video_query_algorithms_amd import feature_store as fs
+    x = so.cfg1_features(n=300, e=3, seed=4)
+    ids = np.arange(300) * 2 + 11
+    present = np.ones((300, 2, 3), dtype=np.uint8)
+    present[17, 0, 1] = 0
+    present[250, 1, :2] = 0
+    path = fs.save_store(str(tmp_path / "store"), x, ids, ("rgb", "warped_optical_flow"), (1, 2, 3), present=present)
+    t = np.stack([[so.scale_feature(x[7, s, e].astype(np.float64)) for e in range(3)] for s in range(2)])
+    ref = vqa.FeatureDB.from_arrays(x, clip_ids=ids, present=present)
+    ref.set_query(t)
+    ref.scan([1.0, 1.5])
+    want = ref.scores()
+    whole = vqa.FeatureDB.from_store(path, chunk_rows=64)
+    whole.set_query(t)
+    whole.scan([1.0, 1.5])
+    assert (whole.scores() == want).all() and (whole.clip_ids == ids).all() and whole.stream_names == ["rgb", "warped_optical_flow"]
+    got = []
+    for row0, rows in ((0, 170), (170, 130)):
+        part = vqa.FeatureDB.from_store(path, row0=row0, rows=rows, chunk_rows=50)
+        part.set_query(t)
+        part.scan([1.0, 1.5])
+        got.append(part.scores())
+        assert part.row_of(int(ids[row0])) == 0
+        part.close()
+    assert (np.concatenate(got) == want).all()
+    with pytest.raises(ValueError):
+        vqa.FeatureDB.from_store(path, row0=200, rows=200)
+    ref.close()
+    whole.close()

@@ -113,6 +113,27 @@ class FeatureDB:
         return db
 
     @classmethod
+    def from_store(cls, path: str, device: int = 0, row0: int = 0, rows: int | None = None,
+                   chunk_rows: int = 16384) -> "FeatureDB":
+        """Rows [row0, row0+rows) of a binary feature store (feature_store.py) -> resident DB; the memory-mapped block
+        is uploaded in chunks of ``chunk_rows`` clips, so host memory stays bounded at any database size."""
+        from .feature_store import open_store
+        meta, feats, ids, present = open_store(path)
+        n_all = feats.shape[0]
+        rows = n_all - row0 if rows is None else int(rows)
+        if row0 < 0 or rows <= 0 or row0 + rows > n_all:
+            raise ValueError("rows [%d,%d) outside the store's %d clips" % (row0, row0 + rows, n_all))
+        db = cls(rows, feats.shape[1], feats.shape[2], feats.shape[3], feats.dtype, device, ids[row0:row0 + rows])
+        for r in range(0, rows, chunk_rows):
+            k = min(chunk_rows, rows - r)
+            db.upload(r, np.ascontiguousarray(feats[row0 + r:row0 + r + k]))
+        if present is not None:
+            db.set_present(np.ascontiguousarray(present[row0:row0 + rows]))
+        db.stream_names = list(meta["streams"])
+        db.slot_splits = [list(meta["splits"])] * len(meta["streams"])
+        return db
+
+    @classmethod
     def synthetic(cls, n: int, n_streams: int, n_splits: int, dim: int = 1024, seed: int = 0,
                   scales: Sequence[float] = (4.0, 1.0), row0: int = 0, dtype=np.float32, device: int = 0,
                   clip_ids=None) -> "FeatureDB":
