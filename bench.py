@@ -118,8 +118,7 @@ def bench_tsn(args, rank, world, device, stream):
         if tiles[i, 3] == 2:
             issued += 2.0 * n_crops * ((t.h + 1) // 2) * ((t.w + 1) // 2) * 16 * op.cin * op.cout
         else:
-            cin_dev = (op.cin + 3) // 4 * 4
-            issued += 2.0 * n_crops * t.h * t.w * op.cout * ((op.k * op.k * cin_dev + 31) // 32 * 32)
+            issued += 2.0 * n_crops * t.h * t.w * op.cout * model.conv_kp[i]       # K as packed (padded to 32)
     n_wino = int((tiles[:, 3] == 2).sum())
     roof = {"bound": "mfma",
             "kernel": "all %d convolution launches of a step: conv_igemm_pipe_kernel / conv_igemm_kernel (direct implicit GEMM, %d) + "

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQ_ABI_VERSION 1
+#define VQ_ABI_VERSION 2
 
 enum {
     VQ_OK = 0,
@@ -182,20 +182,31 @@ typedef struct vq_tensor_desc {
     int32_t h, w, c;             /* NHWC activations, fp32                                    */
 } vq_tensor_desc;
 
-/* Slot 0 is the network input: h x w x (in_channels padded to a multiple of 4), produced on the device
- * from uint8 crops of in_channels channels minus mean; the first convolution's weights are packed for
- * the padded channel count (zeros in the pad).
- * `feature_slot` names the 1x1xD tensor that is the feature blob ("global_pool",
+/* The crops handed to vq_tsn_forward: h x w x c uint8, and how slot 0 (the first layer's source) is produced from
+ * them on the device (value = pixel - mean[channel], zero outside the crop):
+ *   s2d_pad < 0   slot 0 = the h x w image, channels padded with zeros to tensors[0].c (a multiple of 4, < c + 4);
+ *   s2d_pad >= 0  slot 0 = the space-to-depth(2) image of the crop shifted by s2d_pad:
+ *                 slot0[Y][X][(p*2+q)*c + ch] = crop[2Y + p - s2d_pad][2X + q - s2d_pad][ch],  tensors[0].c = 4c.
+ *                 A k x k / stride-2 / pad-s2d_pad first convolution is then an exact ceil(k/2) x ceil(k/2) / stride-1 /
+ *                 pad-0 convolution over slot 0 whose K dimension has no channel padding (the 7x7x3 stem: K = 192
+ *                 instead of 7*7*4 -> 224); its weights must be packed accordingly (zeros for the tap k). */
+typedef struct vq_input_desc {
+    int32_t h, w, c;
+    int32_t s2d_pad;
+    int32_t s2d_kernel;          /* with s2d_pad >= 0: the k of the original first convolution (FLOP accounting only) */
+} vq_input_desc;
+
+/* `feature_slot` names the 1x1xD tensor that is the feature blob ("global_pool",
  * calcSig_wOF.py:95,112,174-175).  Replaces CaffeNet(proto, weights, device) at
  * calcSig_wOF.py:52,55. */
 int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_layer_desc* layers,
                   int32_t n_layers, const vq_conv_segment* segments, int32_t n_segments, const float* blob_host,
-                  int64_t blob_floats, int32_t in_channels, int32_t feature_slot, int32_t max_crops, int32_t device,
+                  int64_t blob_floats, const vq_input_desc* input, int32_t feature_slot, int32_t max_crops, int32_t device,
                   vq_tsn** out);
 int vq_tsn_destroy(vq_tsn* net);
 int vq_tsn_set_stream(vq_tsn* net, void* hip_stream);
 /* crops: uint8 NHWC [n_crops][h][w][c] (host, or device if crops_on_device), n_crops = B*T with the
- * T snippets of one clip contiguous.  mean[in_channels] is subtracted per channel (BGR [104,117,123] /
+ * T snippets of one clip contiguous (h, w, c of the vq_input_desc).  mean[c] is subtracted per channel (BGR [104,117,123] /
  * flow 128).  Outputs (host, may be NULL): per_snippet [n_crops][D] fp32 = the global_pool blob of
  * each snippet (calcSig_wOF.py:95,112); feat [B][D] fp64 = the segment consensus
  * np.array(frame_features).mean(axis=0) (calcSig_wOF.py:82).

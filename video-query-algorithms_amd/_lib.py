@@ -12,6 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvqamd.so")
 
+ABI_VERSION = 2                 # include/vq_amd.h: VQ_ABI_VERSION
 VQ_F32, VQ_F64 = 0, 1
 VQ_OP_CONV, VQ_OP_MAXPOOL, VQ_OP_AVGPOOL, VQ_OP_GLOBAL_AVGPOOL, VQ_OP_CONV_WINOGRAD = 1, 2, 3, 4, 5
 
@@ -34,6 +35,10 @@ class LayerDesc(C.Structure):
 
 class ConvSegment(C.Structure):
     _fields_ = [("cout", C.c_int32), ("dst", C.c_int32), ("dst_coff", C.c_int32), ("relu", C.c_int32)]
+
+
+class InputDesc(C.Structure):
+    _fields_ = [("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("s2d_pad", C.c_int32), ("s2d_kernel", C.c_int32)]
 
 
 class TensorDesc(C.Structure):
@@ -64,8 +69,8 @@ SIGNATURES = {
     "vq_db_scores_grid": [_P, _P, _I32, _P, _I32, _P],
     "vq_db_select": [_P, _F64, _F64, _pI64, _pI64, _pI64], "vq_db_select_fetch": [_P, _P, _I64, _P, _I64],
     "vq_db_topk": [_P, _I64, _P, _P, _pI64], "vq_db_min_score": [_P, _P, _I32, _pF64],
-    "vq_tsn_create": [C.POINTER(TensorDesc), _I32, C.POINTER(LayerDesc), _I32, C.POINTER(ConvSegment), _I32, _P, _I64, _I32, _I32,
-                      _I32, _I32, _PP],
+    "vq_tsn_create": [C.POINTER(TensorDesc), _I32, C.POINTER(LayerDesc), _I32, C.POINTER(ConvSegment), _I32, _P, _I64,
+                      C.POINTER(InputDesc), _I32, _I32, _I32, _PP],
     "vq_tsn_destroy": [_P], "vq_tsn_set_stream": [_P, _P],
     "vq_tsn_forward": [_P, _P, _I32, _I32, _I32, _pF32, _P, _P],
     "vq_tsn_feat_devptr": [_P, _PP, _PP], "vq_tsn_read_tensor": [_P, _I32, _I32, _P],
@@ -105,8 +110,8 @@ def load(path: str | None = None):
         for name, args in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError here = ABI mismatch; fail loudly
             fn.argtypes, fn.restype = args, C.c_int
-        if lib.vq_abi_version() != 1:
-            raise ImportError("libvqamd.so ABI version %d != 1" % lib.vq_abi_version())
+        if lib.vq_abi_version() != ABI_VERSION:
+            raise ImportError("libvqamd.so ABI version %d != %d" % (lib.vq_abi_version(), ABI_VERSION))
         _lib = lib
         return lib
 

@@ -35,6 +35,24 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ src, float* __rest
     for (int c = 0; c < Cpad; ++c) dst[p * Cpad + c] = c < C ? (float)src[p * C + c] - mean[c] : 0.0f;
 }
 
+// Space-to-depth(2) variant (vq_input_desc.s2d_pad >= 0): one thread per (crop, Y, X) of slot 0 writes its 4*C channels,
+// dst[..][(p*2+q)*C + c] = crop[2Y+p-pad][2X+q-pad][c] - mean[c], zeros outside the crop (the first convolution's own
+// zero padding, applied after the mean like Caffe does).
+__global__ void preprocess_s2d_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int64_t ncell, int H, int W, int C,
+                                      int Hs, int Ws, int pad, const float* __restrict__ mean) {
+    const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= ncell) return;
+    const int X = (int)(cell % Ws), Y = (int)((cell / Ws) % Hs);
+    const int64_t n = cell / ((int64_t)Ws * Hs);
+    float* out = dst + cell * (4 * C);
+    for (int pq = 0; pq < 4; ++pq) {
+        const int y = 2 * Y + (pq >> 1) - pad, x = 2 * X + (pq & 1) - pad;
+        const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        const uint8_t* px = src + ((n * H + (in ? y : 0)) * W + (in ? x : 0)) * C;
+        for (int c = 0; c < C; ++c) out[pq * C + c] = in ? (float)px[c] - mean[c] : 0.0f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // convolution (+ folded BN + ReLU) as implicit GEMM on v_mfma_f32_32x32x2_f32
 // ------------------------------------------------------------------------------------------------
@@ -635,6 +653,14 @@ __global__ void consensus_kernel(const float* __restrict__ per_snippet, double* 
 // ------------------------------------------------------------------------------------------------
 // handle + executor
 // ------------------------------------------------------------------------------------------------
+// k*k*Cin of a convolution in ALGORITHMIC terms: a layer that reads slot 0 counts the un-padded input channels and,
+// in space-to-depth form, the kernel size of the original convolution.
+static inline double first_layer_k2c(const vq_input_desc& in, const vq_layer_desc& L) {
+    if (L.src != 0) return (double)L.k * L.k * L.cin;
+    const int k = (in.s2d_pad >= 0 && in.s2d_kernel > 0) ? in.s2d_kernel : L.k;
+    return (double)k * k * in.c;
+}
+
 static inline bool is_conv(int op) { return op == VQ_OP_CONV || op == VQ_OP_CONV_WINOGRAD; }
 
 struct ConvTile {
@@ -649,6 +675,7 @@ struct vq_tsn {
     int cus = 256;
     int max_crops = 0;
     int in_channels = 0;
+    vq_input_desc input = {0, 0, 0, -1, 0};
     std::vector<vq_tensor_desc> tensors;
     std::vector<vq_layer_desc> layers;
     std::map<int, std::vector<int>> tuned;   // n_crops -> per-layer index into kTiles (autotuned)
@@ -1033,17 +1060,26 @@ extern "C" {
 
 int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_layer_desc* layers, int32_t n_layers,
                   const vq_conv_segment* segments, int32_t n_segments, const float* blob_host, int64_t blob_floats,
-                  int32_t in_channels, int32_t feature_slot, int32_t max_crops, int32_t device, vq_tsn** out) {
+                  const vq_input_desc* input, int32_t feature_slot, int32_t max_crops, int32_t device, vq_tsn** out) {
     VQ_REQUIRE(out, "out is NULL");
     *out = nullptr;
-    VQ_REQUIRE(tensors && layers && blob_host, "NULL argument");
+    VQ_REQUIRE(tensors && layers && blob_host && input, "NULL argument");
+    const int in_channels = input->c;
     VQ_REQUIRE(n_tensors > 0 && n_layers > 0 && blob_floats > 0 && max_crops > 0, "sizes must be positive");
     VQ_REQUIRE(n_segments >= 0 && (n_segments == 0 || segments), "bad segment table");
     VQ_REQUIRE(feature_slot > 0 && feature_slot < n_tensors, "feature_slot out of range");
     VQ_REQUIRE(tensors[feature_slot].h == 1 && tensors[feature_slot].w == 1, "feature slot must be 1x1xD");
     VQ_REQUIRE(tensors[0].c % 4 == 0, "input slot channels must be padded to a multiple of 4 (got %d)", tensors[0].c);
-    VQ_REQUIRE(in_channels > 0 && in_channels <= tensors[0].c && tensors[0].c - in_channels < 4, "in_channels %d does not fit the %d-channel input slot",
-               in_channels, tensors[0].c);
+    VQ_REQUIRE(input->h > 0 && input->w > 0 && in_channels > 0, "input crops must be h x w x c with positive sizes");
+    if (input->s2d_pad < 0) {
+        VQ_REQUIRE(tensors[0].h == input->h && tensors[0].w == input->w, "input slot is %dx%d but the crops are %dx%d", tensors[0].h,
+                   tensors[0].w, input->h, input->w);
+        VQ_REQUIRE(in_channels <= tensors[0].c && tensors[0].c - in_channels < 4, "in_channels %d does not fit the %d-channel input slot",
+                   in_channels, tensors[0].c);
+    } else {
+        VQ_REQUIRE(tensors[0].c == 4 * in_channels, "space-to-depth input slot needs 4 x %d channels (got %d)", in_channels, tensors[0].c);
+        VQ_REQUIRE(input->s2d_pad <= 64, "space-to-depth shift out of range");
+    }
     // validate every layer against the tensor table BEFORE anything is launched: a mismatch here would be
     // an out-of-bounds access on the device
     double macs = 0;
@@ -1086,7 +1122,7 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
             VQ_REQUIRE(L.b_off >= 0 && L.b_off + L.cout <= blob_floats, "layer %d: bias outside the blob", i);
             VQ_REQUIRE(L.cin % KPAD == 0 || L.src_coff == 0, "layer %d: small-Cin convolution must read a whole slot", i);
             VQ_REQUIRE(L.cin % KPAD == 0 || L.cin == ts.c, "layer %d: small-Cin convolution must read a whole slot", i);
-            macs += (double)td.h * td.w * L.cout * (L.src == 0 ? in_channels : L.cin) * L.k * L.k;   // algorithmic, un-padded
+            macs += (double)td.h * td.w * L.cout * first_layer_k2c(*input, L);   // algorithmic, un-padded
         } else if (L.op == VQ_OP_CONV_WINOGRAD) {
             VQ_REQUIRE(L.k == 3 && L.stride == 1 && L.pad == 1 && L.seg_count == 0, "layer %d: Winograd form is 3x3 / stride 1 / pad 1, one destination", i);
             VQ_REQUIRE(L.cin % 8 == 0 && L.cout % 32 == 0, "layer %d: Winograd form needs Cin %% 8 == 0 and Cout %% 32 == 0", i);
@@ -1115,6 +1151,7 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
     net->device = device;
     net->max_crops = max_crops;
     net->in_channels = in_channels;
+    net->input = *input;
     net->tensors.assign(tensors, tensors + n_tensors);
     net->layers.assign(layers, layers + n_layers);
     net->feature_slot = feature_slot;
@@ -1239,7 +1276,7 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
     DeviceGuard g(net->device);
     const vq_tensor_desc& t0 = net->tensors[0];
     const int in_c = net->in_channels;
-    const int64_t npix = (int64_t)n_crops * t0.h * t0.w;
+    const int64_t npix = (int64_t)n_crops * net->input.h * net->input.w;
     const uint8_t* src = crops;
     if (!crops_on_device) {
         const size_t bytes = (size_t)npix * in_c;
@@ -1254,7 +1291,13 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
         src = net->crops_dev;
     }
     VQ_HIP(hipMemcpyAsync(net->mean_dev, mean_host, in_c * sizeof(float), hipMemcpyHostToDevice, net->stream));
-    preprocess_kernel<<<cdiv(npix, 256), 256, 0, net->stream>>>(src, net->slots[0], npix, in_c, t0.c, net->mean_dev);
+    if (net->input.s2d_pad < 0) {
+        preprocess_kernel<<<cdiv(npix, 256), 256, 0, net->stream>>>(src, net->slots[0], npix, in_c, t0.c, net->mean_dev);
+    } else {
+        const int64_t ncell = (int64_t)n_crops * t0.h * t0.w;
+        preprocess_s2d_kernel<<<cdiv(ncell, 256), 256, 0, net->stream>>>(src, net->slots[0], ncell, net->input.h, net->input.w, in_c,
+                                                                       t0.h, t0.w, net->input.s2d_pad, net->mean_dev);
+    }
     VQ_CHECK_LAUNCH();
     if (net->autotune && !getenv("VQ_TSN_TILE") && net->tuned.find(n_crops) == net->tuned.end()) {
         const char* env = getenv("VQ_TSN_AUTOTUNE");
@@ -1397,7 +1440,7 @@ int vq_tsn_layer_times(vq_tsn* net, float* ms, double* flops, int32_t n_layers) 
         for (int i = 0; i < n_layers; ++i) {
             const vq_layer_desc& L = net->layers[i];
             const vq_tensor_desc& td = net->tensors[L.dst];
-            flops[i] = is_conv(L.op) ? 2.0 * net->last_crops * td.h * td.w * L.cout * (L.src == 0 ? net->in_channels : L.cin) * L.k * L.k
+            flops[i] = is_conv(L.op) ? 2.0 * net->last_crops * td.h * td.w * L.cout * first_layer_k2c(net->input, L)
                                           : 0.0;
         }
     }

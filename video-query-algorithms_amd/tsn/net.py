@@ -14,7 +14,7 @@ from typing import Dict, Sequence
 import numpy as np
 
 from .. import _lib
-from .._lib import ConvSegment, LayerDesc, TensorDesc, call
+from .._lib import ConvSegment, InputDesc, LayerDesc, TensorDesc, call
 from .bn_inception import Graph, Plan
 
 BK = 32                      # K granularity of the implicit-GEMM kernel (csrc/vq_tsn.hip)
@@ -87,10 +87,29 @@ def pad4(c: int) -> int:
     return (c + 3) // 4 * 4
 
 
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def s2d_stem_weights(W: np.ndarray) -> np.ndarray:
+    """[Cout][C][k][k] of a stride-2 convolution -> [Cout][k2][k2][4C] (k2 = ceil(k/2)) for the space-to-depth input
+    slot0[Y][X][(p*2+q)*C + c]: W2[o][a][b][(p*2+q)*C + c] = W[o][c][2a+p][2b+q] (zero where 2a+p or 2b+q reaches k)."""
+    cout, c, k, _ = W.shape
+    k2 = (k + 1) // 2
+    out = np.zeros((cout, k2, k2, 4 * c), dtype=W.dtype)
+    for a in range(k2):
+        for b in range(k2):
+            for p in range(2):
+                for q in range(2):
+                    if 2 * a + p < k and 2 * b + q < k:
+                        out[:, a, b, (p * 2 + q) * c:(p * 2 + q + 1) * c] = W[:, :, 2 * a + p, 2 * b + q]
+    return out
+
+
 class TsnNet:
     def __init__(self, graph: Graph, weights: Dict[str, Dict[str, np.ndarray]], max_crops: int = 96, device: int = 0,
                  feature_blob: str = "global_pool", bn_eps: float = 1e-5, fuse: bool = True,
-                 winograd: bool | None = None):
+                 winograd: bool | None = None, stem_s2d: bool | None = None):
         self.graph = graph
         self.plan: Plan = graph.plan(feature_blob, fuse=fuse)
         self.in_channels = graph.input_shape[0]
@@ -99,9 +118,29 @@ class TsnNet:
         self.winograd = winograd_default() if winograd is None else bool(winograd)
         plan = self.plan
         cin_pad = pad4(self.in_channels)
+        self.in_h, self.in_w = plan.tensors[0].h, plan.tensors[0].w
+        # Space-to-depth stem: a k x k / stride-2 first convolution on very few channels is evaluated as a
+        # ceil(k/2)^2 / stride-1 convolution over the 2x2-decimated input with 4x the channels -- K has no channel padding
+        # (7x7x3: 16 taps x 12 = 192 instead of 49 x 4 -> 224) and every load is 16-byte aligned.  Taken when it
+        # shrinks the packed K (RGB yes; the 10-channel flow stack no: 16 x 40 = 640 > 49 x 12 -> 608).
+        stem = [op for op in plan.ops if op.src == 0]
+        self.stem_s2d = False
+        if (stem_s2d if stem_s2d is not None else os.environ.get("VQ_TSN_STEM_S2D", "1") != "0") and len(stem) == 1:
+            op = stem[0]
+            k2 = (op.k + 1) // 2
+            if op.kind == "conv" and op.stride == 2 and not op.segments and op.k >= 3 and \
+                    _round_up(k2 * k2 * 4 * self.in_channels, BK) < _round_up(op.k * op.k * cin_pad, BK):
+                self.stem_s2d = True
+        in_slot_c = 4 * self.in_channels if self.stem_s2d else cin_pad
         tensors = (TensorDesc * len(plan.tensors))()
         for i, t in enumerate(plan.tensors):
-            tensors[i] = TensorDesc(t.h, t.w, cin_pad if i == 0 else t.c)
+            tensors[i] = TensorDesc(t.h, t.w, t.c)
+        if self.stem_s2d:
+            to_ = plan.tensors[stem[0].dst]
+            tensors[0] = TensorDesc(to_.h + (stem[0].k + 1) // 2 - 1, to_.w + (stem[0].k + 1) // 2 - 1, in_slot_c)
+        else:
+            tensors[0] = TensorDesc(self.in_h, self.in_w, cin_pad)
+        self.conv_kp = {}                                  # op index -> packed K of the direct kernel (bench accounting)
         layers = (LayerDesc * len(plan.ops))()
         seg_list = []
         chunks = []
@@ -141,8 +180,22 @@ class TsnNet:
                     if not op.bias:
                         b = np.zeros_like(b)
                     d.op = _lib.VQ_OP_CONV_WINOGRAD
+                elif self.stem_s2d and op.src == 0:
+                    W, b = fold_bn(weights[op.name], weights[op.bn] if op.bn else None, bn_eps)
+                    if W.shape != (op.cout, op.cin, op.k, op.k):
+                        raise ValueError("weights of %s have shape %s" % (op.name, W.shape))
+                    w2 = s2d_stem_weights(W)
+                    cin_dev = in_slot_c
+                    kdim = w2.shape[1] * w2.shape[2] * cin_dev
+                    packed = np.zeros((op.cout, _round_up(kdim, BK)), dtype=np.float32)
+                    packed[:, :kdim] = w2.reshape(op.cout, kdim)
+                    if not op.bias:
+                        b = np.zeros_like(b)
+                    d.k, d.stride, d.pad = w2.shape[1], 1, 0
                 else:
                     packed, b = packed_conv(op.name, op.bn, op.cin, op.cout, op.k, cin_dev, op.bias)
+                if d.op == _lib.VQ_OP_CONV:
+                    self.conv_kp[i] = packed.shape[1]
                 d.cin = cin_dev
                 d.w_off = off
                 chunks.append(packed.reshape(-1))
@@ -166,12 +219,13 @@ class TsnNet:
         segs = (ConvSegment * max(len(seg_list), 1))(*seg_list)
         blob = np.ascontiguousarray(np.concatenate(chunks))
         self._h = C.c_void_p()
+        inp = InputDesc(self.in_h, self.in_w, self.in_channels, stem[0].pad if self.stem_s2d else -1, stem[0].k if self.stem_s2d else 0)
         call("vq_tsn_create", tensors, len(plan.tensors), layers, len(plan.ops), segs, len(seg_list),
-             blob.ctypes.data_as(C.c_void_p), blob.size, self.in_channels, plan.feature_slot, self.max_crops, device,
+             blob.ctypes.data_as(C.c_void_p), blob.size, C.byref(inp), plan.feature_slot, self.max_crops, device,
              C.byref(self._h))
         self.feature_dim = plan.feature_dim
-        self.in_h, self.in_w = plan.tensors[0].h, plan.tensors[0].w
-        self._tensor_c = [cin_pad if i == 0 else t.c for i, t in enumerate(plan.tensors)]
+        self._tensor_c = [tensors[i].c for i in range(len(plan.tensors))]
+        self._tensor_hw = [(tensors[i].h, tensors[i].w) for i in range(len(plan.tensors))]
 
     # ------------------------------------------------------------------
     def set_stream(self, hip_stream: int):
@@ -208,10 +262,18 @@ class TsnNet:
     def read_blob(self, name: str, n_crops: int) -> np.ndarray:
         """Activation of blob `name` from the last forward, NHWC [n_crops, h, w, c] (per-layer parity)."""
         slot, coff, c = self.plan.blob_loc[name]
-        t = self.plan.tensors[slot]
+        h, w = self._tensor_hw[slot]
         cs = self._tensor_c[slot]
-        buf = np.empty((n_crops, t.h, t.w, cs), dtype=np.float32)
+        buf = np.empty((n_crops, h, w, cs), dtype=np.float32)
         call("vq_tsn_read_tensor", self._h, slot, n_crops, buf.ctypes.data_as(C.c_void_p))
+        if slot == 0 and self.stem_s2d:                   # undo the space-to-depth packing of the input slot
+            pad = [op for op in self.plan.ops if op.src == 0][0].pad
+            ci = self.in_channels
+            img = np.zeros((n_crops, 2 * h, 2 * w, ci), dtype=np.float32)
+            for p in range(2):
+                for q in range(2):
+                    img[:, p::2, q::2] = buf[..., (p * 2 + q) * ci:(p * 2 + q + 1) * ci]
+            return img[:, pad:pad + self.in_h, pad:pad + self.in_w]
         return buf[..., coff:coff + c]
 
     def set_profile(self, depth: int):
