@@ -66,6 +66,8 @@ def host_cores():
 
 
 def bench_tsn(args, rank, world, device, stream):
+    if args.profile_only:
+        os.environ["VQ_TSN_SPLIT"] = "1"             # read when the network handle is created
     g = bn_inception.bn_inception(CH)
     weights = tsn_net.synthetic_weights(g, seed=2)
     n_crops = B_CLIPS * T_SEG
@@ -136,19 +138,22 @@ def bench_tsn(args, rank, world, device, stream):
     model.set_profile(0)
     # The same K steps once more WITHOUT per-layer events: the configuration a user runs (two sub-batches on two
     # streams, VQ_TSN_SPLIT=2; profiled forwards run on one stream).  Reported beside `value`, never instead of it.
+    if args.profile_only:
+        roof["unprofiled_ms_per_step"] = float("nan")
     with torch.cuda.stream(stream):
-        for _ in range(max(args.warmup, 2)):
+        for _ in range(0 if args.profile_only else max(args.warmup, 2)):
             step()                                   # first un-profiled forward autotunes the sub-batch size
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(0 if args.profile_only else args.steps):
             step()
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
-        roof["unprofiled_ms_per_step"] = (time.perf_counter() - t1) / args.steps * 1e3
+        if not args.profile_only:
+            roof["unprofiled_ms_per_step"] = (time.perf_counter() - t1) / args.steps * 1e3
     if args.tiles and rank == 0 and not os.path.exists(args.tiles):
         os.makedirs(os.path.dirname(os.path.abspath(args.tiles)), exist_ok=True)
         with open(args.tiles, "w") as f:
@@ -259,6 +264,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--skip-sim", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--profile-only", action="store_true",
+                    help="for rocprofv3 comparisons: every forward of the process runs like the timed region (one stream, "
+                         "VQ_TSN_SPLIT=1) and the un-profiled production-mode pass is skipped")
     ap.add_argument("--tiles", default=None, help="JSON file: load the conv tiling table if it exists, else write it")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -292,9 +300,10 @@ def main():
     up = torch.tensor([roof.pop("unprofiled_ms_per_step")], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(up, op=dist.ReduceOp.MAX)
-    out["production_mode"] = {"value": world * B_CLIPS / float(up.item()) * 1e3, "unit": "clips/s", "ms_per_step": float(up.item()),
-                              "note": "same K steps, same bracketing, without the per-layer profiling events of the timed region "
-                                      "(batch split over 2 HIP streams active)"}
+    if not args.profile_only:
+        out["production_mode"] = {"value": world * B_CLIPS / float(up.item()) * 1e3, "unit": "clips/s", "ms_per_step": float(up.item()),
+                                  "note": "same K steps, same bracketing, without the per-layer profiling events of the timed region "
+                                          "(batch split over 2 HIP streams active)"}
     if rank == 0 and world == 1 and not args.skip_cpu:
         base, ps_cpu = cpu_baseline_tsn(crops.cpu().numpy(), (model.graph, tsn_net.synthetic_weights(model.graph, seed=2)))
         out["cpu_baseline"] = base
