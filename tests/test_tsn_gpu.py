@@ -103,7 +103,7 @@ WINO_CASES = [
 
 @pytest.mark.parametrize("cin,h,cout,n", WINO_CASES)
 def test_winograd_conv_layer(tsn, monkeypatch, cin, h, cout, n):
-    """Both workgroup shapes of the Winograd kernel against the fp64 oracle (same tolerance as the direct kernel),
+    """All three variants of the Winograd kernel against the fp64 oracle (same tolerance as the direct kernel),
     bit-identical to each other, and within the stated tolerance of the direct kernel."""
     bi, net = tsn
     monkeypatch.delenv("VQ_TSN_TILE", raising=False)
@@ -114,21 +114,21 @@ def test_winograd_conv_layer(tsn, monkeypatch, cin, h, cout, n):
     want = to.forward(g.layers, "data", w, to.preprocess(crops, mean), keep=("c_bn", "gp"))
     tol = 2e-5 * np.abs(want["c_bn"]).max()
     outs = []
-    for bn in (32, 64):
+    for bn, bk in ((32, 8), (64, 8), (32, 16)):                      # 32/64 channels per workgroup; (32, 16) = deep schedule
         m = net.TsnNet(g, w, max_crops=n, feature_blob="gp", winograd=True)
         tiles = m.layer_tiles(n)
         assert tiles[0].tolist()[2:] == [8, 2]                       # the conv layer is in Winograd form
-        tiles[0] = (128, bn, 8, 2)
+        tiles[0] = (128, bn, bk, 2)
         m.set_layer_tiles(n, tiles)
         feat, ps = m.forward(crops, 1, mean)
         got = _nchw(m.read_blob("c_bn", n))
-        assert m.layer_tiles(n)[0].tolist() == [128, bn, 8, 2]
+        assert m.layer_tiles(n)[0].tolist() == [128, bn, bk, 2]
         assert np.abs(got - want["c_bn"]).max() <= tol
         assert (got >= 0).all()
         assert np.abs(ps - want["gp"].reshape(n, -1)).max() <= tol
         outs.append(got)
         m.close()
-    assert (outs[0] == outs[1]).all()
+    assert (outs[0] == outs[1]).all() and (outs[0] == outs[2]).all()
     m = net.TsnNet(g, w, max_crops=n, feature_blob="gp", winograd=False)
     assert m.layer_tiles(n)[0, 3] != 2
     m.forward(crops, 1, mean)
