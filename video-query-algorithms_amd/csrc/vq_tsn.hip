@@ -369,7 +369,15 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     }
 
     floatx4 ra[2][NA], rb[2][NB];   // two staging sets: tile kc+1 waits in one while tile kc+2 is fetched into the other
-    int kh = 0, kw = 0, c0 = 0, tap = 0, tap_off = 0;   // tap_off: byte offset of (kh, kw, c0) relative to tap (0,0)
+    int kh = 0, kw = 0, c0 = 0, tap = 0;
+    // Aligned mode: the address of a staged chunk is (pixel + tap) [per lane, changes only when the tap changes] +
+    // c0 [uniform, changes every step].  The first part lives in a_voff (0xFFFFFFFF when the tap falls into the
+    // padding) and is recomputed on tap changes only; the second rides in the scalar offset of the buffer load, which
+    // the hardware range check accounts for.  The VALU and the matrix pipe share issue bandwidth
+    // (tools/ubench/mfma_coissue.hip), so the steady state of the K loop carries no address arithmetic at all.
+    unsigned a_voff[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a_voff[i] = (a_mask[i] & 1ull) ? (unsigned)a_off[i] : 0xFFFFFFFFu;
     const unsigned cpt = (unsigned)a.Cin >> 2, inv_cpt = 65536u / cpt + 1u, inv_k = 65536u / (unsigned)a.k + 1u;   // small-Cin decode
 
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -407,13 +415,12 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
                 const unsigned ok_ = (unsigned)(a_mask[ii] >> (tap_ & 63u)) & (tap_ < 64u ? 1u : 0u);          \
                 off = ok_ ? (unsigned)(a_off[ii] + (int)(((th_ * a.W + tw_) * a.Cs_in + c4_ * 4) * 4)) : 0xFFFFFFFFu; \
             } else {                                                                                           \
-                off = ((a_mask[ii] >> tap) & 1ull) ? (unsigned)(a_off[ii] + tap_off) : 0xFFFFFFFFu;            \
+                off = a_voff[ii];                                                                              \
             }                                                                                                  \
-            ra[SET][ii] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0)); \
+            ra[SET][ii] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, SMALL_CIN ? 0 : c0 * 4, 0)); \
         } else {                                                                                               \
             const int ii = (IDX) >= NA ? (IDX) - NA : 0;                                                       \
-            const unsigned off = b_off[ii] == 0xFFFFFFFFu ? 0xFFFFFFFFu : b_off[ii] + (unsigned)(KC) * (BK * 4); \
-            rb[SET][ii] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, off, 0, 0)); \
+            rb[SET][ii] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_off[ii], (KC) * (BK * 4), 0)); \
         }                                                                                                      \
     }
 #define VQ_G_STORE(IDX, BUF, SET)                                                                              \
@@ -428,18 +435,22 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
                 *reinterpret_cast<floatx4*>(&sm.b[BUF][b_row[ii]][b_col[ii] * 4]) = rb[SET][ii];               \
         }                                                                                                      \
     }
-#define VQ_ADVANCE_TAP()                                        \
-    if (!SMALL_CIN) {                                           \
-        c0 += BK;                                               \
-        if (c0 >= a.Cin) {                                      \
-            c0 = 0;                                             \
-            ++tap;                                              \
-            if (++kw == a.k) {                                  \
-                kw = 0;                                         \
-                ++kh;                                           \
-            }                                                   \
-        }                                                       \
-        tap_off = ((kh * a.W + kw) * a.Cs_in + c0) * 4;         \
+#define VQ_ADVANCE_TAP()                                                                     \
+    if (!SMALL_CIN) {                                                                        \
+        c0 += BK;                                                                            \
+        if (c0 >= a.Cin) {                                                                   \
+            c0 = 0;                                                                          \
+            ++tap;                                                                           \
+            if (++kw == a.k) {                                                               \
+                kw = 0;                                                                      \
+                ++kh;                                                                        \
+            }                                                                                \
+            asm volatile("" ::: "memory"); /* keep this a (rarely taken, uniform) branch: if-converted, the    \
+                                              recomputation below would run on every step */                 \
+            const int tap_pix = ((kh * a.W + kw) * a.Cs_in) * 4;                             \
+            _Pragma("unroll") for (int i = 0; i < NA; ++i)                                   \
+                a_voff[i] = ((a_mask[i] >> tap) & 1ull) ? (unsigned)(a_off[i] + tap_pix) : 0xFFFFFFFFu; \
+        }                                                                                    \
     }
 // One K-step on LDS buffer BUF (compute on tile KC); its first fragments are already in fa[0] / fb[0].
 // DO_STORE: tile KC+1, fetched during the previous step into staging set SS, goes to LDS buffer BUF^1 behind the first
