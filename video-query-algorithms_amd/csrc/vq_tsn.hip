@@ -73,7 +73,8 @@ struct ConvArgs {
     const float* zeros;  // >= 16 bytes of zeros: where masked-off lanes load from (no branches around loads)
     int H, W, Cs_in, coff_in, Cin;
     int Ho, Wo, Cs_out, coff_out, Cout;
-    int k, stride, pad;
+    int k, stride, pad;  // k kernel rows ...
+    int kw;              // ... of kw taps each (= k, or 1 when a kernel row is folded into the channel axis, see launch_conv_layer)
     int M, Kp, relu;
     int out_row0;        // first output row (pixel) of this launch inside the destination slots (sub-batch launches)
     int tiles_m, tiles_n;
@@ -202,9 +203,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             if (SMALL_CIN) {                                                                                       \
                 const int kidx = ((KC) * CPR + a_col[i]) * 4;                                                      \
                 const int tap = kidx / a.Cin, c = kidx - tap * a.Cin;                                              \
-                const int th = tap / a.k, tw = tap - th * a.k;                                                     \
+                const int th = tap / a.kw, tw = tap - th * a.kw;                                                   \
                 const int ih = a_ih0[i] + th, iw = a_iw0[i] + tw;                                                  \
-                if (tap < a.k * a.k && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)               \
+                if (tap < a.k * a.kw && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)              \
                     src = a_img[i] + ((size_t)ih * a.W + iw) * a.Cs_in + c;                                        \
             } else {                                                                                               \
                 const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;                                                  \
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             c0 += BK;                                                                                              \
             if (c0 >= a.Cin) {                                                                                     \
                 c0 = 0;                                                                                            \
-                if (++kw == a.k) {                                                                                 \
+                if (++kw == a.kw) {                                                                                \
                     kw = 0;                                                                                        \
                     ++kh;                                                                                          \
                 }                                                                                                  \
@@ -353,8 +354,8 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         a_off[i] = (((n_img * a.H + ih0) * a.W + iw0) * a.Cs_in + a.coff_in + (SMALL_CIN ? 0 : a_col[i] * 4)) * 4;
         unsigned long long mask = 0;
         for (int th = 0; th < a.k; ++th)
-            for (int tw = 0; tw < a.k; ++tw)
-                if (ok && (unsigned)(ih0 + th) < (unsigned)a.H && (unsigned)(iw0 + tw) < (unsigned)a.W) mask |= 1ull << (th * a.k + tw);
+            for (int tw = 0; tw < a.kw; ++tw)
+                if (ok && (unsigned)(ih0 + th) < (unsigned)a.H && (unsigned)(iw0 + tw) < (unsigned)a.W) mask |= 1ull << (th * a.kw + tw);
         a_mask[i] = mask;
     }
     unsigned b_off[NB];
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     unsigned a_voff[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) a_voff[i] = (a_mask[i] & 1ull) ? (unsigned)a_off[i] : 0xFFFFFFFFu;
-    const unsigned cpt = (unsigned)a.Cin >> 2, inv_cpt = 65536u / cpt + 1u, inv_k = 65536u / (unsigned)a.k + 1u;   // small-Cin decode
+    const unsigned cpt = (unsigned)a.Cin >> 2, inv_cpt = 65536u / cpt + 1u, inv_k = 65536u / (unsigned)a.kw + 1u;   // small-Cin decode
 
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
             if (SMALL_CIN) {                                                                                   \
                 const unsigned g_ = (unsigned)(KC) * CPR + a_col[ii];                                          \
                 const unsigned tap_ = (g_ * inv_cpt) >> 16, c4_ = g_ - tap_ * cpt;                             \
-                const unsigned th_ = (tap_ * inv_k) >> 16, tw_ = tap_ - th_ * a.k;                             \
+                const unsigned th_ = (tap_ * inv_k) >> 16, tw_ = tap_ - th_ * a.kw;                            \
                 const unsigned ok_ = (unsigned)(a_mask[ii] >> (tap_ & 63u)) & (tap_ < 64u ? 1u : 0u);          \
                 off = ok_ ? (unsigned)(a_off[ii] + (int)(((th_ * a.W + tw_) * a.Cs_in + c4_ * 4) * 4)) : 0xFFFFFFFFu; \
             } else {                                                                                           \
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         if (c0 >= a.Cin) {                                                                   \
             c0 = 0;                                                                          \
             ++tap;                                                                           \
-            if (++kw == a.k) {                                                               \
+            if (++kw == a.kw) {                                                              \
                 kw = 0;                                                                      \
                 ++kh;                                                                        \
             }                                                                                \
@@ -852,6 +853,7 @@ static void fill_conv_args(vq_tsn* net, int li, int n_crops, ConvArgs& a) {
     a.coff_out = L.dst_coff;
     a.Cout = L.cout;
     a.k = L.k;
+    a.kw = L.k;
     a.stride = L.stride;
     a.pad = L.pad;
     a.M = n_crops * td.h * td.w;
@@ -869,8 +871,18 @@ static void fill_conv_args(vq_tsn* net, int li, int n_crops, ConvArgs& a) {
 static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
     ConvArgs a;
     fill_conv_args(net, li, n_crops, a);
-    const bool small = (net->layers[li].cin % KPAD) != 0;
+    const vq_layer_desc& L = net->layers[li];
     if (kTiles[tile_idx].pipe && a.in_bytes >= 0x7FFFFFF0u) tile_idx = heuristic_tile(a.M, a.Cout, net->cus);   // 32-bit offsets
+    // A convolution without padding that reads ALL channels of its slot finds the kw taps of a kernel row side by side
+    // in memory ([kw][Cin] is one contiguous run of the NHWC row, and the packed weights have the same order): fold the
+    // row into the channel axis -- k rows of one tap with kw*Cin channels.  The space-to-depth stem (4x4 over 12
+    // channels) becomes 4 taps of 48 contiguous floats and, with BK = 16, runs on the aligned path: no per-chunk tap
+    // decoding in its K loop.
+    if (L.pad == 0 && L.k > 1 && L.cin == net->tensors[L.src].c && L.src_coff == 0) {
+        a.kw = 1;
+        a.Cin = L.k * L.cin;
+    }
+    const bool small = (a.Cin % kTiles[tile_idx].bk) != 0;
     if (kTiles[tile_idx].pipe == 1) return small ? launch_conv_pipe<true>(net, a, kTiles[tile_idx]) : launch_conv_pipe<false>(net, a, kTiles[tile_idx]);
     return small ? launch_conv<true>(net, a, kTiles[tile_idx]) : launch_conv<false>(net, a, kTiles[tile_idx]);
 }
