@@ -103,7 +103,7 @@ WINO_CASES = [
 
 @pytest.mark.parametrize("cin,h,cout,n", WINO_CASES)
 def test_winograd_conv_layer(tsn, monkeypatch, cin, h, cout, n):
-    """All three variants of the Winograd kernel against the fp64 oracle (same tolerance as the direct kernel),
+    """Both workgroup shapes of the Winograd kernel against the fp64 oracle (same tolerance as the direct kernel),
     bit-identical to each other, and within the stated tolerance of the direct kernel."""
     bi, net = tsn
     monkeypatch.delenv("VQ_TSN_TILE", raising=False)
@@ -114,7 +114,7 @@ def test_winograd_conv_layer(tsn, monkeypatch, cin, h, cout, n):
     want = to.forward(g.layers, "data", w, to.preprocess(crops, mean), keep=("c_bn", "gp"))
     tol = 2e-5 * np.abs(want["c_bn"]).max()
     outs = []
-    for bn, bk in ((32, 8), (64, 8), (32, 16)):                      # 32/64 channels per workgroup; (32, 16) = deep schedule
+    for bn, bk in ((32, 8), (64, 8)):                                # 32 / 64 output channels per workgroup
         m = net.TsnNet(g, w, max_crops=n, feature_blob="gp", winograd=True)
         tiles = m.layer_tiles(n)
         assert tiles[0].tolist()[2:] == [8, 2]                       # the conv layer is in Winograd form
@@ -128,7 +128,7 @@ def test_winograd_conv_layer(tsn, monkeypatch, cin, h, cout, n):
         assert np.abs(ps - want["gp"].reshape(n, -1)).max() <= tol
         outs.append(got)
         m.close()
-    assert (outs[0] == outs[1]).all() and (outs[0] == outs[2]).all()
+    assert (outs[0] == outs[1]).all()
     m = net.TsnNet(g, w, max_crops=n, feature_blob="gp", winograd=False)
     assert m.layer_tiles(n)[0, 3] != 2
     m.forward(crops, 1, mean)

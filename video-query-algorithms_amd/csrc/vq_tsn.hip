@@ -1478,10 +1478,10 @@ int vq_tsn_layer_tiles(vq_tsn* net, int32_t n_crops, int32_t* tiles, int32_t n_l
     for (int i = 0; i < n_layers; ++i) {
         tiles[4 * i] = tiles[4 * i + 1] = tiles[4 * i + 2] = tiles[4 * i + 3] = 0;
         if (net->layers[i].op == VQ_OP_CONV_WINOGRAD) {   // 32 tiles (128 pixels) x 32 (v+1) channels, 8 channels per step
-            const int v = it != net->tuned.end() ? it->second[i] : 0;       // variant 2 (deep schedule) reports BK = 16
+            const int v = it != net->tuned.end() ? it->second[i] : 0;
             tiles[4 * i] = 128;
-            tiles[4 * i + 1] = v == 1 ? 64 : 32;
-            tiles[4 * i + 2] = v == 2 ? 16 : 8;
+            tiles[4 * i + 1] = 32 * (v + 1);
+            tiles[4 * i + 2] = 8;
             tiles[4 * i + 3] = 2;
             continue;
         }
@@ -1504,9 +1504,9 @@ int vq_tsn_set_layer_tiles(vq_tsn* net, int32_t n_crops, const int32_t* tiles, i
     for (int i = 0; i < n_layers; ++i) {
         if (net->layers[i].op == VQ_OP_CONV_WINOGRAD) {
             const int bn = tiles[4 * i + 1], bk = tiles[4 * i + 2];
-            VQ_REQUIRE(tiles[4 * i + 3] == 2 && ((bn == 32 && (bk == 8 || bk == 16)) || (bn == 64 && bk == 8)),
-                       "layer %d: no Winograd variant for tile %dx%dx%d", i, tiles[4 * i], bn, bk);
-            choice[i] = bn == 64 ? 1 : (bk == 16 ? 2 : 0);
+            VQ_REQUIRE(tiles[4 * i + 3] == 2 && (bn == 32 || bn == 64) && bk == 8, "layer %d: no Winograd variant for tile %dx%dx%d", i,
+                       tiles[4 * i], bn, bk);
+            choice[i] = bn / 32 - 1;
             continue;
         }
         if (net->layers[i].op != VQ_OP_CONV) continue;

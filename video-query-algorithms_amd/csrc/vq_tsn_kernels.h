@@ -30,7 +30,7 @@ struct WinoArgs {
 #endif
 };
 
-constexpr int kWinoVariants = 3;   // 0: 32 output channels per workgroup, 4 waves/SIMD; 1: 64 channels; 2: 32 channels, deep schedule
+constexpr int kWinoVariants = 2;   // output-channel blocks of 32 per workgroup: variant v -> v + 1
 
 // Launch on `stream`; variant in [0, kWinoVariants).  ev_start / ev_stop (both or neither): events that receive the
 // kernel's own begin / end timestamps (hipExtLaunchKernelGGL) for per-layer profiling.  Returns a VQ_* status.

@@ -79,16 +79,9 @@ constexpr int BP = 32;    // tiles per workgroup
 constexpr int KC = 8;     // channels per step
 constexpr int HS_STAGE = 4 * 4 * BP * KC;   // floats: h[r][j][tile][k]
 
-// DEEP (NB = 1 only): the latency-tolerant schedule for layers that cannot fill the chip (the 7x7-pixel layers run
-// ~1 wave per SIMD) and for the last, thin round of every launch.  Two register sets for the activation rows and the
-// filter fragments keep every global load two K-steps ahead of its use, the LDS stage of step k+1 is written under
-// the first MFMAs of step k, ONE barrier sits in the middle of the step, and the first A fragments of step k+1 are
-// read under the last MFMAs of step k -- a lone wave then issues its 16 MFMAs per step back to back.  Costs 2
-// waves/SIMD instead of 4, so the autotuner decides per layer.
-template <int NB, bool DEEP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NB == 1 && !DEEP) ? 4 : 2, (NB == 1 && !DEEP) ? 4 : 2)))
+template <int NB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 4 : 2, NB == 1 ? 4 : 2)))
 void wino_f2x2_3x3_kernel(WinoArgs a) {
-    static_assert(!DEEP || NB == 1, "the deep schedule exists for NB = 1");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* hs = reinterpret_cast<float*>(smem_raw);        // [2][4][4][32][8] (K loop); [4][2][32][32] (epilogue)
 
@@ -148,80 +141,6 @@ void wino_f2x2_3x3_kernel(WinoArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.f;
 
-    if constexpr (DEEP) {
-        floatx4 dd[2][4];             // activation rows: dd[s] is consumed in a step of parity s^1 (it feeds step k+1)
-        floatx4 bb[2][4];             // filter fragments of step k in bb[k & 1]
-        floatx4 a0[2][2], a1[2][2];   // A fragments: set 0 = positions 0,1 (read during the previous step), set 1 = positions 2,3
-#define VQ_D_LOAD_PATCH(S, KSTEP)                                                                               \
-    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                               \
-        dd[S][c] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, poff[c], (KSTEP) * (KC * 4), 0));
-#define VQ_D_LOAD_U(S, KSTEP, J)                                                                                \
-    bb[S][J] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, uvoff[0], (KSTEP) * u_step + u_wave + (J) * u_pos, 0));
-#define VQ_D_STORE_H(S, ST)                                                                                     \
-    {                                                                                                           \
-        float* dst = hs + (ST) * HS_STAGE + hs_store;                                                           \
-        *reinterpret_cast<floatx4*>(dst + 0 * BP * KC) = pk_sub(dd[S][0], dd[S][2]);                            \
-        *reinterpret_cast<floatx4*>(dst + 1 * BP * KC) = pk_add(dd[S][1], dd[S][2]);                            \
-        *reinterpret_cast<floatx4*>(dst + 2 * BP * KC) = pk_sub(dd[S][2], dd[S][1]);                            \
-        *reinterpret_cast<floatx4*>(dst + 3 * BP * KC) = pk_sub(dd[S][1], dd[S][3]);                            \
-    }
-#define VQ_D_READ_A(ST, GRP, SET)                                                                               \
-    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                             \
-        a0[SET][q] = *reinterpret_cast<const floatx4*>(hs + (ST) * HS_STAGE + fa_off + (2 * (GRP) + q) * BP * KC); \
-        a1[SET][q] = *reinterpret_cast<const floatx4*>(hs + (ST) * HS_STAGE + fb_off + (2 * (GRP) + q) * BP * KC); \
-    }
-#define VQ_D_MFMA(P, GRP)                                                                                       \
-    {                                                                                                           \
-        floatx4 av[2];                                                                                          \
-        _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                           \
-            av[q] = pk_fma(a1[GRP][q], sgn2, a0[GRP][q]);                                                          \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                           \
-            _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                       \
-                acc[2 * (GRP) + q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][e], bb[P][2 * (GRP) + q][e], acc[2 * (GRP) + q][0], 0, 0, 0); \
-    }
-// Step KSTEP (parity P, LDS stage P).  Loads that reach past the last step read zeros or values nobody uses.
-#define VQ_D_STEP(KSTEP, P)                                                                                     \
-    {                                                                                                           \
-        VQ_D_READ_A(P, 1, 1)                       /* positions 2,3 of this step */                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-        VQ_D_MFMA(P, 0)                                                                                         \
-        if (!(a.dbg & 8)) VQ_D_STORE_H((P) ^ 1, (P) ^ 1) /* rows of step KSTEP+1 (fetched two steps ago) -> other stage */ \
-        VQ_D_LOAD_PATCH((P) ^ 1, (KSTEP) + 3)                                                                   \
-        VQ_D_LOAD_U(P, (KSTEP) + 2, 0)                                                                          \
-        VQ_D_LOAD_U(P, (KSTEP) + 2, 1)                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-        if (!(a.dbg & 4)) __syncthreads(); /* stage P^1 is complete; everybody has read all of stage P */       \
-        VQ_D_READ_A((P) ^ 1, 0, 0)                 /* positions 0,1 of step KSTEP+1 */                           \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-        VQ_D_MFMA(P, 1)                                                                                         \
-        VQ_D_LOAD_U(P, (KSTEP) + 2, 2)                                                                          \
-        VQ_D_LOAD_U(P, (KSTEP) + 2, 3)                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-    }
-        const int nk = a.Cin / KC;                 // even (the launcher falls back to the plain schedule otherwise)
-        VQ_D_LOAD_PATCH(0, 0)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) VQ_D_LOAD_U(0, 0, j)
-        VQ_D_LOAD_PATCH(1, 1)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) VQ_D_LOAD_U(1, 1, j)
-        VQ_D_STORE_H(0, 0)
-        VQ_D_LOAD_PATCH(0, 2)
-        __syncthreads();
-        VQ_D_READ_A(0, 0, 0)
-        VQ_PHASE(1)
-        for (int kc = 0; kc < nk; kc += 2) {
-            VQ_D_STEP(kc, 0)
-            VQ_D_STEP(kc + 1, 1)
-        }
-        VQ_PHASE(2)
-#undef VQ_D_LOAD_PATCH
-#undef VQ_D_LOAD_U
-#undef VQ_D_STORE_H
-#undef VQ_D_READ_A
-#undef VQ_D_MFMA
-#undef VQ_D_STEP
-    } else {
     constexpr int G = NB == 1 ? 2 : 1, NGRP = 4 / G;   // positions per MFMA group, groups per step
     floatx4 d[4];          // patch row in flight (next step)
     floatx4 bq[4][NB];     // filter fragments of the current step; reloaded for the next step right after use
@@ -296,8 +215,6 @@ void wino_f2x2_3x3_kernel(WinoArgs a) {
 #undef VQ_W_STEP
 #undef VQ_W_READ_A
 
-    }
-
     // ---- epilogue: Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]] ---------------------------------------------------
     // This thread finishes output pixel (a_, b_) of tile p0 + (tid >> 3), channels (tid & 7)*4 .. +4 of each block.
     const int et = tid >> 3, ec = tid & 7;
@@ -354,12 +271,12 @@ void wino_f2x2_3x3_kernel(WinoArgs a) {
     VQ_PHASE(3)
 }
 
-template <int NB, bool DEEP>
+template <int NB>
 int launch_t(const WinoArgs& a0, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     WinoArgs a = a0;
     a.tiles_m = cdiv(a.P, BP);
     a.tiles_n = cdiv(a.Cout, 32 * NB);
-    auto kern = wino_f2x2_3x3_kernel<NB, DEEP>;
+    auto kern = wino_f2x2_3x3_kernel<NB>;
     const size_t lds = 2 * HS_STAGE * sizeof(float);
     VQ_LAUNCH(kern, a.tiles_m * a.tiles_n, 256, lds, stream, ev_start, ev_stop, a);
     VQ_CHECK_LAUNCH();
@@ -373,9 +290,8 @@ namespace vq {
 int launch_wino(const WinoArgs& a, int variant, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     VQ_REQUIRE(a.Cin % KC == 0 && a.Cout % 32 == 0 && a.Cs_out % 4 == 0 && a.coff_out % 4 == 0 && a.Cs_in % 4 == 0 && a.coff_in % 4 == 0,
                "Winograd convolution needs Cin %% 8 == 0, Cout %% 32 == 0 and 16-byte aligned channel offsets");
-    if (variant == 0 || (variant == 2 && a.Cin % (2 * KC) != 0)) return launch_t<1, false>(a, stream, ev_start, ev_stop);
-    if (variant == 1) return launch_t<2, false>(a, stream, ev_start, ev_stop);
-    if (variant == 2) return launch_t<1, true>(a, stream, ev_start, ev_stop);
+    if (variant == 0) return launch_t<1>(a, stream, ev_start, ev_stop);
+    if (variant == 1) return launch_t<2>(a, stream, ev_start, ev_stop);
     return fail(VQ_E_INVALID, "no Winograd kernel variant %d", variant);
 }
 
