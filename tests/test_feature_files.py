@@ -163,3 +163,24 @@ def test_feature_store_round_trip_and_csv_tree_import(tmp_path):
     assert (np.asarray(f2) == x).all() and i2.tolist() == [9, 4, 7, 1, 3] and pr2 is None and m2["dim"] == 8
     with pytest.raises(ValueError):
         fs.save_store(str(tmp_path / "s3"), x, [1, 1, 2, 3, 4], ("rgb", "warped_optical_flow"), (1, 2, 3))
+
+
+REF_TREE = "/root/reference/data/features/stock-video-clips_features"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_TREE), reason="the reference checkout (build container only) is not here")
+def test_store_from_the_reference_csv_tree_matches_the_golden_subset(tmp_path):
+    """The shipped data/features tree of the reference -> binary store (fp64): the 24 golden clips (tests/golden/
+    real_subset_x.npy, written by oracle/gen_golden.py from the same files) come back value for value."""
+    import video_query_algorithms_amd  # noqa: F401
+    from video_query_algorithms_amd import feature_store as fs
+    out = fs.store_from_csv_tree(REF_TREE, str(tmp_path / "store"), dtype=np.float64)
+    meta, feats, ids, present = fs.open_store(out)
+    assert meta["splits"] == [1, 2, 3] and meta["dim"] == 1024 and present is None          # dense: 87 clips x 2 x 3
+    clips = json.load(open(os.path.join(out, "clips.json")))
+    assert len(clips) == 87 and all(c["video"] == "DowntownBrooklynDrive_480p" for c in clips)
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real_subset.json")))
+    gx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real_subset_x.npy"))
+    row_of = {c["clip"]: i for i, c in enumerate(clips)}
+    for k, clip in enumerate(golden["clip_ids"]):
+        assert (feats[row_of[clip]] == gx[k]).all()

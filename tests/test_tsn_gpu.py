@@ -352,6 +352,32 @@ def test_calcsig_command_line_end_to_end(tsn, tmp_path):
             cn.close()
 
 
+def test_branch_lanes_do_not_change_a_bit(tsn, monkeypatch):
+    """VQ_TSN_LANES=3: the independent arms of every inception module on three HIP streams with cross-stream events
+    derived from the slot read/write sets (off by default).  Same bits as one stream, and the schedule really forks."""
+    bi, net = tsn
+    g = bi.bn_inception(3)
+    w = net.synthetic_weights(g, seed=2)
+    crops = np.random.default_rng(9).integers(0, 256, (3, 224, 224, 3), dtype=np.uint8)
+    monkeypatch.setenv("VQ_TSN_SPLIT", "1")
+    monkeypatch.setenv("VQ_TSN_LANES", "1")
+    m = net.TsnNet(g, w, max_crops=3)
+    assert (m.layer_lanes() == 0).all()
+    f1, p1 = m.forward(crops, 3, net.RGB_MEAN)
+    m.close()
+    monkeypatch.setenv("VQ_TSN_LANES", "3")
+    m = net.TsnNet(g, w, max_crops=3)
+    lanes = m.layer_lanes()
+    assert set(lanes.tolist()) == {0, 1, 2}
+    names = [o.name for o in m.plan.ops]
+    i3, id1, id2 = names.index("inception_3a/3x3"), names.index("inception_3a/double_3x3_1"), names.index("inception_3a/double_3x3_2")
+    assert lanes[i3] != lanes[id1] and lanes[id1] == lanes[id2]        # sibling arms apart, a chain on one stream
+    for _ in range(3):
+        f2, p2 = m.forward(crops, 3, net.RGB_MEAN)
+        assert (p1 == p2).all() and (f1 == f2).all()
+    m.close()
+
+
 @pytest.mark.parametrize("split", ["1", "2", "3", "2,1"])
 def test_batch_split_streams_do_not_change_a_bit(tsn, monkeypatch, split):
     """VQ_TSN_SPLIT: sub-batches of one forward on separate HIP streams (default 2).  Every crop is independent and
