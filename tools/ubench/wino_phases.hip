@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
     a.H = a.W = H; a.Cs_in = Cin; a.coff_in = 0; a.Cin = Cin;
     a.Cs_out = Cout; a.coff_out = 0; a.Cout = Cout;
     a.th = a.tw = (H + 1) / 2; a.P = crops * a.th * a.tw; a.relu = 1;
-    a.in_bytes = (unsigned)(n_in * 4); a.u_bytes = (unsigned)(n_u * 4); a.dbg = argc > 6 ? atoi(argv[6]) : 0;
+    a.in_bytes = (unsigned)(n_in * 4); a.u_bytes = (unsigned)(n_u * 4);
     const int nb = variant == 1 ? 2 : 1;                     // variants 0 and 2 own 32 output channels per workgroup
     const int nwg = ((a.P + 31) / 32) * ((Cout + 32 * nb - 1) / (32 * nb));
     hipMalloc(&a.phases, (size_t)nwg * 6 * sizeof(long long));

@@ -79,8 +79,6 @@ struct ConvArgs {
     int out_row0;        // first output row (pixel) of this launch inside the destination slots (sub-batch launches)
     int tiles_m, tiles_n;
     unsigned in_bytes, w_bytes;   // extents for the buffer descriptors (out-of-range offsets read as zero)
-    int dbg;             // timing experiments only: bit0 skip staging loads, bit1 skip LDS stores, bit2 skip barriers
-    int desync;          // 1: odd hardware wave slots run at raised priority (see desync_simd_partners)
 };
 
 constexpr int KPAD = 32;       // weights are packed [Cout][Kp] with Kp a multiple of 32
@@ -92,15 +90,6 @@ struct ConvSmem {
     float a[2][BM][BK + 4];
     float b[2][BN][BK + 4];
 };
-
-// Waves that share a SIMD run the same program and drift into lockstep: both are in their MFMA phase together
-// (each at half speed) and both in their staging / barrier phase together (matrix pipe idle).  Giving the waves
-// in odd hardware wave slots a higher issue priority breaks the symmetry, so one wave's staging phase overlaps
-// its neighbour's MFMA phase.  HW_REG_HW_ID (id 4) bits [3:0] = wave slot within the SIMD.
-__device__ __forceinline__ void desync_simd_partners() {
-    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
-    if (slot & 1) __builtin_amdgcn_s_setprio(1);
-}
 
 // Epilogue shared by both kernels: + bias (folded BN), ReLU, store at the channel offset of the destination slot.
 // In the MFMA C/D layout a lane holds ONE channel of 16 pixels (column = lane & 31, row = (r & 3) + 8 (r >> 2) +
@@ -151,7 +140,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     ConvSmem<BM, BN, BK>& sm = *reinterpret_cast<ConvSmem<BM, BN, BK>*>(smem_raw);
 
-    if (a.desync) desync_simd_partners();
     const int tid = threadIdx.x;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / a.tiles_n) * BM;
@@ -261,13 +249,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         seg_v[j] = a.segs[nb_ < a.Cout ? nb_ >> 5 : 0];
     }
 
-    const int nk = (a.dbg & 8) ? 1 : ((a.dbg & 16) ? 2 * (a.Kp / BK) : a.Kp / BK);   // dbg: 1 K-step only / K doubled (timing only)
+    const int nk = a.Kp / BK;
     VQ_LOAD_TILES(0)
     VQ_STORE_TILES(0)
     __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
-        if (kc + 1 < nk && !(a.dbg & 1)) VQ_LOAD_TILES(kc + 1)   // global loads in flight under the MFMAs below
+        if (kc + 1 < nk) VQ_LOAD_TILES(kc + 1)   // global loads in flight under the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             // lane (row r, half h) holds k = 8 kk + 4 h + j for MFMA step j: the two halves of a step cover a
@@ -285,8 +273,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
-        if (kc + 1 < nk && !(a.dbg & 2)) VQ_STORE_TILES(buf ^ 1)
-        if (!(a.dbg & 4)) __syncthreads();
+        if (kc + 1 < nk) VQ_STORE_TILES(buf ^ 1)
+        __syncthreads();
     }
 
     VQ_EPILOGUE()
@@ -322,7 +310,6 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     ConvSmem<BM, BN, BK>& sm = *reinterpret_cast<ConvSmem<BM, BN, BK>*>(smem_raw);
 
-    if (a.desync) desync_simd_partners();
     const int tid = threadIdx.x;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / a.tiles_n) * BM;
@@ -862,10 +849,6 @@ static void fill_conv_args(vq_tsn* net, int li, int n_crops, ConvArgs& a) {
     a.tiles_m = a.tiles_n = 0;
     a.in_bytes = (unsigned)std::min<size_t>((size_t)n_crops * ts.h * ts.w * ts.c * sizeof(float), 0xFFFFFFF0u);
     a.w_bytes = (unsigned)((size_t)L.cout * a.Kp * sizeof(float));
-    static const int desync = getenv("VQ_TSN_DESYNC") ? atoi(getenv("VQ_TSN_DESYNC")) : 0;   // experiment knob; no measured gain
-    a.desync = desync;
-    static const int dbg = getenv("VQ_TSN_DBG") ? atoi(getenv("VQ_TSN_DBG")) : 0;
-    a.dbg = dbg;
 }
 
 static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
@@ -911,8 +894,6 @@ static int launch_wino_layer(vq_tsn* net, int li, int n_crops, int variant) {
     a.tiles_m = a.tiles_n = 0;
     a.in_bytes = (unsigned)std::min<size_t>((size_t)n_crops * ts.h * ts.w * ts.c * sizeof(float), 0xFFFFFFF0u);
     a.u_bytes = (unsigned)((size_t)16 * L.cout * L.cin * sizeof(float));
-    static const int dbg = getenv("VQ_TSN_DBG") ? atoi(getenv("VQ_TSN_DBG")) : 0;
-    a.dbg = dbg;
     return launch_wino(a, variant, net->ls, net->ev_start, net->ev_stop);
 }
 

@@ -24,7 +24,6 @@ struct WinoArgs {
     int relu;
     int tiles_m, tiles_n;
     unsigned in_bytes, u_bytes;   // extents for the buffer descriptors (out-of-range offsets read as zero)
-    int dbg;             // timing experiments only (VQ_TSN_DBG): bit0 no activation traffic, bit1 no filter traffic
 #ifdef VQ_WINO_PHASES
     long long* phases;   // tools/ubench/wino_phases.hip: [workgroup][4] s_memtime stamps
 #endif

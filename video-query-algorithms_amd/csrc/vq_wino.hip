@@ -111,7 +111,7 @@ void wino_f2x2_3x3_kernel(WinoArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int x = x0 + c;
-            poff[c] = (row_ok && (unsigned)x < (unsigned)a.W && !(a.dbg & 1))
+            poff[c] = (row_ok && (unsigned)x < (unsigned)a.W)
                           ? (unsigned)((((n_img * a.H + y) * a.W + x) * a.Cs_in + a.coff_in + c4 * 4) * 4)
                           : 0xFFFFFFFFu;
         }
@@ -128,7 +128,7 @@ void wino_f2x2_3x3_kernel(WinoArgs a) {
     const int fb_off = rb * 4 * BP * KC + l31 * KC + half * 4;
     unsigned uvoff[NB];                                    // lane part of the filter fragment address
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) uvoff[nb] = (n0 + 32 * nb < a.Cout && !(a.dbg & 2)) ? (unsigned)((l31 * 8 + half * 4) * 4) : 0xFFFFFFFFu;
+    for (int nb = 0; nb < NB; ++nb) uvoff[nb] = (n0 + 32 * nb < a.Cout) ? (unsigned)((l31 * 8 + half * 4) * 4) : 0xFFFFFFFFu;
     const unsigned u_step = (unsigned)(16 * a.Cout * 8 * 4);          // bytes between consecutive 8-channel groups
     const unsigned u_wave = (unsigned)(((wave * 4) * a.Cout + n0) * 8 * 4);
     const unsigned u_pos = (unsigned)(a.Cout * 8 * 4);                  // bytes between positions
@@ -204,8 +204,8 @@ void wino_f2x2_3x3_kernel(WinoArgs a) {
         VQ_W_LOAD_PATCH(kc + 1)
         __builtin_amdgcn_sched_barrier(0);
         VQ_W_STEP(st, kc, true)
-        if (!(a.dbg & 8)) VQ_W_STORE_H(st ^ 1)
-        if (!(a.dbg & 4)) __syncthreads();        // stage st^1 complete; everybody is done reading stage st
+        VQ_W_STORE_H(st ^ 1)
+        __syncthreads();                          // stage st^1 complete; everybody is done reading stage st
     }
     VQ_W_STEP(kc & 1, kc, false)
     VQ_PHASE(2)
