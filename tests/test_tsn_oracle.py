@@ -165,3 +165,31 @@ def test_winograd_filter_transform_and_layout():
             y[:, :, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = np.einsum("ai,noij,bj->noab", At, M, At)
     want = to.conv_direct(x, W, np.zeros(cout), 1, 1)
     assert np.abs(y[:, :, :h, :h] - want).max() <= 1e-6 * np.abs(want).max()     # U is rounded to fp32
+
+
+def test_space_to_depth_stem_rewrite_is_exact():
+    """net.s2d_stem_weights + the space-to-depth input layout (include/vq_amd.h: vq_input_desc.s2d_pad): a k x k /
+    stride-2 / pad-p convolution equals the ceil(k/2)^2 / stride-1 / pad-0 convolution over the decimated input --
+    same products, so the fp64 results agree to rounding-order level."""
+    import video_query_algorithms_amd  # noqa: F401
+    from video_query_algorithms_amd.tsn import net
+    rng = np.random.default_rng(8)
+    for (c, h, k, p, cout) in [(3, 32, 7, 3, 8), (3, 17, 7, 3, 4), (2, 12, 3, 1, 4), (3, 20, 5, 2, 4)]:
+        x = rng.standard_normal((2, c, h, h))
+        W = rng.standard_normal((cout, c, k, k))
+        want = to.conv_direct(x, W, np.zeros(cout), 2, p)
+        out = want.shape[2]
+        k2 = (k + 1) // 2
+        hs = out + k2 - 1
+        S = np.zeros((2, hs, hs, 4 * c))
+        for Y in range(hs):
+            for X in range(hs):
+                for pp in range(2):
+                    for q in range(2):
+                        y, xx = 2 * Y + pp - p, 2 * X + q - p
+                        if 0 <= y < h and 0 <= xx < h:
+                            S[:, Y, X, (pp * 2 + q) * c:(pp * 2 + q + 1) * c] = x[:, :, y, xx]
+        W2 = net.s2d_stem_weights(W)                                   # [cout][k2][k2][4c]
+        got = to.conv_direct(S.transpose(0, 3, 1, 2), W2.transpose(0, 3, 1, 2), np.zeros(cout), 1, 0)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
