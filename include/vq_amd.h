@@ -106,6 +106,15 @@ int vq_db_bootstrap_target(vq_db* db, const int64_t* valid_rows, int32_t n_valid
  * keep_sims != 0 additionally keeps the per-split dot products for vq_db_read_similarities. */
 int vq_db_scan(vq_db* db, const double* w_host, int32_t keep_sims);
 /* score[c] from the cached avg[N][S] (no DB read): Ticket.compute_scores, ticket.py:165-180. */
+/* Batched scan: n_queries (<= 8) queries in ONE pass over the database -- the all-pairs form of the scan for a broker
+ * that holds several tickets.  Per (query, clip) exactly the arithmetic of vq_db_scan with weights (ticket.py:120-180):
+ * the scores are bit-identical to n_queries single scans.  The database is read once (slice by slice, the slice's
+ * query vectors in LDS), so queries/s grow almost linearly with n_queries until the fp64 FMA rate binds.
+ * t_host [n_queries][S][E][D] fp64, w_host [n_queries][S] fp64, scores_host [n_queries][N] fp64 (may be NULL: use
+ * vq_db_batch_scores_devptr).  Does not touch the state of the single-query path (query, avg, scores).
+ * Needs D in {256, 512, 768, 1024}. */
+int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const double* w_host, double* scores_host);
+int vq_db_batch_scores_devptr(vq_db* db, void** dev_ptr /* double [n_queries][N] */, int32_t* n_queries);
 int vq_db_rescore(vq_db* db, const double* w_host);
 /* Copy results to the host.  Any pointer may be NULL.  avg [N][S], n_e [N][S], sims [N][S][E]. */
 int vq_db_read_similarities(vq_db* db, double* avg_host, int32_t* n_e_host, double* sims_host);

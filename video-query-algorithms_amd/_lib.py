@@ -64,6 +64,7 @@ SIGNATURES = {
     "vq_bootstrap_targets": [_P, _I32, _I32, _P, _P, _I32, _F64, _I32, _P],
     "vq_db_bootstrap_target": [_P, _P, _I32, _P, _I32, _F64, _P, _I32],
     "vq_db_scan": [_P, _P, _I32], "vq_db_rescore": [_P, _P],
+    "vq_db_scan_batch": [_P, _I32, _P, _P, _P], "vq_db_batch_scores_devptr": [_P, _PP, _pI32],
     "vq_db_read_similarities": [_P, _P, _P, _P], "vq_db_read_scores": [_P, _P],
     "vq_db_scores_devptr": [_P, _PP], "vq_db_avg_devptr": [_P, _PP], "vq_db_write_avg": [_P, _P, _P],
     "vq_db_scores_grid": [_P, _P, _I32, _P, _I32, _P],

@@ -221,6 +221,141 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(ScanArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// batched scan: Q queries per pass over the database
+// ------------------------------------------------------------------------------------------------
+// The single-query scan keeps the whole fp64 query (S*E*D*8 = 80 KB at cfg 4) in LDS; Q of them do not fit.  The
+// batched scan therefore walks the database one (stream, split) slice at a time: the slice's Q query vectors
+// (Q*D*8 <= 64 KB) sit in LDS, a wave loads a clip's vector once and multiplies it against all Q of them.  Each
+// (query, clip, vector) dot uses the same per-lane FMA chain and the same wave butterfly as scan_kernel, so the
+// batched scores equal the single-query ones bit for bit.  The dots go to sims[q][c][v]; a second kernel applies
+// the ensemble mean and the weighted score exactly like the epilogue of scan_kernel.
+struct BatchArgs {
+    const void* feats;
+    const double* t;          // [Q][NV][D]
+    double* sims;             // [Q][n][NV]
+    int64_t n;
+    int32_t Q, NV, D, v;
+};
+
+// Eight wave sums at once.  wave_sum() is the xor butterfly 32, 16, 8, 4, 2, 1; doing it for eight values costs 48
+// exchanges.  Here every exchange step also halves the number of values a lane carries (after 32 / 16 / 8 a lane
+// keeps the value whose index bits equal its lane bits 5 / 4 / 3), so the eight sums cost 4 + 2 + 1 + 3 exchanges.
+// Each kept partial is own + partner exactly as in wave_sum, so lane l ends up with the bit-identical wave_sum of
+// value q = (l >> 3) & 7.
+__device__ __forceinline__ double wave_sum8(const double (&v)[8], int lane) {
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+    double u[4], w[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double recv = __shfl_xor(b5 ? v[i] : v[i + 4], 32, 64);
+        u[i] = (b5 ? v[i + 4] : v[i]) + recv;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double recv = __shfl_xor(b4 ? u[i] : u[i + 2], 16, 64);
+        w[i] = (b4 ? u[i + 2] : u[i]) + recv;
+    }
+    double x = (b3 ? w[1] : w[0]) + __shfl_xor(b3 ? w[0] : w[1], 8, 64);
+    x += __shfl_xor(x, 4, 64);
+    x += __shfl_xor(x, 2, 64);
+    x += __shfl_xor(x, 1, 64);
+    return x;
+}
+
+// Two clips per wave iteration share every query fragment read from LDS (the LDS, one per CU, is the busiest unit of
+// this kernel); the next pair's vectors are in flight meanwhile.
+template <typename T, int CH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))   // 64 KB of LDS per workgroup: 2 waves/SIMD anyway
+void batch_slice_kernel(BatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double tq[];
+    constexpr int D = CH * 256;
+    for (int i = threadIdx.x; i < 8 * D; i += blockDim.x) {
+        const int q = i / D, k = i - q * D;
+        tq[t_lds_index(D, q, k)] = q < a.Q ? a.t[((size_t)q * a.NV + a.v) * D + k] : 0.0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const T* feats = static_cast<const T*>(a.feats) + (int64_t)a.v * D;
+    const int64_t clip_elems = (int64_t)a.NV * D;
+    const int myq = (lane >> 3) & 7;
+    Quad<T> cur[2][CH], nxt[2][CH];
+    int64_t c = wave;                  // this iteration: clips c and c + nwaves
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        if (c + h * nwaves < a.n) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) cur[h][j].load(feats + (c + h * nwaves) * clip_elems + j * 256 + lane * 4);
+        }
+    while (c < a.n) {
+        const int64_t cn = c + 2 * nwaves;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (cn + h * nwaves < a.n) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) nxt[h][j].load(feats + (cn + h * nwaves) * clip_elems + j * 256 + lane * 4);
+            }
+        double p0[8], p1[8];
+#pragma clang loop unroll(full)
+        for (int q = 0; q < 8; ++q) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma clang loop unroll(full)
+            for (int j = 0; j < CH; ++j) {
+                const double2 ta = *reinterpret_cast<const double2*>(&tq[q * D + j * 256 + lane * 2]);
+                const double2 tb = *reinterpret_cast<const double2*>(&tq[q * D + j * 256 + 128 + lane * 2]);
+                s0 = fma(cur[0][j].x0(), ta.x, s0);
+                s1 = fma(cur[1][j].x0(), ta.x, s1);
+                s0 = fma(cur[0][j].x1(), ta.y, s0);
+                s1 = fma(cur[1][j].x1(), ta.y, s1);
+                s0 = fma(cur[0][j].x2(), tb.x, s0);
+                s1 = fma(cur[1][j].x2(), tb.x, s1);
+                s0 = fma(cur[0][j].x3(), tb.y, s0);
+                s1 = fma(cur[1][j].x3(), tb.y, s1);
+            }
+            p0[q] = s0;
+            p1[q] = s1;
+            __builtin_amdgcn_sched_barrier(0);   // one query at a time: hoisting all 64 LDS reads spills the register file
+        }
+        const double r0 = wave_sum8(p0, lane), r1 = wave_sum8(p1, lane);
+        if ((lane & 7) == 0 && myq < a.Q) {
+            a.sims[((size_t)myq * a.n + c) * a.NV + a.v] = r0;
+            if (c + nwaves < a.n) a.sims[((size_t)myq * a.n + c + nwaves) * a.NV + a.v] = r1;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < CH; ++j) cur[h][j] = nxt[h][j];
+        c = cn;
+    }
+}
+
+// scores[q][c] from sims[q][c][.]: ticket.py:155-160 (mean over the splits present) + :172-180, the operations of
+// clip_add / clip_close_stream / score_from_avg in the same order.
+__global__ void batch_finalize_kernel(const double* sims, const uint8_t* present, const double* w, double* scores, int64_t n, int Q,
+                                      int S, int E) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)Q * n) return;
+    const int q = (int)(i / n);
+    const int64_t c = i - (int64_t)q * n;
+    double av[8], ww[8];
+    for (int s = 0; s < S; ++s) {
+        double acc = 0.0;
+        int cnt = 0;
+        for (int e = 0; e < E; ++e) {
+            const int64_t idx = (c * S + s) * E + e;
+            if (present ? present[idx] != 0 : true) {
+                acc = acc + sims[i * (S * E) + s * E + e];
+                ++cnt;
+            }
+        }
+        av[s] = acc / (double)cnt;
+        ww[s] = w[q * S + s];
+    }
+    scores[i] = score_from_avg(av, ww, S);
+}
+
 __global__ void rescore_kernel(const double* avg, const double* w, double* scores, int64_t n, int S) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
@@ -524,6 +659,9 @@ struct vq_db {
     int64_t last_n0 = 0, last_n1 = 0;
     uint64_t* tk_state = nullptr;    // [2]
     unsigned int* tk_hist = nullptr; // [256]
+    double* batch_buf = nullptr;     // batched scan: queries [Q][NV][D] | weights [Q][S] | sims [Q][N][NV] | scores [Q][N]
+    int64_t batch_cap = 0;           // doubles
+    int batch_q = 0;                 // queries of the last batched scan
     double* grid_buf = nullptr;      // scratch for grid / gathers
     int64_t grid_cap = 0;
     size_t elem() const { return dtype == VQ_F64 ? 8 : 4; }
@@ -532,7 +670,7 @@ struct vq_db {
 static int db_free(vq_db* db) {
     if (db->owns_feats && db->feats) (void)hipFree(db->feats);
     void* ptrs[] = {db->present, db->t,       db->w,        db->sims,  db->avg,      db->ne,      db->scores, db->blk_cnt,
-                    db->blk_max, db->blk_arg, db->sel_result, db->rows0, db->rows1, db->tk_state, db->tk_hist, db->grid_buf};
+                    db->blk_max, db->blk_arg, db->sel_result, db->rows0, db->rows1, db->tk_state, db->tk_hist, db->grid_buf, db->batch_buf};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     return VQ_OK;
@@ -872,6 +1010,80 @@ int vq_db_scan(vq_db* db, const double* w_host, int32_t keep_sims) {
     db->have_avg = true;
     db->have_sims = keep_sims != 0;
     db->have_scores = w_host != nullptr;
+    return VQ_OK;
+}
+
+int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const double* w_host, double* scores_host) {
+    VQ_REQUIRE(db && t_host && w_host, "NULL argument");
+    VQ_REQUIRE(n_queries >= 1 && n_queries <= 8, "n_queries must be in [1,8] (got %d)", n_queries);
+    VQ_REQUIRE(db->D % 256 == 0 && db->D <= 1024, "batched scan needs D in {256,512,768,1024} (got %d)", db->D);
+    VQ_REQUIRE(db->S <= 8, "at most 8 streams");
+    std::lock_guard<std::mutex> lk(db->mu);
+    DeviceGuard g(db->device);
+    const int Q = n_queries, NV = db->S * db->E;
+    const int64_t n_t = (int64_t)Q * NV * db->D, n_w = (int64_t)Q * db->S, n_s = (int64_t)Q * db->n * NV, n_sc = (int64_t)Q * db->n;
+    const int64_t need = n_t + n_w + n_s + n_sc;
+    if (db->batch_cap < need) {
+        if (db->batch_buf) VQ_HIP(hipFree(db->batch_buf));
+        db->batch_buf = nullptr;
+        db->batch_cap = 0;
+        VQ_HIP(hipMalloc((void**)&db->batch_buf, (size_t)need * 8));
+        db->batch_cap = need;
+    }
+    double* d_t = db->batch_buf;
+    double* d_w = d_t + n_t;
+    double* d_sims = d_w + n_w;
+    double* d_scores = d_sims + n_s;
+    VQ_HIP(hipMemcpyAsync(d_t, t_host, (size_t)n_t * 8, hipMemcpyHostToDevice, db->stream));
+    VQ_HIP(hipMemcpyAsync(d_w, w_host, (size_t)n_w * 8, hipMemcpyHostToDevice, db->stream));
+    BatchArgs a;
+    a.feats = db->feats;
+    a.t = d_t;
+    a.sims = d_sims;
+    a.n = db->n;
+    a.Q = Q;
+    a.NV = NV;
+    a.D = db->D;
+    const size_t lds = (size_t)8 * db->D * 8;      // always eight query slots (unused ones hold zeros)
+    const int blocks = (int)std::min<int64_t>((db->n + 3) / 4, (int64_t)db->cus * 8);
+    for (int v = 0; v < NV; ++v) {
+        a.v = v;
+#define VQ_BATCH_LAUNCH(T, CH)                                                                                             \
+    {                                                                                                                      \
+        auto kern = batch_slice_kernel<T, CH>;                                                                             \
+        static bool attr = false;                                                                                          \
+        if (!attr) {                                                                                                       \
+            VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); \
+            attr = true;                                                                                                   \
+        }                                                                                                                  \
+        kern<<<blocks, 256, lds, db->stream>>>(a);                                                                         \
+    }
+        const int ch = db->D / 256;
+        if (db->dtype == VQ_F32) {
+            if (ch == 4) VQ_BATCH_LAUNCH(float, 4) else if (ch == 3) VQ_BATCH_LAUNCH(float, 3) else if (ch == 2) VQ_BATCH_LAUNCH(float, 2) else VQ_BATCH_LAUNCH(float, 1)
+        } else {
+            if (ch == 4) VQ_BATCH_LAUNCH(double, 4) else if (ch == 3) VQ_BATCH_LAUNCH(double, 3) else if (ch == 2) VQ_BATCH_LAUNCH(double, 2) else VQ_BATCH_LAUNCH(double, 1)
+        }
+#undef VQ_BATCH_LAUNCH
+        VQ_CHECK_LAUNCH();
+    }
+    batch_finalize_kernel<<<cdiv(n_sc, 256), 256, 0, db->stream>>>(d_sims, db->present, d_w, d_scores, db->n, Q, db->S, db->E);
+    VQ_CHECK_LAUNCH();
+    db->batch_q = Q;
+    if (scores_host) {
+        VQ_HIP(hipMemcpyAsync(scores_host, d_scores, (size_t)n_sc * 8, hipMemcpyDeviceToHost, db->stream));
+        VQ_HIP(hipStreamSynchronize(db->stream));
+    }
+    return VQ_OK;
+}
+
+int vq_db_batch_scores_devptr(vq_db* db, void** dev_ptr, int32_t* n_queries) {
+    VQ_REQUIRE(db && dev_ptr, "NULL argument");
+    std::lock_guard<std::mutex> lk(db->mu);
+    if (db->batch_q == 0) return fail(VQ_E_STATE, "no batched scan has run");
+    const int NV = db->S * db->E;
+    *dev_ptr = db->batch_buf + (int64_t)db->batch_q * NV * db->D + (int64_t)db->batch_q * db->S + (int64_t)db->batch_q * db->n * NV;
+    if (n_queries) *n_queries = db->batch_q;
     return VQ_OK;
 }
 

@@ -217,6 +217,17 @@ class FeatureDB:
             raise ValueError("one weight per stream")
         call("vq_db_scan", self._h, _np_ptr(w) if w is not None else None, 1 if keep_sims else 0)
 
+    def scan_batch(self, targets: np.ndarray, weights: np.ndarray, want: bool = True):
+        """Q <= 8 queries in one pass over the database: targets [Q,S,E,D] fp64, weights [Q,S] -> scores [Q,N]
+        (bit-identical to Q single scans; the single-query state of the DB is left alone)."""
+        t = np.ascontiguousarray(targets, dtype=np.float64)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        if t.ndim != 4 or t.shape[1:] != (self.S, self.E, self.D) or w.shape != (t.shape[0], self.S):
+            raise ValueError("targets must be [Q,%d,%d,%d] and weights [Q,%d]" % (self.S, self.E, self.D, self.S))
+        out = np.empty((t.shape[0], self.n), dtype=np.float64) if want else None
+        call("vq_db_scan_batch", self._h, t.shape[0], _np_ptr(t), _np_ptr(w), _np_ptr(out) if want else None)
+        return out
+
     def rescore(self, weights: Sequence[float]):
         w = np.ascontiguousarray(weights, dtype=np.float64)
         if w.shape != (self.S,):
