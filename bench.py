@@ -134,6 +134,13 @@ def bench_tsn(args, rank, world, device, stream):
             "mfma_issued_frac": issued / conv_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS,
             "note": "achieved/frac use ALGORITHMIC direct-convolution FLOPs (SURVEY 8(d): 2 x MACs of Appendix A); the "
                     "Winograd layers issue 2.25x fewer multiplies, so mfma_issued_* is what the matrix pipe really ran"}
+    # HBM bytes per conv launch from the PMC counters (tools/pmc_tsn.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    # passes over this very command, committed; FETCH_SIZE doubled as the microarchitecture guide prescribes for gfx950)
+    tpath = os.path.join(ROOT, "profiles", "r01_tsn_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            roof["traffic"] = json.load(f)["hbm_bytes_per_launch"]
+        roof["traffic_source"] = "profiles/r01_tsn_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over the 44 conv launches of a step)"
     feats = feat.clone()
     model.set_profile(0)
     # The same K steps once more WITHOUT per-layer events: the configuration a user runs (two sub-batches on two

@@ -1,0 +1,26 @@
+#!/bin/bash
+# HBM traffic of the convolution kernels of one cfg-2 step (separate --pmc passes, kernel-trace only; the program runs
+# with --profile-only: every forward on one stream, no autotune if gpurun_out/tiles_cfg2.json exists).
+set -e
+mkdir -p gpurun_out
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-.}"
+test -f gpurun_out/tiles_cfg2.json || python3 bench.py --tiles gpurun_out/tiles_cfg2.json --skip-sim --skip-cpu --steps 3 > /dev/null 2>&1
+rm -rf gpurun_out/pmc_tsn_fetch gpurun_out/pmc_tsn_write
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_tsn_fetch --output-format csv -- python3 bench.py --tiles gpurun_out/tiles_cfg2.json --skip-sim --skip-cpu --profile-only --steps 5 --warmup 1 > gpurun_out/pmc_tsn_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_tsn_write --output-format csv -- python3 bench.py --tiles gpurun_out/tiles_cfg2.json --skip-sim --skip-cpu --profile-only --steps 5 --warmup 1 > gpurun_out/pmc_tsn_write.log 2>&1
+python3 - <<'PY'
+import csv, glob, json
+def total(pattern, counter):
+    rows = list(csv.DictReader(open(glob.glob(pattern)[0])))
+    conv = [r for r in rows if r["Counter_Name"] == counter and ("conv_igemm" in r["Kernel_Name"] or "wino_f2x2" in r["Kernel_Name"])]
+    return sum(float(r["Counter_Value"]) for r in conv), len(conv)
+f, nf = total("gpurun_out/pmc_tsn_fetch/*/*counter_collection.csv", "FETCH_SIZE")
+w, nw = total("gpurun_out/pmc_tsn_write/*/*counter_collection.csv", "WRITE_SIZE")
+steps = nf / 44.0
+out = {"workload": "cfg 2: 96 crops per step, all 44 convolution launches of a step", "launches_counted": nf, "steps": steps,
+       "FETCH_SIZE_KB_per_step": f / steps, "WRITE_SIZE_KB_per_step": w / (nw / 44.0),
+       "correction": "gfx950: FETCH_SIZE x2 for 16-B-per-lane reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as is",
+       "hbm_bytes_per_step": (2 * f / steps + w / (nw / 44.0)) * 1024, "hbm_bytes_per_launch": (2 * f / steps + w / (nw / 44.0)) * 1024 / 44}
+json.dump(out, open("gpurun_out/tsn_traffic.json", "w"), indent=1)
+print(json.dumps(out))
+PY
