@@ -415,3 +415,48 @@ def test_cfg5_pipeline_small(tsn, tmp_path, capsys):
     assert out["clips"] == 24 and out["rounds"] == 3 and out["csv_clips"] == 5
     assert 0 < out["final_matches"] <= 21 and 0.5 <= out["final_weights"]["warped_optical_flow"] <= 2.5
     assert os.path.exists(os.path.join(str(tmp_path), "synthetic_video", "UCF101_split2", "warped_optical_flow_global_pool_features.csv"))
+
+
+def test_handles_are_thread_safe_and_do_not_leak(tsn):
+    """The broker re-arms itself from timer threads (broker.py:91-92): two threads hammer one handle (internally
+    locked) and a second handle at the same time; results stay bit-identical.  Creating and destroying handles in a loop
+    must not eat device memory (streams, events and slots are released)."""
+    import threading
+    import torch
+    bi, net = tsn
+    g = _mini(bi, 32, 28, 28, 64, 3, 1, 1, pool=("MAX", 3, 2, 0))
+    w = net.synthetic_weights(g, seed=4)
+    crops = np.random.default_rng(2).integers(0, 256, (6, 28, 28, 32), dtype=np.uint8)
+    mean = np.full(32, 120.0, dtype=np.float32)
+    m1 = net.TsnNet(g, w, max_crops=6, feature_blob="gp")
+    m2 = net.TsnNet(g, w, max_crops=6, feature_blob="gp")
+    want, _ = m1.forward(crops, 3, mean)
+    errors = []
+
+    def worker(m, n):
+        try:
+            for _ in range(n):
+                f, _ = m.forward(crops, 3, mean)
+                if not (f == want).all():
+                    errors.append("mismatch")
+        except Exception as e:           # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(m1, 20)), threading.Thread(target=worker, args=(m1, 20)),
+               threading.Thread(target=worker, args=(m2, 20))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    m1.close()
+    m2.close()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(15):
+        m = net.TsnNet(g, w, max_crops=6, feature_blob="gp")
+        m.forward(crops, 3, mean)
+        m.close()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, (free0, free1)
