@@ -678,7 +678,8 @@ struct vq_tsn {
     std::vector<vq_tensor_desc> tensors;
     std::vector<vq_layer_desc> layers;
     std::map<int, std::vector<int>> tuned;   // n_crops -> per-layer index into kTiles (autotuned)
-    bool autotune = true;
+    bool autotune = true;                 // VQ_TSN_AUTOTUNE != 0 (read at creation)
+    int forced_tile = -1;                 // VQ_TSN_TILE = "BMxBN[xBK[xP]]" (read at creation): every direct conv uses this tiling
     std::vector<float*> slots;            // device activations, max_crops each
     float* zeros = nullptr;               // 256 bytes of zeros (load target of masked lanes)
     ConvSeg* seg_table = nullptr;         // destination tables of all conv layers, back to back
@@ -939,13 +940,7 @@ static int run_layer(vq_tsn* net, int li, int n_crops) {
     const vq_tensor_desc& ts = net->tensors[L.src];
     const vq_tensor_desc& td = net->tensors[L.dst];
     if (L.op == VQ_OP_CONV) {
-        int t = -1;
-        if (const char* force = getenv("VQ_TSN_TILE")) {   // test / tuning aid: "BMxBN" or "BMxBNxBK"
-            int bm = 0, bn = 0, bk = 32, pipe = 0;   // "BMxBN", "BMxBNxBK" or "BMxBNxBKxP" (P = 1: pipelined kernel)
-            if (sscanf(force, "%dx%dx%dx%d", &bm, &bn, &bk, &pipe) >= 2)
-                for (int i = 0; i < kNumTiles; ++i)
-                    if (kTiles[i].bm == bm && kTiles[i].bn == bn && kTiles[i].bk == bk && kTiles[i].pipe == pipe) t = i;
-        }
+        int t = net->forced_tile;   // VQ_TSN_TILE (read at creation): test / tuning aid
         if (t < 0) {
             auto it = net->tuned.find(n_crops);
             t = it != net->tuned.end() ? it->second[li] : heuristic_tile(n_crops * td.h * td.w, L.cout, net->cus);
@@ -1205,6 +1200,13 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
         if (e != hipSuccess) return bail("hipMemcpy(destination tables)", e);
     }
     {
+        if (const char* at = getenv("VQ_TSN_AUTOTUNE")) net->autotune = atoi(at) != 0;
+        if (const char* force = getenv("VQ_TSN_TILE")) {
+            int bm = 0, bn = 0, bk = 32, pipe = 0;   // "BMxBN", "BMxBNxBK" or "BMxBNxBKxP" (P = 1: pipelined kernel)
+            if (sscanf(force, "%dx%dx%dx%d", &bm, &bn, &bk, &pipe) >= 2)
+                for (int i = 0; i < kNumTiles; ++i)
+                    if (kTiles[i].bm == bm && kTiles[i].bn == bn && kTiles[i].bk == bk && kTiles[i].pipe == pipe) net->forced_tile = i;
+        }
         const char* env = getenv("VQ_TSN_LANES");
         net->n_lanes = std::min(std::max(env ? atoi(env) : 1, 1), 8);
         const char* sp = getenv("VQ_TSN_SPLIT");
@@ -1303,12 +1305,9 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
                                                                        t0.h, t0.w, net->input.s2d_pad, net->mean_dev);
     }
     VQ_CHECK_LAUNCH();
-    if (net->autotune && !getenv("VQ_TSN_TILE") && net->tuned.find(n_crops) == net->tuned.end()) {
-        const char* env = getenv("VQ_TSN_AUTOTUNE");
-        if (!env || atoi(env) != 0) {
-            const int rc = autotune(net, n_crops);
-            if (rc != VQ_OK) return rc;
-        }
+    if (net->autotune && net->forced_tile < 0 && net->tuned.find(n_crops) == net->tuned.end()) {
+        const int rc = autotune(net, n_crops);
+        if (rc != VQ_OK) return rc;
     }
     hipEvent_t* ev = nullptr;
     if (net->profile_depth > 0) {
@@ -1327,12 +1326,9 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
             o += sub[sb];
         }
     for (int sb = 0; sb < n_split && n_split > 1; ++sb)
-        if (net->autotune && !getenv("VQ_TSN_TILE") && net->tuned.find(sub[sb]) == net->tuned.end()) {
-            const char* env = getenv("VQ_TSN_AUTOTUNE");
-            if (!env || atoi(env) != 0) {
-                const int rc = autotune(net, sub[sb]);
-                if (rc != VQ_OK) return rc;
-            }
+        if (net->autotune && net->forced_tile < 0 && net->tuned.find(sub[sb]) == net->tuned.end()) {
+            const int rc = autotune(net, sub[sb]);
+            if (rc != VQ_OK) return rc;
         }
     if (lanes_on || n_split > 1) {
         VQ_HIP(hipEventRecord(net->fork_ev, net->stream));
