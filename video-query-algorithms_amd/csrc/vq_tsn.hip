@@ -7,9 +7,13 @@
 //
 // Layout: activations NHWC fp32 in HBM, one tensor slot per blob; a Concat output is one slot and
 // its producers write at their channel offset (zero-copy concat).  Convolution + frozen BN + ReLU is a
-// single implicit-GEMM kernel: M = crops*Ho*Wo pixels, N = Cout, K = k*k*Cin, computed on the fp32
-// matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains, 256 FLOP/clk/CU) from LDS-staged,
-// register-prefetched tiles.  All B*T crops of a batch go through each layer in one launch.
+// single kernel launch over all B*T crops of a batch:
+//   * direct form (this file): implicit GEMM, M = crops*Ho*Wo pixels, N = Cout, K = k*k*Cin, on the fp32
+//     matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains, 256 FLOP/clk/CU) from LDS-staged,
+//     register-prefetched tiles -- the 1x1, stride-2 and stem layers;
+//   * Winograd F(2x2,3x3) form (vq_wino.hip) -- the 3x3 / stride-1 layers.
+// The executor below validates the plan once, autotunes the tiling per layer and batch size, and runs the
+// layer list on one stream (profiling) or as sub-batches on several (production).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
