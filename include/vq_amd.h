@@ -149,6 +149,17 @@ int vq_db_min_score(vq_db* db, const int64_t* rows_host, int32_t L, double* min_
  * ------------------------------------------------------------------------------------------ */
 typedef struct vq_tsn vq_tsn;
 
+/* Frame ingest (the step in front of vq_tsn_forward): n decoded frames [n][h][w][c] uint8 (host, or device if
+ * frames_on_device) -> bilinear resize to resize_w x resize_h with half-pixel centres -> over-sample crop 0 (top-left
+ * crop x crop), written as channels [dst_channel0, dst_channel0 + c) of the device buffer crops_dev
+ * [n][crop][crop][dst_channels] (so the 10 grey flow frames of a stack interleave into one 10-channel crop).
+ * Replaces the resize/over-sample half of CaffeNet.predict_single_frame / predict_single_flow_stack(...,
+ * frame_size=(340,256)) at calcSig_wOF.py:94,111.  Same bytes as tsn/frames.py:crop0 (fp64 arithmetic, round half to
+ * even); parity with cv2's fixed-point uint8 path is unpinned. */
+int vq_resize_crop(const uint8_t* frames, int32_t frames_on_device, int32_t n, int32_t h, int32_t w, int32_t c,
+                   int32_t resize_w, int32_t resize_h, int32_t crop, uint8_t* crops_dev, int32_t dst_channels,
+                   int32_t dst_channel0, int32_t device, void* hip_stream);
+
 enum {
     VQ_OP_CONV = 1,
     VQ_OP_MAXPOOL = 2,

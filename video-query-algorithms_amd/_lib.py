@@ -70,6 +70,7 @@ SIGNATURES = {
     "vq_db_scores_grid": [_P, _P, _I32, _P, _I32, _P],
     "vq_db_select": [_P, _F64, _F64, _pI64, _pI64, _pI64], "vq_db_select_fetch": [_P, _P, _I64, _P, _I64],
     "vq_db_topk": [_P, _I64, _P, _P, _pI64], "vq_db_min_score": [_P, _P, _I32, _pF64],
+    "vq_resize_crop": [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _P],
     "vq_tsn_create": [C.POINTER(TensorDesc), _I32, C.POINTER(LayerDesc), _I32, C.POINTER(ConvSegment), _I32, _P, _I64,
                       C.POINTER(InputDesc), _I32, _I32, _I32, _PP],
     "vq_tsn_destroy": [_P], "vq_tsn_set_stream": [_P, _P],

@@ -54,6 +54,8 @@ def build_parser():
     # additions (not in the reference)
     parser.add_argument('--frame_ext', type=str, default='.jpg', help='frame file extension (.jpg needs cv2 or PIL)')
     parser.add_argument('--batch_clips', type=int, default=32, help='clips per forward pass')
+    parser.add_argument('--host_resize', action='store_true',
+                        help='resize + crop the frames on the host (numpy) instead of on the GPU; same bytes either way')
     return parser
 
 
@@ -105,13 +107,20 @@ def main(argv=None):
                     frame_cnt = f_info[s['cnt_indexer']][vid]
                     ticks = frames.frame_ticks(frame_cnt, T, s['stack_depth'])
                     if s['modality'] == 'rgb':
-                        crops.append(frames.load_rgb_snippets(f_info[0][vid], ticks, args.rgb_prefix, args.frame_ext))
+                        load = frames.load_rgb_snippets if args.host_resize else frames.load_rgb_frames
+                        crops.append(load(f_info[0][vid], ticks, args.rgb_prefix, args.frame_ext))
                     else:
-                        crops.append(frames.load_flow_snippets(f_info[0][vid], ticks, frame_cnt, s['stack_depth'],
-                                                               args.flow_x_prefix, args.flow_y_prefix, args.frame_ext))
+                        load = frames.load_flow_snippets if args.host_resize else frames.load_flow_frames
+                        crops.append(load(f_info[0][vid], ticks, frame_cnt, s['stack_depth'], args.flow_x_prefix, args.flow_y_prefix,
+                                          args.frame_ext))
                     print('video {} for {} modality done'.format(vid, s['modality']))
                 if crops:
-                    mine.append(net.extract_clips(np.concatenate(crops, axis=0), T))
+                    if args.host_resize:
+                        mine.append(net.extract_clips(np.concatenate(crops, axis=0), T))
+                    elif len({c.shape[1:] for c in crops}) == 1:
+                        mine.append(net.extract_clips_from_frames(np.concatenate(crops, axis=0), T))   # resize + crop on the GPU
+                    else:                                        # clips of different frame sizes in one batch
+                        mine.append(np.concatenate([net.extract_clips_from_frames(c, T) for c in crops], axis=0))
             local_feat = np.concatenate(mine, axis=0) if mine else np.zeros((0, net.feature_dim))
             if world > 1:
                 import torch

@@ -1,0 +1,99 @@
+// Frame ingest on gfx950: decoded frames -> the crops the TSN forward consumes.
+//
+// What it replaces (paths relative to the reference checkout): the resize + over-sample part of
+//   src/features_GPU_compute/calcSig_wOF.py:94,111   CaffeNet.predict_single_frame / predict_single_flow_stack(...,
+//                                                    frame_size=(340, 256))  ->  crop 0 (top-left 224 x 224, un-mirrored)
+// i.e. per frame: bilinear resize to 340 x 256 with half-pixel centres (the sampling grid of cv2.resize INTER_LINEAR),
+// then the top-left crop.  Only the crop x crop pixels that survive are computed.  The arithmetic is the fp64
+// restatement of tsn/frames.py:resize_bilinear operation for operation (contraction off), so host and device paths
+// give the same bytes; cv2's own uint8 path uses 11-bit fixed-point coefficients and may differ by one grey level --
+// "parity unpinned" for lack of cv2 and of the reference's frames (frames.py says the same).
+#include "vq_common.h"
+
+using namespace vq;
+
+namespace {
+
+struct ResizeArgs {
+    const uint8_t* src;   // [n][h][w][c]
+    uint8_t* dst;         // [n][crop][crop][dst_c], this plane at channel dst_c0
+    int64_t total;        // n * crop * crop
+    int h, w, c, rw, rh, crop, dst_c, dst_c0;
+};
+
+__global__ void resize_crop_kernel(ResizeArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.total) return;
+    const int x = (int)(i % a.crop), y = (int)((i / a.crop) % a.crop);
+    const int64_t n = i / ((int64_t)a.crop * a.crop);
+    // frames.py: ys = clip((arange(h) + 0.5) * ih / h - 0.5, 0, ih - 1)
+    double ys = ((double)y + 0.5) * (double)a.h / (double)a.rh - 0.5;
+    double xs = ((double)x + 0.5) * (double)a.w / (double)a.rw - 0.5;
+    ys = fmin(fmax(ys, 0.0), (double)(a.h - 1));
+    xs = fmin(fmax(xs, 0.0), (double)(a.w - 1));
+    const int y0 = (int)floor(ys), x0 = (int)floor(xs);
+    const int y1 = min(y0 + 1, a.h - 1), x1 = min(x0 + 1, a.w - 1);
+    const double wy = ys - (double)y0, wx = xs - (double)x0;
+    const uint8_t* img = a.src + n * (int64_t)a.h * a.w * a.c;
+    uint8_t* out = a.dst + (n * a.crop * a.crop + (int64_t)y * a.crop + x) * a.dst_c + a.dst_c0;
+    for (int ch = 0; ch < a.c; ++ch) {
+        const double a00 = img[((int64_t)y0 * a.w + x0) * a.c + ch], a01 = img[((int64_t)y0 * a.w + x1) * a.c + ch];
+        const double a10 = img[((int64_t)y1 * a.w + x0) * a.c + ch], a11 = img[((int64_t)y1 * a.w + x1) * a.c + ch];
+        // a[y0][:, x0] * (1 - wy) * (1 - wx) + a[y0][:, x1] * (1 - wy) * wx + a[y1][:, x0] * wy * (1 - wx) + a[y1][:, x1] * wy * wx
+        double v = a00 * (1.0 - wy) * (1.0 - wx);
+        v = v + a01 * (1.0 - wy) * wx;
+        v = v + a10 * wy * (1.0 - wx);
+        v = v + a11 * wy * wx;
+        v = fmin(fmax(rint(v), 0.0), 255.0);      // np.clip(np.rint(out), 0, 255)
+        out[ch] = (uint8_t)v;
+    }
+}
+
+}  // namespace
+
+extern "C" int vq_resize_crop(const uint8_t* frames, int32_t frames_on_device, int32_t n, int32_t h, int32_t w, int32_t c,
+                              int32_t resize_w, int32_t resize_h, int32_t crop, uint8_t* crops_dev, int32_t dst_channels,
+                              int32_t dst_channel0, int32_t device, void* stream) {
+    VQ_REQUIRE(frames && crops_dev, "NULL argument");
+    VQ_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0, "frames must be [n][h][w][c] with positive sizes");
+    VQ_REQUIRE(resize_w >= crop && resize_h >= crop && crop > 0, "crop %d does not fit the %dx%d resized frame", crop, resize_w, resize_h);
+    VQ_REQUIRE(dst_channel0 >= 0 && dst_channel0 + c <= dst_channels, "channels [%d,%d) outside the %d-channel crop buffer", dst_channel0,
+               dst_channel0 + c, dst_channels);
+    int ndev = 0;
+    VQ_HIP(hipGetDeviceCount(&ndev));
+    VQ_REQUIRE(device >= 0 && device < ndev, "device %d out of range (%d visible)", device, ndev);
+    DeviceGuard g(device);
+    hipStream_t st = (hipStream_t)stream;
+    const uint8_t* src = frames;
+    uint8_t* staged = nullptr;
+    if (!frames_on_device) {
+        const size_t bytes = (size_t)n * h * w * c;
+        VQ_HIP(hipMalloc((void**)&staged, bytes));
+        hipError_t e = hipMemcpyAsync(staged, frames, bytes, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) {
+            (void)hipFree(staged);
+            return fail(VQ_E_HIP, "hipMemcpyAsync(frames) failed: %s", hipGetErrorString(e));
+        }
+        src = staged;
+    }
+    ResizeArgs a;
+    a.src = src;
+    a.dst = crops_dev;
+    a.total = (int64_t)n * crop * crop;
+    a.h = h;
+    a.w = w;
+    a.c = c;
+    a.rw = resize_w;
+    a.rh = resize_h;
+    a.crop = crop;
+    a.dst_c = dst_channels;
+    a.dst_c0 = dst_channel0;
+    resize_crop_kernel<<<cdiv(a.total, 256), 256, 0, st>>>(a);
+    hipError_t le = hipGetLastError();
+    if (staged) {
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(staged);
+    }
+    if (le != hipSuccess) return fail(VQ_E_HIP, "kernel launch failed: %s", hipGetErrorString(le));
+    return VQ_OK;
+}

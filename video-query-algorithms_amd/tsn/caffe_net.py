@@ -85,6 +85,53 @@ class CaffeNet:
             out.append(feat)
         return np.concatenate(out, axis=0)
 
+    def crops_from_frames(self, frames_: np.ndarray, frame_size=(340, 256), crop=224):
+        """Decoded frames -> device crops (torch uint8 [n, crop, crop, C]) through vq_resize_crop: RGB frames
+        [n, H, W, 3], or flow planes [n, C, H, W] (grey x/y frames in stack order).  Same bytes as frames.crop0."""
+        import ctypes as C
+        import torch
+        from .._lib import call
+        f = np.ascontiguousarray(frames_, dtype=np.uint8)
+        if f.ndim != 4:
+            raise ValueError("frames must be [n,H,W,3] (RGB) or [n,C,H,W] (flow planes)")
+        dev = torch.device("cuda", self._model.device)
+        n = f.shape[0]
+        out = torch.empty((n, crop, crop, self._channels), dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if self._channels == 3:
+            if f.shape[3] != 3:
+                raise ValueError("RGB frames must be [n,H,W,3]")
+            call("vq_resize_crop", f.ctypes.data_as(C.c_void_p), 0, n, f.shape[1], f.shape[2], 3, frame_size[0], frame_size[1], crop,
+                 C.c_void_p(out.data_ptr()), 3, 0, self._model.device, C.c_void_p(stream))
+        else:
+            if f.shape[1] != self._channels:
+                raise ValueError("flow planes must be [n,%d,H,W]" % self._channels)
+            for k in range(self._channels):
+                plane = np.ascontiguousarray(f[:, k])
+                call("vq_resize_crop", plane.ctypes.data_as(C.c_void_p), 0, n, f.shape[2], f.shape[3], 1, frame_size[0], frame_size[1],
+                     crop, C.c_void_p(out.data_ptr()), self._channels, k, self._model.device, C.c_void_p(stream))
+        return out
+
+    def extract_clips_from_frames(self, frames_: np.ndarray, T: int, frame_size=(340, 256)):
+        """Decoded frames of B*T snippets -> consensus features [B, D]: resize + crop 0 on the device, then the
+        batched forward on the resident crops (no host-side image processing at all)."""
+        import torch
+        per = (self._model.max_crops // T) * T
+        if per == 0:
+            raise ValueError("max_crops (%d) is smaller than T (%d)" % (self._model.max_crops, T))
+        dev = torch.device("cuda", self._model.device)
+        out = []
+        for i in range(0, frames_.shape[0], per):
+            crops = self.crops_from_frames(frames_[i:i + per], frame_size)
+            torch.cuda.current_stream(dev).synchronize()
+            nb = crops.shape[0]
+            self._model.forward_device(crops.data_ptr(), nb, T, self._mean)
+            fptr, _ = self._model.feat_devptr()
+            feat = np.empty((nb // T, self._model.feature_dim), dtype=np.float64)
+            self._model.read_features(feat)
+            out.append(feat)
+        return np.concatenate(out, axis=0)
+
     @property
     def feature_dim(self):
         return self._model.feature_dim

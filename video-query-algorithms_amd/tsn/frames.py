@@ -136,6 +136,24 @@ def crop0(img: np.ndarray, frame_size=(340, 256), crop=224) -> np.ndarray:
     return resize_bilinear(img, frame_size)[:crop, :crop]
 
 
+def load_rgb_frames(clip_dir: str, ticks: List[int], rgb_prefix='img_', ext='.jpg') -> np.ndarray:
+    """[T, H, W, 3] uint8 BGR: the decoded frames of the snippets, NOT resized (the device does that: vq_resize_crop)."""
+    return np.stack([imread(os.path.join(clip_dir, '{}{:05d}{}'.format(rgb_prefix, t, ext)), True) for t in ticks])
+
+
+def load_flow_frames(clip_dir: str, ticks: List[int], frame_cnt: int, stk_depth=5, flow_x_prefix='flow_x_',
+                     flow_y_prefix='flow_y_', ext='.jpg') -> np.ndarray:
+    """[T, 2*stk_depth, H, W] uint8: the x/y flow frames of every snippet in stack order (x0, y0, x1, y1, ...), NOT resized."""
+    out = []
+    for tick in ticks:
+        planes = []
+        for idx in flow_stack_indices(tick, frame_cnt, stk_depth):
+            planes.append(imread(os.path.join(clip_dir, '{}{:05d}{}'.format(flow_x_prefix, idx, ext)), False))
+            planes.append(imread(os.path.join(clip_dir, '{}{:05d}{}'.format(flow_y_prefix, idx, ext)), False))
+        out.append(np.stack(planes))
+    return np.stack(out)
+
+
 def load_rgb_snippets(clip_dir: str, ticks: List[int], rgb_prefix='img_', ext='.jpg') -> np.ndarray:
     """[T, 224, 224, 3] uint8 BGR (calcSig_wOF.py:88-96)."""
     return np.stack([crop0(imread(os.path.join(clip_dir, '{}{:05d}{}'.format(rgb_prefix, t, ext)), True)) for t in ticks])

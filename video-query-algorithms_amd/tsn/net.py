@@ -254,6 +254,18 @@ class TsnNet:
         m = np.ascontiguousarray(mean, dtype=np.float32)
         call("vq_tsn_forward", self._h, C.c_void_p(crops_dev_ptr), 1, n, T, m.ctypes.data_as(C.POINTER(C.c_float)), None, None)
 
+    def read_features(self, out: np.ndarray):
+        """Copy the consensus features [B, D] fp64 of the last forward_device to the host (synchronises)."""
+        import torch
+        f, _ = self.feat_devptr()
+
+        class _V:
+            __cuda_array_interface__ = {"shape": tuple(out.shape), "typestr": "<f8", "data": (int(f), False), "version": 2}
+        dev = torch.device("cuda", self.device)
+        torch.cuda.synchronize(dev)
+        out[...] = torch.as_tensor(_V(), device=dev).cpu().numpy()
+        return out
+
     def feat_devptr(self):
         f, p = C.c_void_p(), C.c_void_p()
         call("vq_tsn_feat_devptr", self._h, C.byref(f), C.byref(p))
