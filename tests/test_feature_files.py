@@ -184,3 +184,12 @@ def test_store_from_the_reference_csv_tree_matches_the_golden_subset(tmp_path):
     row_of = {c["clip"]: i for i, c in enumerate(clips)}
     for k, clip in enumerate(golden["clip_ids"]):
         assert (feats[row_of[clip]] == gx[k]).all()
+
+
+def test_clip_plan_follows_create_clip():
+    """build_wof_clips.py:78-128: full 150-frame clips, a short last clip only if it lasts >= 2 s (30 frames at 15 fps)."""
+    assert frames.clip_plan(450) == ([(1, 1, 150), (2, 151, 300), (3, 301, 450)], 0)
+    assert frames.clip_plan(479) == ([(1, 1, 150), (2, 151, 300), (3, 301, 450)], 29)          # 29 frames < 2 s: dropped
+    assert frames.clip_plan(480) == ([(1, 1, 150), (2, 151, 300), (3, 301, 450), (4, 451, 480)], 0)
+    assert frames.clip_plan(100) == ([(1, 1, 100)], 0) and frames.clip_plan(20) == ([], 20)
+    assert frames.clip_plan(310, frames_per_clip=100, frames_per_second=5) == ([(1, 1, 100), (2, 101, 200), (3, 201, 300), (4, 301, 310)], 0)
