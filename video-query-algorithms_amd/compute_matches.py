@@ -1,9 +1,11 @@
 """Drop-in for the reference's ``compute_matches`` (src/models/compute_matches.py:8-107).
 
-Same orchestration, same call order on the ticket (so the REST side effects of the reference's
-Ticket methods happen in the same sequence); the arithmetic calls land on the GPU through
-``TicketScoring`` / ``Hyperparameter``.  ``ticket_factory(update_object, url)`` lets the caller
-supply the Ticket class to use (the reference's, patched by ``install``; or the offline ``Ticket``).
+The orchestration of one broker pass: every pending query update becomes a ticket, gets its target, is scanned,
+re-weighted, scored and turned into the next review set.  The sequence of calls on the ticket is the reference's (so
+the REST side effects of its Ticket methods happen in the same order); the arithmetic behind ``compute_similarities``,
+``optimize_weights``, ``compute_scores`` and ``select_clips_to_review`` runs on the GPU (``TicketScoring``,
+``Hyperparameter``, ``TargetClip``).  ``ticket_factory(update_object, url)`` supplies the Ticket class -- the reference's
+own, patched by ``install``, or the offline ``Ticket``.
 """
 from __future__ import annotations
 
@@ -11,66 +13,76 @@ import os
 
 from .target_clip import TargetClip
 
+_IN_PROGRESS, _PROCESSED, _ERROR, _FINALIZED = 3, 4, 5, 7      # process states, compute_matches.py:42,50,104,107
+
+
+def _choose_weights(kind, update, tk, hp):
+    """compute_matches.py:60-67: defaults for a new query (or one without matches yet), else re-fit on the labels."""
+    if kind == "new" or not update["matches"]:
+        hp.weights = hp.default_weights
+        hp.threshold = hp.default_threshold
+    elif kind in ("revise", "finalize"):
+        hp.optimize_weights(tk)
+    else:
+        raise Exception('update type is invalid')
+
+
+def _review_budget(kind, tk, hp):
+    """compute_matches.py:78-88: (how many matches go out, how far below the threshold to look).  A finalize pass
+    reports everything and reaches down to the lowest-scoring match the user confirmed."""
+    if kind != "finalize":
+        return tk.number_of_matches_to_review, hp.near_miss_default
+    lowest, _clip = tk.lowest_scoring_user_match()
+    reach = max(hp.threshold - lowest, 0) / max(1 - hp.threshold, float(os.environ["COMPUTE_EPS"]))
+    return float("inf"), reach
+
+
+def _one_update(kind, update, url, hp, ticket_factory, target_factory):
+    tk = ticket_factory(update, url)
+    tk.change_process_state(_IN_PROGRESS)
+    fatal, warning = tk.catch_errors(kind)                                  # :47-52
+    if fatal:
+        tk.change_process_state(_ERROR, message=fatal)
+        return
+    if warning:
+        tk.add_note(warning)
+
+    tk.target = target_factory(tk, hp)                                      # :55-58
+    tk.target.get_target_features()
+    tk.compute_similarities(hp)
+    _choose_weights(kind, update, tk, hp)
+
+    round_no = 1 if kind == 'new' else tk.latest_query_result["round"] + 1  # :70-74
+    result_id = tk.create_query_result(round_no, hp)
+
+    tk.compute_scores(hp.weights)                                           # :77
+    budget, reach = _review_budget(kind, tk, hp)
+    tk.select_clips_to_review(hp.threshold, budget, reach)
+    if not tk.matches:                                                      # :92-94
+        catch_no_matches_error(tk)
+        return
+    tk.add_matches_to_database(result_id)                                   # :97
+    if kind == "finalize":                                                  # :102-107
+        tk.create_final_report(hp, result_id)
+        tk.change_process_state(_FINALIZED)
+    else:
+        tk.change_process_state(_PROCESSED)
+
 
 def compute_matches(query_updates, hyperparameters, ticket_factory=None, target_factory=TargetClip):
-    updates_needed = query_updates.get_status()                                    # compute_matches.py:34
+    pending = query_updates.get_status()                                    # :34
     if ticket_factory is None:
         from .ticket import Ticket as _Ticket
 
         def ticket_factory(update_object, url):
             return _Ticket(update_object)
-    for update_type, update_object in updates_needed.items():                      # :37
-        if update_object is None:
-            continue
-        ticket = ticket_factory(update_object, query_updates.url)
-        ticket.change_process_state(3)
-        fatal_error_message, error_message = ticket.catch_errors(update_type)     # :47-52
-        if fatal_error_message:
-            ticket.change_process_state(5, message=fatal_error_message)
-            continue
-        if error_message:
-            ticket.add_note(error_message)
-
-        ticket.target = target_factory(ticket, hyperparameters)                    # :55-58
-        ticket.target.get_target_features()
-        ticket.compute_similarities(hyperparameters)
-
-        if (update_type == "new") or not update_object["matches"]:                 # :61-67
-            hyperparameters.weights = hyperparameters.default_weights
-            hyperparameters.threshold = hyperparameters.default_threshold
-        elif update_type == "revise" or update_type == "finalize":
-            hyperparameters.optimize_weights(ticket)
-        else:
-            raise Exception('update type is invalid')
-
-        new_round = 1 if update_type == 'new' else ticket.latest_query_result["round"] + 1   # :70-74
-        new_result_id = ticket.create_query_result(new_round, hyperparameters)
-
-        ticket.compute_scores(hyperparameters.weights)                             # :77-89
-        if update_type == "finalize":
-            max_number_matches = float("inf")
-            low_score, __ = ticket.lowest_scoring_user_match()
-            near_miss = max(hyperparameters.threshold - low_score, 0) / \
-                max(1 - hyperparameters.threshold, float(os.environ["COMPUTE_EPS"]))
-        else:
-            max_number_matches = ticket.number_of_matches_to_review
-            near_miss = hyperparameters.near_miss_default
-        ticket.select_clips_to_review(hyperparameters.threshold, max_number_matches, near_miss)
-
-        if not ticket.matches:                                                     # :92-94
-            catch_no_matches_error(ticket)
-            continue
-        ticket.add_matches_to_database(new_result_id)                              # :97
-        if update_type == "finalize":                                              # :102-107
-            ticket.create_final_report(hyperparameters, new_result_id)
-            ticket.change_process_state(7)
-            continue
-        else:
-            ticket.change_process_state(4)
+    for kind, update in pending.items():                                    # :37
+        if update is not None:
+            _one_update(kind, update, query_updates.url, hyperparameters, ticket_factory, target_factory)
 
 
 def catch_no_matches_error(ticket):
     """compute_matches.py:110-114."""
-    mround = ticket.latest_query_result["round"] if ticket.latest_query_result else 1
-    error_message = "*** Error: No matches were found for round {} of query {}! ***".format(mround, ticket.query_id)
-    ticket.change_process_state(5, message=error_message)
+    which = ticket.latest_query_result["round"] if ticket.latest_query_result else 1
+    ticket.change_process_state(_ERROR, message="*** Error: No matches were found for round {} of query {}! ***".format(
+        which, ticket.query_id))
