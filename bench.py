@@ -305,12 +305,20 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
+    # VQ_BENCH_REHEARSE=1: every rank on cuda:0 with the gloo backend -- rehearses the N > 1 control flow (sharding,
+    # barriers, gathers, max-over-ranks timing) on a one-GPU box; the numbers of such a run mean nothing.
+    rehearse = os.environ.get("VQ_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     stream = torch.cuda.Stream(device=device)
 
     dt, roof, model, crops, feats = bench_tsn(args, rank, world, device, stream)

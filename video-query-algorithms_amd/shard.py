@@ -34,6 +34,8 @@ def all_gather_rows(local, n_total: int, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return local
+    if local.is_cuda and dist.get_backend(group) == "gloo":      # rehearsal of the N > 1 path without RCCL: stage through the host
+        return all_gather_rows(local.cpu(), n_total, group).to(local.device)
     max_rows = -(-n_total // world)
     tail = tuple(local.shape[1:])
     padded = local
