@@ -485,3 +485,24 @@ def test_device_resize_crop_equals_the_host_path(tsn, h, w):
     feats = cf.extract_clips_from_frames(planes, 2)
     assert (feats == cf.extract_clips(want, 2)).all()
     cf.close()
+
+
+def test_bench_two_rank_control_flow_rehearsal(tsn):
+    """bench.py under torch.distributed.run with 2 ranks, both on this one GPU through gloo (VQ_BENCH_REHEARSE=1): the
+    weak-scaling control flow the driver runs on 2/4/8 GPUs -- per-rank batches, feature all-gather, barriers,
+    max-over-ranks timing, one JSON line from rank 0 -- must hold together.  The numbers of such a run mean nothing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VQ_BENCH_REHEARSE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--skip-sim",
+           "--skip-cpu"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["roofline"]["launches_per_step"] == 44 and 0 < out["roofline"]["frac"] < 2
