@@ -318,7 +318,7 @@ def test_calcsig_command_line_end_to_end(tsn, tmp_path):
     out_dir = tmp_path / "features"
     rc = calcSig_wOF.main([str(root), protos["rgb"], wfile["rgb"], protos["flow"], wfile["flow"], "--num_frame_per_video", "3",
                            "--outFeatures_dir", str(out_dir), "--modelname", "UCF101_split1", "--frame_ext", ".ppm",
-                           "--batch_clips", "2"])
+                           "--batch_clips", "2", "--num_worker", "3"])
     assert rc == 0
     nsplit, streams = feature_csv.read_split_dir(str(out_dir / "myvideo" / "UCF101_split1"))
     assert nsplit == 1 and set(streams) == {"rgb", "warped_optical_flow"}

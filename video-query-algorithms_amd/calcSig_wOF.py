@@ -44,7 +44,7 @@ def build_parser():
     parser.add_argument('--flow_x_prefix', type=str, help="prefix of x direction flow images", default='flow_x_')
     parser.add_argument('--flow_y_prefix', type=str, help="prefix of y direction flow images", default='flow_y_')
     parser.add_argument('--num_frame_per_video', type=int, default=25, help="number of frames to evaluate in each video")
-    parser.add_argument('--num_worker', type=int, default=1, help="accepted for compatibility; batching replaces workers")
+    parser.add_argument('--num_worker', type=int, default=1, help="decoder threads (the reference's worker processes; the GPU side is batched instead)")
     parser.add_argument("--gpus", type=int, nargs='+', default=None, help='GPU ids; one process per GPU under torchrun')
     parser.add_argument('--outFeatures_dir', type=str, default=None, help='Specify directory to write out feature files')
     parser.add_argument('--delimiter', type=str, default=',', help='delimiter used in feature files')
@@ -90,6 +90,8 @@ def main(argv=None):
                  {'modality': 'flow', 'mode': 'warped_optical_flow', 'net_proto': args.net_proto_flow,
                   'net_weights': args.net_weights_flow, 'cnt_indexer': 2, 'stack_depth': 5}]   # calcSig_wOF.py:185-189
     nets = {}
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=max(1, args.num_worker))
     for video_path in sorted(glob.glob(frame_path + '*/')):                            # calcSig_wOF.py:193-195
         f_info = frames.parse_directory(video_path, args.rgb_prefix, args.flow_x_prefix, args.flow_y_prefix)
         clip_list = sorted(list(f_info[0]), key=lambda clip: int(clip[-4:]))           # calcSig_wOF.py:199-200
@@ -101,18 +103,24 @@ def main(argv=None):
                                                max_crops=args.batch_clips * T, feature_blob=args.featureBlob)
             net = nets[s['modality']]
             mine = []
-            for b0 in range(first, first + count, args.batch_clips):
-                crops = []
-                for vid in clip_list[b0:min(b0 + args.batch_clips, first + count)]:
-                    frame_cnt = f_info[s['cnt_indexer']][vid]
-                    ticks = frames.frame_ticks(frame_cnt, T, s['stack_depth'])
-                    if s['modality'] == 'rgb':
-                        load = frames.load_rgb_snippets if args.host_resize else frames.load_rgb_frames
-                        crops.append(load(f_info[0][vid], ticks, args.rgb_prefix, args.frame_ext))
-                    else:
-                        load = frames.load_flow_snippets if args.host_resize else frames.load_flow_frames
-                        crops.append(load(f_info[0][vid], ticks, frame_cnt, s['stack_depth'], args.flow_x_prefix, args.flow_y_prefix,
-                                          args.frame_ext))
+
+            def load_clip(vid, s=s):
+                frame_cnt = f_info[s['cnt_indexer']][vid]
+                ticks = frames.frame_ticks(frame_cnt, T, s['stack_depth'])
+                if s['modality'] == 'rgb':
+                    load = frames.load_rgb_snippets if args.host_resize else frames.load_rgb_frames
+                    return load(f_info[0][vid], ticks, args.rgb_prefix, args.frame_ext)
+                load = frames.load_flow_snippets if args.host_resize else frames.load_flow_frames
+                return load(f_info[0][vid], ticks, frame_cnt, s['stack_depth'], args.flow_x_prefix, args.flow_y_prefix, args.frame_ext)
+
+            # --num_worker decoder threads (the reference runs that many worker PROCESSES, each with its own net,
+            # calcSig_wOF.py:204-210); the batch after the one on the GPU is decoded meanwhile
+            batches = [clip_list[b0:min(b0 + args.batch_clips, first + count)] for b0 in range(first, first + count, args.batch_clips)]
+            pending = [pool.submit(load_clip, vid) for vid in batches[0]] if batches else []
+            for bi, vids in enumerate(batches):
+                crops = [f.result() for f in pending]
+                pending = [pool.submit(load_clip, vid) for vid in batches[bi + 1]] if bi + 1 < len(batches) else []
+                for vid in vids:
                     print('video {} for {} modality done'.format(vid, s['modality']))
                 if crops:
                     if args.host_resize:
@@ -134,6 +142,7 @@ def main(argv=None):
             video = video_path.split('/')[-2]
             write_features(args.outFeatures_dir, video, video_path, args.modelname, args.featureBlob, clip_list, features,
                            {'rgb': args.net_weights_rgb, 'warped_optical_flow': args.net_weights_flow})
+    pool.shutdown()
     for n in nets.values():
         n.close()
     return 0
