@@ -32,29 +32,40 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------
 // preprocess: uint8 NHWC crops -> fp32 NHWC (channels padded to a multiple of 4), minus mean
 // ------------------------------------------------------------------------------------------------
-__global__ void preprocess_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int64_t npix, int C, int Cpad,
+// One thread per 16-byte chunk of the output (4 consecutive channels of one pixel): coalesced float4 stores.
+__global__ void preprocess_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int64_t nchunk, int C, int Cpad,
                                   const float* __restrict__ mean) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npix) return;
-    for (int c = 0; c < Cpad; ++c) dst[p * Cpad + c] = c < C ? (float)src[p * C + c] - mean[c] : 0.0f;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nchunk) return;
+    const int cpp = Cpad >> 2;                      // chunks per pixel
+    const int64_t p = i / cpp;
+    const int c0 = (int)(i - p * cpp) * 4;
+    floatx4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = c0 + e < C ? (float)src[p * C + c0 + e] - mean[c0 + e] : 0.0f;
+    *reinterpret_cast<floatx4*>(dst + p * Cpad + c0) = v;
 }
 
-// Space-to-depth(2) variant (vq_input_desc.s2d_pad >= 0): one thread per (crop, Y, X) of slot 0 writes its 4*C channels,
-// dst[..][(p*2+q)*C + c] = crop[2Y+p-pad][2X+q-pad][c] - mean[c], zeros outside the crop (the first convolution's own
-// zero padding, applied after the mean like Caffe does).
-__global__ void preprocess_s2d_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int64_t ncell, int H, int W, int C,
+// Space-to-depth(2) variant (vq_input_desc.s2d_pad >= 0): slot0[n][Y][X][(p*2+q)*C + c] = crop[2Y+p-pad][2X+q-pad][c] -
+// mean[c], zeros outside the crop (the first convolution's own zero padding, applied after the mean like Caffe does).
+// One thread per 16-byte chunk of the 4*C output channels of a cell.
+__global__ void preprocess_s2d_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int64_t nchunk, int H, int W, int C,
                                       int Hs, int Ws, int pad, const float* __restrict__ mean) {
-    const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (cell >= ncell) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nchunk) return;
+    const int64_t cell = i / C;                     // 4*C channels = C chunks of 4 per cell
+    const int j0 = (int)(i - cell * C) * 4;
     const int X = (int)(cell % Ws), Y = (int)((cell / Ws) % Hs);
     const int64_t n = cell / ((int64_t)Ws * Hs);
-    float* out = dst + cell * (4 * C);
-    for (int pq = 0; pq < 4; ++pq) {
+    floatx4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = j0 + e, pq = j / C, c = j - pq * C;
         const int y = 2 * Y + (pq >> 1) - pad, x = 2 * X + (pq & 1) - pad;
         const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        const uint8_t* px = src + ((n * H + (in ? y : 0)) * W + (in ? x : 0)) * C;
-        for (int c = 0; c < C; ++c) out[pq * C + c] = in ? (float)px[c] - mean[c] : 0.0f;
+        v[e] = in ? (float)src[((n * H + y) * W + x) * C + c] - mean[c] : 0.0f;
     }
+    *reinterpret_cast<floatx4*>(dst + cell * (4 * C) + j0) = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1302,11 +1313,12 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
     }
     VQ_HIP(hipMemcpyAsync(net->mean_dev, mean_host, in_c * sizeof(float), hipMemcpyHostToDevice, net->stream));
     if (net->input.s2d_pad < 0) {
-        preprocess_kernel<<<cdiv(npix, 256), 256, 0, net->stream>>>(src, net->slots[0], npix, in_c, t0.c, net->mean_dev);
+        const int64_t nchunk = npix * (t0.c / 4);
+        preprocess_kernel<<<cdiv(nchunk, 256), 256, 0, net->stream>>>(src, net->slots[0], nchunk, in_c, t0.c, net->mean_dev);
     } else {
-        const int64_t ncell = (int64_t)n_crops * t0.h * t0.w;
-        preprocess_s2d_kernel<<<cdiv(ncell, 256), 256, 0, net->stream>>>(src, net->slots[0], ncell, net->input.h, net->input.w, in_c,
-                                                                       t0.h, t0.w, net->input.s2d_pad, net->mean_dev);
+        const int64_t nchunk = (int64_t)n_crops * t0.h * t0.w * in_c;
+        preprocess_s2d_kernel<<<cdiv(nchunk, 256), 256, 0, net->stream>>>(src, net->slots[0], nchunk, net->input.h, net->input.w, in_c,
+                                                                        t0.h, t0.w, net->input.s2d_pad, net->mean_dev);
     }
     VQ_CHECK_LAUNCH();
     if (net->autotune && net->forced_tile < 0 && net->tuned.find(n_crops) == net->tuned.end()) {

@@ -121,15 +121,18 @@ class TsnNet:
         self.in_h, self.in_w = plan.tensors[0].h, plan.tensors[0].w
         # Space-to-depth stem: a k x k / stride-2 first convolution on very few channels is evaluated as a
         # ceil(k/2)^2 / stride-1 convolution over the 2x2-decimated input with 4x the channels -- K has no channel padding
-        # (7x7x3: 16 taps x 12 = 192 instead of 49 x 4 -> 224) and every load is 16-byte aligned.  Taken when it
-        # shrinks the packed K (RGB yes; the 10-channel flow stack no: 16 x 40 = 640 > 49 x 12 -> 608).
+        # (7x7x3: 16 taps x 12 = 192 instead of 49 x 4 -> 224), every load is 16-byte aligned and, being padding-free,
+        # the layer runs on the aligned kernel path with its kernel rows folded into the channel axis.  Taken when the
+        # packed K does not grow by more than 6 % (RGB: 224 -> 192; the 10-channel flow stack: 608 -> 640, still 7 %
+        # faster because the per-chunk tap decoding disappears).
         stem = [op for op in plan.ops if op.src == 0]
         self.stem_s2d = False
-        if (stem_s2d if stem_s2d is not None else os.environ.get("VQ_TSN_STEM_S2D", "1") != "0") and len(stem) == 1:
+        mode = os.environ.get("VQ_TSN_STEM_S2D", "1") if stem_s2d is None else ("2" if stem_s2d else "0")   # 2 = whenever possible
+        if mode != "0" and len(stem) == 1:
             op = stem[0]
             k2 = (op.k + 1) // 2
             if op.kind == "conv" and op.stride == 2 and not op.segments and op.k >= 3 and \
-                    _round_up(k2 * k2 * 4 * self.in_channels, BK) < _round_up(op.k * op.k * cin_pad, BK):
+                    (mode == "2" or _round_up(k2 * k2 * 4 * self.in_channels, BK) <= 1.06 * _round_up(op.k * op.k * cin_pad, BK)):
                 self.stem_s2d = True
         in_slot_c = 4 * self.in_channels if self.stem_s2d else cin_pad
         tensors = (TensorDesc * len(plan.tensors))()
