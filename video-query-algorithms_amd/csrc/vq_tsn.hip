@@ -705,6 +705,7 @@ struct vq_tsn {
     uint8_t* crops_dev = nullptr;
     size_t crops_cap = 0;
     float* mean_dev = nullptr;
+    std::vector<float> mean_cached;       // what mean_dev holds (uploaded only when the caller's mean changes)
     double* feat_dev = nullptr;           // [max_crops][D] (B <= max_crops)
     double flops_per_crop = 0;
     int last_crops = 0;
@@ -1311,7 +1312,11 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
         VQ_HIP(hipMemcpyAsync(net->crops_dev, crops, bytes, hipMemcpyHostToDevice, net->stream));
         src = net->crops_dev;
     }
-    VQ_HIP(hipMemcpyAsync(net->mean_dev, mean_host, in_c * sizeof(float), hipMemcpyHostToDevice, net->stream));
+    if (net->mean_cached.size() != (size_t)in_c || memcmp(net->mean_cached.data(), mean_host, in_c * sizeof(float)) != 0) {
+        net->mean_cached.assign(mean_host, mean_host + in_c);     // pageable copy from a buffer that outlives this call
+        VQ_HIP(hipMemcpyAsync(net->mean_dev, net->mean_cached.data(), in_c * sizeof(float), hipMemcpyHostToDevice, net->stream));
+        VQ_HIP(hipStreamSynchronize(net->stream));
+    }
     if (net->input.s2d_pad < 0) {
         const int64_t nchunk = npix * (t0.c / 4);
         preprocess_kernel<<<cdiv(nchunk, 256), 256, 0, net->stream>>>(src, net->slots[0], nchunk, in_c, t0.c, net->mean_dev);
