@@ -88,12 +88,13 @@ def bench_tsn(args, rank, world, device, stream):
             all_gather_rows(feat, world * B_CLIPS)           # RCCL over xGMI: per-GPU feature blocks
 
     with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
+        model.set_profile(1)                         # warm up in the mode of the timed region (tunes this batch size)
+        for _ in range(max(args.warmup, 1)):
             step()
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
-        model.set_profile(min(args.steps, 1024))     # HIP events around every layer launch, no host sync
+        model.set_profile(min(args.steps, 1024))     # start/stop events on every layer launch, no host sync
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()

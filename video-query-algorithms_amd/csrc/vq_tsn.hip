@@ -951,6 +951,21 @@ static int autotune(vq_tsn* net, int n_crops) {
     return VQ_OK;
 }
 
+// Make sure a tiling table exists for this batch size.  The first size seen is autotuned; a later size within 1.5x of
+// a tuned one borrows that table (the ragged last batch of a video must not cost 2 s of tuning launches -- every
+// tiling gives the same bits, only the speed differs); anything further away is tuned itself.
+static int ensure_tuned(vq_tsn* net, int n_crops) {
+    if (!net->autotune || net->forced_tile >= 0 || net->tuned.find(n_crops) != net->tuned.end()) return VQ_OK;
+    int nearest = 0;
+    for (const auto& kv : net->tuned)
+        if (nearest == 0 || std::abs(kv.first - n_crops) < std::abs(nearest - n_crops)) nearest = kv.first;
+    if (nearest > 0 && 2 * std::max(nearest, n_crops) <= 3 * std::min(nearest, n_crops)) {
+        net->tuned[n_crops] = net->tuned[nearest];
+        return VQ_OK;
+    }
+    return autotune(net, n_crops);
+}
+
 static int run_layer(vq_tsn* net, int li, int n_crops) {
     const vq_layer_desc& L = net->layers[li];
     const vq_tensor_desc& ts = net->tensors[L.src];
@@ -1326,10 +1341,6 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
                                                                         t0.h, t0.w, net->input.s2d_pad, net->mean_dev);
     }
     VQ_CHECK_LAUNCH();
-    if (net->autotune && net->forced_tile < 0 && net->tuned.find(n_crops) == net->tuned.end()) {
-        const int rc = autotune(net, n_crops);
-        if (rc != VQ_OK) return rc;
-    }
     hipEvent_t* ev = nullptr;
     if (net->profile_depth > 0) {
         ev = net->events.data() + (size_t)(net->profile_count % net->profile_depth) * (2 * net->layers.size());
@@ -1346,11 +1357,10 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
             sub_off[sb] = o;
             o += sub[sb];
         }
-    for (int sb = 0; sb < n_split && n_split > 1; ++sb)
-        if (net->autotune && net->forced_tile < 0 && net->tuned.find(sub[sb]) == net->tuned.end()) {
-            const int rc = autotune(net, sub[sb]);
-            if (rc != VQ_OK) return rc;
-        }
+    for (int sb = 0; sb < n_split; ++sb) {      // n_split == 1: sub[0] is the whole batch
+        const int rc = ensure_tuned(net, sub[sb]);
+        if (rc != VQ_OK) return rc;
+    }
     if (lanes_on || n_split > 1) {
         VQ_HIP(hipEventRecord(net->fork_ev, net->stream));
         for (int l = 1; l < std::max(net->n_lanes, n_split); ++l) VQ_HIP(hipStreamWaitEvent(net->lane_streams[l], net->fork_ev, 0));
