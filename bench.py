@@ -291,8 +291,8 @@ def cpu_baseline_sim(db, row0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--skip-sim", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--profile-only", action="store_true",
