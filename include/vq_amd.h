@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQ_ABI_VERSION 2
+#define VQ_ABI_VERSION 3
 
 enum {
     VQ_OK = 0,
@@ -138,6 +138,11 @@ int vq_db_select(vq_db* db, double threshold, double lower, int64_t* n_match, in
                  int64_t* near_argmax);
 int vq_db_select_fetch(vq_db* db, int64_t* match_rows_host, int64_t cap_match, int64_t* near_rows_host,
                        int64_t cap_near);
+/* vq_db_select + vq_db_select_fetch under ONE lock of the handle (broker threads share handles: a top-k or another
+ * selection can otherwise slip in between the two calls).  The two host buffers must hold cap_match / cap_near rows
+ * (N each is always enough); VQ_E_INVALID with the counts filled in if one is too small. */
+int vq_db_select_rows(vq_db* db, double threshold, double lower, int64_t* match_rows_host, int64_t cap_match,
+                      int64_t* near_rows_host, int64_t cap_near, int64_t* n_match, int64_t* n_near, int64_t* near_argmax);
 /* Rows of the k largest scores, descending, ties by ascending row (the stable sort of the final
  * report, ticket.py:266).  *k_out = min(k, number of non-NaN scores). */
 int vq_db_topk(vq_db* db, int64_t k, int64_t* rows_host, double* vals_host, int64_t* k_out);
@@ -258,6 +263,32 @@ int vq_tsn_set_layer_tiles(vq_tsn* net, int32_t n_crops, const int32_t* tiles, i
 int vq_tsn_layer_lanes(vq_tsn* net, int32_t* lanes, int32_t n_layers);
 /* Algorithmic FLOPs (2*MACs of the conv layers) of one crop, for roofline accounting. */
 int vq_tsn_flops_per_crop(vq_tsn* net, double* flops);
+
+/* ------------------------------------------------------------------------------------------
+ * Comm group: one process per GPU, RCCL over xGMI
+ * ------------------------------------------------------------------------------------------
+ * The reference's only exchange is multiprocessing.Pool pickling per-clip features back to the parent
+ * (src/features_GPU_compute/calcSig_wOF.py:204-210); these entry points are what a non-torch host (cgo, JNI, plain C)
+ * binds to drive the sharded path.  librccl is resolved at run time (VQ_RCCL_LIB, else the RCCL already mapped into
+ * the process, else librccl.so.1); VQ_E_UNSUPPORTED if there is none.  A torch host can keep using torch.distributed
+ * (backend "nccl" = the same RCCL): the Python package does. */
+typedef struct vq_comm vq_comm;
+#define VQ_COMM_ID_BYTES 128
+/* Rank 0 creates the 128-byte rendezvous id and hands it to the other ranks by any host-side means. */
+int vq_comm_unique_id(void* id_out);
+/* Collective over all ranks.  Makes `device` current on the calling thread and binds the communicator to it. */
+int vq_comm_init(int32_t rank, int32_t world, const void* rccl_unique_id, int32_t device, vq_comm** out);
+int vq_comm_destroy(vq_comm* comm);
+int vq_comm_info(vq_comm* comm, int32_t* rank, int32_t* world, int32_t* device);
+/* Half A -> half B hand-off: every rank contributes block_bytes of device memory (its [clips of the rank][S][1024]
+ * feature block, padded to the largest shard); all_dev receives [world][block_bytes] in rank order = global clip order
+ * for contiguous shards.  One all-gather on hip_stream, asynchronous. */
+int vq_allgather_features(vq_comm* comm, const void* block_dev, int64_t block_bytes, void* all_dev, void* hip_stream);
+/* Sharded scan: gathers the score slice of every rank's row shard (db's scores[n], zero-padded to slice_rows) into
+ * all_scores_dev [world][slice_rows] fp64 on every rank -- N x 8 bytes cross xGMI, never the features. */
+int vq_allgather_scores(vq_comm* comm, vq_db* db, int64_t slice_rows, double* all_scores_dev, void* hip_stream);
+/* The 80 KB query block t[S][E][D] (or any small device buffer) from `root` to every rank, in place. */
+int vq_broadcast_query(vq_comm* comm, void* buf_dev, int64_t bytes, int32_t root, void* hip_stream);
 
 #ifdef __cplusplus
 }

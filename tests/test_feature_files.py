@@ -34,16 +34,45 @@ def test_writer_layout_and_number_format(tmp_path):
     assert nsplit == 2 and set(streams) == {"rgb", "warped_optical_flow"}
 
 
-def test_writer_reproduces_a_shipped_reference_file_byte_for_byte(tmp_path):
-    if not os.path.exists(REF_CSV):
+REF_CSV_G12 = ("/root/reference/data/features/SHRP2_Forward_clips_features/S06NDS_Sample_120406_1451_00186_Forward/"
+               "UCF101_split2/warped_optical_flow_global_pool_features.csv")
+
+
+@pytest.mark.parametrize("path,number_format", [(REF_CSV, "repr"), (REF_CSV_G12, "g12")])
+def test_writer_reproduces_a_shipped_reference_file_byte_for_byte(tmp_path, path, number_format):
+    """The reference ships files of both numpy float-str generations (feature_csv docstring); each is reproduced
+    byte for byte by the matching number_format."""
+    if not os.path.exists(path):
         pytest.skip("reference checkout not present (GPU box)")
-    meta, clips, feats = feature_csv.read_features(REF_CSV)
-    raw = open(REF_CSV, "rb").read()
+    meta, clips, feats = feature_csv.read_features(path)
+    raw = open(path, "rb").read()
     header = raw.split(b"\n", 1)[0].decode()
     fields = [h.split("=")[-1] for h in header.split(", ")]
-    files = feature_csv.write_features(str(tmp_path), fields[0], fields[1], "UCF101_split1", fields[3],
-                                       ["clip_%04d" % c for c in clips], {"rgb": feats}, {"rgb": fields[4]})
+    stream = fields[2]
+    files = feature_csv.write_features(str(tmp_path), fields[0], fields[1], "UCF101_splitX", fields[3],
+                                       ["clip_%04d" % c for c in clips], {stream: feats}, {stream: fields[4]},
+                                       number_format=number_format)
     assert open(files[0], "rb").read() == raw
+
+
+def test_g12_format_truncates_full_precision_values(tmp_path):
+    """Full-precision float64 features under the numpy < 1.14 rule: every field equals '%.12g' (+ '.0' when
+    integral), as in the shipped S06NDS files; the default format keeps all digits."""
+    rng = np.random.default_rng(5)
+    feat = np.abs(rng.standard_normal((3, 16))) * np.array([1e-6, 1, 1e3, 1e15] * 4)
+    feat[0, :3] = [0.0, 3.0, 1.4111196446412344]
+    names = ["clip_0001", "clip_0002", "clip_0003"]
+    f12 = feature_csv.write_features(str(tmp_path / "a"), "v", "/p/", "m1", "global_pool", names, {"rgb": feat}, {"rgb": "w"}, "g12")
+    full = feature_csv.write_features(str(tmp_path / "b"), "v", "/p/", "m1", "global_pool", names, {"rgb": feat}, {"rgb": "w"})
+    rows12 = [l.split(",")[1:] for l in open(f12[0]).read().split("\n")[1:-1]]
+    assert rows12[0][:3] == ["0.0", "3.0", "1.41111964464"]
+    for got, vals in zip(rows12, feat):
+        for tok, v in zip(got, vals):
+            want = "%.12g" % v
+            assert tok == (want if ("." in want or "e" in want) else want + ".0")
+            assert abs(float(tok) - v) <= 5e-12 * abs(v)
+    _, _, back = feature_csv.read_features(full[0])
+    assert (back == feat).all()
 
 
 def test_ticks_and_stacks_match_the_oracle():
@@ -71,6 +100,22 @@ def test_parse_directory_and_image_io(tmp_path):
     (tmp_path / "video" / "clip_0002" / "flow_y_00004.pgm").unlink()
     with pytest.raises(ValueError):
         frames.parse_directory(str(tmp_path / "video"))
+
+
+def test_host_resize_equals_the_pixel_loop_oracle():
+    """tsn/frames.py (the --host_resize path) against oracle/frames_oracle.py, byte for byte; and how far the exact
+    bilinear weights are from cv2's 11-bit fixed-point rule as remembered (reported, at most one grey level; PARITY
+    UNPINNED -- no cv2 and no reference frames here)."""
+    import frames_oracle as fo
+    rng = np.random.default_rng(3)
+    for shape in ((360, 480, 3), (240, 320), (256, 340, 3), (97, 131)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        assert (frames.crop0(img) == fo.crop0(img)).all()
+    img = rng.integers(0, 256, (360, 480), dtype=np.uint8)
+    exact = frames.crop0(img)
+    rows = img.tolist()
+    diff = [abs(fo.fixed_point_resize_pixel(rows, y, x, 256, 340, None) - int(exact[y, x])) for y in range(0, 224, 5) for x in range(0, 224, 5)]
+    assert max(diff) <= 1
 
 
 def test_resize_and_crop0():

@@ -338,3 +338,127 @@ def test_batched_scan_equals_single_scans_bit_for_bit(vqa, dtype, q):
     with pytest.raises(vqa.VqError):
         db.scan_batch(np.zeros((9, 2, 3, 1024)), np.ones((9, 2)))
     db.close()
+
+
+def test_cfg4_full_size_scan_one_million_clips(vqa):
+    """BASELINE configs[3] at FULL size on one GPU: 1 query x 1 000 000 clips x 2 streams x 5 splits x 1024 fp32
+    (40.96 GB resident, generated on the device), the real ``scan_kernel<float,2,5,4>`` launch of the bench.
+    Parity on 4 x 4096-row oracle slices (regenerated on the host from the counter-based seed); size-independent
+    properties over all rows: scores bit-exact given the averages, the reference clip scores 1 and is the arg-max,
+    top-k / partition equal numpy on the full array, and a second scan reproduces every bit."""
+    n, s, e, d = 1_000_000, 2, 5, 1024
+    scales = (4.0, 1.0)
+    db = vqa.FeatureDB.synthetic(n, s, e, d, seed=23, scales=scales)
+    ref_row = 765_432
+    t = db.set_query_from_row(ref_row)
+    db.scan(weights=[1.0, 1.5])
+    avg, n_e = db.similarities()
+    sc = db.scores()
+    assert (n_e == e).all() and np.isfinite(sc).all()
+    for row0 in (0, 333_333, ref_row - 100, n - 4096):
+        x = so.synth_features(23, row0, 4096, s, e, d, scales)
+        _, o_avg, _ = so.dense_similarities(x, t)
+        assert np.abs(avg[row0:row0 + 4096] - o_avg).max() <= SIM_TOL
+    assert (sc == so.dense_scores(avg, [1.0, 1.5])).all()
+    assert abs(sc[ref_row] - 1.0) <= 1e-14 and sc.argmax() == ref_row
+    rows, vals = db.topk(20)
+    o_rows, o_vals = so.dense_topk(sc, 20)
+    assert np.array_equal(rows, o_rows) and (vals == o_vals).all()
+    th, lower = float(np.quantile(sc, 0.9999)), float(np.quantile(sc, 0.999))
+    m, r, amax = db.select(th, lower)
+    assert np.array_equal(m, np.flatnonzero(sc >= th)) and np.array_equal(r, np.flatnonzero((lower <= sc) & (sc < th)))
+    assert amax == int(r[np.argmax(sc[r])])
+    db.scan(weights=[1.0, 1.5])
+    assert (db.scores() == sc).all() and (db.similarities()[0] == avg).all()
+    db.close()
+
+
+def test_a_topk_between_select_and_fetch_is_detected(vqa):
+    """Handles are shared between broker threads (broker.py:91-92).  The two-call form of the selection
+    (vq_db_select, then vq_db_select_fetch) must not hand out another call's rows: a top-k in between invalidates
+    the lists (VQ_E_STATE); the one-call form FeatureDB.select uses is atomic under the handle's lock."""
+    import ctypes as C
+    from video_query_algorithms_amd._lib import call
+    rng = np.random.default_rng(4)
+    db = vqa.FeatureDB(5000, 2, 1, 1024)
+    sc = rng.random(5000)
+    avg = np.stack([sc, sc], axis=1)
+    db.write_avg(avg, np.ones((5000, 2), dtype=np.int32))
+    db.rescore([1.0, 1.0])
+    got = db.scores()
+    nm, nn, am = C.c_int64(), C.c_int64(), C.c_int64()
+    call("vq_db_select", db._h, 0.7, 0.6, C.byref(nm), C.byref(nn), C.byref(am))
+    db.topk(10)
+    m = np.empty(nm.value, dtype=np.int64)
+    r = np.empty(nn.value, dtype=np.int64)
+    with pytest.raises(vqa.VqError) as ei:
+        call("vq_db_select_fetch", db._h, m.ctypes.data_as(C.c_void_p), m.size, r.ctypes.data_as(C.c_void_p), r.size)
+    assert ei.value.code == -4
+    m2, r2, _ = db.select(0.7, 0.6)
+    assert np.array_equal(m2, np.flatnonzero(got >= 0.7)) and np.array_equal(r2, np.flatnonzero((0.6 <= got) & (got < 0.7)))
+    # hammer one handle from three threads: selections and top-k interleave, every selection stays self-consistent
+    import threading
+    errors = []
+
+    def selector(th):
+        try:
+            for _ in range(30):
+                a, b, _ = db.select(th, th - 0.1)
+                if not (np.array_equal(a, np.flatnonzero(got >= th)) and np.array_equal(b, np.flatnonzero((th - 0.1 <= got) & (got < th)))):
+                    errors.append("select(%g) returned foreign rows" % th)
+        except Exception as exc:       # noqa: BLE001
+            errors.append(repr(exc))
+
+    def ranker():
+        try:
+            for _ in range(30):
+                rows, _ = db.topk(50)
+                if not np.array_equal(rows, so.dense_topk(got, 50)[0]):
+                    errors.append("topk")
+        except Exception as exc:       # noqa: BLE001
+            errors.append(repr(exc))
+    threads = [threading.Thread(target=selector, args=(0.9,)), threading.Thread(target=selector, args=(0.5,)), threading.Thread(target=ranker)]
+    for th_ in threads:
+        th_.start()
+    for th_ in threads:
+        th_.join()
+    assert not errors, errors[:3]
+    db.close()
+
+
+def test_comm_group_of_the_c_abi_single_rank(vqa):
+    """The Comm exports (vq_comm_*, vq_allgather_*, vq_broadcast_query) with a world of one rank on this one GPU: the
+    RCCL communicator comes up from a unique id, the score slice of a sharded scan lands zero-padded in its slot, a
+    feature block is gathered byte for byte.  (world > 1 needs one GPU per rank: the driver's multi-GPU run.)"""
+    import ctypes as C
+    import torch
+    from video_query_algorithms_amd._lib import call
+    dev = torch.device("cuda", 0)
+    uid = (C.c_char * 128)()
+    call("vq_comm_unique_id", uid)
+    comm = C.c_void_p()
+    call("vq_comm_init", 0, 1, uid, 0, C.byref(comm))
+    rank, world, device = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+    call("vq_comm_info", comm, C.byref(rank), C.byref(world), C.byref(device))
+    assert (rank.value, world.value, device.value) == (0, 1, 0)
+    db = vqa.FeatureDB.synthetic(3000, 2, 3, 1024, seed=3, scales=(4.0, 1.0))
+    db.set_query_from_row(5, want=False)
+    db.scan(weights=[1.0, 1.5])
+    want = db.scores()
+    out = torch.full((3072,), -1.0, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    call("vq_allgather_scores", comm, db._h, 3072, C.c_void_p(out.data_ptr()), C.c_void_p(stream))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert (got[:3000] == want).all() and (got[3000:] == 0).all()
+    block = torch.randint(0, 256, (1 << 20,), dtype=torch.uint8, device=dev)
+    allb = torch.zeros_like(block)
+    call("vq_allgather_features", comm, C.c_void_p(block.data_ptr()), block.numel(), C.c_void_p(allb.data_ptr()), C.c_void_p(stream))
+    q = torch.arange(2 * 3 * 1024, dtype=torch.float64, device=dev)
+    call("vq_broadcast_query", comm, C.c_void_p(q.data_ptr()), q.numel() * 8, 0, C.c_void_p(stream))
+    torch.cuda.synchronize()
+    assert torch.equal(allb, block) and torch.equal(q.cpu(), torch.arange(2 * 3 * 1024, dtype=torch.float64))
+    with pytest.raises(vqa.VqError):
+        call("vq_allgather_scores", comm, db._h, 100, C.c_void_p(out.data_ptr()), C.c_void_p(stream))   # slice too small
+    call("vq_comm_destroy", comm)
+    db.close()

@@ -463,27 +463,33 @@ def test_handles_are_thread_safe_and_do_not_leak(tsn):
 
 
 @pytest.mark.parametrize("h,w", [(360, 480), (256, 340), (240, 320), (480, 854)])
-def test_device_resize_crop_equals_the_host_path(tsn, h, w):
-    """vq_resize_crop (frame ingest on the GPU) against tsn/frames.py:crop0, byte for byte: RGB frames and the
-    10 interleaved grey planes of a flow stack; frames already at 340x256 pass through untouched."""
-    from video_query_algorithms_amd.tsn import caffe_net, frames
+def test_device_resize_crop_against_the_pixel_loop_oracle(tsn, h, w):
+    """vq_resize_crop (frame ingest on the GPU) against oracle/frames_oracle.py -- an independent
+    scalar-loop restatement of the resize + crop-0 step behind calcSig_wOF.py:94,111 -- byte for byte: RGB frames and
+    the 10 interleaved grey planes of a flow stack; frames already at 340x256 pass through untouched.  The host path of
+    the product (tsn/frames.py, used by --host_resize) is held to the same oracle in tests/test_feature_files.py.
+    cv2's own fixed-point uint8 path: PARITY UNPINNED (no cv2, no reference frames; frames_oracle docstring)."""
+    import frames_oracle as fo
+    from video_query_algorithms_amd.tsn import caffe_net
     bi, net = tsn
     rng = np.random.default_rng(h + w)
     g3 = bi.bn_inception(3)
     cn = caffe_net.CaffeNet(g3, net.synthetic_weights(g3, seed=2), max_crops=4)
     rgb = rng.integers(0, 256, (3, h, w, 3), dtype=np.uint8)
     got = cn.crops_from_frames(rgb).cpu().numpy()
-    want = np.stack([frames.crop0(f) for f in rgb])
+    want = np.stack([fo.crop0(f) for f in rgb])
     assert got.shape == (3, 224, 224, 3) and (got == want).all()
     cn.close()
     g10 = bi.bn_inception(10)
     cf = caffe_net.CaffeNet(g10, net.synthetic_weights(g10, seed=2), max_crops=4)
     planes = rng.integers(0, 256, (2, 10, h, w), dtype=np.uint8)
     got = cf.crops_from_frames(planes).cpu().numpy()
-    want = np.stack([np.stack([frames.crop0(p) for p in snip], axis=-1) for snip in planes])
+    want = np.stack([fo.flow_stack_crop0(snip) for snip in planes])
     assert got.shape == (2, 224, 224, 10) and (got == want).all()
     feats = cf.extract_clips_from_frames(planes, 2)
     assert (feats == cf.extract_clips(want, 2)).all()
+    dev_feats = cf.extract_clips_from_frames(planes, 2, on_device=True)           # the block a rank all-gathers
+    assert dev_feats.is_cuda and (dev_feats.cpu().numpy() == feats).all()
     cf.close()
 
 

@@ -71,7 +71,9 @@ def extract(args, device, rank, world, timings):
     return first, count, out
 
 
-def main(argv=None):
+def main(argv=None, observer=None):
+    """``observer`` (tests): an object whose ``start(feats, clip_ids, ticket, hp)`` is called once before the rounds and
+    ``round(r, ticket, hp, prev_weights, prev_threshold, labels, rng_state_before_select)`` after each one."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--clips", type=int, default=10000)
     ap.add_argument("--segments", type=int, default=7)
@@ -87,7 +89,7 @@ def main(argv=None):
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")
+        dist.init_process_group("nccl", device_id=device)
     timings = {"clips": args.clips, "segments": args.segments, "world": world}
     t_all = time.perf_counter()
     first, count, mine = extract(args, device, rank, world, timings)
@@ -147,6 +149,8 @@ def main(argv=None):
     stage = {"similarities": 0.0, "optimize_weights": 0.0, "scores": 0.0, "select": 0.0}
     rng = np.random.default_rng(5)
     random.seed(a=SEED)
+    if observer is not None:
+        observer.start(feats, clip_ids, tk, hp)
     t_rounds = time.perf_counter()
     for r in range(args.rounds):
         t0 = time.perf_counter()
@@ -154,12 +158,13 @@ def main(argv=None):
         stage["similarities"] += time.perf_counter() - t0
         if r == 0:
             hp.weights, hp.threshold = dict(hp.default_weights), hp.default_threshold
+        prev_weights, prev_threshold = dict(hp.weights), hp.threshold
         t0 = time.perf_counter()
         tk.compute_scores(hp.weights)                 # scores under the previous round's weights: what the user reviewed
         stage["scores"] += time.perf_counter() - t0
         # 20 seeded labels on the current top scores (the user's review of the previous round)
         top_rows, top_vals = db.topk(args.labels)
-        tk.matches = [{"video_clip": int(clip_ids[row]), "user_match": bool(rng.random() < 0.5 + 0.4 * (i < args.labels // 2)),
+        tk_labels = tk.matches = [{"video_clip": int(clip_ids[row]), "user_match": bool(rng.random() < 0.5 + 0.4 * (i < args.labels // 2)),
                        "is_match": bool(v >= hp.threshold)} for i, (row, v) in enumerate(zip(top_rows, top_vals))]
         t0 = time.perf_counter()
         hp.optimize_weights(tk)
@@ -167,9 +172,12 @@ def main(argv=None):
         t0 = time.perf_counter()
         tk.compute_scores(hp.weights)
         stage["scores"] += time.perf_counter() - t0
+        rng_state = random.getstate() if observer is not None else None
         t0 = time.perf_counter()
         tk.select_clips_to_review(hp.threshold, 20, hp.near_miss_default)
         stage["select"] += time.perf_counter() - t0
+        if observer is not None:
+            observer.round(r, tk, hp, prev_weights, prev_threshold, tk_labels, rng_state)
     timings["rounds"] = args.rounds
     timings["rounds_total_s"] = time.perf_counter() - t_rounds
     for k, v in stage.items():

@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvqamd.so")
 
-ABI_VERSION = 2                 # include/vq_amd.h: VQ_ABI_VERSION
+ABI_VERSION = 3                 # include/vq_amd.h: VQ_ABI_VERSION
 VQ_F32, VQ_F64 = 0, 1
 VQ_OP_CONV, VQ_OP_MAXPOOL, VQ_OP_AVGPOOL, VQ_OP_GLOBAL_AVGPOOL, VQ_OP_CONV_WINOGRAD = 1, 2, 3, 4, 5
 
@@ -69,6 +69,7 @@ SIGNATURES = {
     "vq_db_scores_devptr": [_P, _PP], "vq_db_avg_devptr": [_P, _PP], "vq_db_write_avg": [_P, _P, _P],
     "vq_db_scores_grid": [_P, _P, _I32, _P, _I32, _P],
     "vq_db_select": [_P, _F64, _F64, _pI64, _pI64, _pI64], "vq_db_select_fetch": [_P, _P, _I64, _P, _I64],
+    "vq_db_select_rows": [_P, _F64, _F64, _P, _I64, _P, _I64, _pI64, _pI64, _pI64],
     "vq_db_topk": [_P, _I64, _P, _P, _pI64], "vq_db_min_score": [_P, _P, _I32, _pF64],
     "vq_resize_crop": [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _P],
     "vq_tsn_create": [C.POINTER(TensorDesc), _I32, C.POINTER(LayerDesc), _I32, C.POINTER(ConvSegment), _I32, _P, _I64,
@@ -79,6 +80,10 @@ SIGNATURES = {
     "vq_tsn_flops_per_crop": [_P, _pF64], "vq_tsn_layer_lanes": [_P, _P, _I32],
     "vq_tsn_layer_tiles": [_P, _I32, _P, _I32], "vq_tsn_set_layer_tiles": [_P, _I32, _P, _I32],
     "vq_tsn_set_profile": [_P, _I32], "vq_tsn_layer_times": [_P, _P, _P, _I32],
+    "vq_comm_unique_id": [_P], "vq_comm_init": [_I32, _I32, _P, _I32, _PP], "vq_comm_destroy": [_P],
+    "vq_comm_info": [_P, _pI32, _pI32, _pI32],
+    "vq_allgather_features": [_P, _P, _I64, _P, _P], "vq_allgather_scores": [_P, _P, _I64, _P, _P],
+    "vq_broadcast_query": [_P, _P, _I64, _I32, _P],
 }
 _SPECIAL = {"vq_last_error": ([], C.c_char_p), "vq_abi_version": ([], C.c_int)}
 

@@ -5,7 +5,8 @@ sampling (:67-72), same consensus (:82), same output tree and CSV bytes (:116-13
 one network per stream is built once (not per video, :205-210), all B*T crops of a batch of clips go through the
 network in one pass instead of one 10-crop forward per snippet (only crop 0 was ever kept, :95), and with
 ``torchrun`` the clips of a video are sharded over the ranks (one process per GPU) and the per-GPU feature blocks
-are all-gathered over RCCL; rank 0 writes the files.  ``--num_worker`` is accepted and ignored.
+are all-gathered over RCCL (from device memory); rank 0 writes the files.  ``--num_worker`` sizes the pool of decoder
+threads (the reference's worker processes, calcSig_wOF.py:204-210).
 
     python calcSig_wOF.py frames/ rgb.prototxt rgb_weights.npz flow.prototxt flow_weights.npz \
         --outFeatures_dir features/ --modelname UCF101_split1 [--num_frame_per_video 25] [--gpus 0]
@@ -56,34 +57,54 @@ def build_parser():
     parser.add_argument('--batch_clips', type=int, default=32, help='clips per forward pass')
     parser.add_argument('--host_resize', action='store_true',
                         help='resize + crop the frames on the host (numpy) instead of on the GPU; same bytes either way')
+    parser.add_argument('--number_format', choices=('repr', 'g12'), default='repr',
+                        help="how str(numpy.float64) printed under the numpy the reference ran with: shortest round-trip "
+                             "(numpy >= 1.14, lossless) or 12 significant digits (numpy < 1.14); the reference ships files of both kinds")
     return parser
 
 
-def _dist():
-    try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            return dist
-    except ImportError:
-        pass
-    return None
+def _join_world(device: int):
+    """(rank, world) of this process.  Under torchrun the rank binds its GPU BEFORE the communicator exists
+    (``set_device`` + ``device_id``: RCCL then builds the communicator on that device instead of guessing at the first
+    collective); backend "nccl" = RCCL, or gloo on a box without GPUs / with VQ_DIST_BACKEND=gloo (a rehearsal of the
+    N > 1 path on one card)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "RANK" not in os.environ or world <= 1:
+        return 0, 1
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        backend = os.environ.get("VQ_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
+    return dist.get_rank(), dist.get_world_size()
 
 
-def main(argv=None):
+def _stack_rows(blocks, width):
+    """Per-batch feature blocks (numpy, or torch tensors still on the GPU) -> one [rows, width] block of the same kind."""
+    if not blocks:
+        return np.zeros((0, width))
+    if isinstance(blocks[0], np.ndarray):
+        return np.concatenate(blocks, axis=0)
+    import torch
+    return torch.cat(blocks, dim=0)
+
+
+def main(argv=None, net_factory=None):
+    """``net_factory(net_proto, net_weights, device, max_crops=, feature_blob=)`` builds the per-stream extractor
+    (default: the HIP ``CaffeNet``; the CPU tests of the sharding logic pass a stand-in)."""
     args = build_parser().parse_args(argv)
+    net_factory = net_factory or CaffeNet
     if args.modelname is None:                                                         # calcSig_wOF.py:179-180
         args.modelname = args.net_weights_rgb.split('/')[-1][:-11] + '_' + args.net_weights_flow.split('/')[-1][:-11]
     T = args.num_frame_per_video
-    rank, world = 0, 1
-    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        import torch
-        import torch.distributed as dist
-        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-        if not dist.is_initialized():
-            dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
     gpu_list = args.gpus
     local = int(os.environ.get("LOCAL_RANK", "0"))
     device = gpu_list[local % len(gpu_list)] if gpu_list else local                    # calcSig_wOF.py:50-55
+    rank, world = _join_world(device)
     frame_path = args.frame_path if args.frame_path[-1] == '/' else args.frame_path + '/'
     streamCNN = [{'modality': 'rgb', 'mode': 'rgb', 'net_proto': args.net_proto_rgb, 'net_weights': args.net_weights_rgb,
                   'cnt_indexer': 1, 'stack_depth': 1},
@@ -99,8 +120,8 @@ def main(argv=None):
         features = {}
         for s in streamCNN:
             if s['modality'] not in nets:
-                nets[s['modality']] = CaffeNet(s['net_proto'], s['net_weights'], device,
-                                               max_crops=args.batch_clips * T, feature_blob=args.featureBlob)
+                nets[s['modality']] = net_factory(s['net_proto'], s['net_weights'], device,
+                                                  max_crops=args.batch_clips * T, feature_blob=args.featureBlob)
             net = nets[s['modality']]
             mine = []
 
@@ -123,25 +144,26 @@ def main(argv=None):
                 for vid in vids:
                     print('video {} for {} modality done'.format(vid, s['modality']))
                 if crops:
+                    on_gpu = world > 1                   # blocks that will be all-gathered never visit the host
                     if args.host_resize:
-                        mine.append(net.extract_clips(np.concatenate(crops, axis=0), T))
+                        mine.append(net.extract_clips(np.concatenate(crops, axis=0), T, on_device=on_gpu))
                     elif len({c.shape[1:] for c in crops}) == 1:
-                        mine.append(net.extract_clips_from_frames(np.concatenate(crops, axis=0), T))   # resize + crop on the GPU
+                        mine.append(net.extract_clips_from_frames(np.concatenate(crops, axis=0), T, on_device=on_gpu))   # resize + crop on the GPU
                     else:                                        # clips of different frame sizes in one batch
-                        mine.append(np.concatenate([net.extract_clips_from_frames(c, T) for c in crops], axis=0))
-            local_feat = np.concatenate(mine, axis=0) if mine else np.zeros((0, net.feature_dim))
+                        mine += [net.extract_clips_from_frames(c, T, on_device=on_gpu) for c in crops]
+            local_feat = _stack_rows(mine, net.feature_dim)
             if world > 1:
                 import torch
-                dev = "cuda:%d" % device if torch.cuda.is_available() else "cpu"
-                gathered = all_gather_rows(torch.from_numpy(local_feat).to(dev), len(clip_list))
-                local_feat = gathered.cpu().numpy()
+                if isinstance(local_feat, np.ndarray):
+                    local_feat = torch.from_numpy(np.ascontiguousarray(local_feat, dtype=np.float64))
+                local_feat = all_gather_rows(local_feat, len(clip_list)).cpu().numpy()
             features[s['mode']] = local_feat
         numFeatures = features['rgb'].shape[1] if len(clip_list) else args.featureBlob_size
         assert numFeatures == args.featureBlob_size                                      # calcSig_wOF.py:219-220
         if rank == 0 and clip_list:
             video = video_path.split('/')[-2]
             write_features(args.outFeatures_dir, video, video_path, args.modelname, args.featureBlob, clip_list, features,
-                           {'rgb': args.net_weights_rgb, 'warped_optical_flow': args.net_weights_flow})
+                           {'rgb': args.net_weights_rgb, 'warped_optical_flow': args.net_weights_flow}, args.number_format)
     pool.shutdown()
     for n in nets.values():
         n.close()

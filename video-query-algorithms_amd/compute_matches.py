@@ -6,6 +6,11 @@ the REST side effects of its Ticket methods happen in the same order); the arith
 ``optimize_weights``, ``compute_scores`` and ``select_clips_to_review`` runs on the GPU (``TicketScoring``,
 ``Hyperparameter``, ``TargetClip``).  ``ticket_factory(update_object, url)`` supplies the Ticket class -- the reference's
 own, patched by ``install``, or the offline ``Ticket``.
+
+In production this module is NOT needed: after ``install()`` the reference's own ``compute_matches.py`` runs
+unmodified on the patched classes.  It exists as the offline harness -- a broker pass with no REST
+server (tests, ``tools/e2e_cfg5.py``): with no ``ticket_factory`` every update object carries its own search set
+(``records`` and/or ``feature_db``) and the side effects land in ``Ticket.ledger``.
 """
 from __future__ import annotations
 
@@ -75,7 +80,9 @@ def compute_matches(query_updates, hyperparameters, ticket_factory=None, target_
         from .ticket import Ticket as _Ticket
 
         def ticket_factory(update_object, url):
-            return _Ticket(update_object)
+            # offline: the update object itself carries the search set (API feature records and/or a resident
+            # FeatureDB); the REST side effects of the round are kept in the ticket's ledger
+            return _Ticket(update_object, records=update_object.get("records"), feature_db=update_object.get("feature_db"))
     for kind, update in pending.items():                                    # :37
         if update is not None:
             _one_update(kind, update, query_updates.url, hyperparameters, ticket_factory, target_factory)

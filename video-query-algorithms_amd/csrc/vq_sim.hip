@@ -1201,9 +1201,39 @@ int vq_db_select(vq_db* db, double threshold, double lower, int64_t* n_match, in
     return VQ_OK;
 }
 
+static int fetch_selected(vq_db* db, int64_t* match_rows_host, int64_t cap_match, int64_t* near_rows_host, int64_t cap_near);
+
 int vq_db_select_fetch(vq_db* db, int64_t* match_rows_host, int64_t cap_match, int64_t* near_rows_host, int64_t cap_near) {
     VQ_REQUIRE(db, "db is NULL");
     std::lock_guard<std::mutex> lk(db->mu);
+    return fetch_selected(db, match_rows_host, cap_match, near_rows_host, cap_near);
+}
+
+int vq_db_select_rows(vq_db* db, double threshold, double lower, int64_t* match_rows_host, int64_t cap_match,
+                      int64_t* near_rows_host, int64_t cap_near, int64_t* n_match, int64_t* n_near, int64_t* near_argmax) {
+    VQ_REQUIRE(db && match_rows_host && near_rows_host && n_match && n_near, "NULL argument");
+    std::lock_guard<std::mutex> lk(db->mu);          // partition and copy-out under ONE lock: no other thread's
+    if (!db->have_scores) return fail(VQ_E_STATE, "no scores computed (scan with weights, or rescore)");
+    DeviceGuard g(db->device);                       // selection or top-k can slip in between
+    SelPred pred;
+    pred.mode = 0;
+    pred.th = threshold;
+    pred.lower = lower;
+    pred.pivot = 0;
+    int64_t res[3];
+    const int rc = run_select(db, pred, -1, res);
+    if (rc != VQ_OK) return rc;
+    db->last_n0 = res[0];
+    db->last_n1 = res[1];
+    *n_match = res[0];
+    *n_near = res[1];
+    if (near_argmax) *near_argmax = res[2];
+    return fetch_selected(db, match_rows_host, cap_match, near_rows_host, cap_near);
+}
+
+static int fetch_selected(vq_db* db, int64_t* match_rows_host, int64_t cap_match, int64_t* near_rows_host, int64_t cap_near) {
+    if (db->last_n0 < 0 || db->last_n1 < 0)
+        return fail(VQ_E_STATE, "the selection lists were overwritten by a later top-k on this handle (select again)");
     DeviceGuard g(db->device);
     if (match_rows_host) {
         VQ_REQUIRE(cap_match >= db->last_n0, "match buffer too small (%lld < %lld)", (long long)cap_match, (long long)db->last_n0);
@@ -1243,6 +1273,7 @@ int vq_db_topk(vq_db* db, int64_t k, int64_t* rows_host, double* vals_host, int6
     pred.th = pred.lower = 0.0;
     pred.pivot = st[0];
     int64_t res[3];
+    db->last_n0 = db->last_n1 = -1;      // the shared row lists no longer hold a vq_db_select partition
     int rc = run_select(db, pred, (int64_t)st[1], res);
     if (rc != VQ_OK) return rc;
     const int64_t n_gt = res[0], n_eq = res[1];

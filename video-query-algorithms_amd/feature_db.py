@@ -158,15 +158,38 @@ class FeatureDB:
         self._keepalive = keepalive
 
     def set_present(self, present):
+        """The database's OWN presence mask [N,S,E] (None = dense).  Per-query restrictions go through
+        :meth:`restrict_slots` and never change it."""
         if present is None:
             self.present = None
-            call("vq_db_set_present", self._h, None)
+        else:
+            p = np.ascontiguousarray(np.asarray(present).astype(np.uint8))
+            if p.shape != (self.n, self.S, self.E):
+                raise ValueError("present must be [N,S,E]")
+            self.present = p
+        self._slots_hidden = None
+        call("vq_db_set_present", self._h, None if self.present is None else _np_ptr(self.present))
+
+    def restrict_slots(self, slot_used):
+        """Hide the (stream, split) slots a query's target lacks (the reference never visits them, ticket.py:146-148)
+        for the scans that follow; ``None`` / all-true lifts the restriction.  The mask on the device is rebuilt from
+        the database's own mask every time, so one ragged query leaves nothing behind for the next."""
+        used = None if slot_used is None else np.asarray(slot_used, dtype=bool)
+        if used is not None and used.shape != (self.S, self.E):
+            raise ValueError("slot_used must be [S,E]")
+        if used is not None and used.all():
+            used = None
+        hidden = None if used is None else ~used
+        before = getattr(self, "_slots_hidden", None)
+        if (hidden is None and before is None) or (hidden is not None and before is not None and (hidden == before).all()):
             return
-        p = np.ascontiguousarray(np.asarray(present).astype(np.uint8))
-        if p.shape != (self.n, self.S, self.E):
-            raise ValueError("present must be [N,S,E]")
-        self.present = p
-        call("vq_db_set_present", self._h, _np_ptr(p))
+        if hidden is None:
+            effective = self.present
+        else:
+            base = self.present if self.present is not None else np.ones((self.n, self.S, self.E), dtype=np.uint8)
+            effective = np.ascontiguousarray(base * used[None].astype(np.uint8))
+        call("vq_db_set_present", self._h, None if effective is None else _np_ptr(effective))
+        self._slots_hidden = hidden
 
     def set_stream(self, hip_stream: int):
         call("vq_db_set_stream", self._h, C.c_void_p(hip_stream))
@@ -261,13 +284,14 @@ class FeatureDB:
         return out
 
     def select(self, threshold: float, lower: float):
-        """Order-preserving partition (ticket.py:325-340): (match_rows, near_rows, near_argmax)."""
+        """Order-preserving partition (ticket.py:325-340): (match_rows, near_rows, near_argmax).  Partition and
+        copy-out are one locked call of the library, so handles shared between broker threads stay consistent."""
         nm, nn, am = C.c_int64(), C.c_int64(), C.c_int64()
-        call("vq_db_select", self._h, float(threshold), float(lower), C.byref(nm), C.byref(nn), C.byref(am))
-        m = np.empty(nm.value, dtype=np.int64)
-        r = np.empty(nn.value, dtype=np.int64)
-        call("vq_db_select_fetch", self._h, _np_ptr(m), m.size, _np_ptr(r), r.size)
-        return m, r, am.value
+        m = np.empty(self.n, dtype=np.int64)
+        r = np.empty(self.n, dtype=np.int64)
+        call("vq_db_select_rows", self._h, float(threshold), float(lower), _np_ptr(m), m.size, _np_ptr(r), r.size,
+             C.byref(nm), C.byref(nn), C.byref(am))
+        return m[:nm.value].copy(), r[:nn.value].copy(), am.value
 
     def topk(self, k: int):
         k = int(min(k, self.n))

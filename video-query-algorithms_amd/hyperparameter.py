@@ -1,10 +1,13 @@
-"""Drop-in for the reference's ``Hyperparameter`` (src/models/hyperparameter.py).
+"""The tunables of a query and their re-fit from the user's verdicts: the seam of the reference's ``Hyperparameter``
+(src/models/hyperparameter.py) over the resident database.
 
-Same constructor, grids and ``optimize_weights(ticket)`` contract (hyperparameter.py:9-76).  The 40
-full rescoring passes of the reference (hyperparameter.py:57-58) are one launch of the grid kernel
-over the labelled clips only -- the loss (hyperparameter.py:60-64) reads nothing else -- and a last
-rescoring at the final grid weight so that ``ticket.scores`` is left exactly as the reference
-leaves it (at w = 2.45).
+The constructor signature, the attribute names and the two grids are the seam (broker.py:36-59 builds the object,
+``compute_matches`` and ``TargetClip`` read its fields).  ``optimize_weights(ticket)`` keeps the contract of
+hyperparameter.py:29-76 -- it sets ``weights`` and ``threshold`` and leaves ``ticket.scores`` at the last grid
+weight -- but works on arrays: the 40 full rescoring passes of :57-58 become one launch of the grid kernel over the
+labelled rows only (the loss of :60-64 reads nothing else), the 40 x 31 loss surface is accumulated clip by clip in
+the reference's order so every cell sees the same sequence of fp64 additions, and the sub-grid refinement (:78-114)
+is the separable three-point parabola below.
 """
 from __future__ import annotations
 
@@ -13,99 +16,80 @@ import os
 
 import numpy as np
 
+FIT_TOLERANCE = 1e-6          # summed misfit above which the refinement is distrusted (hyperparameter.py:99)
+
+
+def parabola_through(xs, y_lo, y_mid, y_hi):
+    """Vertex and curvature of the parabola through (xs[0], y_lo), (xs[1], y_mid), (xs[2], y_hi) -- one axis of the
+    separable surface a (w - w0)^2 + b (th - th0)^2 + c of hyperparameter.py:85-93 (same operation order)."""
+    lo, mid, hi = xs
+    rise, fall_hi, fall_lo = y_hi - y_lo, y_mid - y_hi, y_mid - y_lo
+    vertex = 0.5 * (rise * mid ** 2 + fall_hi * lo ** 2 - fall_lo * hi ** 2) / (rise * mid + fall_hi * lo - fall_lo * hi)
+    return vertex, fall_lo / ((mid - vertex) ** 2 - (lo - vertex) ** 2)
+
 
 class Hyperparameter:
     def __init__(self, default_weights, default_threshold=0.8, ballast=0.3, near_miss_default=0.5, mu=.3,
                  streams=('rgb', 'warped_optical_flow'), feature_name='global_pool', f_bootstrap=0.5, f_memory=0.5,
                  bootstrap_type='simple', nbags=3):
-        # hyperparameter.py:9-26
-        self.default_weights = default_weights
-        self.weights = {}
-        self.default_threshold = default_threshold
-        self.threshold = self.default_threshold
-        self.near_miss_default = near_miss_default
-        self.streams = streams
-        self.feature_name = feature_name
-        self.ballast = ballast
-        self.weight_grid = np.arange(0.5, 2.5, 0.05)
+        self.streams, self.feature_name = streams, feature_name
+        self.default_weights, self.default_threshold = default_weights, default_threshold
+        self.weights, self.threshold = {}, default_threshold
+        self.ballast, self.near_miss_default = ballast, near_miss_default
+        self.mu, self.f_bootstrap, self.f_memory = mu, f_bootstrap, f_memory
+        self.bootstrap_type, self.nbags = bootstrap_type, nbags
+        self.weight_grid = np.arange(0.5, 2.5, 0.05)           # hyperparameter.py:20-21
         self.threshold_grid = np.arange(0.5, 1.1, 0.02)
-        self.mu = mu
-        self.f_bootstrap = f_bootstrap
-        self.f_memory = f_memory
-        self.bootstrap_type = bootstrap_type
-        self.nbags = nbags
 
     def optimize_weights(self, ticket):
-        """hyperparameter.py:29-76."""
-        eps_threshold = float(os.environ["COMPUTE_EPS"])          # hyperparameter.py:5
-        match_status = {}
-        for match in ticket.matches:                               # hyperparameter.py:45-50
-            if match["user_match"] is not None:
-                match_status[match['video_clip']] = match["user_match"]
-            else:
-                match_status[match['video_clip']] = match["is_match"]
-        clips = list(match_status)
-        labels = [match_status[c] for c in clips]
+        rows, labels = self._labelled_rows(ticket)
         db = ticket.feature_db
-        rows = [db.row_of(c) for c in clips]                       # KeyError like ticket.scores[clip] would
-        s0 = ticket._stream_names.index(self.streams[0])
-        s1 = ticket._stream_names.index(self.streams[1])
-        w_grid = np.zeros((self.weight_grid.shape[0], db.S), dtype=np.float64)
-        w_grid[:, s0] = 1.0
-        w_grid[:, s1] = self.weight_grid
-        grid_scores = db.scores_grid(w_grid, rows)                 # [40, L] on the GPU
-        # loss grid (hyperparameter.py:56-65): accumulate over the labelled clips in dict order so
-        # that every entry sees the same sequence of fp64 additions as the reference's scalar loop
+        first, second = (ticket._stream_names.index(st) for st in self.streams[:2])
+        candidates = np.zeros((len(self.weight_grid), db.S))
+        candidates[:, first], candidates[:, second] = 1.0, self.weight_grid
+        graded = db.scores_grid(candidates, rows)                                   # [40][L] in one launch
         th = self.threshold_grid[None, :]
-        losses = np.broadcast_to(0.5 * th, (w_grid.shape[0], th.shape[1])).copy()
-        for j, y in enumerate(labels):
-            d = grid_scores[:, j][:, None] - th
-            losses = losses + (np.heaviside(d, 1) - y) * d * (1 + y * self.ballast)
-        losses = losses / len(match_status)
-        iw0, ith0 = np.unravel_index(np.argmin(losses, axis=None), losses.shape)
-        # leave ticket.scores at the last grid weight, like the reference's loop does
-        ticket.compute_scores({self.streams[0]: 1.0, self.streams[1]: self.weight_grid[-1]})
-        if iw0 == 0 or ith0 == 0 or iw0 == len(self.weight_grid) - 1 or ith0 == len(self.threshold_grid) - 1:
-            weight_optimum = self.weight_grid[iw0]
-            threshold_optimum = self.threshold_grid[ith0]
-        else:
-            weight_optimum, threshold_optimum = self.fine_tune(iw0, ith0, losses)
-        self.threshold = threshold_optimum - eps_threshold
-        self.weights = {self.streams[0]: 1.0, self.streams[1]: weight_optimum}
-
-    def fine_tune(self, iw0, ith0, losses):
-        """hyperparameter.py:78-83."""
-        wg, tg = self.weight_grid, self.threshold_grid
-        xrange = [(wg[iw0 - 1], wg[iw0], wg[iw0 + 1]), (tg[ith0 - 1], tg[ith0], tg[ith0 + 1])]
-        ydata = [losses[iw0 - 1, ith0], losses[iw0, ith0 - 1], losses[iw0, ith0], losses[iw0, ith0 + 1],
-                 losses[iw0 + 1, ith0]]
-        return self._quad_fit(xrange, ydata)
+        surface = np.tile(0.5 * th, (len(self.weight_grid), 1))
+        for column, y in zip(graded.T, labels):                                     # dict order, one clip at a time
+            margin = column[:, None] - th
+            surface = surface + (np.heaviside(margin, 1) - y) * margin * (1 + y * self.ballast)
+        surface = surface / len(labels)
+        iw, it = np.unravel_index(np.argmin(surface), surface.shape)                # first minimum, row-major
+        ticket.compute_scores({self.streams[0]: 1.0, self.streams[1]: self.weight_grid[-1]})   # what the 40 passes leave
+        on_rim = iw in (0, len(self.weight_grid) - 1) or it in (0, len(self.threshold_grid) - 1)
+        w_best, th_best = (self.weight_grid[iw], self.threshold_grid[it]) if on_rim else self._refine(surface, iw, it)
+        self.weights = {self.streams[0]: 1.0, self.streams[1]: w_best}
+        self.threshold = th_best - float(os.environ["COMPUTE_EPS"])                 # hyperparameter.py:5,75
 
     @staticmethod
-    def _quad_fit(x, y):
-        """hyperparameter.py:85-114: vertex of a0 (w - w0)^2 + b0 (th - th0)^2 + c0 through five points."""
-        (wl, wc, wr), (tl, tc, tr) = x
-        y_wl, y_tl, y_c, y_tr, y_wr = y
+    def _labelled_rows(ticket):
+        """(DB rows, labels) of the clips of the previous round: the user's verdict where there is one, the engine's own
+        call otherwise (hyperparameter.py:45-50).  A clip listed twice keeps its first position and last label, like
+        the dict of the reference; an unknown clip is a KeyError, like ``ticket.scores[clip]`` there."""
+        label = {}
+        for m in ticket.matches:
+            verdict = m["user_match"]
+            label[m["video_clip"]] = m["is_match"] if verdict is None else verdict
+        return [ticket.feature_db.row_of(clip) for clip in label], list(label.values())
 
-        def vertex(lo, mid, hi, y_lo, y_hi):
-            num = (y_hi - y_lo) * mid ** 2 + (y_c - y_hi) * lo ** 2 - (y_c - y_lo) * hi ** 2
-            v = 0.5 * num / ((y_hi - y_lo) * mid + (y_c - y_hi) * lo - (y_c - y_lo) * hi)
-            curv = (y_c - y_lo) / ((mid - v) ** 2 - (lo - v) ** 2)
-            return v, curv
+    def _refine(self, surface, iw, it):
+        """Minimum of the separable parabola through the best cell and its four neighbours, clamped to the
+        neighbouring grid lines; falls back to the cell itself when the five points are not reproduced
+        (hyperparameter.py:78-114)."""
+        ws, ths = self.weight_grid[iw - 1:iw + 2], self.threshold_grid[it - 1:it + 2]
+        centre = surface[iw, it]
+        west, east, south, north = surface[iw - 1, it], surface[iw + 1, it], surface[iw, it - 1], surface[iw, it + 1]
+        w0, a = parabola_through(ws, west, centre, east)
+        th0, b = parabola_through(ths, south, centre, north)
+        c = centre - a * (ws[1] - w0) ** 2 - b * (ths[1] - th0) ** 2
+        w0, th0 = max(min(w0, ws[2]), ws[0]), max(min(th0, ths[2]), ths[0])
 
-        w0, a0 = vertex(wl, wc, wr, y_wl, y_wr)
-        th0, b0 = vertex(tl, tc, tr, y_tl, y_tr)
-        c0 = y_c - a0 * (wc - w0) ** 2 - b0 * (tc - th0) ** 2
-        w0 = max(min(w0, wr), wl)          # round-off on flat data may leave the bracket
-        th0 = max(min(th0, tr), tl)
-        fit = [a0 * (wl - w0) ** 2 + b0 * (tc - th0) ** 2 + c0,
-               a0 * (wc - w0) ** 2 + b0 * (tl - th0) ** 2 + c0,
-               a0 * (wc - w0) ** 2 + b0 * (tc - th0) ** 2 + c0,
-               a0 * (wc - w0) ** 2 + b0 * (tr - th0) ** 2 + c0,
-               a0 * (wr - w0) ** 2 + b0 * (tc - th0) ** 2 + c0]
-        err = abs(y[0] - fit[0]) + abs(y[1] - fit[1]) + abs(y[2] - fit[2]) + abs(y[3] - fit[3]) + abs(y[4] - fit[4])
-        if err > 10 ** -6:
+        def model(w, t):
+            return a * (w - w0) ** 2 + b * (t - th0) ** 2 + c
+        misfit = (abs(west - model(ws[0], ths[1])) + abs(south - model(ws[1], ths[0])) + abs(centre - model(ws[1], ths[1]))
+                  + abs(north - model(ws[1], ths[2])) + abs(east - model(ws[2], ths[1])))
+        if misfit > FIT_TOLERANCE:
             logging.warning("hyperparameter quadratic fine tuning failed - resort to selecting optimum on grid "
                             "without further interpolation")
-            w0, th0 = wc, tc
+            return ws[1], ths[1]
         return w0, th0

@@ -111,10 +111,7 @@ class TicketScoring:
                 if st in target_features and sp in target_features[st]:
                     t[s, e] = np.asarray(target_features[st][sp], dtype=np.float64)
                     slot_used[s, e] = True
-        if not slot_used.all():
-            # the target lacks this (stream, split): the reference never visits it (ticket.py:146-148)
-            base = db.present if db.present is not None else np.ones((db.n, db.S, db.E), dtype=np.uint8)
-            db.set_present(base * slot_used[None].astype(np.uint8))
+        db.restrict_slots(slot_used)          # per query; the database's own mask is never modified
         db.set_query(t)
         db.scan(weights=None)
         avg, n_e = db.similarities()
@@ -166,16 +163,13 @@ class TicketScoring:
         matches = {int(ids[r]): vals[r] for r in picked}
         if near_max_row is not None:
             matches[int(ids[near_max_row])] = vals[near_max_row]
-        # forced inclusions (ticket.py:346-356)
-        if self.ref_clip_id in self.scores:
-            previous_user_evals = {self.ref_clip_id: self.scores[self.ref_clip_id]}
-        else:
-            previous_user_evals = {}
-        if self.user_matches:
-            for clip, value in self.user_matches.items():
-                if value is True:
-                    previous_user_evals.update({int(clip): self.scores[int(clip)]})
-        matches.update(previous_user_evals)
+        # clips the user has already judged stay in the review set whatever their score: the reference clip (when it is
+        # part of the search set) and every confirmed match (ticket.py:346-356); a confirmed match that is not in the
+        # search set is a KeyError there and here
+        forced = [self.ref_clip_id] if self.ref_clip_id in self.scores else []
+        forced += [int(clip) for clip, verdict in (self.user_matches or {}).items() if verdict is True]
+        for clip in forced:
+            matches[clip] = self.scores[clip]
         self.matches = matches
 
 
@@ -219,14 +213,77 @@ class Ticket(TicketScoring):
             return {"results": chunk, "pagination": {"nextPage": nxt}}
         raise KeyError("offline Ticket has no endpoint %r" % (action,))
 
+    # -- the REST side of a query round, kept in memory (the reference posts these to the API: ticket.py:59-118,
+    #    :276-299).  Enough for ``compute_matches(query_updates, hyperparameters)`` to run with no server; what the
+    #    server would have received can be read back from ``ledger``.
+    @property
+    def ledger(self):
+        return self.__dict__.setdefault("_ledger", {"process_state": [], "notes": [], "query_results": [], "matches": [],
+                                                    "final_report": None})
+
+    def change_process_state(self, process_state, message=None):
+        self.ledger["process_state"].append(process_state)
+        if message:
+            self.add_note(message)
+        return process_state
+
+    def add_note(self, note):
+        self.ledger["notes"].append(note)
+
+    def catch_errors(self, job_type):
+        """(fatal message, warning) -- the three consistency checks of ticket.py:80-110; the third one switches
+        dynamic target adjustment off for the round when the user confirmed nothing."""
+        fatal, warnings = [], []
+        if self.ref_clip_id is None:
+            fatal.append("*** Fatal Error: A video clip corresponding to the reference time does not exist in the database. ***")
+        if job_type != "new" and not self.matches:
+            fatal.append("*** Fatal Error: This is not a new query but there are 0 matches computed for the previous round.")
+        if job_type != "new" and self.dynamic_target_adjustment is True \
+                and not any(m["user_match"] is True for m in self.matches):
+            warnings.append("*** Error: Dynamic target adjustment is True but there are no user matches provided for the "
+                            "previous round. Changing dynamic target adjustment to False")
+            self.dynamic_target_adjustment = False
+        return "\n".join(fatal), "\n".join(warnings)
+
+    def create_query_result(self, nround, hyperparameters):
+        import json
+        results = self.ledger["query_results"]
+        results.append({"id": len(results) + 1, "round": nround, "match_criterion": hyperparameters.threshold,
+                        "weights": [hyperparameters.weights[st] for st in hyperparameters.streams], "query": self.query_id,
+                        "bootstrapped_target": json.dumps(self.target.target_features)})
+        return results[-1]["id"]
+
+    def add_matches_to_database(self, new_result_id):
+        for clip, score in self.matches.items():
+            self.ledger["matches"].append({"query_result": new_result_id, "score": score, "video_clip": clip,
+                                           "user_match": self.user_matches.get(str(clip))})
+
+    def create_final_report(self, hyperparameters, query_result_id):
+        """The rows of the report of ticket.py:244-268: every selected clip, best score first (stable)."""
+        criterion = self.ledger["query_results"][query_result_id - 1]["match_criterion"]
+
+        def kind(clip, score):
+            verdict = self.user_matches.get(str(clip))
+            if verdict is not None:
+                return "user-identified match" if verdict is True else "user-identified non-match"
+            return "inferred match" if score >= criterion else "inferred non-match"
+        rows = [[clip, kind(clip, score), score] for clip, score in self.matches.items()]
+        rows.sort(key=lambda row: row[2], reverse=True)
+        self.ledger["final_report"] = rows
+
 
 def install(ticket_cls, hyperparameter_cls=None, target_clip_cls=None):
     """Patch the reference's classes in place so broker.py / compute_matches.py see a drop-in."""
     if target_clip_cls is not None:                       # dynamic target adjustment: matrix formulas on the GPU
-        from .target_clip import TargetClip as _TC
-        for name in ("get_target_features", "avg_new_old_targets", "_previous", "dynamic_target_adjustment", "target_by_bagging",
-                     "_draw", "_solve", "_stack"):
-            setattr(target_clip_cls, name, getattr(_TC, name))
+        from . import target_clip as _tc
+        for name in _tc.GRAFTED:
+            setattr(target_clip_cls, name, _tc.TargetClip.__dict__[name])      # __dict__: staticmethods stay static
+        construct = target_clip_cls.__init__
+
+        def remember_ticket(self, ticket, hyperparameters):
+            construct(self, ticket, hyperparameters)
+            self._ticket = ticket                          # lets the round use rows of a resident ticket.feature_db
+        target_clip_cls.__init__ = remember_ticket
     for name in ("compute_similarities", "compute_scores", "lowest_scoring_user_match", "select_clips_to_review"):
         setattr(ticket_cls, name, getattr(TicketScoring, name))
     for name in ("feature_db", "feature_db_dtype", "device"):
@@ -234,6 +291,5 @@ def install(ticket_cls, hyperparameter_cls=None, target_clip_cls=None):
             setattr(ticket_cls, name, getattr(TicketScoring, name))
     if hyperparameter_cls is not None:
         from .hyperparameter import Hyperparameter
-        hyperparameter_cls.optimize_weights = Hyperparameter.optimize_weights
-        hyperparameter_cls.fine_tune = Hyperparameter.fine_tune
-        hyperparameter_cls._quad_fit = staticmethod(Hyperparameter._quad_fit)
+        for name in ("optimize_weights", "_labelled_rows", "_refine"):
+            setattr(hyperparameter_cls, name, Hyperparameter.__dict__[name])

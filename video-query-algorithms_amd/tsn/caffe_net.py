@@ -74,15 +74,25 @@ class CaffeNet:
         return None
 
     # -- the batched path ------------------------------------------------------------------------------------
-    def extract_clips(self, crops: np.ndarray, T: int):
-        """crops uint8 [B*T, 224, 224, C] -> consensus features [B, D] float64 (calcSig_wOF.py:82)."""
+    def extract_clips(self, crops: np.ndarray, T: int, on_device: bool = False):
+        """crops uint8 [B*T, 224, 224, C] -> consensus features [B, D] float64 (calcSig_wOF.py:82); with
+        ``on_device`` a torch tensor that never left the GPU (the block a rank contributes to the all-gather)."""
         out = []
         per = (self._model.max_crops // T) * T
         if per == 0:
             raise ValueError("max_crops (%d) is smaller than T (%d)" % (self._model.max_crops, T))
         for i in range(0, crops.shape[0], per):
-            feat, _ = self._model.forward(crops[i:i + per], T, self._mean, want_per_snippet=False)
-            out.append(feat)
+            if on_device:
+                import torch
+                chunk = torch.from_numpy(np.ascontiguousarray(crops[i:i + per], dtype=np.uint8)).to(torch.device("cuda", self._model.device))
+                self._model.forward_device(chunk.data_ptr(), chunk.shape[0], T, self._mean)
+                out.append(self._model.features_tensor(chunk.shape[0] // T).clone())
+            else:
+                feat, _ = self._model.forward(crops[i:i + per], T, self._mean, want_per_snippet=False)
+                out.append(feat)
+        if on_device:
+            import torch
+            return torch.cat(out, dim=0)
         return np.concatenate(out, axis=0)
 
     def crops_from_frames(self, frames_: np.ndarray, frame_size=(340, 256), crop=224):
@@ -112,9 +122,9 @@ class CaffeNet:
                      crop, C.c_void_p(out.data_ptr()), self._channels, k, self._model.device, C.c_void_p(stream))
         return out
 
-    def extract_clips_from_frames(self, frames_: np.ndarray, T: int, frame_size=(340, 256)):
+    def extract_clips_from_frames(self, frames_: np.ndarray, T: int, frame_size=(340, 256), on_device: bool = False):
         """Decoded frames of B*T snippets -> consensus features [B, D]: resize + crop 0 on the device, then the
-        batched forward on the resident crops (no host-side image processing at all)."""
+        batched forward on the resident crops (no host-side image processing at all).  ``on_device``: see extract_clips."""
         import torch
         per = (self._model.max_crops // T) * T
         if per == 0:
@@ -126,11 +136,11 @@ class CaffeNet:
             torch.cuda.current_stream(dev).synchronize()
             nb = crops.shape[0]
             self._model.forward_device(crops.data_ptr(), nb, T, self._mean)
-            fptr, _ = self._model.feat_devptr()
-            feat = np.empty((nb // T, self._model.feature_dim), dtype=np.float64)
-            self._model.read_features(feat)
-            out.append(feat)
-        return np.concatenate(out, axis=0)
+            if on_device:
+                out.append(self._model.features_tensor(nb // T).clone())
+            else:
+                out.append(self._model.read_features(np.empty((nb // T, self._model.feature_dim), dtype=np.float64)))
+        return torch.cat(out, dim=0) if on_device else np.concatenate(out, axis=0)
 
     @property
     def feature_dim(self):

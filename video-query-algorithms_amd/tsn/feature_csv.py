@@ -1,10 +1,16 @@
 """The on-disk feature layout both sides of the reference agree on.
 
-Writer: byte-for-byte what ``writeFeatures`` produces (src/features_GPU_compute/calcSig_wOF.py:116-134) --
+Writer: what ``writeFeatures`` produces (src/features_GPU_compute/calcSig_wOF.py:116-134) --
 ``<out>/<video>/<modelname>/<stream>_<blob>_features.csv``, one header line
 ``video =<v>, video url =<path>, CNN stream =<mode>, feature blob =<blob>, caffe model =<weights>`` and one row
-per clip: ``int(clip_dir[-4:])`` then the 1024 values printed with ``str(float64)`` (shortest round-trip repr),
-LF line ends, trailing newline.  Reader: the parsing rules of ``load_db`` (src/api/api_load_records.py:41-58).
+per clip: ``int(clip_dir[-4:])`` then the 1024 values as ``str(numpy.float64)``, LF line ends, trailing newline.
+
+What ``str(numpy.float64)`` prints depends on the numpy the script ran under, and the reference ships BOTH kinds:
+``data/features/.../DowntownBrooklynDrive_480p`` holds shortest-round-trip reprs (numpy >= 1.14, up to 17 digits),
+``SHRP2_Forward_clips_features/S06NDS_Sample_120406_1451_00186_Forward`` holds 12 significant digits (numpy < 1.14: ``'%.12g'`` plus ``'.0'``
+for integral values).  ``number_format="repr"`` (default: lossless, so ``load_db`` gets the exact features) and
+``"g12"`` reproduce one each byte for byte (tests/test_feature_files.py).
+Reader: the parsing rules of ``load_db`` (src/api/api_load_records.py:41-58).
 """
 from __future__ import annotations
 
@@ -17,9 +23,19 @@ import numpy as np
 STREAM_MODES = ("rgb", "warped_optical_flow")          # calcSig_wOF.py:120
 
 
+def _g12(v: float) -> str:
+    """``str(numpy.float64)`` of numpy < 1.14: 12 significant digits, integral values keep a ``.0``."""
+    s = "%.12g" % v
+    return s if ("." in s or "e" in s or "n" in s) else s + ".0"
+
+
+NUMBER_FORMATS = {"repr": repr, "g12": _g12}
+
+
 def write_features(out_dir: str, video: str, video_path: str, modelname: str, blob: str, clip_names: Sequence[str],
-                   features: Dict[str, np.ndarray], weights_files: Dict[str, str]) -> List[str]:
+                   features: Dict[str, np.ndarray], weights_files: Dict[str, str], number_format: str = "repr") -> List[str]:
     """features[mode] is [n_clips, D] float64 in clip order; returns the files written."""
+    fmt = NUMBER_FORMATS[number_format]
     f_output_dir = os.path.join(out_dir, video, modelname)
     os.makedirs(f_output_dir, exist_ok=True)
     written = []
@@ -34,7 +50,7 @@ def write_features(out_dir: str, video: str, video_path: str, modelname: str, bl
             fout.write(header_txt + "\n")
             for i, vid in enumerate(clip_names):
                 clip_no = int(vid[-4:])
-                fout.write(str(clip_no) + "," + ",".join(map(repr, feat[i].tolist())) + "\n")
+                fout.write(str(clip_no) + "," + ",".join(map(fmt, feat[i].tolist())) + "\n")
         written.append(outfile)
     return written
 

@@ -257,16 +257,21 @@ class TsnNet:
         m = np.ascontiguousarray(mean, dtype=np.float32)
         call("vq_tsn_forward", self._h, C.c_void_p(crops_dev_ptr), 1, n, T, m.ctypes.data_as(C.POINTER(C.c_float)), None, None)
 
-    def read_features(self, out: np.ndarray):
-        """Copy the consensus features [B, D] fp64 of the last forward_device to the host (synchronises)."""
+    def features_tensor(self, n_clips: int):
+        """Zero-copy torch view [n_clips, D] fp64 of the consensus features of the last forward (device memory owned
+        by the handle: clone it before the next forward).  Synchronises the device first."""
         import torch
         f, _ = self.feat_devptr()
 
         class _V:
-            __cuda_array_interface__ = {"shape": tuple(out.shape), "typestr": "<f8", "data": (int(f), False), "version": 2}
+            __cuda_array_interface__ = {"shape": (int(n_clips), self.feature_dim), "typestr": "<f8", "data": (int(f), False), "version": 2}
         dev = torch.device("cuda", self.device)
         torch.cuda.synchronize(dev)
-        out[...] = torch.as_tensor(_V(), device=dev).cpu().numpy()
+        return torch.as_tensor(_V(), device=dev)
+
+    def read_features(self, out: np.ndarray):
+        """Copy the consensus features [B, D] fp64 of the last forward_device to the host (synchronises)."""
+        out[...] = self.features_tensor(out.shape[0]).cpu().numpy()
         return out
 
     def feat_devptr(self):
