@@ -242,12 +242,12 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
 int vq_tsn_feat_devptr(vq_tsn* net, void** feat_dev /* double [B][D] */, void** per_snippet_dev);
 /* Copy an activation slot of the last forward to the host ([n_crops][h][w][c] fp32): per-layer parity. */
 int vq_tsn_read_tensor(vq_tsn* net, int32_t slot, int32_t n_crops, float* host);
-/* Roofline accounting: with depth > 0 every layer launch of a forward carries a start and a stop HIP event
+/* Roofline accounting: with depth > 0 every launch of a forward carries a start and a stop HIP event
  * (hipExtLaunchKernelGGL: the dispatch packet's own begin / end timestamps, i.e. the kernel alone, as rocprofv3
  * reports it) from a ring of `depth` event sets -- no host synchronisation and no extra packets inside the forward;
  * profiled forwards run on the handle's stream only (no batch split).
  * vq_tsn_layer_times returns the per-layer device time averaged over the profiled forwards since
- * vq_tsn_set_profile and (optionally) each layer's algorithmic FLOPs for the last batch size (2*MACs with
+ * vq_tsn_set_profile (a launch shared by several layers is split between them in proportion to their matrix-core work) and (optionally) each layer's algorithmic FLOPs for the last batch size (2*MACs with
  * the un-padded channel counts; 0 for pooling).  depth = 0 switches profiling off. */
 int vq_tsn_set_profile(vq_tsn* net, int32_t depth);
 int vq_tsn_layer_times(vq_tsn* net, float* ms, double* flops, int32_t n_layers);
@@ -257,10 +257,13 @@ int vq_tsn_layer_times(vq_tsn* net, float* ms, double* flops, int32_t n_layers);
 int vq_tsn_layer_tiles(vq_tsn* net, int32_t n_crops, int32_t* tiles, int32_t n_layers);
 /* Install a tiling table (as returned by vq_tsn_layer_tiles) for batch size n_crops instead of autotuning. */
 int vq_tsn_set_layer_tiles(vq_tsn* net, int32_t n_crops, const int32_t* tiles, int32_t n_layers);
-/* The fixed schedule: the lane (HIP stream) of every layer.  Independent arms of the graph run on different lanes
- * (lane 0 is the stream of vq_tsn_set_stream; VQ_TSN_LANES, default 1 = one stream, read at creation).
- * Results do not depend on the lane count. */
-int vq_tsn_layer_lanes(vq_tsn* net, int32_t* lanes, int32_t n_layers);
+/* The launch sequence of a forward: layers are levelled by their dependencies and run level by level; the Winograd
+ * convolutions of one level (the 3x3 and the first double-3x3 arm of an inception module) share ONE kernel launch.
+ * item_of_layer[l] = index of the launch that executes layer l; *n_items = launches per forward (per sub-batch).
+ * VQ_TSN_GROUP=0 (read at creation) gives every layer its own launch; results never depend on the grouping. */
+int vq_tsn_launch_items(vq_tsn* net, int32_t* item_of_layer, int32_t n_layers, int32_t* n_items);
+/* Batch sizes that hold a tiling table (autotuned or installed): *n of them, the first min(*n, cap) in sizes[]. */
+int vq_tsn_tuned_sizes(vq_tsn* net, int32_t* sizes, int32_t cap, int32_t* n);
 /* Algorithmic FLOPs (2*MACs of the conv layers) of one crop, for roofline accounting. */
 int vq_tsn_flops_per_crop(vq_tsn* net, double* flops);
 

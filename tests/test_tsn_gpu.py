@@ -269,6 +269,28 @@ def test_bad_shapes_are_rejected_before_launch(tsn):
     m.close()
 
 
+def _write_protos(bi, tmp_path):
+    """The two deploy prototxts of the reference's layout, written from the built-in graph (and parsed back)."""
+    protos = {}
+    for name, c in (("rgb", 3), ("flow", 10)):
+        g = bi.bn_inception(c)
+        lines = ['name: "BN-Inception"', 'input: "data"', "input_dim: 1", "input_dim: %d" % c, "input_dim: 224", "input_dim: 224"]
+        for l in g.layers:
+            body = 'layer { name: "%s" type: "%s" %s %s' % (l.name, l.type, " ".join('bottom: "%s"' % b for b in l.bottoms),
+                                                            " ".join('top: "%s"' % t for t in l.tops))
+            if l.type == "Convolution":
+                body += " convolution_param { num_output: %d pad: %d kernel_size: %d stride: %d }" % (l.num_output, l.pad, l.kernel, l.stride)
+            elif l.type == "Pooling":
+                body += " pooling_param { pool: %s kernel_size: %d stride: %d pad: %d }" % (l.pool, l.kernel, l.stride, l.pad)
+            elif l.type == "InnerProduct":
+                body += " inner_product_param { num_output: %d }" % l.num_output
+            lines.append(body + " }")
+        protos[name] = str(tmp_path / ("%s.prototxt" % name))
+        open(protos[name], "w").write("\n".join(lines))
+        assert bi.load_prototxt(protos[name]).layers == g.layers
+    return protos
+
+
 def test_calcsig_command_line_end_to_end(tsn, tmp_path):
     """The drop-in CLI on a synthetic frame tree: two clips of one video, T = 3, both streams; the CSVs it writes
     must parse with load_db's rules and carry the oracle's features; the reference's own per-snippet loop run on the
@@ -287,23 +309,7 @@ def test_calcsig_command_line_end_to_end(tsn, tmp_path):
             # grayscale (P5) content; the reader goes by the magic number, so one extension serves both
             frames.write_pnm(str(d / ("flow_x_%05d.ppm" % i)), rng.integers(0, 256, (256, 340), dtype=np.uint8))
             frames.write_pnm(str(d / ("flow_y_%05d.ppm" % i)), rng.integers(0, 256, (256, 340), dtype=np.uint8))
-    protos = {}
-    for name, c in (("rgb", 3), ("flow", 10)):
-        g = bi.bn_inception(c)
-        lines = ['name: "BN-Inception"', 'input: "data"', "input_dim: 1", "input_dim: %d" % c, "input_dim: 224", "input_dim: 224"]
-        for l in g.layers:
-            body = 'layer { name: "%s" type: "%s" %s %s' % (l.name, l.type, " ".join('bottom: "%s"' % b for b in l.bottoms),
-                                                            " ".join('top: "%s"' % t for t in l.tops))
-            if l.type == "Convolution":
-                body += " convolution_param { num_output: %d pad: %d kernel_size: %d stride: %d }" % (l.num_output, l.pad, l.kernel, l.stride)
-            elif l.type == "Pooling":
-                body += " pooling_param { pool: %s kernel_size: %d stride: %d pad: %d }" % (l.pool, l.kernel, l.stride, l.pad)
-            elif l.type == "InnerProduct":
-                body += " inner_product_param { num_output: %d }" % l.num_output
-            lines.append(body + " }")
-        protos[name] = str(tmp_path / ("%s.prototxt" % name))
-        open(protos[name], "w").write("\n".join(lines))
-        assert bi.load_prototxt(protos[name]).layers == g.layers
+    protos = _write_protos(bi, tmp_path)
     wfile = {}
     weights = {}
     for name, c, seed in (("rgb", 3, 2), ("flow", 10, 5)):
@@ -352,30 +358,67 @@ def test_calcsig_command_line_end_to_end(tsn, tmp_path):
             cn.close()
 
 
-def test_branch_lanes_do_not_change_a_bit(tsn, monkeypatch):
-    """VQ_TSN_LANES=3: the independent arms of every inception module on three HIP streams with cross-stream events
-    derived from the slot read/write sets (off by default).  Same bits as one stream, and the schedule really forks."""
+def test_grouped_winograd_launches_do_not_change_a_bit(tsn, monkeypatch):
+    """The Winograd convolutions of one dependency level (the 3x3 and the first double-3x3 arm of an inception module)
+    share one kernel launch.  VQ_TSN_GROUP=0 gives every layer its own launch: same bits either way, and the launch
+    table really groups sibling arms while a chain (double_3x3_1 -> double_3x3_2) stays in separate launches."""
     bi, net = tsn
     g = bi.bn_inception(3)
     w = net.synthetic_weights(g, seed=2)
     crops = np.random.default_rng(9).integers(0, 256, (3, 224, 224, 3), dtype=np.uint8)
     monkeypatch.setenv("VQ_TSN_SPLIT", "1")
-    monkeypatch.setenv("VQ_TSN_LANES", "1")
+    monkeypatch.setenv("VQ_TSN_GROUP", "0")
     m = net.TsnNet(g, w, max_crops=3)
-    assert (m.layer_lanes() == 0).all()
+    items, n_items = m.launch_items()
+    assert n_items == len(m.plan.ops) and len(set(items.tolist())) == n_items
     f1, p1 = m.forward(crops, 3, net.RGB_MEAN)
+    b1 = m.read_blob("inception_4c/output", 3)
     m.close()
-    monkeypatch.setenv("VQ_TSN_LANES", "3")
+    monkeypatch.setenv("VQ_TSN_GROUP", "1")
     m = net.TsnNet(g, w, max_crops=3)
-    lanes = m.layer_lanes()
-    assert set(lanes.tolist()) == {0, 1, 2}
+    items, n_items = m.launch_items()
     names = [o.name for o in m.plan.ops]
-    i3, id1, id2 = names.index("inception_3a/3x3"), names.index("inception_3a/double_3x3_1"), names.index("inception_3a/double_3x3_2")
-    assert lanes[i3] != lanes[id1] and lanes[id1] == lanes[id2]        # sibling arms apart, a chain on one stream
-    for _ in range(3):
-        f2, p2 = m.forward(crops, 3, net.RGB_MEAN)
-        assert (p1 == p2).all() and (f1 == f2).all()
+    for blk in ("3a", "3b", "4a", "4b", "4c", "4d", "5a", "5b"):
+        i3, id1, id2 = (names.index("inception_%s/%s" % (blk, x)) for x in ("3x3", "double_3x3_1", "double_3x3_2"))
+        assert items[i3] == items[id1] and items[id2] > items[id1]
+    assert n_items == len(m.plan.ops) - 8
+    order = np.argsort(items, kind="stable")                       # a valid order: every producer's launch precedes its consumers'
+    assert items[names.index("inception_3a/pool")] < items[names.index("inception_3b/3x3")]
+    f2, p2 = m.forward(crops, 3, net.RGB_MEAN)
+    b2 = m.read_blob("inception_4c/output", 3)
     m.close()
+    assert (p1 == p2).all() and (f1 == f2).all() and (b1 == b2).all() and len(order) == len(names)
+
+
+@pytest.mark.parametrize("channels,split", [(3, "1"), (10, "2")])
+def test_every_winograd_variant_writes_all_it_owns(tsn, monkeypatch, channels, split):
+    """VQ_TSN_POISON=1 fills every activation slot with NaN patterns before a forward, so an output element a kernel
+    variant fails to write (and that would otherwise silently keep the value of an earlier forward or of an autotune
+    launch -- which is how a wrong variant hides from a plain A/B comparison) turns into NaN.  Both Winograd workgroup
+    shapes, forced on every 3x3 layer at a batch so small that every layer has ragged tile blocks and some have a
+    single 64-channel block: no NaN anywhere, identical bits."""
+    bi, net = tsn
+    monkeypatch.setenv("VQ_TSN_POISON", "1")
+    monkeypatch.setenv("VQ_TSN_SPLIT", split)
+    g = bi.bn_inception(channels)
+    w = net.synthetic_weights(g, seed=5)
+    mean = net.RGB_MEAN if channels == 3 else net.FLOW_MEAN
+    crops = np.random.default_rng(1).integers(0, 256, (6, 224, 224, channels), dtype=np.uint8)
+    m = net.TsnNet(g, w, max_crops=6)
+    m.forward(crops, 3, mean)
+    got = {}
+    for variant in (0, 1):
+        for n in m.tuned_sizes():
+            t = m.layer_tiles(n)
+            t[t[:, 3] == 2, 1] = 32 * (variant + 1)
+            m.set_layer_tiles(n, t)
+        f, p = m.forward(crops, 3, mean)
+        assert np.isfinite(p).all() and np.isfinite(f).all()
+        for name in m.plan.blob_loc:
+            assert np.isfinite(m.read_blob(name, 6)).all(), (variant, name)
+        got[variant] = p
+    m.close()
+    assert (got[0] == got[1]).all()
 
 
 @pytest.mark.parametrize("split", ["1", "2", "3", "2,1"])
@@ -491,6 +534,46 @@ def test_device_resize_crop_against_the_pixel_loop_oracle(tsn, h, w):
     dev_feats = cf.extract_clips_from_frames(planes, 2, on_device=True)           # the block a rank all-gathers
     assert dev_feats.is_cuda and (dev_feats.cpu().numpy() == feats).all()
     cf.close()
+
+
+def test_calcsig_two_ranks_write_the_same_bytes_as_one(tsn, tmp_path):
+    """The N > 1 path of the drop-in command line with the REAL extractor: two ranks under torch.distributed.run, both
+    on this one GPU with the gloo backend (VQ_DIST_BACKEND=gloo; RCCL refuses two ranks on one device), clips sharded
+    5 = 3 + 2, feature blocks kept on the device until the gather, rank 0 writes.  The CSV tree must equal the one-rank
+    run byte for byte (calcSig_wOF.py:204-210: the result must not depend on how many workers shared the clips)."""
+    import subprocess
+    import sys
+    bi, net = tsn
+    from video_query_algorithms_amd.tsn import frames
+    rng = np.random.default_rng(17)
+    root = tmp_path / "frames"
+    for clip, n in (("clip_0001", 7), ("clip_0002", 9), ("clip_0003", 7), ("clip_0004", 8), ("clip_0007", 7)):
+        d = root / "vid" / clip
+        d.mkdir(parents=True)
+        for i in range(1, n + 1):
+            frames.write_pnm(str(d / ("img_%05d.ppm" % i)), rng.integers(0, 256, (120, 160, 3), dtype=np.uint8))
+            frames.write_pnm(str(d / ("flow_x_%05d.ppm" % i)), rng.integers(0, 256, (120, 160), dtype=np.uint8))
+            frames.write_pnm(str(d / ("flow_y_%05d.ppm" % i)), rng.integers(0, 256, (120, 160), dtype=np.uint8))
+    protos = _write_protos(bi, tmp_path)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(repo, "video-query-algorithms_amd", "calcSig_wOF.py")
+    outs = {}
+    for world in (1, 2):
+        out_dir = tmp_path / ("features_%d" % world)
+        argv = [str(root), protos["rgb"], "synthetic:2", protos["flow"], "synthetic:5", "--num_frame_per_video", "3",
+                "--outFeatures_dir", str(out_dir), "--modelname", "UCF101_split1", "--frame_ext", ".ppm", "--batch_clips", "2"]
+        if world == 1:
+            cmd = [sys.executable, cli] + argv
+        else:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                   "--master-port", "29541", cli] + argv + ["--gpus", "0"]
+        p = subprocess.run(cmd, env=dict(os.environ, VQ_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[world] = {f: open(os.path.join(str(out_dir), "vid", "UCF101_split1", f), "rb").read()
+                       for f in ("rgb_global_pool_features.csv", "warped_optical_flow_global_pool_features.csv")}
+    assert outs[1] == outs[2]
+    rows = outs[2]["rgb_global_pool_features.csv"].decode().split("\n")
+    assert [r.split(",")[0] for r in rows[1:-1]] == ["1", "2", "3", "4", "7"] and len(rows[1].split(",")) == 1025
 
 
 def test_bench_two_rank_control_flow_rehearsal(tsn):

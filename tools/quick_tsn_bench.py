@@ -19,9 +19,9 @@ def bench(channels, n_crops, T, reps=5):
     mean = net.RGB_MEAN if channels == 3 else net.FLOW_MEAN
     torch.cuda.synchronize()
     m.forward_device(crops.data_ptr(), n_crops, T, mean)
-    if os.environ.get("VQ_SHOW_LANES"):
-        for o, l in zip(m.plan.ops, m.layer_lanes()):
-            print("  lane %d  %s" % (l, o.name))
+    if os.environ.get("VQ_SHOW_LAUNCHES"):
+        for o, l in zip(m.plan.ops, m.launch_items()[0]):
+            print("  launch %2d  %s" % (l, o.name))
     tm = C.c_void_p()
     call("vq_timer_create", C.byref(tm))
     times = []

@@ -33,22 +33,25 @@ int main(int argc, char** argv) {
     hipMemcpy(din, hin.data(), n_in * 4, hipMemcpyHostToDevice);
     hipMemcpy(du, hu.data(), n_u * 4, hipMemcpyHostToDevice);
     hipMemcpy(db, hb.data(), Cout * 4, hipMemcpyHostToDevice);
-    vq::WinoArgs a{};
+    vq::WinoGroup g{};
+    g.n_jobs = 1;
+    vq::WinoJob& a = g.job[0];
     a.in = din; a.u = du; a.bias = db; a.out = dout;
     a.H = a.W = H; a.Cs_in = Cin; a.coff_in = 0; a.Cin = Cin;
     a.Cs_out = Cout; a.coff_out = 0; a.Cout = Cout;
     a.th = a.tw = (H + 1) / 2; a.P = crops * a.th * a.tw; a.relu = 1;
-    a.in_bytes = (unsigned)(n_in * 4); a.u_bytes = (unsigned)(n_u * 4);
-    const int nb = variant == 1 ? 2 : 1;                     // variants 0 and 2 own 32 output channels per workgroup
-    const int nwg = ((a.P + 31) / 32) * ((Cout + 32 * nb - 1) / (32 * nb));
+    a.in_bytes = (unsigned)(n_in * 4); a.u_bytes = (unsigned)(n_u * 4); a.out_bytes = (unsigned)(n_out * 4);
+    const int nb = variant == 1 ? 2 : 1;                     // variant 1 owns 64 output channels per workgroup
+    const int nwg = ((((a.P + 31) / 32) * ((Cout + 32 * nb - 1) / (32 * nb))) + 7) & ~7;
     hipMalloc(&a.phases, (size_t)nwg * 6 * sizeof(long long));
+    hipMemset(a.phases, 0, (size_t)nwg * 6 * sizeof(long long));
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int w = 0; w < 3; ++w) vq::launch_wino(a, variant, nullptr, nullptr, nullptr);
+    for (int w = 0; w < 3; ++w) vq::launch_wino_group(g, variant, nullptr, nullptr, nullptr);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    if (vq::launch_wino(a, variant, nullptr, nullptr, nullptr) != 0) {
+    if (vq::launch_wino_group(g, variant, nullptr, nullptr, nullptr) != 0) {
         printf("launch failed: %s\n", vq::last_error_ref().c_str());
         return 1;
     }

@@ -653,6 +653,34 @@ __global__ void gavgpool_kernel(const float* __restrict__ in, float* __restrict_
     out[(size_t)img * Cs_out + coff_out + c] = acc / (float)HW;
 }
 
+// global average pool + segment consensus in one pass: a snippet's global_pool value is formed exactly
+// like gavgpool_kernel does (sequential fp32 sum over h, w, then / (H*W)) and stored as the per-snippet blob
+// (calcSig_wOF.py:95,112); the T values of a clip meet in LDS and are summed in fp64 in numpy's axis-0 order
+// (calcSig_wOF.py:82) -- the same bits as the two separate kernels.  Clips of up to kMaxFusedT snippets.
+constexpr int kMaxFusedT = 16;
+__global__ void gavgpool_consensus_kernel(const float* __restrict__ in, float* __restrict__ out, double* __restrict__ feat, int T,
+                                          int HW, int Cs_in, int coff_in, int C, int Cs_out, int coff_out) {
+    // block = 64 channels x T snippets of clip blockIdx.y; thread (c, t) pools snippet t, thread (c, 0) forms the consensus
+    __shared__ float pooled[kMaxFusedT][64];
+    const int c = blockIdx.x * 64 + threadIdx.x, t = threadIdx.y, b = blockIdx.y;
+    float v = 0.f;
+    if (c < C) {
+        const int img = b * T + t;
+        const float* p = in + (size_t)img * HW * Cs_in + coff_in + c;
+        float acc = 0.f;
+        for (int q = 0; q < HW; ++q) acc += p[(size_t)q * Cs_in];
+        v = acc / (float)HW;
+        out[(size_t)img * Cs_out + coff_out + c] = v;
+    }
+    pooled[t][threadIdx.x] = v;
+    __syncthreads();
+    if (t == 0 && c < C) {
+        double cons = (double)pooled[0][threadIdx.x];
+        for (int s = 1; s < T; ++s) cons = cons + (double)pooled[s][threadIdx.x];
+        feat[(size_t)b * C + c] = cons / (double)T;
+    }
+}
+
 // segment consensus (calcSig_wOF.py:82): fp64 mean over the T snippets of a clip, sequential like numpy's
 // axis-0 reduction of the (T, 1, D) float64 array
 __global__ void consensus_kernel(const float* __restrict__ per_snippet, double* __restrict__ feat, int B, int T, int D, int Cs) {
@@ -682,6 +710,13 @@ struct ConvTile {
     int pipe;   // 1 = software-pipelined kernel (aligned Cin only)
 };
 
+// One kernel launch of a forward: a single layer, or the Winograd convolutions of one graph level together.
+struct LaunchItem {
+    int kind = 0;              // 0 = one layer, 1 = Winograd group
+    std::vector<int> layers;   // kind 1: longest K loop first (its workgroups are dispatched first; the short ones fill the tail)
+    int max_crops = 0;         // crops one launch may cover: every slot it touches stays below 2^31 bytes (32-bit offsets)
+};
+
 struct vq_tsn {
     std::mutex mu;
     int device = 0;
@@ -692,8 +727,14 @@ struct vq_tsn {
     vq_input_desc input = {0, 0, 0, -1, 0};
     std::vector<vq_tensor_desc> tensors;
     std::vector<vq_layer_desc> layers;
-    std::map<int, std::vector<int>> tuned;   // n_crops -> per-layer index into kTiles (autotuned)
+    std::vector<LaunchItem> items;        // the launch sequence (a topological order of the layer graph by levels)
+    std::vector<int> item_of_layer;
+    int consensus_layer = -1;             // the global-pool layer that writes the feature slot: runs fused with the consensus
+    std::map<int, std::vector<int>> tuned;   // n_crops -> per-layer index into kTiles / Winograd variant (autotuned)
     bool autotune = true;                 // VQ_TSN_AUTOTUNE != 0 (read at creation)
+    bool group_wino = true;               // VQ_TSN_GROUP != 0 (read at creation): independent Winograd layers share a launch
+    bool poison = false;                  // VQ_TSN_POISON=1 (read at creation): NaN-fill every activation slot before a forward (debug:
+                                          // a layer that reads what no earlier layer of THIS forward wrote then yields NaN features)
     int forced_tile = -1;                 // VQ_TSN_TILE = "BMxBN[xBK[xP]]" (read at creation): every direct conv uses this tiling
     std::vector<float*> slots;            // device activations, max_crops each
     float* zeros = nullptr;               // 256 bytes of zeros (load target of masked lanes)
@@ -709,36 +750,28 @@ struct vq_tsn {
     double* feat_dev = nullptr;           // [max_crops][D] (B <= max_crops)
     double flops_per_crop = 0;
     int last_crops = 0;
-    int profile_depth = 0;                // > 0: HIP events around every layer launch (bench roofline accounting)
+    int cur_T = 1;                        // snippets per clip of the forward in flight
+    bool fused_consensus = false;         // this forward: the global pool launch also forms the consensus (whole clips per launch, T <= kMaxFusedT)
+    int profile_depth = 0;                // > 0: HIP events around every launch (bench roofline accounting)
     int profile_count = 0;                // profiled forwards so far (ring of profile_depth event sets)
-    std::vector<hipEvent_t> events;       // profile_depth x n_layers x {start, stop}
-    // Lanes: independent branches of the graph (the 3x3 / double-3x3 / pooling arms of an inception module) run on
-    // separate HIP streams so that a layer too small to fill 256 CUs shares the chip with its siblings.  Lane 0 is
-    // the caller's stream; the others are owned.  The schedule is fixed at creation from the slot read/write sets.
-    int crop_off = 0;                     // first crop of the sub-batch the next launch works on (batch split)
+    std::vector<hipEvent_t> events;       // profile_depth x n_items x {start, stop}
+    int crop_off = 0;                     // first crop the next launch works on (sub-batches, 32-bit offset chunks)
     int n_split = 1;                      // VQ_TSN_SPLIT: sub-batches of one forward run on separate streams
     std::vector<int> split_parts;         // VQ_TSN_SPLIT=a,b,..: relative sizes of the sub-batches (default equal)
     hipStream_t ls = nullptr;             // stream the next launch goes to
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // per-layer profiling: events of the next launch
-    int n_lanes = 1;
-    std::vector<hipStream_t> lane_streams;        // [n_lanes]; entry 0 unused (caller's stream)
-    std::vector<int> lane;                        // per layer
-    std::vector<std::vector<int>> xdeps;          // per layer: latest producer/hazard on each *other* lane
-    std::vector<char> needs_event;                // per layer: some later layer on another lane waits for it
-    std::vector<hipEvent_t> done;                 // per layer (created only where needs_event)
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // profiling: events of the next launch
+    std::vector<hipStream_t> split_streams;       // [n_split]; entry 0 unused (caller's stream)
     hipEvent_t fork_ev = nullptr;
-    std::vector<hipEvent_t> join_ev;              // per aux lane
+    std::vector<hipEvent_t> join_ev;              // per extra stream
 };
 
 static void tsn_free(vq_tsn* net) {
     for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
     net->events.clear();
-    for (hipEvent_t e : net->done)
-        if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : net->join_ev)
         if (e) (void)hipEventDestroy(e);
     if (net->fork_ev) (void)hipEventDestroy(net->fork_ev);
-    for (hipStream_t st : net->lane_streams)
+    for (hipStream_t st : net->split_streams)
         if (st) (void)hipStreamDestroy(st);
     for (float* p : net->slots)
         if (p) (void)hipFree(p);
@@ -864,7 +897,7 @@ static void fill_conv_args(vq_tsn* net, int li, int n_crops, ConvArgs& a) {
     a.Kp = (L.k * L.k * L.cin + KPAD - 1) / KPAD * KPAD;
     a.relu = L.relu;
     a.tiles_m = a.tiles_n = 0;
-    a.in_bytes = (unsigned)std::min<size_t>((size_t)n_crops * ts.h * ts.w * ts.c * sizeof(float), 0xFFFFFFF0u);
+    a.in_bytes = (unsigned)((size_t)n_crops * ts.h * ts.w * ts.c * sizeof(float));   // < 2^31: LaunchItem::max_crops
     a.w_bytes = (unsigned)((size_t)L.cout * a.Kp * sizeof(float));
 }
 
@@ -872,7 +905,6 @@ static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
     ConvArgs a;
     fill_conv_args(net, li, n_crops, a);
     const vq_layer_desc& L = net->layers[li];
-    if (kTiles[tile_idx].pipe && a.in_bytes >= 0x7FFFFFF0u) tile_idx = heuristic_tile(a.M, a.Cout, net->cus);   // 32-bit offsets
     // A convolution without padding that reads ALL channels of its slot finds the kw taps of a kernel row side by side
     // in memory ([kw][Cin] is one contiguous run of the NHWC row, and the packed weights have the same order): fold the
     // row into the channel axis -- k rows of one tap with kw*Cin channels.  The space-to-depth stem (4x4 over 12
@@ -887,11 +919,11 @@ static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
     return small ? launch_conv<true>(net, a, kTiles[tile_idx]) : launch_conv<false>(net, a, kTiles[tile_idx]);
 }
 
-static int launch_wino_layer(vq_tsn* net, int li, int n_crops, int variant) {
+static void fill_wino_job(vq_tsn* net, int li, int n_crops, WinoJob& a) {
     const vq_layer_desc& L = net->layers[li];
     const vq_tensor_desc& ts = net->tensors[L.src];
     const vq_tensor_desc& td = net->tensors[L.dst];
-    WinoArgs a;
+    memset(&a, 0, sizeof a);
     a.in = net->slots[L.src] + (size_t)net->crop_off * ts.h * ts.w * ts.c;
     a.u = net->blob + L.w_off;
     a.bias = net->blob + L.b_off;
@@ -908,32 +940,75 @@ static int launch_wino_layer(vq_tsn* net, int li, int n_crops, int variant) {
     a.tw = (ts.w + 1) / 2;
     a.P = n_crops * a.th * a.tw;
     a.relu = L.relu;
-    a.tiles_m = a.tiles_n = 0;
-    a.in_bytes = (unsigned)std::min<size_t>((size_t)n_crops * ts.h * ts.w * ts.c * sizeof(float), 0xFFFFFFF0u);
+    a.in_bytes = (unsigned)((size_t)n_crops * ts.h * ts.w * ts.c * sizeof(float));
+    a.out_bytes = (unsigned)((size_t)n_crops * td.h * td.w * td.c * sizeof(float));
     a.u_bytes = (unsigned)((size_t)16 * L.cout * L.cin * sizeof(float));
-    return launch_wino(a, variant, net->ls, net->ev_start, net->ev_stop);
 }
 
-// Time every candidate tiling of every conv layer at this batch size (activations hold whatever the slots
+// The Winograd layers `members` (independent of each other) as one launch.
+static int launch_wino_layers(vq_tsn* net, const std::vector<int>& members, int n_crops, int variant) {
+    WinoGroup g;
+    memset(&g, 0, sizeof g);
+    VQ_REQUIRE(!members.empty() && (int)members.size() <= kWinoMaxJobs, "a Winograd launch carries 1..%d layers", kWinoMaxJobs);
+    g.n_jobs = (int)members.size();
+    for (int q = 0; q < g.n_jobs; ++q) fill_wino_job(net, members[q], n_crops, g.job[q]);
+    return launch_wino_group(g, variant, net->ls, net->ev_start, net->ev_stop);
+}
+
+static int run_layer(vq_tsn* net, int li, int n_crops, int tune_key);
+
+// Launch one item on crops [crop0, crop0 + n_crops) of the batch; tune_key = the batch size whose tuning table applies.
+// A launch addresses its slots with 32-bit byte offsets, so an item whose slots exceed 2^31 bytes at this batch size
+// runs as several launches over crop ranges (the results do not depend on the cut: every crop is independent).
+static int run_item(vq_tsn* net, const LaunchItem& it, int crop0, int n_crops, int tune_key) {
+    const hipEvent_t e0 = net->ev_start, e1 = net->ev_stop;
+    for (int done = 0; done < n_crops;) {
+        const int n = std::min(n_crops - done, it.max_crops);
+        net->crop_off = crop0 + done;
+        // profiling: the first chunk carries the start event, the last one the stop event
+        net->ev_start = done == 0 ? e0 : nullptr;
+        net->ev_stop = done + n == n_crops ? e1 : nullptr;
+        int rc;
+        if (it.kind == 1) {
+            auto tn = net->tuned.find(tune_key);
+            rc = launch_wino_layers(net, it.layers, n, tn != net->tuned.end() ? tn->second[it.layers[0]] : 0);
+        } else {
+            rc = run_layer(net, it.layers[0], n, tune_key);
+        }
+        if (rc != VQ_OK) {
+            net->crop_off = 0;
+            net->ev_start = net->ev_stop = nullptr;
+            return rc;
+        }
+        done += n;
+    }
+    net->crop_off = 0;
+    net->ev_start = net->ev_stop = nullptr;
+    return VQ_OK;
+}
+
+// Time every candidate tiling of every conv launch at this batch size (activations hold whatever the slots
 // contain; only durations matter) and keep the fastest.
 static int autotune(vq_tsn* net, int n_crops) {
     std::vector<int>& choice = net->tuned[n_crops];
     choice.assign(net->layers.size(), 0);
     net->ls = net->stream;
-    net->crop_off = 0;
     hipEvent_t e0, e1;
     VQ_HIP(hipEventCreate(&e0));
     VQ_HIP(hipEventCreate(&e1));
-    for (int li = 0; li < (int)net->layers.size(); ++li) {
+    for (const LaunchItem& it : net->items) {
+        const int li = it.layers[0];
         if (!is_conv(net->layers[li].op)) continue;
-        const bool wino = net->layers[li].op == VQ_OP_CONV_WINOGRAD;
         float best = 1e30f;
+        int win = 0;
+        const bool wino = net->layers[li].op == VQ_OP_CONV_WINOGRAD;
         for (int t = 0; t < (wino ? kWinoVariants : kNumTiles); ++t) {
-            int rc = wino ? launch_wino_layer(net, li, n_crops, t) : launch_conv_layer(net, li, n_crops, t);   // warm
+            for (int m : it.layers) choice[m] = t;             // a grouped launch runs one variant for all its members
+            int rc = run_item(net, it, 0, n_crops, n_crops);   // warm
             if (rc != VQ_OK) return rc;
             VQ_HIP(hipEventRecord(e0, net->stream));
             for (int r = 0; r < 3; ++r) {
-                rc = wino ? launch_wino_layer(net, li, n_crops, t) : launch_conv_layer(net, li, n_crops, t);
+                rc = run_item(net, it, 0, n_crops, n_crops);
                 if (rc != VQ_OK) return rc;
             }
             VQ_HIP(hipEventRecord(e1, net->stream));
@@ -942,9 +1017,10 @@ static int autotune(vq_tsn* net, int n_crops) {
             VQ_HIP(hipEventElapsedTime(&ms, e0, e1));
             if (ms < best) {
                 best = ms;
-                choice[li] = t;
+                win = t;
             }
         }
+        for (int m : it.layers) choice[m] = win;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -966,21 +1042,21 @@ static int ensure_tuned(vq_tsn* net, int n_crops) {
     return autotune(net, n_crops);
 }
 
-static int run_layer(vq_tsn* net, int li, int n_crops) {
+static int run_layer(vq_tsn* net, int li, int n_crops, int tune_key) {
     const vq_layer_desc& L = net->layers[li];
     const vq_tensor_desc& ts = net->tensors[L.src];
     const vq_tensor_desc& td = net->tensors[L.dst];
     if (L.op == VQ_OP_CONV) {
         int t = net->forced_tile;   // VQ_TSN_TILE (read at creation): test / tuning aid
         if (t < 0) {
-            auto it = net->tuned.find(n_crops);
+            auto it = net->tuned.find(tune_key);
             t = it != net->tuned.end() ? it->second[li] : heuristic_tile(n_crops * td.h * td.w, L.cout, net->cus);
         }
         return launch_conv_layer(net, li, n_crops, t);
     }
     if (L.op == VQ_OP_CONV_WINOGRAD) {
-        auto it = net->tuned.find(n_crops);
-        return launch_wino_layer(net, li, n_crops, it != net->tuned.end() ? it->second[li] : 0);
+        auto it = net->tuned.find(tune_key);
+        return launch_wino_layers(net, std::vector<int>{li}, n_crops, it != net->tuned.end() ? it->second[li] : 0);
     }
     if (L.op == VQ_OP_MAXPOOL || L.op == VQ_OP_AVGPOOL) {
         PoolArgs a;
@@ -1012,8 +1088,16 @@ static int run_layer(vq_tsn* net, int li, int n_crops) {
     if (L.op == VQ_OP_GLOBAL_AVGPOOL) {
         const float* gin = net->slots[L.src] + (size_t)net->crop_off * ts.h * ts.w * ts.c;
         float* gout = net->slots[L.dst] + (size_t)net->crop_off * td.c;
-        VQ_LAUNCH(gavgpool_kernel, cdiv((int64_t)n_crops * L.cin, 256), 256, 0, net->ls, net->ev_start, net->ev_stop, gin, gout, n_crops,
-                  ts.h * ts.w, ts.c, L.src_coff, L.cin, td.c, L.dst_coff);
+        const int T = net->cur_T;
+        if (li == net->consensus_layer && net->fused_consensus) {
+            // the feature blob: global pool and segment consensus in one pass (the launch covers whole clips)
+            const int B = n_crops / T;
+            VQ_LAUNCH(gavgpool_consensus_kernel, dim3(cdiv(L.cin, 64), B), dim3(64, T), 0, net->ls, net->ev_start, net->ev_stop, gin, gout,
+                      net->feat_dev + (size_t)(net->crop_off / T) * net->D, T, ts.h * ts.w, ts.c, L.src_coff, L.cin, td.c, L.dst_coff);
+        } else {
+            VQ_LAUNCH(gavgpool_kernel, cdiv((int64_t)n_crops * L.cin, 256), 256, 0, net->ls, net->ev_start, net->ev_stop, gin, gout, n_crops,
+                      ts.h * ts.w, ts.c, L.src_coff, L.cin, td.c, L.dst_coff);
+        }
         VQ_CHECK_LAUNCH();
         return VQ_OK;
     }
@@ -1037,12 +1121,12 @@ static bool overlaps(const std::vector<SlotRange>& x, const std::vector<SlotRang
     return false;
 }
 
-// Assign every layer to a lane and list the cross-lane waits.  Layer i depends on an earlier layer j when i reads
-// what j wrote, overwrites what j read, or writes the same channels; slots are never recycled, so in a valid plan
-// only the first kind occurs, but all three are honoured.  A layer continues the lane of a producer whose lane
-// has not moved on since (a chain stays on one stream and needs no event); otherwise it takes the lane that has
-// been idle longest.
-static void build_schedule(vq_tsn* net, const vq_conv_segment* segments) {
+// The launch sequence.  Layer i depends on an earlier layer j when i reads what j wrote, overwrites what j read, or
+// writes the same channels (slots are never recycled, so in a valid plan only the first kind occurs, but all three are
+// honoured).  Layers are levelled (level = 1 + deepest dependency) and launched level by level, which is a topological
+// order; inside a level every layer is independent of every other, so the level's Winograd convolutions -- the 3x3 and
+// the first double-3x3 arm of an inception module -- share ONE launch (vq_wino.hip).
+static void build_items(vq_tsn* net, const vq_conv_segment* segments) {
     const int n = (int)net->layers.size();
     std::vector<std::vector<SlotRange>> rd(n), wr(n);
     for (int i = 0; i < n; ++i) {
@@ -1057,32 +1141,56 @@ static void build_schedule(vq_tsn* net, const vq_conv_segment* segments) {
         else
             wr[i].push_back(SlotRange{L.dst, L.dst_coff, L.dst_coff + L.cout});
     }
-    net->lane.assign(n, 0);
-    net->xdeps.assign(n, {});
-    net->needs_event.assign(n, 0);
-    std::vector<int> tail(net->n_lanes, -1);   // last layer put on each lane
+    std::vector<int> level(n, 0);
+    int n_levels = 0;
     for (int i = 0; i < n; ++i) {
-        std::vector<int> deps;
         for (int j = 0; j < i; ++j)
-            if (overlaps(wr[j], rd[i]) || overlaps(rd[j], wr[i]) || overlaps(wr[j], wr[i])) deps.push_back(j);
-        int pick = -1;
-        for (int d : deps)
-            if (tail[net->lane[d]] == d && (pick < 0 || d > tail[pick])) pick = net->lane[d];
-        if (pick < 0) {
-            pick = 0;
-            for (int l = 1; l < net->n_lanes; ++l)
-                if (tail[l] < tail[pick]) pick = l;
+            if (overlaps(wr[j], rd[i]) || overlaps(rd[j], wr[i]) || overlaps(wr[j], wr[i])) level[i] = std::max(level[i], level[j] + 1);
+        n_levels = std::max(n_levels, level[i] + 1);
+    }
+    auto slot_bytes_per_crop = [&](int slot) {
+        const vq_tensor_desc& t = net->tensors[slot];
+        return (size_t)t.h * t.w * t.c * sizeof(float);
+    };
+    auto item_limit = [&](const std::vector<int>& members) {
+        size_t worst = 1;
+        for (int li : members) {
+            const vq_layer_desc& L = net->layers[li];
+            worst = std::max(worst, slot_bytes_per_crop(L.src));
+            if (L.op == VQ_OP_CONV && L.seg_count > 0)
+                for (int q = 0; q < L.seg_count; ++q) worst = std::max(worst, slot_bytes_per_crop(segments[L.seg_first + q].dst));
+            else
+                worst = std::max(worst, slot_bytes_per_crop(L.dst));
         }
-        net->lane[i] = pick;
-        tail[pick] = i;
-        std::vector<int> latest(net->n_lanes, -1);
-        for (int d : deps)
-            if (net->lane[d] != pick) latest[net->lane[d]] = std::max(latest[net->lane[d]], d);
-        for (int l = 0; l < net->n_lanes; ++l)
-            if (latest[l] >= 0) {
-                net->xdeps[i].push_back(latest[l]);
-                net->needs_event[latest[l]] = 1;
+        return (int)std::max<size_t>(1, (size_t)0x7FFFFFF0u / worst);
+    };
+    net->items.clear();
+    net->item_of_layer.assign(n, -1);
+    for (int lv = 0; lv < n_levels; ++lv) {
+        std::vector<int> wino;
+        for (int i = 0; i < n; ++i) {
+            if (level[i] != lv) continue;
+            if (net->layers[i].op == VQ_OP_CONV_WINOGRAD && net->group_wino) {
+                wino.push_back(i);
+                continue;
             }
+            LaunchItem it;
+            it.kind = 0;
+            it.layers = {i};
+            it.max_crops = item_limit(it.layers);
+            net->item_of_layer[i] = (int)net->items.size();
+            net->items.push_back(it);
+        }
+        // longest K loop first: the hardware hands out workgroups in index order, so the short ones fill the tail
+        std::stable_sort(wino.begin(), wino.end(), [&](int x, int y) { return net->layers[x].cin > net->layers[y].cin; });
+        for (size_t q = 0; q < wino.size(); q += kWinoMaxJobs) {
+            LaunchItem it;
+            it.kind = 1;
+            it.layers.assign(wino.begin() + q, wino.begin() + std::min(wino.size(), q + kWinoMaxJobs));
+            it.max_crops = item_limit(it.layers);
+            for (int m : it.layers) net->item_of_layer[m] = (int)net->items.size();
+            net->items.push_back(it);
+        }
     }
 }
 
@@ -1120,6 +1228,10 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
                    "layer %d: bad tensor slots %d -> %d", i, L.src, L.dst);
         const vq_tensor_desc& ts = tensors[L.src];
         const vq_tensor_desc& td = tensors[L.dst];
+        // one crop of any slot must stay addressable with a signed 32-bit byte offset (the kernels' buffer offsets);
+        // larger batches are cut into crop ranges per launch (LaunchItem::max_crops)
+        VQ_REQUIRE((size_t)ts.h * ts.w * ts.c * sizeof(float) <= 0x7FFFFFF0u && (size_t)td.h * td.w * td.c * sizeof(float) <= 0x7FFFFFF0u,
+                   "layer %d: one crop of a tensor slot exceeds 2 GiB", i);
         VQ_REQUIRE(L.src_coff >= 0 && L.cin > 0 && L.src_coff + L.cin <= ts.c, "layer %d: reads channels [%d,%d) of a %d-channel slot",
                    i, L.src_coff, L.src_coff + L.cin, ts.c);
         VQ_REQUIRE(multi || (L.dst_coff >= 0 && L.cout > 0 && L.dst_coff + L.cout <= td.c),
@@ -1188,6 +1300,9 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
     net->D = tensors[feature_slot].c;
     net->blob_floats = blob_floats;
     net->flops_per_crop = 2.0 * macs;
+    for (int i = 0; i < n_layers; ++i)
+        if (layers[i].op == VQ_OP_GLOBAL_AVGPOOL && layers[i].dst == feature_slot && layers[i].dst_coff == 0 && layers[i].cout == net->D)
+            net->consensus_layer = i;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) net->cus = prop.multiProcessorCount;
     net->slots.assign(n_tensors, nullptr);
@@ -1232,14 +1347,14 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
     }
     {
         if (const char* at = getenv("VQ_TSN_AUTOTUNE")) net->autotune = atoi(at) != 0;
+        if (const char* gr = getenv("VQ_TSN_GROUP")) net->group_wino = atoi(gr) != 0;
+        if (const char* po = getenv("VQ_TSN_POISON")) net->poison = atoi(po) != 0;
         if (const char* force = getenv("VQ_TSN_TILE")) {
             int bm = 0, bn = 0, bk = 32, pipe = 0;   // "BMxBN", "BMxBNxBK" or "BMxBNxBKxP" (P = 1: pipelined kernel)
             if (sscanf(force, "%dx%dx%dx%d", &bm, &bn, &bk, &pipe) >= 2)
                 for (int i = 0; i < kNumTiles; ++i)
                     if (kTiles[i].bm == bm && kTiles[i].bn == bn && kTiles[i].bk == bk && kTiles[i].pipe == pipe) net->forced_tile = i;
         }
-        const char* env = getenv("VQ_TSN_LANES");
-        net->n_lanes = std::min(std::max(env ? atoi(env) : 1, 1), 8);
         const char* sp = getenv("VQ_TSN_SPLIT");
         if (sp && strchr(sp, ',')) {                   // "2,1": sub-batches of 2/3 and 1/3 of the crops
             for (const char* q = sp; *q;) {
@@ -1254,25 +1369,17 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
             net->n_split = std::min(std::max(sp ? atoi(sp) : 2, 1), 8);
             net->split_parts.assign(net->n_split, 1);
         }
-        if (net->n_split > 1) net->n_lanes = 1;   // one or the other
-        build_schedule(net, segments);
-        const int n_streams = std::max(net->n_lanes, net->n_split);
-        net->lane_streams.assign(n_streams, nullptr);
-        net->join_ev.assign(n_streams, nullptr);
-        net->done.assign(n_layers, nullptr);
-        for (int l = 1; l < n_streams; ++l) {
-            e = hipStreamCreateWithFlags(&net->lane_streams[l], hipStreamNonBlocking);
-            if (e != hipSuccess) return bail("hipStreamCreate(lane)", e);
+        build_items(net, segments);
+        net->split_streams.assign(net->n_split, nullptr);
+        net->join_ev.assign(net->n_split, nullptr);
+        for (int l = 1; l < net->n_split; ++l) {
+            e = hipStreamCreateWithFlags(&net->split_streams[l], hipStreamNonBlocking);
+            if (e != hipSuccess) return bail("hipStreamCreate(sub-batch)", e);
             e = hipEventCreateWithFlags(&net->join_ev[l], hipEventDisableTiming);
-            if (e != hipSuccess) return bail("hipEventCreate(lane join)", e);
+            if (e != hipSuccess) return bail("hipEventCreate(sub-batch join)", e);
         }
         e = hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming);
-        if (e != hipSuccess) return bail("hipEventCreate(lane fork)", e);
-        for (int i = 0; i < n_layers; ++i)
-            if (net->needs_event[i]) {
-                e = hipEventCreateWithFlags(&net->done[i], hipEventDisableTiming);
-                if (e != hipSuccess) return bail("hipEventCreate(layer)", e);
-            }
+        if (e != hipSuccess) return bail("hipEventCreate(fork)", e);
     }
     e = hipMalloc((void**)&net->zeros, 256);
     if (e != hipSuccess) return bail("hipMalloc(zero page)", e);
@@ -1332,6 +1439,11 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
         VQ_HIP(hipMemcpyAsync(net->mean_dev, net->mean_cached.data(), in_c * sizeof(float), hipMemcpyHostToDevice, net->stream));
         VQ_HIP(hipStreamSynchronize(net->stream));
     }
+    if (net->poison)
+        for (size_t i = 0; i < net->slots.size(); ++i) {
+            const vq_tensor_desc& t = net->tensors[i];
+            VQ_HIP(hipMemsetAsync(net->slots[i], 0xFF, (size_t)net->max_crops * t.h * t.w * t.c * sizeof(float), net->stream));
+        }
     if (net->input.s2d_pad < 0) {
         const int64_t nchunk = npix * (t0.c / 4);
         preprocess_kernel<<<cdiv(nchunk, 256), 256, 0, net->stream>>>(src, net->slots[0], nchunk, in_c, t0.c, net->mean_dev);
@@ -1341,70 +1453,69 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
                                                                         t0.h, t0.w, net->input.s2d_pad, net->mean_dev);
     }
     VQ_CHECK_LAUNCH();
+    net->cur_T = T;
+    const int n_items = (int)net->items.size();
     hipEvent_t* ev = nullptr;
-    if (net->profile_depth > 0) {
-        ev = net->events.data() + (size_t)(net->profile_count % net->profile_depth) * (2 * net->layers.size());
-    }
-    // Per-layer profiling serialises the graph on the caller's stream (each duration is then the layer alone).
-    const bool lanes_on = net->n_lanes > 1 && !ev;
+    if (net->profile_depth > 0) ev = net->events.data() + (size_t)(net->profile_count % net->profile_depth) * (2 * n_items);
+    // Per-launch profiling keeps everything on the caller's stream (each duration is then the launch alone).
     int parts_sum = 0;
     for (int v : net->split_parts) parts_sum += v;
-    const int n_split = (!ev && net->n_split > 1 && n_crops % parts_sum == 0) ? net->n_split : 1;
+    int n_split = (!ev && net->n_split > 1 && n_crops % parts_sum == 0) ? net->n_split : 1;
     std::vector<int> sub(n_split, n_crops), sub_off(n_split, 0);
-    if (n_split > 1)
+    if (n_split > 1) {
         for (int sb = 0, o = 0; sb < n_split; ++sb) {
             sub[sb] = n_crops / parts_sum * net->split_parts[sb];
             sub_off[sb] = o;
             o += sub[sb];
         }
+    }
+    {   // the consensus rides in the global-pool launch when every launch of that layer covers whole clips
+        bool whole = net->consensus_layer >= 0 && T <= kMaxFusedT;
+        if (whole) {
+            const int cap = net->items[net->item_of_layer[net->consensus_layer]].max_crops;
+            for (int sb = 0; sb < n_split; ++sb)
+                if (sub[sb] % T != 0 || sub_off[sb] % T != 0 || (sub[sb] > cap && cap % T != 0)) whole = false;
+        }
+        net->fused_consensus = whole;
+    }
     for (int sb = 0; sb < n_split; ++sb) {      // n_split == 1: sub[0] is the whole batch
         const int rc = ensure_tuned(net, sub[sb]);
         if (rc != VQ_OK) return rc;
     }
-    if (lanes_on || n_split > 1) {
-        VQ_HIP(hipEventRecord(net->fork_ev, net->stream));
-        for (int l = 1; l < std::max(net->n_lanes, n_split); ++l) VQ_HIP(hipStreamWaitEvent(net->lane_streams[l], net->fork_ev, 0));
-    }
     if (n_split > 1) {
-        // Batch split: the sub-batches are independent, so each runs the whole layer list on its own stream with no
+        // Batch split: the sub-batches are independent, so each runs the whole launch list on its own stream with no
         // synchronisation in between; one sub-batch's launch ramp and tail overlap the other's steady state.
-        for (int li = 0; li < (int)net->layers.size(); ++li)
+        VQ_HIP(hipEventRecord(net->fork_ev, net->stream));
+        for (int l = 1; l < n_split; ++l) VQ_HIP(hipStreamWaitEvent(net->split_streams[l], net->fork_ev, 0));
+        for (const LaunchItem& it : net->items)
             for (int sb = 0; sb < n_split; ++sb) {
-                net->ls = sb > 0 ? net->lane_streams[sb] : net->stream;
-                net->crop_off = sub_off[sb];
-                const int rc = run_layer(net, li, sub[sb]);
-                if (rc != VQ_OK) {
-                    net->crop_off = 0;
-                    return rc;
-                }
+                net->ls = sb > 0 ? net->split_streams[sb] : net->stream;
+                const int rc = run_item(net, it, sub_off[sb], sub[sb], sub[sb]);
+                if (rc != VQ_OK) return rc;
             }
-        net->crop_off = 0;
-    } else {
-        for (int li = 0; li < (int)net->layers.size(); ++li) {
-            net->ls = lanes_on && net->lane[li] > 0 ? net->lane_streams[net->lane[li]] : net->stream;
-            if (lanes_on)
-                for (int d : net->xdeps[li]) VQ_HIP(hipStreamWaitEvent(net->ls, net->done[d], 0));
-            if (ev) {
-                net->ev_start = ev[2 * li];
-                net->ev_stop = ev[2 * li + 1];
-            }
-            const int rc = run_layer(net, li, n_crops);
-            net->ev_start = net->ev_stop = nullptr;
-            if (rc != VQ_OK) return rc;
-            if (lanes_on && net->needs_event[li]) VQ_HIP(hipEventRecord(net->done[li], net->ls));
-        }
-    }
-    net->ls = net->stream;
-    if (lanes_on || n_split > 1)
-        for (int l = 1; l < std::max(net->n_lanes, n_split); ++l) {
-            VQ_HIP(hipEventRecord(net->join_ev[l], net->lane_streams[l]));
+        net->ls = net->stream;
+        for (int l = 1; l < n_split; ++l) {
+            VQ_HIP(hipEventRecord(net->join_ev[l], net->split_streams[l]));
             VQ_HIP(hipStreamWaitEvent(net->stream, net->join_ev[l], 0));
         }
+    } else {
+        net->ls = net->stream;
+        for (int q = 0; q < n_items; ++q) {
+            if (ev) {
+                net->ev_start = ev[2 * q];
+                net->ev_stop = ev[2 * q + 1];
+            }
+            const int rc = run_item(net, net->items[q], 0, n_crops, n_crops);
+            if (rc != VQ_OK) return rc;
+        }
+    }
     if (ev) ++net->profile_count;
     const int B = n_crops / T;
-    consensus_kernel<<<cdiv((int64_t)B * net->D, 256), 256, 0, net->stream>>>(net->slots[net->feature_slot], net->feat_dev, B, T,
-                                                                              net->D, net->D);
-    VQ_CHECK_LAUNCH();
+    if (!net->fused_consensus) {                  // consensus not fused into the global-pool launch: separate pass
+        consensus_kernel<<<cdiv((int64_t)B * net->D, 256), 256, 0, net->stream>>>(net->slots[net->feature_slot], net->feat_dev, B, T,
+                                                                                  net->D, net->D);
+        VQ_CHECK_LAUNCH();
+    }
     net->last_crops = n_crops;
     if (feat_host)
         VQ_HIP(hipMemcpyAsync(feat_host, net->feat_dev, (size_t)B * net->D * sizeof(double), hipMemcpyDeviceToHost, net->stream));
@@ -1443,11 +1554,18 @@ int vq_tsn_set_profile(vq_tsn* net, int32_t depth) {
     VQ_HIP(hipStreamSynchronize(net->stream));
     for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
     net->events.clear();
-    net->events.resize((size_t)depth * 2 * net->layers.size());
+    net->events.resize((size_t)depth * 2 * net->items.size());
     for (hipEvent_t& e : net->events) VQ_HIP(hipEventCreate(&e));
     net->profile_depth = depth;
     net->profile_count = 0;
     return VQ_OK;
+}
+
+// Share of a grouped launch's time attributed to one member: its matrix-core work (16 multiplies per tile, channel pair).
+static double wino_weight(const vq_tsn* net, int li) {
+    const vq_layer_desc& L = net->layers[li];
+    const vq_tensor_desc& td = net->tensors[L.dst];
+    return (double)((td.h + 1) / 2) * ((td.w + 1) / 2) * L.cin * L.cout;
 }
 
 int vq_tsn_layer_times(vq_tsn* net, float* ms, double* flops, int32_t n_layers) {
@@ -1458,13 +1576,18 @@ int vq_tsn_layer_times(vq_tsn* net, float* ms, double* flops, int32_t n_layers) 
     DeviceGuard g(net->device);
     VQ_HIP(hipStreamSynchronize(net->stream));
     const int sets = std::min(net->profile_count, net->profile_depth);
+    const int n_items = (int)net->items.size();
     for (int i = 0; i < n_layers; ++i) ms[i] = 0.f;
     for (int sidx = 0; sidx < sets; ++sidx) {
-        hipEvent_t* ev = net->events.data() + (size_t)sidx * (2 * n_layers);
-        for (int i = 0; i < n_layers; ++i) {
+        hipEvent_t* ev = net->events.data() + (size_t)sidx * (2 * n_items);
+        for (int q = 0; q < n_items; ++q) {
             float t = 0.f;
-            VQ_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
-            ms[i] += t / sets;                                   // mean over the profiled forwards
+            VQ_HIP(hipEventElapsedTime(&t, ev[2 * q], ev[2 * q + 1]));
+            const LaunchItem& it = net->items[q];
+            double wsum = 0;
+            for (int m : it.layers) wsum += it.kind == 1 ? wino_weight(net, m) : 1.0;
+            for (int m : it.layers)                               // a grouped launch: split by matrix-core work
+                ms[m] += (float)(t / sets * ((it.kind == 1 ? wino_weight(net, m) : 1.0) / wsum));
         }
     }
     if (flops) {
@@ -1478,6 +1601,26 @@ int vq_tsn_layer_times(vq_tsn* net, float* ms, double* flops, int32_t n_layers) 
     return VQ_OK;
 }
 
+int vq_tsn_launch_items(vq_tsn* net, int32_t* item_of_layer, int32_t n_layers, int32_t* n_items) {
+    VQ_REQUIRE(net && item_of_layer && n_items, "NULL argument");
+    VQ_REQUIRE(n_layers == (int)net->layers.size(), "n_layers must be %d", (int)net->layers.size());
+    for (int i = 0; i < n_layers; ++i) item_of_layer[i] = net->item_of_layer[i];
+    *n_items = (int)net->items.size();
+    return VQ_OK;
+}
+
+int vq_tsn_tuned_sizes(vq_tsn* net, int32_t* sizes, int32_t cap, int32_t* n) {
+    VQ_REQUIRE(net && n && (cap == 0 || sizes), "NULL argument");
+    std::lock_guard<std::mutex> lk(net->mu);
+    int k = 0;
+    for (const auto& kv : net->tuned) {
+        if (k < cap) sizes[k] = kv.first;
+        ++k;
+    }
+    *n = k;
+    return VQ_OK;
+}
+
 int vq_tsn_layer_tiles(vq_tsn* net, int32_t n_crops, int32_t* tiles, int32_t n_layers) {
     VQ_REQUIRE(net && tiles, "NULL argument");
     VQ_REQUIRE(n_layers == (int)net->layers.size(), "n_layers must be %d", (int)net->layers.size());
@@ -1486,7 +1629,8 @@ int vq_tsn_layer_tiles(vq_tsn* net, int32_t n_crops, int32_t* tiles, int32_t n_l
     for (int i = 0; i < n_layers; ++i) {
         tiles[4 * i] = tiles[4 * i + 1] = tiles[4 * i + 2] = tiles[4 * i + 3] = 0;
         if (net->layers[i].op == VQ_OP_CONV_WINOGRAD) {   // 32 tiles (128 pixels) x 32 (v+1) channels, 8 channels per step
-            const int v = it != net->tuned.end() ? it->second[i] : 0;
+            const int lead = net->items[net->item_of_layer[i]].layers[0];   // a grouped launch runs ONE variant: its first member's
+            const int v = it != net->tuned.end() ? it->second[lead] : 0;
             tiles[4 * i] = 128;
             tiles[4 * i + 1] = 32 * (v + 1);
             tiles[4 * i + 2] = 8;
@@ -1529,13 +1673,6 @@ int vq_tsn_set_layer_tiles(vq_tsn* net, int32_t n_crops, const int32_t* tiles, i
     }
     std::lock_guard<std::mutex> lk(net->mu);
     net->tuned[n_crops] = choice;
-    return VQ_OK;
-}
-
-int vq_tsn_layer_lanes(vq_tsn* net, int32_t* lanes, int32_t n_layers) {
-    VQ_REQUIRE(net && lanes, "NULL argument");
-    VQ_REQUIRE(n_layers == (int)net->layers.size(), "n_layers must be %d", (int)net->layers.size());
-    for (int i = 0; i < n_layers; ++i) lanes[i] = net->lane[i];
     return VQ_OK;
 }
 

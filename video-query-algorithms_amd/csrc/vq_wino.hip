@@ -4,7 +4,7 @@
 // src/features_GPU_compute/models/ucf101/tsn_bn_inception_rgb_deploy.prototxt).  For a 2x2 output tile
 //     Y = A^T [ (G g G^T) . (B^T d B) ] A          d: 4x4 input patch, g: 3x3 filter, "." elementwise
 // turns 36 multiplies per (tile, cin, cout) into 16: the layer becomes 16 independent GEMMs
-//     M_xi[tile][cout] = sum_cin V_xi[tile][cin] * U_xi[cin][cout],   xi = 4 i + j  (position in the 4x4 patch)
+//     M_xi[cout][tile] = sum_cin U_xi[cout][cin] * V_xi[cin][tile],   xi = 4 i + j  (position in the 4x4 patch)
 // that run on v_mfma_f32_32x32x2_f32, 2.25x fewer matrix-core cycles than the direct form.  Everything is fused in
 // one kernel: the input transform happens on the way into LDS / out of LDS, the output transform in the epilogue.
 //
@@ -12,14 +12,28 @@
 // the 4x4 position grid (4 GEMMs, accumulators 4 x (BN/32) x 16 registers).  Cin is walked 8 channels per step.
 //   activations: wave r loads patch row r of every tile (4 pixels x 8 channels), applies the column half of the
 //                transform (h = d B, 4 adds per channel) and stores h[r][j] to LDS; the row half is applied when
-//                wave i reads its A fragment: V[i][j] = h[ra][j] +- h[rb][j]  (two ds_read_b128 and 4 FMAs for 4 k's).
+//                wave i reads its fragment: V[i][j] = h[ra][j] +- h[rb][j]  (two ds_read_b128 and 4 FMAs for 4 k's).
 //   filters:     U is pre-transformed on the host (fp64, rounded once) and laid out [Cin/8][16][Cout][8], which
-//                is exactly the MFMA B-fragment order: each wave loads its own fragments straight from L2 into
+//                is exactly the MFMA fragment order: each wave loads its own fragments straight from L2 into
 //                registers, a full step ahead, with no LDS traffic and no sharing between waves.
+//   MFMA roles:  the FILTER fragment is the A operand (rows = output channels), the activation fragment the B
+//                operand (columns = tiles).  A lane then holds 4 CONSECUTIVE output channels of one tile in 4
+//                consecutive accumulator registers, so everything behind the K loop moves 16 bytes per instruction.
 //   epilogue:    wave i reduces its 4 positions along j in registers (A^T along columns), the 4 waves exchange
-//                through LDS for the reduction along i, then bias + ReLU and 16-byte NHWC stores.
-// The k order of every output element is fixed (channels ascending in groups of 8), so the BN variants produce
-// identical bits.  Rounding differs from the direct kernel (Winograd F(2,3) error is ~1-2.5x the direct fp32
+//                through LDS (ds_write_b128) for the reduction along i, then ReLU and 16-byte NHWC buffer stores.
+//                The bias costs nothing: A^T e_11 A = all ones, so starting the accumulator of position (1,1) at the
+//                bias adds it to all four outputs of the tile.
+//
+// The fp32 matrix instructions execute on the SIMD's fp32 lanes -- every VALU instruction of any co-resident wave takes
+// matrix-pipe time (tools/ubench/mfma_coissue.hip).  The code around the K loop is therefore written for few VALU
+// instructions: the tile -> (image, row, column) decoding of a workgroup is done once on the scalar unit with
+// multiply-high reciprocals (the per-lane part is a walk of at most 31 tiles from there), transforms use packed fp32
+// instructions, addresses are 32-bit buffer offsets whose out-of-range value doubles as the padding / tail mask.
+//
+// A launch carries up to kWinoMaxJobs independent convolutions (WinoGroup: the 3x3 and the first double-3x3 arm of an
+// inception module): their workgroups fill each other's tail rounds and one kernel boundary disappears.
+// The k order of every output element is fixed (channels ascending in groups of 8), so all variants and groupings
+// produce identical bits.  Rounding differs from the direct kernel (Winograd F(2,3) error is ~1-2.5x the direct fp32
 // error, measured against the fp64 oracle: tests/test_tsn_gpu.py).
 #include "vq_common.h"
 #include "vq_tsn_kernels.h"
@@ -28,14 +42,13 @@ using namespace vq;
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef unsigned uintx4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
 
 namespace {
 
-// The VALU and the matrix pipe of a SIMD do not overlap well (tools/ubench/mfma_coissue.hip: every v_fma_f32 placed
-// behind an MFMA adds ~3-4 cycles even with four waves per SIMD), so the transform arithmetic is written as packed
-// fp32 instructions (v_pk_add_f32 / v_pk_fma_f32: two floats per lane per instruction; inline asm, because the compiler
-// scalarises float4 subtraction).  Only used where the result goes to LDS (see pk_fma below).
-typedef float floatx2 __attribute__((ext_vector_type(2)));
+// Packed fp32 arithmetic (v_pk_add_f32 / v_pk_fma_f32: two floats per lane per instruction; inline asm, because the
+// compiler scalarises float4 subtraction).  Only used where the result goes to LDS or memory (see pk_fma below).
 __device__ __forceinline__ floatx2 pk_add2(floatx2 x, floatx2 y) {
     floatx2 r;
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
@@ -54,12 +67,20 @@ __device__ __forceinline__ floatx4 pk_sub(floatx4 x, floatx4 y) {
     const floatx2 lo = pk_sub2(x.xy, y.xy), hi = pk_sub2(x.zw, y.zw);
     return (floatx4){lo.x, lo.y, hi.x, hi.y};
 }
-// x * s + z on the A-fragment side.  NOT inline asm: the result feeds an MFMA, and the compiler's hazard recogniser
+// x * s + z on the fragment side.  NOT inline asm: the result feeds an MFMA, and the compiler's hazard recogniser
 // only inserts the VALU -> MFMA wait states for instructions it can see (an asm VALU in front of an MFMA read stale
 // registers); the elementwise builtin lets it emit v_pk_fma_f32 where it wants and keep the hazards right.
 __device__ __forceinline__ floatx4 pk_fma(floatx4 x, floatx2 s, floatx4 z) {
     const floatx2 lo = __builtin_elementwise_fma(x.xy, s, z.xy), hi = __builtin_elementwise_fma(x.zw, s, z.zw);
     return (floatx4){lo.x, lo.y, hi.x, hi.y};
+}
+
+// max(x, 0) as ONE instruction: fmaxf() on a value that comes out of inline asm costs a canonicalising v_max(x, x)
+// first (the compiler cannot know it is not a signalling NaN); the result only goes to memory.
+__device__ __forceinline__ float relu1(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 
 #ifdef VQ_WINO_PHASES   // tools/ubench/wino_phases.hip: where a workgroup's time goes
@@ -77,22 +98,39 @@ __device__ __forceinline__ floatx4 pk_fma(floatx4 x, floatx2 s, floatx4 z) {
 
 constexpr int BP = 32;    // tiles per workgroup
 constexpr int KC = 8;     // channels per step
-constexpr int HS_STAGE = 4 * 4 * BP * KC;   // floats: h[r][j][tile][k]
+constexpr int HS_STAGE = 4 * 4 * BP * KC;     // floats: h[r][j][tile][k]
+constexpr int EP_ROW = 36;                    // epilogue image: 32 channels of a tile + 4 floats of padding
+constexpr int EP_FLOATS = 2 * 4 * BP * EP_ROW;   // [i][x][tile][EP_ROW]
+constexpr int LDS_FLOATS = EP_FLOATS > 2 * HS_STAGE ? EP_FLOATS : 2 * HS_STAGE;
+
+// Image, tile row and tile column of the t-th tile behind the workgroup's first one (t < 32): a walk, not a division.
+struct TileAt {
+    int img, ty, tx;
+};
+__device__ __forceinline__ TileAt tile_at(int t, int img0, int ty0, int tx0, int th, int tw, unsigned s_th, unsigned s_tw) {
+    const unsigned lin = (unsigned)(tx0 + t);
+    const unsigned q1 = (lin * s_tw) >> 16;
+    const unsigned ly = (unsigned)ty0 + q1;
+    const unsigned q2 = (ly * s_th) >> 16;
+    return TileAt{img0 + (int)q2, (int)(ly - q2 * (unsigned)th), (int)(lin - q1 * (unsigned)tw)};
+}
 
 template <int NB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 4 : 2, NB == 1 ? 4 : 2)))
-void wino_f2x2_3x3_kernel(WinoArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* hs = reinterpret_cast<float*>(smem_raw);        // [2][4][4][32][8] (K loop); [4][2][32][32] (epilogue)
-
+__device__ __forceinline__ void wino_unit(const WinoJob& a, int unit, float* hs) {
     VQ_PHASE(0)
     const int tid = threadIdx.x;
     const int lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int p0 = (tile / a.tiles_n) * BP;
-    const int n0 = (tile % a.tiles_n) * (32 * NB);
-    const int tpi = a.th * a.tw;                           // tiles per image
+    // ---- which tiles, which channels: all on the scalar unit ---------------------------------------------------
+    const int tile = xcd_remap(unit, a.n_units);
+    const int pb = (int)magic_div((unsigned)tile, a.m_tiles_n);
+    const int p0 = pb * BP;
+    const int n0 = (tile - pb * a.tiles_n) * (32 * NB);
+    const int tpi = a.th * a.tw;
+    const int img0 = (int)magic_div((unsigned)p0, a.m_tpi);
+    const int rem0 = p0 - img0 * tpi;
+    const int ty0 = (int)magic_div((unsigned)rem0, a.m_tw);
+    const int tx0 = rem0 - ty0 * a.tw;
 
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
@@ -101,20 +139,14 @@ void wino_f2x2_3x3_kernel(WinoArgs a) {
     unsigned poff[4];                                      // byte offset of pixel c of the row; 0xFFFFFFFF = zero padding
     {
         const int t = lane >> 1, c4 = lane & 1;
-        const int p = p0 + t;
-        const bool ok = p < a.P;
-        const int pp = ok ? p : 0;
-        const int n_img = pp / tpi, rem = pp - n_img * tpi;
-        const int ty = rem / a.tw, tx = rem - ty * a.tw;
-        const int y = 2 * ty - 1 + wave, x0 = 2 * tx - 1;
-        const bool row_ok = ok && (unsigned)y < (unsigned)a.H;
+        const TileAt ta = tile_at(t, img0, ty0, tx0, a.th, a.tw, a.s_th, a.s_tw);
+        const int y = 2 * ta.ty - 1 + wave, x0 = 2 * ta.tx - 1;
+        const bool row_ok = p0 + t < a.P && (unsigned)y < (unsigned)a.H;
+        const int base = (((ta.img * a.H + y) * a.W + x0) * a.Cs_in + a.coff_in + c4 * 4) * 4;
+        const int px = a.Cs_in * 4;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int x = x0 + c;
-            poff[c] = (row_ok && (unsigned)x < (unsigned)a.W)
-                          ? (unsigned)((((n_img * a.H + y) * a.W + x) * a.Cs_in + a.coff_in + c4 * 4) * 4)
-                          : 0xFFFFFFFFu;
-        }
+        for (int c = 0; c < 4; ++c)
+            poff[c] = (row_ok && (unsigned)(x0 + c) < (unsigned)a.W) ? (unsigned)(base + c * px) : 0xFFFFFFFFu;
     }
     const int hs_store = (wave * 4 * BP * KC) + lane * 4;  // + j * BP * KC (+ stage)
 
@@ -133,6 +165,8 @@ void wino_f2x2_3x3_kernel(WinoArgs a) {
     const unsigned u_wave = (unsigned)(((wave * 4) * a.Cout + n0) * 8 * 4);
     const unsigned u_pos = (unsigned)(a.Cout * 8 * 4);                  // bytes between positions
 
+    // Accumulators: register e of a lane is output channel (e & 3) + 8 (e >> 2) + 4 half of tile l31.  Position (1,1)
+    // starts at the bias (see the header), everything else at zero.
     floatx16 acc[4][NB];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -140,6 +174,18 @@ void wino_f2x2_3x3_kernel(WinoArgs a) {
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.f;
+    if (wave == 1) {
+        const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, (unsigned)a.Cout * 4u, 0x00020000);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const floatx4 bv = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                   b_rsrc, (unsigned)((n0 + 32 * nb + 8 * g + 4 * half) * 4), 0, 0));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[1][nb][4 * g + r] = bv[r];
+            }
+    }
 
     constexpr int G = NB == 1 ? 2 : 1, NGRP = 4 / G;   // positions per MFMA group, groups per step
     floatx4 d[4];          // patch row in flight (next step)
@@ -162,7 +208,7 @@ void wino_f2x2_3x3_kernel(WinoArgs a) {
         *reinterpret_cast<floatx4*>(dst + 3 * BP * KC) = pk_sub(d[1], d[3]);                                    \
     }
 // One step on LDS stage ST: 4 positions x 4 k-pairs x NB MFMAs, in groups of G positions chosen so that two
-// accumulators alternate (consecutive MFMAs never chain on one accumulator).  The A fragments of group g+1 are read
+// accumulators alternate (consecutive MFMAs never chain on one accumulator).  The fragments of group g+1 are read
 // under the MFMAs of group g; with NEXT, a group's filter registers are refilled for step KSTEP+1 as soon as its
 // MFMAs are issued (the loads then have a whole step to land).  sched_barrier pins that order: left alone, the
 // compiler sinks every global load to the end of the step and waits for it on the spot.
@@ -183,7 +229,7 @@ void wino_f2x2_3x3_kernel(WinoArgs a) {
             _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                       \
                 _Pragma("unroll") for (int q = 0; q < G; ++q)                                                   \
                     _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                           \
-                        acc[G * g + q][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][e], bq[G * g + q][nb][e], acc[G * g + q][nb], 0, 0, 0); \
+                        acc[G * g + q][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[G * g + q][nb][e], av[q][e], acc[G * g + q][nb], 0, 0, 0); \
             if (NEXT) {                                                                                         \
                 _Pragma("unroll") for (int q = 0; q < G; ++q) VQ_W_LOAD_U((KSTEP) + 1, G * g + q)               \
             }                                                                                                   \
@@ -216,55 +262,61 @@ void wino_f2x2_3x3_kernel(WinoArgs a) {
 #undef VQ_W_READ_A
 
     // ---- epilogue: Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]] ---------------------------------------------------
-    // This thread finishes output pixel (a_, b_) of tile p0 + (tid >> 3), channels (tid & 7)*4 .. +4 of each block.
+    // Exchange image: ep[i][x][tile][channel], x = the two sums along j of position row i.  This thread then finishes
+    // the four output pixels of tile et, channels ec*4 .. +4 of each 32-channel block.
     const int et = tid >> 3, ec = tid & 7;
-    const int ep = p0 + et;
-    const bool ep_ok = ep < a.P;
-    const int epp = ep_ok ? ep : 0;
-    const int e_img = epp / tpi, e_rem = epp - e_img * tpi;
-    const int ety = e_rem / a.tw, etx = e_rem - ety * a.tw;
+    const TileAt te = tile_at(et, img0, ty0, tx0, a.th, a.tw, a.s_th, a.s_tw);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
+    const int oy = 2 * te.ty, ox = 2 * te.tx;
+    const int obase = (((te.img * a.H + oy) * a.W + ox) * a.Cs_out + a.coff_out + n0 + ec * 4) * 4;
+    const bool tile_ok = p0 + et < a.P;
+    unsigned ooff[4];                                      // (a_, b_) = (u >> 1, u & 1); 0xFFFFFFFF: the store is dropped
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        ooff[u] = (tile_ok && oy + (u >> 1) < a.H && ox + (u & 1) < a.W) ? (unsigned)(obase + ((u >> 1) * a.W + (u & 1)) * a.Cs_out * 4)
+                                                                           : 0xFFFFFFFFu;
+    float* ep_w = hs + ((wave * 2) * BP + l31) * EP_ROW + 4 * half;      // + x * BP * EP_ROW + 8 g
+    const float* ep_r = hs + et * EP_ROW + ec * 4;                        // + (i * 2 + b_) * BP * EP_ROW
     __syncthreads();            // all waves are done with the K-loop image of the LDS
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const int nbase = n0 + 32 * nb;
-        // along j, in registers; in the MFMA C/D layout register e of a lane is tile row (e&3) + 8 (e>>2) + 4 half,
-        // column (= output channel) l31
+        // along j, in registers, two channels per instruction: t0 = (m0 + m1) + m2, t1 = (m1 - m2) - m3
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * half;
-            const float t0 = (acc[0][nb][e] + acc[1][nb][e]) + acc[2][nb][e];
-            const float t1 = (acc[1][nb][e] - acc[2][nb][e]) - acc[3][nb][e];
-            hs[((wave * 2 + 0) * 32 + row) * 32 + l31] = t0;
-            hs[((wave * 2 + 1) * 32 + row) * 32 + l31] = t1;
+        for (int g = 0; g < 4; ++g) {
+            floatx4 t0, t1;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int e = 4 * g + 2 * h2;
+                const floatx2 m0 = {acc[0][nb][e], acc[0][nb][e + 1]}, m1 = {acc[1][nb][e], acc[1][nb][e + 1]};
+                const floatx2 m2 = {acc[2][nb][e], acc[2][nb][e + 1]}, m3 = {acc[3][nb][e], acc[3][nb][e + 1]};
+                const floatx2 s0 = pk_add2(pk_add2(m0, m1), m2), s1 = pk_sub2(pk_sub2(m1, m2), m3);
+                t0[2 * h2] = s0.x;
+                t0[2 * h2 + 1] = s0.y;
+                t1[2 * h2] = s1.x;
+                t1[2 * h2 + 1] = s1.y;
+            }
+            *reinterpret_cast<floatx4*>(ep_w + 8 * g) = t0;
+            *reinterpret_cast<floatx4*>(ep_w + BP * EP_ROW + 8 * g) = t1;
         }
         __syncthreads();
-        if (nbase < a.Cout) {
-            const floatx4 bias = *reinterpret_cast<const floatx4*>(a.bias + nbase + ec * 4);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int a_ = u >> 1, b_ = u & 1;
-                const float* src = hs + (b_ * 32 + et) * 32 + ec * 4;
-                const floatx4 v1 = *reinterpret_cast<const floatx4*>(src + 1 * 2048);
-                const floatx4 v2 = *reinterpret_cast<const floatx4*>(src + 2 * 2048);
-                floatx4 y;
-                if (a_ == 0) {
-                    const floatx4 v0 = *reinterpret_cast<const floatx4*>(src + 0 * 2048);
-                    y = (v0 + v1) + v2;
-                } else {
-                    const floatx4 v3 = *reinterpret_cast<const floatx4*>(src + 3 * 2048);
-                    y = (v1 - v2) - v3;
+        for (int b_ = 0; b_ < 2; ++b_) {
+            const floatx4 v0 = *reinterpret_cast<const floatx4*>(ep_r + (0 * 2 + b_) * BP * EP_ROW);
+            const floatx4 v1 = *reinterpret_cast<const floatx4*>(ep_r + (1 * 2 + b_) * BP * EP_ROW);
+            const floatx4 v2 = *reinterpret_cast<const floatx4*>(ep_r + (2 * 2 + b_) * BP * EP_ROW);
+            const floatx4 v3 = *reinterpret_cast<const floatx4*>(ep_r + (3 * 2 + b_) * BP * EP_ROW);
+            floatx4 y0 = pk_add(pk_add(v0, v1), v2);          // a_ = 0
+            floatx4 y1 = pk_sub(pk_sub(v1, v2), v3);          // a_ = 1
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    y0[r] = relu1(y0[r]);
+                    y1[r] = relu1(y1[r]);
                 }
-                y += bias;
-                if (a.relu) {
-                    y[0] = fmaxf(y[0], 0.f);
-                    y[1] = fmaxf(y[1], 0.f);
-                    y[2] = fmaxf(y[2], 0.f);
-                    y[3] = fmaxf(y[3], 0.f);
-                }
-                const int oy = 2 * ety + a_, ox = 2 * etx + b_;
-                if (ep_ok && oy < a.H && ox < a.W)
-                    *reinterpret_cast<floatx4*>(a.out + ((size_t)(e_img * a.H + oy) * a.W + ox) * a.Cs_out + a.coff_out + nbase + ec * 4) = y;
             }
+            const bool blk_ok = n0 + 32 * nb < a.Cout;                  // a 32-channel block past Cout: stores dropped
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, y0), out_rsrc, blk_ok ? ooff[b_] : 0xFFFFFFFFu, nb * (32 * 4), 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, y1), out_rsrc, blk_ok ? ooff[2 + b_] : 0xFFFFFFFFu, nb * (32 * 4), 0);
         }
         if (nb + 1 < NB) __syncthreads();
     }
@@ -272,13 +324,49 @@ void wino_f2x2_3x3_kernel(WinoArgs a) {
 }
 
 template <int NB>
-int launch_t(const WinoArgs& a0, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    WinoArgs a = a0;
-    a.tiles_m = cdiv(a.P, BP);
-    a.tiles_n = cdiv(a.Cout, 32 * NB);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 4 : 2, NB == 1 ? 4 : 2)))
+void wino_f2x2_3x3_kernel(WinoGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* hs = reinterpret_cast<float*>(smem_raw);        // [2][4][4][32][8] (K loop); [4][2][32][36] (epilogue)
+    const int b = blockIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < kWinoMaxJobs; ++q)
+        if (q < g.n_jobs && b >= g.job[q].unit0) j = q;
+    const WinoJob& a = g.job[j];
+    const int unit = b - a.unit0;
+    if (unit >= a.n_units) return;                       // padding workgroups between jobs
+    wino_unit<NB>(a, unit, hs);
+}
+
+unsigned magic_u32(unsigned d) { return d == 1 ? 0u : (unsigned)(0x100000000ull / d) + 1u; }   // 0 = "divide by one"
+
+template <int NB>
+int launch_t(WinoGroup& g, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    int units = 0;
+    for (int q = 0; q < g.n_jobs; ++q) {
+        WinoJob& a = g.job[q];
+        a.tiles_n = cdiv(a.Cout, 32 * NB);
+        const long long n = (long long)cdiv(a.P, BP) * a.tiles_n;
+        VQ_REQUIRE(n > 0 && n < (1 << 24), "Winograd job %d: %lld workgroups", q, n);
+        a.unit0 = units;
+        a.n_units = (int)n;
+        units += ((int)n + 7) & ~7;
+        const unsigned tpi = (unsigned)(a.th * a.tw);
+        // exactness of the multiply-high divisions (vq_tsn_kernels.h): dividend < 2^32 / divisor
+        VQ_REQUIRE((unsigned long long)n * a.tiles_n < 0x100000000ull && (unsigned long long)(a.P + BP) * tpi < 0x100000000ull &&
+                       a.tw <= 1024 && a.th <= 1024,
+                   "Winograd job %d: shape outside the reciprocal-division range", q);
+        a.m_tiles_n = magic_u32((unsigned)a.tiles_n);
+        a.m_tpi = magic_u32(tpi);
+        a.m_tw = magic_u32((unsigned)a.tw);
+        a.s_tw = 65536u / (unsigned)a.tw + 1u;
+        a.s_th = 65536u / (unsigned)a.th + 1u;
+    }
+    g.total_units = units;
     auto kern = wino_f2x2_3x3_kernel<NB>;
-    const size_t lds = 2 * HS_STAGE * sizeof(float);
-    VQ_LAUNCH(kern, a.tiles_m * a.tiles_n, 256, lds, stream, ev_start, ev_stop, a);
+    const size_t lds = LDS_FLOATS * sizeof(float);
+    VQ_LAUNCH(kern, units, 256, lds, stream, ev_start, ev_stop, g);
     VQ_CHECK_LAUNCH();
     return VQ_OK;
 }
@@ -287,11 +375,17 @@ int launch_t(const WinoArgs& a0, hipStream_t stream, hipEvent_t ev_start, hipEve
 
 namespace vq {
 
-int launch_wino(const WinoArgs& a, int variant, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    VQ_REQUIRE(a.Cin % KC == 0 && a.Cout % 32 == 0 && a.Cs_out % 4 == 0 && a.coff_out % 4 == 0 && a.Cs_in % 4 == 0 && a.coff_in % 4 == 0,
-               "Winograd convolution needs Cin %% 8 == 0, Cout %% 32 == 0 and 16-byte aligned channel offsets");
-    if (variant == 0) return launch_t<1>(a, stream, ev_start, ev_stop);
-    if (variant == 1) return launch_t<2>(a, stream, ev_start, ev_stop);
+int launch_wino_group(WinoGroup& g, int variant, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    VQ_REQUIRE(g.n_jobs >= 1 && g.n_jobs <= kWinoMaxJobs, "a Winograd launch carries 1..%d jobs", kWinoMaxJobs);
+    for (int q = 0; q < g.n_jobs; ++q) {
+        const WinoJob& a = g.job[q];
+        VQ_REQUIRE(a.Cin % KC == 0 && a.Cout % 32 == 0 && a.Cs_out % 4 == 0 && a.coff_out % 4 == 0 && a.Cs_in % 4 == 0 && a.coff_in % 4 == 0,
+                   "Winograd convolution needs Cin %% 8 == 0, Cout %% 32 == 0 and 16-byte aligned channel offsets");
+        VQ_REQUIRE(a.in_bytes <= 0x7FFFFFF0u && a.out_bytes <= 0x7FFFFFF0u,
+                   "Winograd convolution: a launch addresses its slots with signed 32-bit byte offsets (split the batch)");
+    }
+    if (variant == 0) return launch_t<1>(g, stream, ev_start, ev_stop);
+    if (variant == 1) return launch_t<2>(g, stream, ev_start, ev_stop);
     return fail(VQ_E_INVALID, "no Winograd kernel variant %d", variant);
 }
 

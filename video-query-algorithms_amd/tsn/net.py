@@ -315,12 +315,22 @@ class TsnNet:
         call("vq_tsn_layer_tiles", self._h, int(n_crops), out.ctypes.data_as(C.c_void_p), n)
         return out
 
-    def layer_lanes(self) -> np.ndarray:
-        """Lane (HIP stream) of every layer in the fixed schedule; independent arms of a module differ."""
+    def launch_items(self):
+        """(item_of_layer [n_layers], n_items): which kernel launch of a forward executes each layer -- the Winograd
+        convolutions of one dependency level share a launch."""
         n = len(self.plan.ops)
         out = np.zeros(n, dtype=np.int32)
-        call("vq_tsn_layer_lanes", self._h, out.ctypes.data_as(C.c_void_p), n)
-        return out
+        k = C.c_int32()
+        call("vq_tsn_launch_items", self._h, out.ctypes.data_as(C.c_void_p), n, C.byref(k))
+        return out, k.value
+
+    def tuned_sizes(self):
+        """Batch sizes for which a tiling table exists (autotuned on first use, or installed)."""
+        k = C.c_int32()
+        call("vq_tsn_tuned_sizes", self._h, None, 0, C.byref(k))
+        out = np.zeros(max(k.value, 1), dtype=np.int32)
+        call("vq_tsn_tuned_sizes", self._h, out.ctypes.data_as(C.c_void_p), out.size, C.byref(k))
+        return out[:k.value].tolist()
 
     def set_layer_tiles(self, n_crops: int, tiles: np.ndarray):
         """Install a tiling table (from layer_tiles, e.g. of an earlier process) instead of autotuning."""
