@@ -360,8 +360,9 @@ def test_calcsig_command_line_end_to_end(tsn, tmp_path):
 
 def test_grouped_winograd_launches_do_not_change_a_bit(tsn, monkeypatch):
     """The Winograd convolutions of one dependency level (the 3x3 and the first double-3x3 arm of an inception module)
-    share one kernel launch.  VQ_TSN_GROUP=0 gives every layer its own launch: same bits either way, and the launch
-    table really groups sibling arms while a chain (double_3x3_1 -> double_3x3_2) stays in separate launches."""
+    and the level's pooling layer share one kernel launch.  VQ_TSN_GROUP=0 gives every layer its own launch: same bits
+    either way, and the launch table really groups sibling arms while a chain (double_3x3_1 -> double_3x3_2) stays in
+    separate launches."""
     bi, net = tsn
     g = bi.bn_inception(3)
     w = net.synthetic_weights(g, seed=2)
@@ -381,7 +382,10 @@ def test_grouped_winograd_launches_do_not_change_a_bit(tsn, monkeypatch):
     for blk in ("3a", "3b", "4a", "4b", "4c", "4d", "5a", "5b"):
         i3, id1, id2 = (names.index("inception_%s/%s" % (blk, x)) for x in ("3x3", "double_3x3_1", "double_3x3_2"))
         assert items[i3] == items[id1] and items[id2] > items[id1]
-    assert n_items == len(m.plan.ops) - 8
+        assert items[names.index("inception_%s/pool" % blk)] == items[i3]              # the pooling arm rides along
+    for blk in ("3c", "4e"):                                                           # reduction modules: double_3x3_1 + max pool
+        assert items[names.index("inception_%s/pool" % blk)] == items[names.index("inception_%s/double_3x3_1" % blk)]
+    assert n_items <= len(m.plan.ops) - 18
     order = np.argsort(items, kind="stable")                       # a valid order: every producer's launch precedes its consumers'
     assert items[names.index("inception_3a/pool")] < items[names.index("inception_3b/3x3")]
     f2, p2 = m.forward(crops, 3, net.RGB_MEAN)

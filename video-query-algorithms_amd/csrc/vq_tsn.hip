@@ -572,73 +572,11 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
 // pooling (Caffe semantics: ceil-mode output size; MAX ignores padding; AVE divides by the window
 // clipped to the padded extent and accumulates h-major in fp32)
 // ------------------------------------------------------------------------------------------------
-struct PoolArgs {
-    const float* in;
-    float* out;
-    int H, W, Cs_in, coff_in, C;
-    int Ho, Wo, Cs_out, coff_out;
-    int k, stride, pad;
-    int64_t total;   // n * Ho * Wo * C/4
-    const float* bias;   // AVE only: added after the division (finishes a commuted 1x1 projection), may be null
-    int relu;
-};
-
+// PoolArgs / pool_one: vq_tsn_kernels.h (shared with the grouped Winograd launch, which also carries a level's pooling)
 template <bool IS_MAX>
 __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.total) return;
-    const int c4n = a.C >> 2;
-    const int c4 = (int)(i % c4n);
-    int64_t pix = i / c4n;
-    const int pw = (int)(pix % a.Wo);
-    pix /= a.Wo;
-    const int ph = (int)(pix % a.Ho);
-    const int64_t n = pix / a.Ho;
-    int hs = ph * a.stride - a.pad, ws = pw * a.stride - a.pad;
-    int he = min(hs + a.k, a.H + a.pad), we = min(ws + a.k, a.W + a.pad);
-    const float pool_size = (float)((he - hs) * (we - ws));
-    hs = max(hs, 0);
-    ws = max(ws, 0);
-    he = min(he, a.H);
-    we = min(we, a.W);
-    const float* base = a.in + (size_t)n * a.H * a.W * a.Cs_in + a.coff_in + c4 * 4;
-    float4 acc = IS_MAX ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int h = hs; h < he; ++h)
-        for (int w = ws; w < we; ++w) {
-            const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)h * a.W + w) * a.Cs_in);
-            if (IS_MAX) {
-                acc.x = fmaxf(acc.x, v.x);
-                acc.y = fmaxf(acc.y, v.y);
-                acc.z = fmaxf(acc.z, v.z);
-                acc.w = fmaxf(acc.w, v.w);
-            } else {
-                acc.x += v.x;
-                acc.y += v.y;
-                acc.z += v.z;
-                acc.w += v.w;
-            }
-        }
-    if (!IS_MAX) {
-        acc.x /= pool_size;
-        acc.y /= pool_size;
-        acc.z /= pool_size;
-        acc.w /= pool_size;
-        if (a.bias) {
-            const float4 b = *reinterpret_cast<const float4*>(a.bias + c4 * 4);
-            acc.x += b.x;
-            acc.y += b.y;
-            acc.z += b.z;
-            acc.w += b.w;
-        }
-        if (a.relu) {
-            acc.x = fmaxf(acc.x, 0.f);
-            acc.y = fmaxf(acc.y, 0.f);
-            acc.z = fmaxf(acc.z, 0.f);
-            acc.w = fmaxf(acc.w, 0.f);
-        }
-    }
-    float* o = a.out + (((size_t)n * a.Ho + ph) * a.Wo + pw) * a.Cs_out + a.coff_out + c4 * 4;
-    *reinterpret_cast<float4*>(o) = acc;
+    if (i < a.total) pool_one<IS_MAX>(a, i);
 }
 
 // global average pool (Caffe AVE, kernel = whole map): sequential fp32 sum over h, w then / (H*W)
@@ -733,6 +671,7 @@ struct vq_tsn {
     std::map<int, std::vector<int>> tuned;   // n_crops -> per-layer index into kTiles / Winograd variant (autotuned)
     bool autotune = true;                 // VQ_TSN_AUTOTUNE != 0 (read at creation)
     bool group_wino = true;               // VQ_TSN_GROUP != 0 (read at creation): independent Winograd layers share a launch
+    bool group_pool = true;               // VQ_TSN_GROUP_POOL != 0 (read at creation): a level's pooling rides in its Winograd launch
     bool poison = false;                  // VQ_TSN_POISON=1 (read at creation): NaN-fill every activation slot before a forward (debug:
                                           // a layer that reads what no earlier layer of THIS forward wrote then yields NaN features)
     int forced_tile = -1;                 // VQ_TSN_TILE = "BMxBN[xBK[xP]]" (read at creation): every direct conv uses this tiling
@@ -945,13 +884,44 @@ static void fill_wino_job(vq_tsn* net, int li, int n_crops, WinoJob& a) {
     a.u_bytes = (unsigned)((size_t)16 * L.cout * L.cin * sizeof(float));
 }
 
-// The Winograd layers `members` (independent of each other) as one launch.
+static void fill_pool_args(vq_tsn* net, int li, int n_crops, PoolArgs& a) {
+    const vq_layer_desc& L = net->layers[li];
+    const vq_tensor_desc& ts = net->tensors[L.src];
+    const vq_tensor_desc& td = net->tensors[L.dst];
+    memset(&a, 0, sizeof a);
+    a.in = net->slots[L.src] + (size_t)net->crop_off * ts.h * ts.w * ts.c;
+    a.out = net->slots[L.dst] + (size_t)net->crop_off * td.h * td.w * td.c;
+    a.H = ts.h;
+    a.W = ts.w;
+    a.Cs_in = ts.c;
+    a.coff_in = L.src_coff;
+    a.C = L.cin;
+    a.Ho = td.h;
+    a.Wo = td.w;
+    a.Cs_out = td.c;
+    a.coff_out = L.dst_coff;
+    a.k = L.k;
+    a.stride = L.stride;
+    a.pad = L.pad;
+    a.is_max = L.op == VQ_OP_MAXPOOL;
+    a.total = (int64_t)n_crops * td.h * td.w * (L.cin / 4);
+    a.bias = (L.op == VQ_OP_AVGPOOL && L.has_bias) ? net->blob + L.b_off : nullptr;
+    a.relu = (L.op == VQ_OP_AVGPOOL) ? L.relu : 0;
+}
+
+// The Winograd layers among `members` (independent of each other) plus the pooling layers among them as one launch.
 static int launch_wino_layers(vq_tsn* net, const std::vector<int>& members, int n_crops, int variant) {
     WinoGroup g;
     memset(&g, 0, sizeof g);
-    VQ_REQUIRE(!members.empty() && (int)members.size() <= kWinoMaxJobs, "a Winograd launch carries 1..%d layers", kWinoMaxJobs);
-    g.n_jobs = (int)members.size();
-    for (int q = 0; q < g.n_jobs; ++q) fill_wino_job(net, members[q], n_crops, g.job[q]);
+    for (int li : members) {
+        if (net->layers[li].op == VQ_OP_CONV_WINOGRAD) {
+            VQ_REQUIRE(g.n_jobs < kWinoMaxJobs, "a Winograd launch carries at most %d convolutions", kWinoMaxJobs);
+            fill_wino_job(net, li, n_crops, g.job[g.n_jobs++]);
+        } else {
+            VQ_REQUIRE(g.n_pools < kWinoMaxPools, "a Winograd launch carries at most %d pooling layers", kWinoMaxPools);
+            fill_pool_args(net, li, n_crops, g.pool[g.n_pools++]);
+        }
+    }
     return launch_wino_group(g, variant, net->ls, net->ev_start, net->ev_stop);
 }
 
@@ -1060,23 +1030,7 @@ static int run_layer(vq_tsn* net, int li, int n_crops, int tune_key) {
     }
     if (L.op == VQ_OP_MAXPOOL || L.op == VQ_OP_AVGPOOL) {
         PoolArgs a;
-        a.in = net->slots[L.src] + (size_t)net->crop_off * ts.h * ts.w * ts.c;
-        a.out = net->slots[L.dst] + (size_t)net->crop_off * td.h * td.w * td.c;
-        a.H = ts.h;
-        a.W = ts.w;
-        a.Cs_in = ts.c;
-        a.coff_in = L.src_coff;
-        a.C = L.cin;
-        a.Ho = td.h;
-        a.Wo = td.w;
-        a.Cs_out = td.c;
-        a.coff_out = L.dst_coff;
-        a.k = L.k;
-        a.stride = L.stride;
-        a.pad = L.pad;
-        a.total = (int64_t)n_crops * td.h * td.w * (L.cin / 4);
-        a.bias = (L.op == VQ_OP_AVGPOOL && L.has_bias) ? net->blob + L.b_off : nullptr;
-        a.relu = (L.op == VQ_OP_AVGPOOL) ? L.relu : 0;
+        fill_pool_args(net, li, n_crops, a);
         const int64_t blocks = (a.total + 255) / 256;
         if (L.op == VQ_OP_MAXPOOL)
             VQ_LAUNCH(pool_kernel<true>, (unsigned)blocks, 256, 0, net->ls, net->ev_start, net->ev_stop, a);
@@ -1141,12 +1095,33 @@ static void build_items(vq_tsn* net, const vq_conv_segment* segments) {
         else
             wr[i].push_back(SlotRange{L.dst, L.dst_coff, L.dst_coff + L.cout});
     }
-    std::vector<int> level(n, 0);
+    std::vector<int> level(n, 0), floor_level(n, 0);
     int n_levels = 0;
-    for (int i = 0; i < n; ++i) {
-        for (int j = 0; j < i; ++j)
-            if (overlaps(wr[j], rd[i]) || overlaps(rd[j], wr[i]) || overlaps(wr[j], wr[i])) level[i] = std::max(level[i], level[j] + 1);
-        n_levels = std::max(n_levels, level[i] + 1);
+    auto levelise = [&]() {
+        n_levels = 0;
+        for (int i = 0; i < n; ++i) {
+            level[i] = floor_level[i];
+            for (int j = 0; j < i; ++j)
+                if (overlaps(wr[j], rd[i]) || overlaps(rd[j], wr[i]) || overlaps(wr[j], wr[i])) level[i] = std::max(level[i], level[j] + 1);
+            n_levels = std::max(n_levels, level[i] + 1);
+        }
+    };
+    levelise();
+    // A pooling layer that reads a module's input is ready one level before the module's Winograd convolutions (it sits
+    // beside the 1x1 reductions).  Nothing needs it that early: hold it back one level so it can ride in their launch.
+    if (net->group_wino && net->group_pool) {
+        for (int i = 0; i < n; ++i) {
+            const int op = net->layers[i].op;
+            if (op != VQ_OP_MAXPOOL && op != VQ_OP_AVGPOOL) continue;
+            bool here = false, next = false;
+            for (int j = 0; j < n; ++j)
+                if (net->layers[j].op == VQ_OP_CONV_WINOGRAD) {
+                    here |= level[j] == level[i];
+                    next |= level[j] == level[i] + 1;
+                }
+            if (!here && next) floor_level[i] = level[i] + 1;
+        }
+        levelise();
     }
     auto slot_bytes_per_crop = [&](int slot) {
         const vq_tensor_desc& t = net->tensors[slot];
@@ -1167,11 +1142,15 @@ static void build_items(vq_tsn* net, const vq_conv_segment* segments) {
     net->items.clear();
     net->item_of_layer.assign(n, -1);
     for (int lv = 0; lv < n_levels; ++lv) {
-        std::vector<int> wino;
+        std::vector<int> wino, pools;
+        for (int i = 0; i < n; ++i)
+            if (level[i] == lv && net->layers[i].op == VQ_OP_CONV_WINOGRAD && net->group_wino) wino.push_back(i);
         for (int i = 0; i < n; ++i) {
-            if (level[i] != lv) continue;
-            if (net->layers[i].op == VQ_OP_CONV_WINOGRAD && net->group_wino) {
-                wino.push_back(i);
+            if (level[i] != lv || (net->layers[i].op == VQ_OP_CONV_WINOGRAD && net->group_wino)) continue;
+            const int op = net->layers[i].op;
+            // the level's pooling rides in its Winograd launch (few short workgroups that fill the tail)
+            if (!wino.empty() && (op == VQ_OP_MAXPOOL || op == VQ_OP_AVGPOOL) && (int)pools.size() < kWinoMaxPools && net->group_pool) {
+                pools.push_back(i);
                 continue;
             }
             LaunchItem it;
@@ -1187,6 +1166,7 @@ static void build_items(vq_tsn* net, const vq_conv_segment* segments) {
             LaunchItem it;
             it.kind = 1;
             it.layers.assign(wino.begin() + q, wino.begin() + std::min(wino.size(), q + kWinoMaxJobs));
+            if (q == 0) it.layers.insert(it.layers.end(), pools.begin(), pools.end());
             it.max_crops = item_limit(it.layers);
             for (int m : it.layers) net->item_of_layer[m] = (int)net->items.size();
             net->items.push_back(it);
@@ -1348,6 +1328,7 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
     {
         if (const char* at = getenv("VQ_TSN_AUTOTUNE")) net->autotune = atoi(at) != 0;
         if (const char* gr = getenv("VQ_TSN_GROUP")) net->group_wino = atoi(gr) != 0;
+        if (const char* gp = getenv("VQ_TSN_GROUP_POOL")) net->group_pool = atoi(gp) != 0;
         if (const char* po = getenv("VQ_TSN_POISON")) net->poison = atoi(po) != 0;
         if (const char* force = getenv("VQ_TSN_TILE")) {
             int bm = 0, bn = 0, bk = 32, pipe = 0;   // "BMxBN", "BMxBNxBK" or "BMxBNxBKxP" (P = 1: pipelined kernel)
@@ -1561,11 +1542,16 @@ int vq_tsn_set_profile(vq_tsn* net, int32_t depth) {
     return VQ_OK;
 }
 
-// Share of a grouped launch's time attributed to one member: its matrix-core work (16 multiplies per tile, channel pair).
+// Share of a grouped launch's time attributed to one member, as a rough time estimate: matrix-core work of a
+// convolution (16 multiplies per tile and channel pair) at 100 TFLOP/s, bytes of a pooling layer at 4 TB/s.
 static double wino_weight(const vq_tsn* net, int li) {
     const vq_layer_desc& L = net->layers[li];
     const vq_tensor_desc& td = net->tensors[L.dst];
-    return (double)((td.h + 1) / 2) * ((td.w + 1) / 2) * L.cin * L.cout;
+    if (L.op != VQ_OP_CONV_WINOGRAD) {
+        const vq_tensor_desc& ts = net->tensors[L.src];
+        return ((double)ts.h * ts.w + (double)td.h * td.w) * L.cin * 4.0 / 4e12;
+    }
+    return 2.0 * 16.0 * ((td.h + 1) / 2) * ((td.w + 1) / 2) * (double)L.cin * L.cout / 100e12;
 }
 
 int vq_tsn_layer_times(vq_tsn* net, float* ms, double* flops, int32_t n_layers) {

@@ -18,6 +18,81 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // which costs the matrix pipe nothing.
 __device__ __forceinline__ unsigned magic_div(unsigned x, unsigned m) { return m ? __umulhi(x, m) : x; }
 
+// ------------------------------------------------------------------------------------------------
+// pooling (Caffe semantics: ceil-mode output size; MAX ignores padding; AVE divides by the window
+// clipped to the padded extent and accumulates h-major in fp32)
+// ------------------------------------------------------------------------------------------------
+struct PoolArgs {
+    const float* in;
+    float* out;
+    int H, W, Cs_in, coff_in, C;
+    int Ho, Wo, Cs_out, coff_out;
+    int k, stride, pad;
+    int is_max;
+    int64_t total;   // n * Ho * Wo * C/4
+    const float* bias;   // AVE only: added after the division (finishes a commuted 1x1 projection), may be null
+    int relu;
+    int unit0, n_units;  // grouped launch: workgroups [unit0, unit0 + n_units), kPoolPerWG outputs each
+};
+constexpr int kPoolPerWG = 1024;   // float4 outputs per pooling workgroup of a grouped launch
+
+// Output i (4 consecutive channels of one pooled pixel).
+template <bool IS_MAX>
+__device__ __forceinline__ void pool_one(const PoolArgs& a, int64_t i) {
+    const int c4n = a.C >> 2;
+    const int c4 = (int)(i % c4n);
+    int64_t pix = i / c4n;
+    const int pw = (int)(pix % a.Wo);
+    pix /= a.Wo;
+    const int ph = (int)(pix % a.Ho);
+    const int64_t n = pix / a.Ho;
+    int hs = ph * a.stride - a.pad, ws = pw * a.stride - a.pad;
+    int he = min(hs + a.k, a.H + a.pad), we = min(ws + a.k, a.W + a.pad);
+    const float pool_size = (float)((he - hs) * (we - ws));
+    hs = max(hs, 0);
+    ws = max(ws, 0);
+    he = min(he, a.H);
+    we = min(we, a.W);
+    const float* base = a.in + (size_t)n * a.H * a.W * a.Cs_in + a.coff_in + c4 * 4;
+    float4 acc = IS_MAX ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int h = hs; h < he; ++h)
+        for (int w = ws; w < we; ++w) {
+            const float4 v = *reinterpret_cast<const float4*>(base + ((size_t)h * a.W + w) * a.Cs_in);
+            if (IS_MAX) {
+                acc.x = fmaxf(acc.x, v.x);
+                acc.y = fmaxf(acc.y, v.y);
+                acc.z = fmaxf(acc.z, v.z);
+                acc.w = fmaxf(acc.w, v.w);
+            } else {
+                acc.x += v.x;
+                acc.y += v.y;
+                acc.z += v.z;
+                acc.w += v.w;
+            }
+        }
+    if (!IS_MAX) {
+        acc.x /= pool_size;
+        acc.y /= pool_size;
+        acc.z /= pool_size;
+        acc.w /= pool_size;
+        if (a.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(a.bias + c4 * 4);
+            acc.x += b.x;
+            acc.y += b.y;
+            acc.z += b.z;
+            acc.w += b.w;
+        }
+        if (a.relu) {
+            acc.x = fmaxf(acc.x, 0.f);
+            acc.y = fmaxf(acc.y, 0.f);
+            acc.z = fmaxf(acc.z, 0.f);
+            acc.w = fmaxf(acc.w, 0.f);
+        }
+    }
+    float* o = a.out + (((size_t)n * a.Ho + ph) * a.Wo + pw) * a.Cs_out + a.coff_out + c4 * 4;
+    *reinterpret_cast<float4*>(o) = acc;
+}
+
 // One 3x3 / stride 1 / pad 1 convolution (+ folded BN + ReLU) in Winograd F(2x2, 3x3) form: see vq_wino.hip.
 struct WinoJob {
     const float* in;     // NHWC slot (first crop of this launch)
@@ -39,12 +114,16 @@ struct WinoJob {
 };
 
 constexpr int kWinoMaxJobs = 4;
-// Independent layers of one graph level (the 3x3 and the first double-3x3 arm of an inception module) as ONE launch:
-// their workgroups fill each other's tail rounds and one kernel boundary disappears.
+// Independent layers of one graph level (the 3x3 and the first double-3x3 arm of an inception module, and the module's
+// pooling arm) as ONE launch: their workgroups fill each other's tail rounds and kernel boundaries disappear.
+constexpr int kWinoMaxPools = 2;
 struct WinoGroup {
     int n_jobs;
+    int n_pools;         // pooling layers of the same graph level: their (few, short) workgroups come last and fill the tail
     int total_units;     // grid size (jobs padded to multiples of 8 workgroups so every job keeps its XCD mapping)
+    int pool_unit0;      // first pooling workgroup
     WinoJob job[kWinoMaxJobs];
+    PoolArgs pool[kWinoMaxPools];
 };
 
 constexpr int kWinoVariants = 2;   // output-channel blocks of 32 per workgroup: variant v -> v + 1

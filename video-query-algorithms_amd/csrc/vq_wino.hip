@@ -329,6 +329,24 @@ void wino_f2x2_3x3_kernel(WinoGroup g) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* hs = reinterpret_cast<float*>(smem_raw);        // [2][4][4][32][8] (K loop); [4][2][32][36] (epilogue)
     const int b = blockIdx.x;
+    if (b >= g.pool_unit0) {                             // the level's pooling layers: plain streaming work, no LDS
+        int q = 0;
+        if (g.n_pools > 1 && b >= g.pool[1].unit0) q = 1;
+        const PoolArgs& pa = g.pool[q];
+        const int unit = b - pa.unit0;
+        if (unit >= pa.n_units) return;
+#pragma unroll
+        for (int r = 0; r < kPoolPerWG / 256; ++r) {
+            const int64_t i = (int64_t)unit * kPoolPerWG + r * 256 + threadIdx.x;
+            if (i < pa.total) {
+                if (pa.is_max)
+                    pool_one<true>(pa, i);
+                else
+                    pool_one<false>(pa, i);
+            }
+        }
+        return;
+    }
     int j = 0;
 #pragma unroll
     for (int q = 1; q < kWinoMaxJobs; ++q)
@@ -363,6 +381,15 @@ int launch_t(WinoGroup& g, hipStream_t stream, hipEvent_t ev_start, hipEvent_t e
         a.s_tw = 65536u / (unsigned)a.tw + 1u;
         a.s_th = 65536u / (unsigned)a.th + 1u;
     }
+    g.pool_unit0 = units;
+    for (int q = 0; q < g.n_pools; ++q) {
+        PoolArgs& pa = g.pool[q];
+        const long long n = (pa.total + kPoolPerWG - 1) / kPoolPerWG;
+        VQ_REQUIRE(n > 0 && n < (1 << 24), "pooling job %d: %lld workgroups", q, n);
+        pa.unit0 = units;
+        pa.n_units = (int)n;
+        units += (int)n;
+    }
     g.total_units = units;
     auto kern = wino_f2x2_3x3_kernel<NB>;
     const size_t lds = LDS_FLOATS * sizeof(float);
@@ -377,6 +404,7 @@ namespace vq {
 
 int launch_wino_group(WinoGroup& g, int variant, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     VQ_REQUIRE(g.n_jobs >= 1 && g.n_jobs <= kWinoMaxJobs, "a Winograd launch carries 1..%d jobs", kWinoMaxJobs);
+    VQ_REQUIRE(g.n_pools >= 0 && g.n_pools <= kWinoMaxPools, "a Winograd launch carries at most %d pooling layers", kWinoMaxPools);
     for (int q = 0; q < g.n_jobs; ++q) {
         const WinoJob& a = g.job[q];
         VQ_REQUIRE(a.Cin % KC == 0 && a.Cout % 32 == 0 && a.Cs_out % 4 == 0 && a.coff_out % 4 == 0 && a.Cs_in % 4 == 0 && a.coff_in % 4 == 0,
