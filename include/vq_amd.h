@@ -250,6 +250,9 @@ int vq_tsn_read_tensor(vq_tsn* net, int32_t slot, int32_t n_crops, float* host);
  * vq_tsn_set_profile (a launch shared by several layers is split between them in proportion to their matrix-core work) and (optionally) each layer's algorithmic FLOPs for the last batch size (2*MACs with
  * the un-padded channel counts; 0 for pooling).  depth = 0 switches profiling off. */
 int vq_tsn_set_profile(vq_tsn* net, int32_t depth);
+/* While profiling, only every `every`-th forward carries the events (the start/stop signals cost ~3 us per launch);
+ * the forwards in between issue exactly the same launches on the same stream.  Default 1. */
+int vq_tsn_set_profile_every(vq_tsn* net, int32_t every);
 int vq_tsn_layer_times(vq_tsn* net, float* ms, double* flops, int32_t n_layers);
 /* The implicit-GEMM tiling (BM, BN, BK, pipelined?) each conv layer runs with at batch size n_crops: autotuned on the first
  * forward of that batch size (every candidate yields the same bits), else the occupancy heuristic.

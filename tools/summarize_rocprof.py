@@ -7,7 +7,8 @@ stats, bench_json, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
 fam = {}
 for r in csv.DictReader(open(stats)):
     name = r["Name"]
-    key = ("conv (conv_igemm* + wino_f2x2_3x3)" if ("conv_igemm" in name or "wino_f2x2" in name) else "scan_kernel" if "scan_kernel" in name
+    key = ("conv direct (conv_igemm*)" if "conv_igemm" in name else "conv winograd (wino_f2x2_3x3, incl. the pooling that rides along)" if "wino_f2x2" in name
+           else "scan_kernel" if "scan_kernel" in name
            else "pool/gavgpool/preprocess/consensus" if any(k in name for k in ("pool_kernel", "gavgpool", "preprocess", "consensus"))
            else "other")
     f = fam.setdefault(key, [0, 0.0])
@@ -17,7 +18,13 @@ b = json.load(open(bench_json))
 print("family, calls, total_ms, avg_us")
 for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
     print("%s, %d, %.3f, %.2f" % (k, c, t / 1e6, t / c / 1e3))
-c, t = fam["conv (conv_igemm* + wino_f2x2_3x3)"]
+c = sum(v[0] for k, v in fam.items() if k.startswith("conv"))
+t = sum(v[1] for k, v in fam.items() if k.startswith("conv"))
+for k in ("direct", "winograd"):
+    fk = [v for kk, v in fam.items() if kk.startswith("conv " + k)][0]
+    bf = b["roofline"]["families"][k]
+    print("%s: rocprof %d launches, %.4f ms avg; bench.py events %.4f ms avg over %d launches per step"
+          % (k, fk[0], fk[1] / fk[0] / 1e6, bf["ms_per_step"] / bf["launches"], bf["launches"]))
 print("conv: rocprof avg launch %.4f ms over %d launches (%d per forward); bench.py HIP-event avg launch %.4f ms"
       % (t / c / 1e6, c, b["roofline"]["launches_per_step"], b["roofline"]["avg_launch_ms"]))
 if "scan_kernel" in fam:

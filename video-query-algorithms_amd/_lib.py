@@ -79,7 +79,7 @@ SIGNATURES = {
     "vq_tsn_feat_devptr": [_P, _PP, _PP], "vq_tsn_read_tensor": [_P, _I32, _I32, _P],
     "vq_tsn_flops_per_crop": [_P, _pF64], "vq_tsn_launch_items": [_P, _P, _I32, _pI32], "vq_tsn_tuned_sizes": [_P, _P, _I32, _pI32],
     "vq_tsn_layer_tiles": [_P, _I32, _P, _I32], "vq_tsn_set_layer_tiles": [_P, _I32, _P, _I32],
-    "vq_tsn_set_profile": [_P, _I32], "vq_tsn_layer_times": [_P, _P, _P, _I32],
+    "vq_tsn_set_profile": [_P, _I32], "vq_tsn_set_profile_every": [_P, _I32], "vq_tsn_layer_times": [_P, _P, _P, _I32],
     "vq_comm_unique_id": [_P], "vq_comm_init": [_I32, _I32, _P, _I32, _PP], "vq_comm_destroy": [_P],
     "vq_comm_info": [_P, _pI32, _pI32, _pI32],
     "vq_allgather_features": [_P, _P, _I64, _P, _P], "vq_allgather_scores": [_P, _P, _I64, _P, _P],

@@ -693,6 +693,8 @@ struct vq_tsn {
     bool fused_consensus = false;         // this forward: the global pool launch also forms the consensus (whole clips per launch, T <= kMaxFusedT)
     int profile_depth = 0;                // > 0: HIP events around every launch (bench roofline accounting)
     int profile_count = 0;                // profiled forwards so far (ring of profile_depth event sets)
+    int profile_every = 1;                // while profiling: every n-th forward carries the events, all run on one stream
+    int profile_tick = 0;                 // forwards since vq_tsn_set_profile
     std::vector<hipEvent_t> events;       // profile_depth x n_items x {start, stop}
     int crop_off = 0;                     // first crop the next launch works on (sub-batches, 32-bit offset chunks)
     int n_split = 1;                      // VQ_TSN_SPLIT: sub-batches of one forward run on separate streams
@@ -1437,11 +1439,14 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
     net->cur_T = T;
     const int n_items = (int)net->items.size();
     hipEvent_t* ev = nullptr;
-    if (net->profile_depth > 0) ev = net->events.data() + (size_t)(net->profile_count % net->profile_depth) * (2 * n_items);
-    // Per-launch profiling keeps everything on the caller's stream (each duration is then the launch alone).
+    const bool profiling = net->profile_depth > 0;
+    if (profiling && net->profile_tick++ % net->profile_every == 0)
+        ev = net->events.data() + (size_t)(net->profile_count % net->profile_depth) * (2 * n_items);
+    // While profiling everything stays on the caller's stream (each duration is then the launch alone, and the forwards
+    // between two sampled ones issue exactly the same launches).
     int parts_sum = 0;
     for (int v : net->split_parts) parts_sum += v;
-    int n_split = (!ev && net->n_split > 1 && n_crops % parts_sum == 0) ? net->n_split : 1;
+    int n_split = (!profiling && net->n_split > 1 && n_crops % parts_sum == 0) ? net->n_split : 1;
     std::vector<int> sub(n_split, n_crops), sub_off(n_split, 0);
     if (n_split > 1) {
         for (int sb = 0, o = 0; sb < n_split; ++sb) {
@@ -1539,6 +1544,15 @@ int vq_tsn_set_profile(vq_tsn* net, int32_t depth) {
     for (hipEvent_t& e : net->events) VQ_HIP(hipEventCreate(&e));
     net->profile_depth = depth;
     net->profile_count = 0;
+    net->profile_tick = 0;
+    return VQ_OK;
+}
+
+int vq_tsn_set_profile_every(vq_tsn* net, int32_t every) {
+    VQ_REQUIRE(net && every >= 1, "every must be >= 1");
+    std::lock_guard<std::mutex> lk(net->mu);
+    net->profile_every = every;
+    net->profile_tick = 0;
     return VQ_OK;
 }
 

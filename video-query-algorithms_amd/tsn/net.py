@@ -8,6 +8,8 @@ fp64 segment consensus (calcSig_wOF.py:82).
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
+import json
 import os
 from typing import Dict, Sequence
 
@@ -229,6 +231,52 @@ class TsnNet:
         self.feature_dim = plan.feature_dim
         self._tensor_c = [tensors[i].c for i in range(len(plan.tensors))]
         self._tensor_hw = [(tensors[i].h, tensors[i].w) for i in range(len(plan.tensors))]
+        # Tiling tables survive the process: the first forward of a batch size times 24 tilings per layer (~2 s of
+        # launches); the winners are kept per (layer table, library ABI) next to the library and installed at creation.
+        # Every tiling gives the same bits, so a stale or foreign table can only cost speed.  VQ_TUNE_CACHE=0 disables,
+        # VQ_TUNE_CACHE=<dir> moves the files.
+        desc = [(d.op, d.src, d.dst, d.src_coff, d.dst_coff, d.cin, d.cout, d.k, d.stride, d.pad, d.seg_count) for d in layers]
+        shapes = [(tensors[i].h, tensors[i].w, tensors[i].c) for i in range(len(plan.tensors))]
+        self._tune_file = None
+        self._tune_saved = set()
+        self._tune_checked = set()      # batch sizes whose first forward (the one that tunes) is behind us
+        where = os.environ.get("VQ_TUNE_CACHE", os.path.join(os.path.dirname(_lib.LIB_PATH), ".tune_cache"))
+        if where != "0":
+            key = hashlib.sha1(json.dumps([_lib.ABI_VERSION, desc, shapes]).encode()).hexdigest()[:20]
+            self._tune_file = os.path.join(where, key + ".json")
+            try:
+                with open(self._tune_file) as f:
+                    for n_crops, tiles in json.load(f).items():
+                        if int(n_crops) <= self.max_crops:
+                            self.set_layer_tiles(int(n_crops), np.array(tiles, dtype=np.int32))
+                            self._tune_saved.add(int(n_crops))
+            except (OSError, ValueError, _lib.VqError):
+                pass            # no file yet, or one written for another kernel set: tune afresh
+
+    def _persist_tuning(self, n_crops):
+        if self._tune_file is None or n_crops in self._tune_checked:
+            return
+        self._tune_checked.add(n_crops)
+        sizes = set(self.tuned_sizes())
+        if sizes <= self._tune_saved:
+            return
+        try:
+            os.makedirs(os.path.dirname(self._tune_file), exist_ok=True)
+            table = {}
+            try:
+                with open(self._tune_file) as f:
+                    table = json.load(f)
+            except (OSError, ValueError):
+                pass
+            for n in sizes:
+                table[str(n)] = self.layer_tiles(n).tolist()
+            tmp = "%s.%d.tmp" % (self._tune_file, os.getpid())
+            with open(tmp, "w") as f:
+                json.dump(table, f)
+            os.replace(tmp, self._tune_file)
+            self._tune_saved = sizes
+        except OSError:
+            self._tune_file = None      # read-only tree: keep tuning per process
 
     # ------------------------------------------------------------------
     def set_stream(self, hip_stream: int):
@@ -250,12 +298,14 @@ class TsnNet:
         ps = np.empty((n, self.feature_dim), dtype=np.float32) if want_per_snippet else None
         call("vq_tsn_forward", self._h, x.ctypes.data_as(C.c_void_p), 0, n, T, m.ctypes.data_as(C.POINTER(C.c_float)),
              feat.ctypes.data_as(C.c_void_p), ps.ctypes.data_as(C.c_void_p) if ps is not None else None)
+        self._persist_tuning(n)
         return feat, ps
 
     def forward_device(self, crops_dev_ptr: int, n: int, T: int, mean: Sequence[float]):
         """Crops already in HBM (uint8 NHWC); results stay on the device (see feat_devptr)."""
         m = np.ascontiguousarray(mean, dtype=np.float32)
         call("vq_tsn_forward", self._h, C.c_void_p(crops_dev_ptr), 1, n, T, m.ctypes.data_as(C.POINTER(C.c_float)), None, None)
+        self._persist_tuning(n)
 
     def features_tensor(self, n_clips: int):
         """Zero-copy torch view [n_clips, D] fp64 of the consensus features of the last forward (device memory owned
@@ -296,9 +346,11 @@ class TsnNet:
             return img[:, pad:pad + self.in_h, pad:pad + self.in_w]
         return buf[..., coff:coff + c]
 
-    def set_profile(self, depth: int):
-        """depth > 0: keep HIP-event timings of the last `depth` forwards (averaged by layer_times); 0 = off."""
+    def set_profile(self, depth: int, every: int = 1):
+        """depth > 0: keep HIP-event timings of the last `depth` profiled forwards (averaged by layer_times); 0 = off.
+        every = n: only every n-th forward carries the events (all of them run the same launches on one stream)."""
         call("vq_tsn_set_profile", self._h, int(depth))
+        call("vq_tsn_set_profile_every", self._h, int(every))
 
     def layer_times(self):
         """(names, kinds, mean ms[n_layers] over the profiled forwards, flops[n_layers] of the last batch)."""
