@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
     a.th = a.tw = (H + 1) / 2; a.P = crops * a.th * a.tw; a.relu = 1;
     a.in_bytes = (unsigned)(n_in * 4); a.u_bytes = (unsigned)(n_u * 4); a.out_bytes = (unsigned)(n_out * 4);
     const int nb = variant == 1 ? 2 : 1;                     // variant 1 owns 64 output channels per workgroup
-    const int nwg = ((((a.P + 31) / 32) * ((Cout + 32 * nb - 1) / (32 * nb))) + 7) & ~7;
+    int nwg = ((((a.P + 31) / 32) * ((Cout + 32 * nb - 1) / (32 * nb))) + 7) & ~7;
     hipMalloc(&a.phases, (size_t)nwg * 6 * sizeof(long long));
     hipMemset(a.phases, 0, (size_t)nwg * 6 * sizeof(long long));
     hipEvent_t e0, e1;
@@ -61,11 +61,22 @@ int main(int argc, char** argv) {
     hipEventElapsedTime(&ms, e0, e1);
     std::vector<long long> ph((size_t)nwg * 6);
     hipMemcpy(ph.data(), a.phases, ph.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    // padding workgroups (the grid is rounded up to a multiple of 8) leave their stamps at zero: drop them
+    {
+        std::vector<long long> live;
+        for (int i = 0; i < nwg; ++i)
+            if (ph[6 * i] != 0) live.insert(live.end(), ph.begin() + 6 * i, ph.begin() + 6 * i + 6);
+        ph.swap(live);
+    }
+    const int nwg_all = nwg;
+    (void)nwg_all;
     long long t0 = ph[0], t1 = ph[3];
-    for (int i = 0; i < nwg; ++i) {
+    const int nwg_live = (int)(ph.size() / 6);
+    for (int i = 0; i < nwg_live; ++i) {
         t0 = std::min(t0, ph[6 * i]);
         t1 = std::max(t1, ph[6 * i + 3]);
     }
+    nwg = nwg_live;
     const double span = (double)(t1 - t0), tick_us = ms * 1e3 / span;   // event time includes launch overhead: upper bound
     double pro = 0, loop = 0, epi = 0;
     for (int i = 0; i < nwg; ++i) {
