@@ -271,6 +271,37 @@ int vq_tsn_tuned_sizes(vq_tsn* net, int32_t* sizes, int32_t cap, int32_t* n);
 int vq_tsn_flops_per_crop(vq_tsn* net, double* flops);
 
 /* ------------------------------------------------------------------------------------------
+ * Frame / flow preparation in front of hot path A: TV-L1 optical flow
+ * ------------------------------------------------------------------------------------------
+ * Replaces the arithmetic of src/features_GPU_compute/build_wof_clips.py:55-76, which shells out to the third-party
+ * binary `extract_warp_gpu -b 20 -t 1 -s 1` (OpenCV CUDA TV-L1; not in the reference tree -> PARITY UNPINNED).  The
+ * kernels follow the published algorithm (Zach, Pock & Bischof 2007; IPOL 2013 Algorithm 1) with OpenCV's default
+ * parameters, exactly as restated in oracle/tvl1_oracle.py.  The SURF + RANSAC half of dense_flow's camera-motion
+ * compensation is not built: a homography per pair can be supplied and is applied to the second frame. */
+typedef struct vq_flow vq_flow;
+typedef struct vq_tvl1_params {
+    float tau, lambda, theta;    /* 0.25, 0.15, 0.3  */
+    float epsilon;               /* 0.01: a warp's inner loop stops when the mean squared update <= epsilon^2 */
+    float scale_step;            /* 0.8  */
+    int32_t nscales, warps, iterations;   /* 5, 5, 300 */
+    float bound;                 /* 20: flow images map [-bound, bound] px to [0, 255] (extract_warp_gpu -b 20) */
+} vq_tvl1_params;
+int vq_tvl1_default_params(vq_tvl1_params* params);
+/* A batch workspace for up to max_pairs frame pairs of h x w grey pixels.  params NULL = defaults. */
+int vq_flow_create(int32_t max_pairs, int32_t h, int32_t w, const vq_tvl1_params* params, int32_t device, vq_flow** out);
+int vq_flow_destroy(vq_flow* flow);
+/* Pyramid actually used: *n_levels and (h, w) of the first min(*n_levels, cap) levels, finest first. */
+int vq_flow_levels(vq_flow* flow, int32_t* n_levels, int32_t* sizes_hw, int32_t cap);
+/* Flow from frames0[p] to frames1[p] (uint8 grey [n_pairs][h][w], host or device) for every pair of the batch.
+ * homographies_host (optional, [n_pairs][9] row-major fp64): frames1[p] is first warped by it (cv::warpPerspective
+ * semantics, bilinear, replicated border).  Outputs, all optional, host: u1 / u2 = dx / dy fp32 [n_pairs][h][w];
+ * flow_x / flow_y = the 8-bit images extract_warp_gpu writes; iters [levels][warps][n_pairs] (coarsest level first) =
+ * inner iterations each pair ran.  Synchronises on hip_stream before returning. */
+int vq_flow_tvl1(vq_flow* flow, const uint8_t* frames0, const uint8_t* frames1, int32_t frames_on_device, int32_t n_pairs,
+                 const double* homographies_host, float* u1_host, float* u2_host, uint8_t* flow_x_host, uint8_t* flow_y_host,
+                 int32_t* iters_host, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------
  * Comm group: one process per GPU, RCCL over xGMI
  * ------------------------------------------------------------------------------------------
  * The reference's only exchange is multiprocessing.Pool pickling per-clip features back to the parent

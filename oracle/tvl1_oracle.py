@@ -103,6 +103,7 @@ def tvl1_level(i0: np.ndarray, i1: np.ndarray, u1: np.ndarray, u2: np.ndarray, w
     """One pyramid level of IPOL Algorithm 1.  Returns (u1, u2, inner iterations actually run per warp)."""
     i0, i1 = i0.astype(F), i1.astype(F)
     u1, u2 = u1.astype(F).copy(), u2.astype(F).copy()
+    tau, lam, theta, epsilon = float(F(tau)), float(F(lam)), float(F(theta)), float(F(epsilon))   # the C ABI carries float32 parameters
     l_t, taut, th = F(lam * theta), F(tau / theta), F(theta)
     i1x, i1y = centered_gradient(i1)
     p11, p12, p21, p22 = (np.zeros_like(u1) for _ in range(4))
@@ -142,6 +143,7 @@ def tvl1_flow(frame0: np.ndarray, frame1: np.ndarray, nscales: int = NSCALES, wa
     """Flow (u1 = dx, u2 = dy) from grey uint8 (or float, 0..255) frame0 to frame1: coarse-to-fine over the pyramid, the
     flow of a level resized to the next finer one and divided by scale_step."""
     f0, f1 = frame0.astype(F), frame1.astype(F)
+    scale_step = float(F(scale_step))
     sizes = pyramid_sizes(f0.shape[0], f0.shape[1], nscales, scale_step)
     pyr0, pyr1 = [f0], [f1]
     for (h, w) in sizes[1:]:

@@ -41,6 +41,11 @@ class InputDesc(C.Structure):
     _fields_ = [("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("s2d_pad", C.c_int32), ("s2d_kernel", C.c_int32)]
 
 
+class Tvl1Params(C.Structure):
+    _fields_ = [("tau", C.c_float), ("lambda_", C.c_float), ("theta", C.c_float), ("epsilon", C.c_float), ("scale_step", C.c_float),
+                ("nscales", C.c_int32), ("warps", C.c_int32), ("iterations", C.c_int32), ("bound", C.c_float)]
+
+
 class TensorDesc(C.Structure):
     _fields_ = [("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32)]
 
@@ -80,6 +85,10 @@ SIGNATURES = {
     "vq_tsn_flops_per_crop": [_P, _pF64], "vq_tsn_launch_items": [_P, _P, _I32, _pI32], "vq_tsn_tuned_sizes": [_P, _P, _I32, _pI32],
     "vq_tsn_layer_tiles": [_P, _I32, _P, _I32], "vq_tsn_set_layer_tiles": [_P, _I32, _P, _I32],
     "vq_tsn_set_profile": [_P, _I32], "vq_tsn_set_profile_every": [_P, _I32], "vq_tsn_layer_times": [_P, _P, _P, _I32],
+    "vq_tvl1_default_params": [C.POINTER(Tvl1Params)],
+    "vq_flow_create": [_I32, _I32, _I32, C.POINTER(Tvl1Params), _I32, _PP], "vq_flow_destroy": [_P],
+    "vq_flow_levels": [_P, _pI32, _pI32, _I32],
+    "vq_flow_tvl1": [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P],
     "vq_comm_unique_id": [_P], "vq_comm_init": [_I32, _I32, _P, _I32, _PP], "vq_comm_destroy": [_P],
     "vq_comm_info": [_P, _pI32, _pI32, _pI32],
     "vq_allgather_features": [_P, _P, _I64, _P, _P], "vq_allgather_scores": [_P, _P, _I64, _P, _P],
