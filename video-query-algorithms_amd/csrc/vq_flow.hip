@@ -12,7 +12,8 @@
 //
 // Shape of the work: a BATCH of independent frame pairs (one 340 x 256 pair is only 87 k pixels).  Per pyramid level and warp:
 // one warp kernel, then per inner iteration two stencil kernels over all pairs -- the primal step needs every neighbour's dual
-// variable, the dual step every neighbour's new primal value, so the two cannot share a launch without halo recomputation:
+// variable, the dual step every neighbour's new primal value, so the two cannot share a launch without halo recomputation
+// (two launches per iteration; the dual launch also closes the iteration):
 //   tvl1_primal_kernel: thresholding step + u = v + theta div p, per-pair squared update summed in fp64 (one atomic per wave)
 //   tvl1_dual_kernel:   p = (p + tau/theta grad u) / (1 + tau/theta |grad u|)
 // A pair that has converged (mean squared update <= epsilon^2, or the iteration cap) is switched off on the device and its
@@ -82,9 +83,10 @@ __device__ __forceinline__ float sample_bilinear(const float* __restrict__ a, in
 
 struct PairState {
     double err;          // sum of squared primal updates of the iteration in flight
-    int active;          // 1 while the inner loop of the current warp runs
+    int stop_iter;       // iterations >= stop_iter of the current warp do not run (INT_MAX while the inner loop is live)
     int iters;           // inner iterations run in the current warp
 };
+constexpr int kNoStop = 0x7FFFFFFF;
 
 // Start of a warp: I1 and its gradient sampled at x + u, |grad|^2, the constant part of rho; the pair becomes active.
 __global__ void tvl1_warp_kernel(const float* __restrict__ i0, const float* __restrict__ i1, const float* __restrict__ i1x,
@@ -106,7 +108,7 @@ __global__ void tvl1_warp_kernel(const float* __restrict__ i0, const float* __re
     rho_c[i] = w0 - wx * a - wy * b - i0[i];
     if (x == 0 && y == 0) {
         st[p].err = 0.0;
-        st[p].active = 1;
+        st[p].stop_iter = kNoStop;
         st[p].iters = 0;
     }
 }
@@ -116,13 +118,14 @@ struct IterArgs {
     float *u1, *u2, *p11, *p12, *p21, *p22;
     PairState* st;
     int n, h, w;
+    int k;               // index of this inner iteration inside the warp
     float l_t, theta, taut;
 };
 
 // Primal step of one pair per blockIdx.y; blockIdx.x strides over its pixels.
 __global__ __launch_bounds__(256) void tvl1_primal_kernel(IterArgs a) {
     const int p = blockIdx.y;
-    if (!a.st[p].active) return;
+    if (a.st[p].stop_iter <= a.k) return;
     const int hw = a.h * a.w;
     const int64_t base = (int64_t)p * hw;
     double local = 0.0;
@@ -159,10 +162,12 @@ __global__ __launch_bounds__(256) void tvl1_primal_kernel(IterArgs a) {
     if ((threadIdx.x & 63) == 0) atomicAdd(&a.st[p].err, local);
 }
 
-// Dual step (every workgroup of a pair must see the same `active`, so the iteration is closed by a launch of its own).
-__global__ __launch_bounds__(256) void tvl1_dual_kernel(IterArgs a) {
+// Dual step.  Its first thread also closes the iteration: the squared update of the primal step just finished (complete: it
+// ran in the previous launch) decides whether iteration k + 1 runs.  Every workgroup of this launch tests stop_iter > k,
+// which holds for the old value (no stop) and the new one (k + 1) alike, so the write cannot split the pair.
+__global__ __launch_bounds__(256) void tvl1_dual_kernel(IterArgs a, double eps2, int max_iters, int* n_active) {
     const int p = blockIdx.y;
-    if (!a.st[p].active) return;
+    if (a.st[p].stop_iter <= a.k) return;
     const int hw = a.h * a.w;
     const int64_t base = (int64_t)p * hw;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
@@ -178,19 +183,14 @@ __global__ __launch_bounds__(256) void tvl1_dual_kernel(IterArgs a) {
         a.p21[g] = (a.p21[g] + a.taut * u2x) / ng2;
         a.p22[g] = (a.p22[g] + a.taut * u2y) / ng2;
     }
-}
-
-// Between the dual step of iteration k and the primal step of k + 1: one thread per pair closes the iteration.
-__global__ void tvl1_close_kernel(PairState* st, int n, int hw, double eps2, int max_iters, int* n_active) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n || !st[p].active) return;
-    const int it = st[p].iters + 1;
-    st[p].iters = it;
-    const double mean = st[p].err / (double)hw;
-    st[p].err = 0.0;
-    if (!(mean > eps2) || it >= max_iters) {
-        st[p].active = 0;
-        atomicSub(n_active, 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const double mean = a.st[p].err / (double)hw;
+        a.st[p].err = 0.0;
+        a.st[p].iters = a.k + 1;
+        if (!(mean > eps2) || a.k + 1 >= max_iters) {
+            a.st[p].stop_iter = a.k + 1;
+            atomicSub(n_active, 1);
+        }
     }
 }
 
@@ -442,9 +442,9 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
             for (int it = 0; it < P.iterations && live > 0;) {
                 const int chunk = std::min(P.iterations - it, it < 16 ? 8 : 16);
                 for (int k = 0; k < chunk; ++k) {
+                    a.k = it + k;
                     tvl1_primal_kernel<<<grid, 256, 0, st>>>(a);
-                    tvl1_dual_kernel<<<grid, 256, 0, st>>>(a);
-                    tvl1_close_kernel<<<cdiv(n_pairs, 64), 64, 0, st>>>(f->st, n_pairs, L.h * L.w, eps2, P.iterations, f->n_active);
+                    tvl1_dual_kernel<<<grid, 256, 0, st>>>(a, eps2, P.iterations, f->n_active);
                 }
                 VQ_CHECK_LAUNCH();
                 it += chunk;
