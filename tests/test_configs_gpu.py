@@ -168,3 +168,22 @@ def test_cfg5_full_size_ten_thousand_clips_hundred_rounds(tsn, tmp_path, capsys)
     assert os.path.exists(os.path.join(str(tmp_path), "synthetic_video", "UCF101_split1", "rgb_global_pool_features.csv"))
     assert 0.5 <= out["final_weights"]["warped_optical_flow"] <= 2.45 + 1e-9
     print("cfg5 full size: %.1f s extraction, %.3f s for 100 rounds" % (out["extract_total_s"], out["rounds_total_s"]))
+
+
+def test_a_1600_crop_batch_crosses_the_32_bit_offset_limit_correctly(tsn):
+    """`--batch_clips 64 --num_frame_per_video 25` = 1 600 crops per forward: conv1's output slot is 5.1 GB, the
+    kernels address a slot with signed 32-bit byte offsets, so the executor covers such a slot with several launches over
+    crop ranges.  The features of crops on both sides of every cut must equal a small-batch run bit for bit."""
+    bi, net = tsn
+    g = bi.bn_inception(3)
+    w = net.synthetic_weights(g, seed=2)
+    n, T = 1600, 25
+    rng = np.random.default_rng(77)
+    crops = rng.integers(0, 256, (n, 224, 224, 3), dtype=np.uint8)
+    m = net.TsnNet(g, w, max_crops=n)
+    feat, ps = m.forward(crops, T, net.RGB_MEAN)
+    assert np.isfinite(ps).all() and (feat == to.consensus(ps, T)).all()          # T = 25 > 16: the unfused consensus path
+    for lo in (0, 650, 1325, 1575):                                               # spans the cuts at 668 and 1336 crops (conv1)
+        f_small, p_small = m.forward(crops[lo:lo + 25], T, net.RGB_MEAN)
+        assert (p_small == ps[lo:lo + 25]).all(), lo
+    m.close()
