@@ -106,10 +106,11 @@ int vq_db_bootstrap_target(vq_db* db, const int64_t* valid_rows, int32_t n_valid
  * keep_sims != 0 additionally keeps the per-split dot products for vq_db_read_similarities. */
 int vq_db_scan(vq_db* db, const double* w_host, int32_t keep_sims);
 /* score[c] from the cached avg[N][S] (no DB read): Ticket.compute_scores, ticket.py:165-180. */
-/* Batched scan: n_queries (<= 8) queries in ONE pass over the database -- the all-pairs form of the scan for a broker
- * that holds several tickets.  Per (query, clip) exactly the arithmetic of vq_db_scan with weights (ticket.py:120-180):
- * the scores are bit-identical to n_queries single scans.  The database is read once (slice by slice, the slice's
- * query vectors in LDS), so queries/s grow almost linearly with n_queries until the fp64 FMA rate binds.
+/* Batched scan: n_queries (<= 16) queries in ONE pass over the database -- the all-pairs form of the scan for a broker
+ * that holds several tickets.  Per (query, clip) the arithmetic of vq_db_scan with weights (ticket.py:120-180); the dots
+ * run on the fp64 matrix cores (v_mfma_f64_16x16x4: tiles of 16 clips x 16 queries), whose accumulation order differs
+ * from the single-query scan's, so the scores agree with it to rounding (<= 1e-12), not bit for bit.  The database is
+ * read once (slice by slice, the slice's query vectors in LDS) and the pass is HBM-bound: 16 queries cost what one does.
  * t_host [n_queries][S][E][D] fp64, w_host [n_queries][S] fp64, scores_host [n_queries][N] fp64 (may be NULL: use
  * vq_db_batch_scores_devptr).  Does not touch the state of the single-query path (query, avg, scores).
  * Needs D in {256, 512, 768, 1024}. */

@@ -222,112 +222,116 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(ScanArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// batched scan: Q queries per pass over the database
+// batched scan: Q queries per pass over the database, on the fp64 matrix cores
 // ------------------------------------------------------------------------------------------------
 // The single-query scan keeps the whole fp64 query (S*E*D*8 = 80 KB at cfg 4) in LDS; Q of them do not fit.  The
-// batched scan therefore walks the database one (stream, split) slice at a time: the slice's Q query vectors
-// (Q*D*8 <= 64 KB) sit in LDS, a wave loads a clip's vector once and multiplies it against all Q of them.  Each
-// (query, clip, vector) dot uses the same per-lane FMA chain and the same wave butterfly as scan_kernel, so the
-// batched scores equal the single-query ones bit for bit.  The dots go to sims[q][c][v]; a second kernel applies
-// the ensemble mean and the weighted score exactly like the epilogue of scan_kernel.
+// batched scan therefore walks the database one (stream, split) slice at a time: the slice's query vectors (16 slots x
+// D x 8 bytes = 128 KB, unused slots zero) sit in LDS and a wave multiplies a tile of 16 clips against all 16 slots with
+// v_mfma_f64_16x16x4_f64: D[clip][query] += A[clip][k] B[k][query], 256 MFMAs per tile and slice.  Operand layouts
+// (tools/ubench/mfma_f64_layout.hip): A lane l = (clip l % 16, k l / 16), B lane l = (k l / 16, query l % 16), D lane l
+// register r = (clip l / 16 + 4 r, query l % 16).  Per 64-element chunk a lane loads four 16-byte pieces such that one load
+// instruction covers 64 contiguous bytes of each of the 16 clips, converts to fp64 and feeds 16 MFMAs; the matching query
+// values come from LDS with one ds_read_b64 per MFMA (rows swizzled: conflict-free).
+// The fp64 matrix rate (64 cycles per MFMA and SIMD = 78.6 TFLOP/s) puts 16 queries x 41 GB at 4.2 ms of matrix time,
+// under the 6.6 ms the HBM stream takes: the pass is HBM-bound, i.e. 16 queries cost what one does.
+// The dots go to sims[v][q][c] (16 consecutive clips of a query are 128 contiguous bytes); a second kernel applies the ensemble mean and the weighted score exactly like the
+// epilogue of scan_kernel.  The k order of a dot differs from scan_kernel's (matrix-core accumulation), so batched and
+// single-query scores agree to rounding (<= 1e-12, tested), not bit for bit.
 struct BatchArgs {
     const void* feats;
     const double* t;          // [Q][NV][D]
-    double* sims;             // [Q][n][NV]
+    double* sims;             // [NV][Q][n]
     int64_t n;
     int32_t Q, NV, D, v;
 };
+constexpr int kBatchSlots = 16;
 
-// Eight wave sums at once.  wave_sum() is the xor butterfly 32, 16, 8, 4, 2, 1; doing it for eight values costs 48
-// exchanges.  Here every exchange step also halves the number of values a lane carries (after 32 / 16 / 8 a lane
-// keeps the value whose index bits equal its lane bits 5 / 4 / 3), so the eight sums cost 4 + 2 + 1 + 3 exchanges.
-// Each kept partial is own + partner exactly as in wave_sum, so lane l ends up with the bit-identical wave_sum of
-// value q = (l >> 3) & 7.
-__device__ __forceinline__ double wave_sum8(const double (&v)[8], int lane) {
-    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
-    double u[4], w[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double recv = __shfl_xor(b5 ? v[i] : v[i + 4], 32, 64);
-        u[i] = (b5 ? v[i + 4] : v[i]) + recv;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const double recv = __shfl_xor(b4 ? u[i] : u[i + 2], 16, 64);
-        w[i] = (b4 ? u[i + 2] : u[i]) + recv;
-    }
-    double x = (b3 ? w[1] : w[0]) + __shfl_xor(b3 ? w[0] : w[1], 8, 64);
-    x += __shfl_xor(x, 4, 64);
-    x += __shfl_xor(x, 2, 64);
-    x += __shfl_xor(x, 1, 64);
-    return x;
-}
+typedef double doublex4 __attribute__((ext_vector_type(4)));
 
-// Two clips per wave iteration share every query fragment read from LDS (the LDS, one per CU, is the busiest unit of
-// this kernel); the next pair's vectors are in flight meanwhile.
+// One 64-element chunk of a clip's vector as a lane sees it: piece m (0..3) holds elements 16 m + 4 kk .. + 3 of the chunk
+// (kk = the lane's k quarter), so that ONE load instruction covers 64 contiguous bytes per clip across the four k-lanes.
+template <typename T>
+struct Chunk;
+template <>
+struct Chunk<float> {
+    float4 v[4];
+    __device__ __forceinline__ void load(const float* p) {      // p = chunk start + 4 kk
+#pragma unroll
+        for (int m = 0; m < 4; ++m) v[m] = *reinterpret_cast<const float4*>(p + 16 * m);
+    }
+    __device__ __forceinline__ double at(int m, int e) const {
+        return (double)(e == 0 ? v[m].x : e == 1 ? v[m].y : e == 2 ? v[m].z : v[m].w);
+    }
+};
+template <>
+struct Chunk<double> {
+    double2 v[4][2];
+    __device__ __forceinline__ void load(const double* p) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            v[m][0] = *reinterpret_cast<const double2*>(p + 16 * m);
+            v[m][1] = *reinterpret_cast<const double2*>(p + 16 * m + 2);
+        }
+    }
+    __device__ __forceinline__ double at(int m, int e) const { return (e & 1) ? v[m][e >> 1].y : v[m][e >> 1].x; }
+};
+
+// Where query slot q starts in LDS (in doubles): rows of D doubles plus a swizzle that makes the 32 lanes of a
+// ds_read_b64 group (16 queries x 2 k quarters, 4 doubles apart) hit 32 distinct 8-byte bank slots: D is a multiple
+// of 32, so slot = (q % 4) + 8 (q / 4) + 4 kk + const is a bijection onto 0..31.
+__device__ __forceinline__ int query_row(int q, int D) { return q * D + (q & 3) + 8 * (q >> 2); }
+
 template <typename T, int CH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))   // 64 KB of LDS per workgroup: 2 waves/SIMD anyway
-void batch_slice_kernel(BatchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double tq[];
-    constexpr int D = CH * 256;
-    for (int i = threadIdx.x; i < 8 * D; i += blockDim.x) {
+__global__ __launch_bounds__(1024) void batch_mfma_kernel(BatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double tq[];      // 16 swizzled rows of D doubles (+ 32 of slack)
+    constexpr int D = CH * 256, NCHUNK = D / 64;
+    for (int i = threadIdx.x; i < kBatchSlots * D; i += blockDim.x) {
         const int q = i / D, k = i - q * D;
-        tq[t_lds_index(D, q, k)] = q < a.Q ? a.t[((size_t)q * a.NV + a.v) * D + k] : 0.0;
+        tq[query_row(q, D) + k] = q < a.Q ? a.t[((size_t)q * a.NV + a.v) * D + k] : 0.0;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, col = lane & 15, kk = lane >> 4;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const T* feats = static_cast<const T*>(a.feats) + (int64_t)a.v * D;
+    const int64_t ntiles = (a.n + 15) / 16;
+    const T* feats = static_cast<const T*>(a.feats) + (int64_t)a.v * D + 4 * kk;
     const int64_t clip_elems = (int64_t)a.NV * D;
-    const int myq = (lane >> 3) & 7;
-    Quad<T> cur[2][CH], nxt[2][CH];
-    int64_t c = wave;                  // this iteration: clips c and c + nwaves
+    const double* tb = tq + query_row(col, D) + 4 * kk;               // this lane's query (B operand column), its k quarter
+    // NBUF chunks of a clip are in flight per lane (a ring of register buffers, refilled right after use): at 16 MFMAs x 64
+    // cycles x 4 waves per SIMD a chunk lasts ~4 k cycles, so three chunks ahead covers the loaded-HBM latency.
+    constexpr int NBUF = sizeof(T) == 4 ? 4 : 2;
+    static_assert(NCHUNK % NBUF == 0, "chunk ring must divide the vector");
+    for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+        const int64_t c = min(tile * 16 + col, a.n - 1);              // rows past n recompute the last clip; never stored
+        const T* x = feats + c * clip_elems;
+        Chunk<T> buf[NBUF];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-        if (c + h * nwaves < a.n) {
+        for (int bq = 0; bq < NBUF; ++bq) buf[bq].load(x + 64 * bq);
+        doublex4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+        for (int ch0 = 0; ch0 < NCHUNK; ch0 += NBUF) {
 #pragma unroll
-            for (int j = 0; j < CH; ++j) cur[h][j].load(feats + (c + h * nwaves) * clip_elems + j * 256 + lane * 4);
-        }
-    while (c < a.n) {
-        const int64_t cn = c + 2 * nwaves;
+            for (int bq = 0; bq < NBUF; ++bq) {
+                int off = 64 * (ch0 + bq);
+                // the query block never changes, so the compiler would hoist all 256 LDS reads of a tile out of the tile loop
+                // (512 registers: it spilled them to scratch); an opaque offset keeps every read next to its MFMA
+                asm volatile("" : "+v"(off));
+                const double* tbc = tb + off;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-            if (cn + h * nwaves < a.n) {
+                for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int j = 0; j < CH; ++j) nxt[h][j].load(feats + (cn + h * nwaves) * clip_elems + j * 256 + lane * 4);
+                    for (int e = 0; e < 4; ++e)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[bq].at(m, e), tbc[16 * m + e], acc, 0, 0, 0);
+                if (ch0 + bq + NBUF < NCHUNK) buf[bq].load(x + 64 * (ch0 + bq + NBUF));
             }
-        double p0[8], p1[8];
-#pragma clang loop unroll(full)
-        for (int q = 0; q < 8; ++q) {
-            double s0 = 0.0, s1 = 0.0;
-#pragma clang loop unroll(full)
-            for (int j = 0; j < CH; ++j) {
-                const double2 ta = *reinterpret_cast<const double2*>(&tq[q * D + j * 256 + lane * 2]);
-                const double2 tb = *reinterpret_cast<const double2*>(&tq[q * D + j * 256 + 128 + lane * 2]);
-                s0 = fma(cur[0][j].x0(), ta.x, s0);
-                s1 = fma(cur[1][j].x0(), ta.x, s1);
-                s0 = fma(cur[0][j].x1(), ta.y, s0);
-                s1 = fma(cur[1][j].x1(), ta.y, s1);
-                s0 = fma(cur[0][j].x2(), tb.x, s0);
-                s1 = fma(cur[1][j].x2(), tb.x, s1);
-                s0 = fma(cur[0][j].x3(), tb.y, s0);
-                s1 = fma(cur[1][j].x3(), tb.y, s1);
+        }
+        if (col < a.Q) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t cc = tile * 16 + kk + 4 * r;
+                if (cc < a.n) a.sims[((size_t)a.v * a.Q + col) * a.n + cc] = acc[r];   // [v][q][clip]: 16 consecutive clips = 128 B per query
             }
-            p0[q] = s0;
-            p1[q] = s1;
-            __builtin_amdgcn_sched_barrier(0);   // one query at a time: hoisting all 64 LDS reads spills the register file
         }
-        const double r0 = wave_sum8(p0, lane), r1 = wave_sum8(p1, lane);
-        if ((lane & 7) == 0 && myq < a.Q) {
-            a.sims[((size_t)myq * a.n + c) * a.NV + a.v] = r0;
-            if (c + nwaves < a.n) a.sims[((size_t)myq * a.n + c + nwaves) * a.NV + a.v] = r1;
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < CH; ++j) cur[h][j] = nxt[h][j];
-        c = cn;
     }
 }
 
@@ -346,7 +350,7 @@ __global__ void batch_finalize_kernel(const double* sims, const uint8_t* present
         for (int e = 0; e < E; ++e) {
             const int64_t idx = (c * S + s) * E + e;
             if (present ? present[idx] != 0 : true) {
-                acc = acc + sims[i * (S * E) + s * E + e];
+                acc = acc + sims[((int64_t)(s * E + e) * Q + q) * n + c];      // [v][q][clip]
                 ++cnt;
             }
         }
@@ -1015,7 +1019,7 @@ int vq_db_scan(vq_db* db, const double* w_host, int32_t keep_sims) {
 
 int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const double* w_host, double* scores_host) {
     VQ_REQUIRE(db && t_host && w_host, "NULL argument");
-    VQ_REQUIRE(n_queries >= 1 && n_queries <= 8, "n_queries must be in [1,8] (got %d)", n_queries);
+    VQ_REQUIRE(n_queries >= 1 && n_queries <= kBatchSlots, "n_queries must be in [1,%d] (got %d)", kBatchSlots, n_queries);
     VQ_REQUIRE(db->D % 256 == 0 && db->D <= 1024, "batched scan needs D in {256,512,768,1024} (got %d)", db->D);
     VQ_REQUIRE(db->S <= 8, "at most 8 streams");
     std::lock_guard<std::mutex> lk(db->mu);
@@ -1044,19 +1048,21 @@ int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const d
     a.Q = Q;
     a.NV = NV;
     a.D = db->D;
-    const size_t lds = (size_t)8 * db->D * 8;      // always eight query slots (unused ones hold zeros)
-    const int blocks = (int)std::min<int64_t>((db->n + 3) / 4, (int64_t)db->cus * 8);
+    const size_t lds = ((size_t)kBatchSlots * db->D + 32) * 8;   // sixteen swizzled query rows
+    // one 16-wave workgroup per CU (the query block takes most of its LDS); a wave walks tiles of 16 clips
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(((db->n + 15) / 16 + 15) / 16, (int64_t)db->cus));
     for (int v = 0; v < NV; ++v) {
         a.v = v;
 #define VQ_BATCH_LAUNCH(T, CH)                                                                                             \
     {                                                                                                                      \
-        auto kern = batch_slice_kernel<T, CH>;                                                                             \
+        auto kern = batch_mfma_kernel<T, CH>;                                                                              \
         static bool attr = false;                                                                                          \
         if (!attr) {                                                                                                       \
-            VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); \
+            VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                       (kBatchSlots * CH * 256 + 32) * 8));                                                 \
             attr = true;                                                                                                   \
         }                                                                                                                  \
-        kern<<<blocks, 256, lds, db->stream>>>(a);                                                                         \
+        kern<<<blocks, 1024, lds, db->stream>>>(a);                                                                        \
     }
         const int ch = db->D / 256;
         if (db->dtype == VQ_F32) {

@@ -241,8 +241,9 @@ class FeatureDB:
         call("vq_db_scan", self._h, _np_ptr(w) if w is not None else None, 1 if keep_sims else 0)
 
     def scan_batch(self, targets: np.ndarray, weights: np.ndarray, want: bool = True):
-        """Q <= 8 queries in one pass over the database: targets [Q,S,E,D] fp64, weights [Q,S] -> scores [Q,N]
-        (bit-identical to Q single scans; the single-query state of the DB is left alone)."""
+        """Q <= 16 queries in one pass over the database: targets [Q,S,E,D] fp64, weights [Q,S] -> scores [Q,N].  The dots
+        run on the fp64 matrix cores, so the scores equal Q single scans to rounding (<= 1e-12), not bit for bit; the
+        single-query state of the DB is left alone."""
         t = np.ascontiguousarray(targets, dtype=np.float64)
         w = np.ascontiguousarray(weights, dtype=np.float64)
         if t.ndim != 4 or t.shape[1:] != (self.S, self.E, self.D) or w.shape != (t.shape[0], self.S):
