@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQ_ABI_VERSION 3
+#define VQ_ABI_VERSION 4
 
 enum {
     VQ_OK = 0,
@@ -193,6 +193,10 @@ typedef struct vq_layer_desc {
                                     1x1 projection that was commuted with the pool); conv: always biased     */
     int32_t seg_first, seg_count;/* conv with seg_count > 0: its cout columns are split over seg_count
                                     destinations (segments[seg_first ..]); dst/dst_coff/relu are then ignored */
+    int32_t pre_pool_k;          /* VQ_OP_CONV, 1x1/1/0 only: 3 = the convolution reads max over a 3x3 window (stride     */
+    int32_t pre_pool_stride;     /* pre_pool_stride, no padding, Caffe ceil rule) of src, i.e. a MAX Pooling layer and the
+                                    1x1 convolution behind it (pool1/3x3_s2 -> conv2/3x3_reduce, prototxt :44-75) in one
+                                    launch, the pooled tensor never written; 0 = plain convolution                        */
     int64_t w_off;               /* floats into the blob: weights [cout][k][k][cin] (OHWI)   */
     int64_t b_off;               /* floats into the blob: bias [cout]                        */
 } vq_layer_desc;

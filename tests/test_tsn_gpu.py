@@ -179,8 +179,12 @@ def test_bn_inception_rgb_layerwise_and_features(tsn, rgb_case):
     feat, ps = m.forward(crops, 2, net.RGB_MEAN)
     assert abs(m.flops_per_crop() - 2 * 2_031_576_064) < 1
     worst = {}
+    plain = net.TsnNet(g, w, max_crops=4, fuse=False)      # materialises the blobs the fused plan folds away (the stem pools)
+    plain.forward(crops, 2, net.RGB_MEAN)
+    folded = [name for name in keep[:-1] if name not in m.plan.blob_loc]
+    assert folded == ["pool1/3x3_s2"]
     for name in keep[:-1]:
-        got = _nchw(m.read_blob(name, 4))
+        got = _nchw((plain if name in folded else m).read_blob(name, 4))
         d = np.abs(got - want[name]).max() / np.abs(want[name]).max()
         worst[name] = d
         assert d <= 2e-4, (name, d)
@@ -194,6 +198,7 @@ def test_bn_inception_rgb_layerwise_and_features(tsn, rgb_case):
     feat1, ps1 = m.forward(crops[[2, 0]], 1, net.RGB_MEAN)
     assert (ps1[0] == ps[2]).all() and (ps1[1] == ps[0]).all()
     m.close()
+    plain.close()
 
 
 def test_fused_and_unfused_graphs_agree(tsn, rgb_case):
@@ -205,7 +210,8 @@ def test_fused_and_unfused_graphs_agree(tsn, rgb_case):
     m1 = net.TsnNet(g, w, max_crops=4, fuse=True)
     f0, p0 = m0.forward(crops, 2, net.RGB_MEAN)
     f1, p1 = m1.forward(crops, 2, net.RGB_MEAN)
-    for name in ("inception_3a/3x3_reduce_bn", "inception_3a/double_3x3_reduce_bn"):   # same input bits (pool2)
+    # the 1x1 GEMM behind pool1 takes the window maximum in its loader: same bits as pool layer + GEMM
+    for name in ("conv2/3x3_reduce_bn", "inception_3a/3x3_reduce_bn", "inception_3a/double_3x3_reduce_bn"):
         assert (m0.read_blob(name, 4) == m1.read_blob(name, 4)).all(), name
     a0, a1 = m0.read_blob("inception_3a/output", 4), m1.read_blob("inception_3a/output", 4)
     assert (a0[..., :224] == a1[..., :224]).all()                      # 1x1 | 3x3 | double 3x3 branches: identical bits
@@ -598,7 +604,7 @@ def test_bench_two_rank_control_flow_rehearsal(tsn):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["scaling"] == "weak" and out["value"] > 0
-    assert out["roofline"]["launches_per_step"] == 36 and out["roofline"]["all_launches_per_step"] == 39
+    assert out["roofline"]["launches_per_step"] == 36 and out["roofline"]["all_launches_per_step"] == 38
     assert 0 < out["roofline"]["frac"] < 1 and out["roofline"]["frac"] < out["roofline"]["effective_frac"] < 2
 
 

@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvqamd.so")
 
-ABI_VERSION = 3                 # include/vq_amd.h: VQ_ABI_VERSION
+ABI_VERSION = 4                 # include/vq_amd.h: VQ_ABI_VERSION
 VQ_F32, VQ_F64 = 0, 1
 VQ_OP_CONV, VQ_OP_MAXPOOL, VQ_OP_AVGPOOL, VQ_OP_GLOBAL_AVGPOOL, VQ_OP_CONV_WINOGRAD = 1, 2, 3, 4, 5
 
@@ -30,6 +30,7 @@ class LayerDesc(C.Structure):
                 ("dst_coff", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("k", C.c_int32),
                 ("stride", C.c_int32), ("pad", C.c_int32), ("relu", C.c_int32), ("ceil_mode", C.c_int32),
                 ("has_bias", C.c_int32), ("seg_first", C.c_int32), ("seg_count", C.c_int32),
+                ("pre_pool_k", C.c_int32), ("pre_pool_stride", C.c_int32),
                 ("w_off", C.c_int64), ("b_off", C.c_int64)]
 
 

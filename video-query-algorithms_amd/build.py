@@ -12,7 +12,10 @@ SOURCES = ["csrc/vq_sim.hip", "csrc/vq_tsn.hip", "csrc/vq_wino.hip", "csrc/vq_bo
 HEADERS = ["csrc/vq_common.h", "csrc/vq_tsn_kernels.h", "../include/vq_amd.h"]
 OUT = os.path.join(HERE, "libvqamd.so")
 # -ffp-contract=off: score arithmetic must round like the reference's numpy scalars; FMAs are explicit
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-result",
+# -amdgpu-mfma-vgpr-form: MFMA accumulators stay in architectural VGPRs.  Left to itself the register allocator parks part of
+# a large tile's accumulators in AGPRs and copies them in and out on EVERY K step (128 v_accvgpr_read/write per 64 MFMAs in the
+# 128x64 tile's loop) -- VALU work that comes straight out of the fp32 matrix pipe's time.
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Wall", "-Wno-unused-result",
          "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc")]
 
 

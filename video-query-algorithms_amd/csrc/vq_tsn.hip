@@ -92,6 +92,8 @@ struct ConvArgs {
     int kw;              // ... of kw taps each (= k, or 1 when a kernel row is folded into the channel axis, see launch_conv_layer)
     int M, Kp, relu;
     int out_row0;        // first output row (pixel) of this launch inside the destination slots (sub-batch launches)
+    int pool_k, pool_s;  // POOL kernels: the 1x1 convolution reads max over a pool_k x pool_k window (stride pool_s, no padding,
+                         // clipped at the image edge) of the H x W source instead of a pixel; Ho x Wo is the pooled size
     int tiles_m, tiles_n;
     unsigned in_bytes, w_bytes;   // extents for the buffer descriptors (out-of-range offsets read as zero)
 };
@@ -145,10 +147,11 @@ struct ConvSmem {
 
 // One workgroup = 4 waves = one BM x BN output tile; K is walked in steps of BK through a double-buffered LDS
 // image that is filled through registers (global -> VGPR under the MFMAs of the current step -> LDS).
-template <int BM, int BN, int WM, int WN, int BK, bool SMALL_CIN>
+template <int BM, int BN, int WM, int WN, int BK, bool SMALL_CIN, bool POOL = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(BK == 16 || BK == 32, "BK is 16 or 32");
+    static_assert(!(POOL && SMALL_CIN), "the pooled loader walks whole channel chunks");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;   // 32x32 accumulator tiles per wave
     constexpr int CPR = BK / 4;                            // 16-byte chunks per staged row
     constexpr int NA = (BM * CPR + 255) / 256, NB = (BN * CPR + 255) / 256;   // chunks staged per thread
@@ -180,6 +183,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         a_img[i] = a.in + (size_t)n_img * a.H * a.W * a.Cs_in + a.coff_in;
         a_ih0[i] = ok ? oh * a.stride - a.pad : -(1 << 20);
         a_iw0[i] = ow * a.stride - a.pad;
+        if (POOL) {   // first row / column of the pooling window (always inside the image: Caffe's ceil rule)
+            a_ih0[i] = ok ? oh * a.pool_s : -(1 << 20);
+            a_iw0[i] = ow * a.pool_s;
+        }
     }
     const float* b_ptr[NB];
     bool b_ok[NB];
@@ -195,6 +202,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 
     floatx4 ra[NA], rb[NB];   // ext-vector values (a HIP float4 struct copy becomes a memcpy the optimiser leaves in scratch)
+    constexpr int PT = POOL ? 8 : 1;
+    floatx4 rp[NA][PT];       // POOL: the other window taps, in flight under the MFMAs; folded into ra when the tile is stored
     int kh = 0, kw = 0, c0 = 0;   // aligned mode: walk (tap, channel chunk) without divisions
     // Every lane always issues its loads: lanes that fall into the zero padding (or past M / Cout) read the
     // zero page instead, so there is no branch and no exec-mask juggling around the global loads.
@@ -210,6 +219,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 const int ih = a_ih0[i] + th, iw = a_iw0[i] + tw;                                                  \
                 if (tap < a.k * a.kw && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)              \
                     src = a_img[i] + ((size_t)ih * a.W + iw) * a.Cs_in + c;                                        \
+            } else if (POOL) {                                                                                     \
+                /* 3x3 window: taps outside the image re-read the window's first pixel (max is unchanged) */      \
+                const bool ok = a_ih0[i] >= 0;                                                                     \
+                if (ok) src = a_img[i] + ((size_t)a_ih0[i] * a.W + a_iw0[i]) * a.Cs_in + c0 + a_col[i] * 4;        \
+                _Pragma("unroll") for (int t = 1; t < 9; ++t) {                                                    \
+                    const int ih = a_ih0[i] + t / 3, iw = a_iw0[i] + t % 3;                                        \
+                    const float* q = src;                                                                          \
+                    if (ok && ih < a.H && iw < a.W) q = a_img[i] + ((size_t)ih * a.W + iw) * a.Cs_in + c0 + a_col[i] * 4; \
+                    rp[i][t - 1] = *reinterpret_cast<const floatx4*>(q);                                           \
+                }                                                                                                  \
             } else {                                                                                               \
                 const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;                                                  \
                 if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)                                  \
@@ -232,6 +251,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 #define VQ_STORE_TILES(BUF)                                                                                        \
     {                                                                                                              \
+        if (POOL) {                                                                                                \
+            _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                         \
+                _Pragma("unroll") for (int t = 0; t < 8; ++t)                                                      \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) ra[i][e] = fmaxf(ra[i][e], rp[i][t][e]);         \
+        }                                                                                                          \
         _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                             \
             if ((BM * CPR) % 256 == 0 || a_row[i] < BM)                                                            \
                 *reinterpret_cast<floatx4*>(&sm.a[BUF][a_row[i]][a_col[i] * 4]) = ra[i];                           \
@@ -777,6 +801,34 @@ static int launch_conv_pipe(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
     return fail(VQ_E_INVALID, "no pipelined kernel for tile %dx%dx%d", t.bm, t.bn, t.bk);
 }
 
+// The pooled loader keeps 8 extra window taps per staged chunk in registers: tilings that stage at most two chunks per thread.
+static bool pool_tile_ok(const ConvTile& t) { return !t.pipe && (t.bk == 16 || t.bm == 64); }
+
+template <int BM, int BN, int WM, int WN, int BK>
+static int launch_conv_pool_t(vq_tsn* net, ConvArgs& a) {
+    a.tiles_m = cdiv(a.M, BM);
+    a.tiles_n = cdiv(a.Cout, BN);
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, BK, false, true>;
+    const size_t lds = sizeof(ConvSmem<BM, BN, BK>);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    VQ_LAUNCH(kern, a.tiles_m * a.tiles_n, 256, lds, net->ls, net->ev_start, net->ev_stop, a);
+    VQ_CHECK_LAUNCH();
+    return VQ_OK;
+}
+
+static int launch_conv_pool(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
+#define T_(BM_, BN_, WM_, WN_, BK_) \
+    if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_) return launch_conv_pool_t<BM_, BN_, WM_, WN_, BK_>(net, a);
+    T_(128, 128, 2, 2, 16) T_(128, 96, 4, 1, 16) T_(128, 64, 2, 2, 16) T_(64, 128, 2, 2, 32) T_(64, 128, 2, 2, 16)
+    T_(64, 64, 2, 2, 32) T_(64, 64, 2, 2, 16) T_(128, 32, 4, 1, 16)
+#undef T_
+    return fail(VQ_E_INVALID, "no pooled-input kernel for tile %dx%dx%d", t.bm, t.bn, t.bk);
+}
+
 template <bool SMALL>
 static int launch_conv(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
 #define T_(BM_, BN_, WM_, WN_, BK_) \
@@ -837,6 +889,8 @@ static void fill_conv_args(vq_tsn* net, int li, int n_crops, ConvArgs& a) {
     a.M = n_crops * td.h * td.w;
     a.Kp = (L.k * L.k * L.cin + KPAD - 1) / KPAD * KPAD;
     a.relu = L.relu;
+    a.pool_k = L.pre_pool_k;
+    a.pool_s = L.pre_pool_stride;
     a.tiles_m = a.tiles_n = 0;
     a.in_bytes = (unsigned)((size_t)n_crops * ts.h * ts.w * ts.c * sizeof(float));   // < 2^31: LaunchItem::max_crops
     a.w_bytes = (unsigned)((size_t)L.cout * a.Kp * sizeof(float));
@@ -854,6 +908,13 @@ static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
     if (L.pad == 0 && L.k > 1 && L.cin == net->tensors[L.src].c && L.src_coff == 0) {
         a.kw = 1;
         a.Cin = L.k * L.cin;
+    }
+    if (L.pre_pool_k > 0) {
+        // max-pool folded into the loader: any tiling gives the same bits, so an unsupported choice (heuristic, VQ_TSN_TILE)
+        // is replaced by the BK = 16 tiling of the same shape
+        ConvTile t = kTiles[tile_idx];
+        if (!pool_tile_ok(t)) t = ConvTile{t.bm, t.bn, 16, 0};
+        return launch_conv_pool(net, a, t);
     }
     const bool small = (a.Cin % kTiles[tile_idx].bk) != 0;
     if (kTiles[tile_idx].pipe == 1) return small ? launch_conv_pipe<true>(net, a, kTiles[tile_idx]) : launch_conv_pipe<false>(net, a, kTiles[tile_idx]);
@@ -975,6 +1036,7 @@ static int autotune(vq_tsn* net, int n_crops) {
         int win = 0;
         const bool wino = net->layers[li].op == VQ_OP_CONV_WINOGRAD;
         for (int t = 0; t < (wino ? kWinoVariants : kNumTiles); ++t) {
+            if (!wino && net->layers[li].pre_pool_k > 0 && !pool_tile_ok(kTiles[t])) continue;
             for (int m : it.layers) choice[m] = t;             // a grouped launch runs one variant for all its members
             int rc = run_item(net, it, 0, n_crops, n_crops);   // warm
             if (rc != VQ_OK) return rc;
@@ -1238,6 +1300,13 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
                    "layer %d: channel counts and offsets must be multiples of 4", i);
         if (L.op == VQ_OP_CONV) {
             VQ_REQUIRE(L.k <= 8, "layer %d: conv kernels up to 8x8 (the tap mask is 64 bits)", i);
+            if (L.pre_pool_k > 0) {
+                VQ_REQUIRE(L.pre_pool_k == 3 && L.pre_pool_stride >= 1 && L.pre_pool_stride <= 3,
+                           "layer %d: the pooled-input form takes a 3x3 max window with stride 1..3", i);
+                VQ_REQUIRE(L.k == 1 && L.stride == 1 && L.pad == 0 && L.cin % 32 == 0, "layer %d: the pooled-input form is a 1x1 convolution over a multiple of 32 channels", i);
+                VQ_REQUIRE(td.h == pool_out_size(ts.h, 3, L.pre_pool_stride, 0) && td.w == pool_out_size(ts.w, 3, L.pre_pool_stride, 0),
+                           "layer %d: pooled-input size mismatch (Caffe ceil rule)", i);
+            } else
             VQ_REQUIRE(td.h == (ts.h + 2 * L.pad - L.k) / L.stride + 1 && td.w == (ts.w + 2 * L.pad - L.k) / L.stride + 1,
                        "layer %d: conv output size mismatch", i);
             const int64_t kp = (int64_t)(L.k * L.k * L.cin + KPAD - 1) / KPAD * KPAD;

@@ -166,7 +166,8 @@ class TsnNet:
         for i, op in enumerate(plan.ops):
             d = LayerDesc(op=_OPS[op.kind], src=op.src, dst=op.dst, src_coff=op.src_coff, dst_coff=op.dst_coff,
                           cin=op.cin, cout=op.cout, k=op.k, stride=op.stride, pad=op.pad, relu=int(op.relu),
-                          ceil_mode=1, has_bias=0, seg_first=0, seg_count=0, w_off=0, b_off=0)
+                          ceil_mode=1, has_bias=0, seg_first=0, seg_count=0, w_off=0, b_off=0,
+                          pre_pool_k=op.pre_pool[0] if op.pre_pool else 0, pre_pool_stride=op.pre_pool[1] if op.pre_pool else 0)
             if op.kind == "conv":
                 cin_dev = cin_pad if op.src == 0 else op.cin
                 if op.segments:                                            # sibling 1x1 convolutions: one GEMM
@@ -235,7 +236,7 @@ class TsnNet:
         # launches); the winners are kept per (layer table, library ABI) next to the library and installed at creation.
         # Every tiling gives the same bits, so a stale or foreign table can only cost speed.  VQ_TUNE_CACHE=0 disables,
         # VQ_TUNE_CACHE=<dir> moves the files.
-        desc = [(d.op, d.src, d.dst, d.src_coff, d.dst_coff, d.cin, d.cout, d.k, d.stride, d.pad, d.seg_count) for d in layers]
+        desc = [(d.op, d.src, d.dst, d.src_coff, d.dst_coff, d.cin, d.cout, d.k, d.stride, d.pad, d.seg_count, d.pre_pool_k) for d in layers]
         shapes = [(tensors[i].h, tensors[i].w, tensors[i].c) for i in range(len(plan.tensors))]
         self._tune_file = None
         self._tune_saved = set()
@@ -358,7 +359,8 @@ class TsnNet:
         ms = np.empty(n, dtype=np.float32)
         fl = np.empty(n, dtype=np.float64)
         call("vq_tsn_layer_times", self._h, ms.ctypes.data_as(C.c_void_p), fl.ctypes.data_as(C.c_void_p), n)
-        return [o.name for o in self.plan.ops], [o.kind for o in self.plan.ops], ms, fl
+        names = [(o.pre_pool[2] + ">" + o.name) if o.pre_pool else o.name for o in self.plan.ops]
+        return names, [o.kind for o in self.plan.ops], ms, fl
 
     def layer_tiles(self, n_crops: int) -> np.ndarray:
         """[n_layers, 4] (BM, BN, BK, pipelined) implicit-GEMM tiling per conv layer at this batch size."""
