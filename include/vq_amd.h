@@ -281,8 +281,9 @@ int vq_tsn_flops_per_crop(vq_tsn* net, double* flops);
  * Replaces the arithmetic of src/features_GPU_compute/build_wof_clips.py:55-76, which shells out to the third-party
  * binary `extract_warp_gpu -b 20 -t 1 -s 1` (OpenCV CUDA TV-L1; not in the reference tree -> PARITY UNPINNED).  The
  * kernels follow the published algorithm (Zach, Pock & Bischof 2007; IPOL 2013 Algorithm 1) with OpenCV's default
- * parameters, exactly as restated in oracle/tvl1_oracle.py.  The SURF + RANSAC half of dense_flow's camera-motion
- * compensation is not built: a homography per pair can be supplied and is applied to the second frame. */
+ * parameters, exactly as restated in oracle/tvl1_oracle.py.  A homography per pair can be supplied and is applied to the
+ * second frame; vq_flow_good_features + vq_flow_ransac_homography below estimate it the way the binary's flow-match
+ * branch does (its SURF matches are not built). */
 typedef struct vq_flow vq_flow;
 typedef struct vq_tvl1_params {
     float tau, lambda, theta;    /* 0.25, 0.15, 0.3  */
@@ -305,6 +306,26 @@ int vq_flow_levels(vq_flow* flow, int32_t* n_levels, int32_t* sizes_hw, int32_t 
 int vq_flow_tvl1(vq_flow* flow, const uint8_t* frames0, const uint8_t* frames1, int32_t frames_on_device, int32_t n_pairs,
                  const double* homographies_host, float* u1_host, float* u2_host, uint8_t* flow_x_host, uint8_t* flow_y_host,
                  int32_t* iters_host, void* hip_stream);
+
+/* Camera-motion estimation, the flow-match branch of extract_warp_gpu's "warp" step (improved dense trajectories, Wang &
+ * Schmid 2013, as dense_flow applies it): Shi-Tomasi corners of the first frame (cv::goodFeaturesToTrack semantics: 3x3 block,
+ * Sobel 3, candidates = 3x3 local maxima above quality * strongest, strongest first, none closer than min_distance to a kept
+ * one; dense_flow asks for 1000 / 0.001 / 3), each matched to corner + first-pass flow at the corner, then a RANSAC
+ * homography over the matches.  The second frame warped by the INVERSE of that homography (vq_flow_tvl1's homographies
+ * argument) and the flow computed again is the "warped" flow.  The SURF matches the binary merges in are not built.
+ * frames: n frames of the handle's h x w; corners_host [n][max_corners][2] (x, y), counts_host [n]. */
+int vq_flow_good_features(vq_flow* flow, const uint8_t* frames, int32_t frames_on_device, int32_t n, int32_t max_corners, float quality,
+                          float min_distance, float* corners_host, int32_t* counts_host, void* hip_stream);
+/* n independent match sets src -> dst ([n][max_points][2] floats, counts [n]).  `hypotheses` 4-point samples per set, drawn
+ * with a counter hash of (seed, set, hypothesis) so the result does not depend on scheduling; a sample whose two
+ * quadrilaterals are oriented differently is skipped; score = matches with forward reprojection error <= threshold px;
+ * winner = most inliers, first among equals.  refit != 0: the returned matrix is the normalised least-squares fit to the
+ * winner's inliers (cv::findHomography re-estimates likewise; its final Levenberg-Marquardt polish is not applied).
+ * h_host [n][9] row-major (identity when a set has fewer than 4 matches or no valid sample), inliers_host [n],
+ * winner_host [n] (hypothesis index, -1 = none; optional), mask_host [n][max_points] (optional). */
+int vq_flow_ransac_homography(vq_flow* flow, const float* src_host, const float* dst_host, const int32_t* counts_host, int32_t n,
+                              int32_t max_points, float threshold, int32_t hypotheses, uint32_t seed, int32_t refit, double* h_host,
+                              int32_t* inliers_host, int32_t* winner_host, uint8_t* mask_host, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------
  * Comm group: one process per GPU, RCCL over xGMI

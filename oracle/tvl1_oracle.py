@@ -15,8 +15,8 @@ PARITY UNPINNED.  Nothing the reference holds pins any of this: no frames, no fl
 restates the PUBLISHED algorithm -- Zach, Pock & Bischof, "A duality based approach for realtime TV-L1 optical flow"
 (DAGM 2007) in the formulation of Sanchez Perez, Meinhardt-Llopis & Facciolo, "TV-L1 Optical Flow Estimation" (IPOL 2013,
 Algorithm 1 and its reference code), which OpenCV's implementation follows -- with OpenCV's published default parameters
-and its interpolation choices (bilinear warping, bilinear pyramid).  The feature-matching half of the warp step (SURF,
-RANSAC) is NOT restated: ``warp_homography`` takes the 3x3 matrix as an input.
+and its interpolation choices (bilinear warping, bilinear pyramid).  The estimation of the warp step's matrix is restated in
+oracle/warp_oracle.py (flow-match branch; SURF is not restated): ``warp_homography`` here takes the 3x3 matrix as an input.
 
 Everything is float32 with the operation order written out, so that a device kernel can follow it operation for operation.
 """
@@ -171,7 +171,7 @@ def flow_to_image(flow: np.ndarray, bound: float = 20.0) -> np.ndarray:
 
 def warp_homography(img: np.ndarray, hmat: Sequence[Sequence[float]]) -> np.ndarray:
     """cv::warpPerspective(img, H) with INTER_LINEAR and a replicated border: out(x, y) = img(H^-1 (x, y, 1)).  The
-    matrix itself comes from SURF + RANSAC in the reference's binary and is an INPUT here."""
+    matrix itself (feature matches + RANSAC in the reference's binary, oracle/warp_oracle.py) is an INPUT here."""
     h, w = img.shape
     hi = np.linalg.inv(np.asarray(hmat, dtype=np.float64))
     ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)

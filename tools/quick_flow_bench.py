@@ -32,6 +32,19 @@ def main(n_pairs=64):
     gbs = pixel_iters * 22 * 4 / dt / 1e9
     print("%d pairs of 340x256: %.1f ms per batch -> %.0f pairs/s; %.3g pixel-iterations, %.0f GB/s algorithmic (%.1f%% of 8 TB/s); "
           "mean inner iterations per warp %.1f" % (n_pairs, dt * 1e3, n_pairs / dt, pixel_iters, gbs, gbs / 80.0, its.mean()))
+    # the warped flow: first pass, corners + RANSAC homography, second pass on the compensated frame
+    m.warped(f0, f1)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        w = m.warped(f0, f1)
+    dw = (time.perf_counter() - t0) / reps
+    first = m.flow(f0, f1, images=False)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        H, matches, inliers = m.camera_motion(f0, first["u1"], first["u2"])
+    dc = (time.perf_counter() - t0) / reps
+    print("warped flow: %.1f ms per batch -> %.0f pairs/s (camera-motion estimate alone %.1f ms: %d corners and %d inliers per pair on average)"
+          % (dw * 1e3, n_pairs / dw, dc * 1e3, matches.mean(), inliers.mean()))
     t0 = time.perf_counter()
     tv.tvl1_flow(f0[0], f1[0])
     print("oracle (numpy, 1 thread): %.2f s per pair" % (time.perf_counter() - t0))

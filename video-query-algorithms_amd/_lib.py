@@ -90,6 +90,8 @@ SIGNATURES = {
     "vq_flow_create": [_I32, _I32, _I32, C.POINTER(Tvl1Params), _I32, _PP], "vq_flow_destroy": [_P],
     "vq_flow_levels": [_P, _pI32, _pI32, _I32],
     "vq_flow_tvl1": [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P],
+    "vq_flow_good_features": [_P, _P, _I32, _I32, _I32, C.c_float, C.c_float, _P, _P, _P],
+    "vq_flow_ransac_homography": [_P, _P, _P, _P, _I32, _I32, C.c_float, _I32, C.c_uint32, _I32, _P, _P, _P, _P, _P],
     "vq_comm_unique_id": [_P], "vq_comm_init": [_I32, _I32, _P, _I32, _PP], "vq_comm_destroy": [_P],
     "vq_comm_info": [_P, _pI32, _pI32, _pI32],
     "vq_allgather_features": [_P, _P, _I64, _P, _P], "vq_allgather_scores": [_P, _P, _I64, _P, _P],

@@ -46,7 +46,7 @@ def build(force=False, verbose=True):
     cmd = [hipcc, "-shared", "--offload-arch=gfx950", "-fPIC"] + objs + ["-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd + ["-ldl"])
+    subprocess.check_call(cmd + ["-ldl", "-lpthread"])
     return OUT
 
 

@@ -7,8 +7,9 @@
 // PARITY UNPINNED: the reference holds neither frames nor flow images nor the binary.  The kernels follow oracle/
 // tvl1_oracle.py -- the PUBLISHED algorithm (Zach, Pock & Bischof 2007 as formulated in IPOL 2013, Algorithm 1) with OpenCV's
 // default parameters and interpolation choices -- operation for operation in fp32 (contraction off, correctly rounded
-// division and square root), so device and oracle agree to rounding.  The feature-matching half of dense_flow's camera-motion
-// "warp" (SURF + RANSAC homography) is not built; vq_flow_warp_homography applies a GIVEN homography to the second frame.
+// division and square root), so device and oracle agree to rounding.  dense_flow's camera-motion "warp": vq_flow_tvl1 applies a
+// given homography to the second frame; vq_flow_good_features + vq_flow_ransac_homography (end of this file, oracle/
+// warp_oracle.py) estimate it from corners moved by the first-pass flow.  The SURF matches the binary adds are not built.
 //
 // Shape of the work: a BATCH of independent frame pairs (one 340 x 256 pair is only 87 k pixels).  Per pyramid level and warp:
 // one warp kernel, then per inner iteration two stencil kernels over all pairs -- the primal step needs every neighbour's dual
@@ -22,6 +23,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "vq_common.h"
@@ -214,6 +216,235 @@ __global__ void homography_warp_kernel(const float* __restrict__ src, float* __r
     dst[i] = sample_bilinear(src + p * (int64_t)h * w, h, w, (float)x + (sx - (float)x), (float)y + (sy - (float)y));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Camera-motion estimation ("warp" half of extract_warp_gpu, the flow-match branch): Shi-Tomasi corners on the first frame,
+// matched through the first-pass flow, a RANSAC homography over the matches (oracle/warp_oracle.py).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// cv::cornerMinEigenVal(blockSize 3, Sobel 3, BORDER_REFLECT_101) on an 8-bit frame: derivatives scaled by 1 / (4 * 3 * 255),
+// their products summed over the 3 x 3 block (rows first), smaller eigenvalue of the 2 x 2 matrix.
+__global__ void corner_strength_kernel(const uint8_t* __restrict__ frames, float* __restrict__ strength, unsigned* __restrict__ frame_max, int n,
+                                       int h, int w) {
+    // grid (pixel blocks, frame): a block lies inside one frame, so the frame maximum costs one atomic per block
+    __shared__ float wave_top[4];
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = blockIdx.y;
+    const bool live = q < h * w;
+    const int x = live ? q % w : 0, y = live ? q / w : 0;
+    const int64_t i = p * (int64_t)h * w + q;
+    const uint8_t* im = frames + p * (int64_t)h * w;
+    const float scale = (float)(1.0 / (4.0 * 3.0 * 255.0));
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int dy = -1; dy <= 1; ++dy) {
+        float ra = 0.f, rb = 0.f, rc = 0.f;
+        const int yy = reflect101(y + dy, h);
+        const int y0 = reflect101(yy - 1, h), y2 = reflect101(yy + 1, h);
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = reflect101(x + dx, w);
+            const int x0 = reflect101(xx - 1, w), x2 = reflect101(xx + 1, w);
+            const int gx = ((int)im[y0 * w + x2] + 2 * (int)im[yy * w + x2] + (int)im[y2 * w + x2]) -
+                           ((int)im[y0 * w + x0] + 2 * (int)im[yy * w + x0] + (int)im[y2 * w + x0]);
+            const int gy = ((int)im[y2 * w + x0] + 2 * (int)im[y2 * w + xx] + (int)im[y2 * w + x2]) -
+                           ((int)im[y0 * w + x0] + 2 * (int)im[y0 * w + xx] + (int)im[y0 * w + x2]);
+            const float fx = (float)gx * scale, fy = (float)gy * scale;
+            ra += fx * fx;
+            rb += fx * fy;
+            rc += fy * fy;
+        }
+        a += ra;
+        b += rb;
+        c += rc;
+    }
+    a *= 0.5f;
+    c *= 0.5f;
+    const float d = a - c;
+    const float v = (a + c) - __fsqrt_rn(d * d + b * b);
+    if (live) strength[i] = v;
+    float top = live ? fmaxf(v, 0.f) : 0.f;
+    for (int off = 32; off > 0; off >>= 1) top = fmaxf(top, __shfl_xor(top, off));
+    if ((threadIdx.x & 63) == 0) wave_top[threadIdx.x >> 6] = top;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        top = fmaxf(fmaxf(wave_top[0], wave_top[1]), fmaxf(wave_top[2], wave_top[3]));
+        if (top > 0.f) atomicMax(frame_max + p, __float_as_uint(top));   // positive floats order like their bit patterns
+    }
+}
+
+// A candidate corner is an interior pixel that equals the maximum of its 3 x 3 neighbourhood (cv::dilate + compare); others read 0.
+__global__ void corner_peaks_kernel(const float* __restrict__ strength, float* __restrict__ peaks, int n, int h, int w) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * h * w) return;
+    const int x = (int)(i % w), y = (int)((i / w) % h);
+    const float* s = strength + (i - (int64_t)y * w - x);
+    float out = 0.f;
+    if (x >= 1 && y >= 1 && x < w - 1 && y < h - 1) {
+        const float v = s[y * w + x];
+        float m = v;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) m = fmaxf(m, s[(y + dy) * w + x + dx]);
+        out = (v == m) ? v : 0.f;
+    }
+    peaks[i] = out;
+}
+
+__host__ __device__ inline uint32_t mix32(uint32_t x) {   // "lowbias32" integer hash: the hypothesis generator of the RANSAC
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+__device__ inline double orient(const float* a, const float* b, const float* c) {
+    return ((double)b[0] - (double)a[0]) * ((double)c[1] - (double)a[1]) - ((double)b[1] - (double)a[1]) * ((double)c[0] - (double)a[0]);
+}
+
+// The homography through 4 correspondences (h33 = 1): 8 x 8 system, Gaussian elimination with partial pivoting, fp64.
+__device__ bool homography_4pt(const float* const* s, const float* const* d, double* H) {
+    double A[8][9];
+    for (int k = 0; k < 4; ++k) {
+        const double x = s[k][0], y = s[k][1], u = d[k][0], v = d[k][1];
+        double* r0 = A[2 * k];
+        double* r1 = A[2 * k + 1];
+        r0[0] = x; r0[1] = y; r0[2] = 1; r0[3] = 0; r0[4] = 0; r0[5] = 0; r0[6] = -u * x; r0[7] = -u * y; r0[8] = u;
+        r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = x; r1[4] = y; r1[5] = 1; r1[6] = -v * x; r1[7] = -v * y; r1[8] = v;
+    }
+    for (int c = 0; c < 8; ++c) {
+        int piv = c;
+        double best = fabs(A[c][c]);
+        for (int r = c + 1; r < 8; ++r)
+            if (fabs(A[r][c]) > best) {
+                best = fabs(A[r][c]);
+                piv = r;
+            }
+        if (best < 1e-9) return false;
+        if (piv != c)
+            for (int q = c; q < 9; ++q) {
+                const double t = A[c][q];
+                A[c][q] = A[piv][q];
+                A[piv][q] = t;
+            }
+        for (int r = c + 1; r < 8; ++r) {
+            const double f = A[r][c] / A[c][c];
+            for (int q = c; q < 9; ++q) A[r][q] -= f * A[c][q];
+        }
+    }
+    for (int c = 7; c >= 0; --c) {
+        double v = A[c][8];
+        for (int q = c + 1; q < 8; ++q) v -= A[c][q] * H[q];
+        H[c] = v / A[c][c];
+    }
+    H[8] = 1.0;
+    return true;
+}
+
+// One workgroup per pair, one hypothesis per thread and round: 4 distinct matches drawn with mix32, rejected when the two
+// quadrilaterals are not consistently oriented (cv's checkSubset), scored by the number of matches whose forward
+// reprojection error is <= thr2.  The winner is the hypothesis with the most inliers, the lowest index among equals.
+__global__ void ransac_homography_kernel(const float* __restrict__ src, const float* __restrict__ dst, const int* __restrict__ counts, int max_points,
+                                         int hypotheses, uint32_t seed, double thr2, double* __restrict__ best_h, int* __restrict__ best_count,
+                                         int* __restrict__ best_index, uint8_t* __restrict__ mask) {
+    extern __shared__ float pts[];               // [max_points][4]: sx, sy, dx, dy
+    __shared__ int win_count[256], win_index[256];
+    __shared__ double win_h[9];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int n = counts[p];
+    for (int i = tid; i < n; i += blockDim.x) {
+        pts[4 * i] = src[((size_t)p * max_points + i) * 2];
+        pts[4 * i + 1] = src[((size_t)p * max_points + i) * 2 + 1];
+        pts[4 * i + 2] = dst[((size_t)p * max_points + i) * 2];
+        pts[4 * i + 3] = dst[((size_t)p * max_points + i) * 2 + 1];
+    }
+    __syncthreads();
+    int my_count = -1, my_index = 0x7fffffff;
+    double my_h[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (n >= 4) {
+        for (int j = tid; j < hypotheses; j += blockDim.x) {
+            int idx[4];
+            bool ok = true;
+            const uint32_t base = mix32(mix32(seed + (uint32_t)p) + (uint32_t)j);
+            for (int k = 0; k < 4 && ok; ++k) {
+                ok = false;
+                for (uint32_t a = 0; a < 64 && !ok; ++a) {
+                    const int cand = (int)(mix32(base + 16u * a + (uint32_t)k) % (uint32_t)n);
+                    bool fresh = true;
+                    for (int q = 0; q < k; ++q) fresh = fresh && idx[q] != cand;
+                    if (fresh) {
+                        idx[k] = cand;
+                        ok = true;
+                    }
+                }
+            }
+            if (!ok) continue;
+            const float* s4[4];
+            const float* d4[4];
+            for (int k = 0; k < 4; ++k) {
+                s4[k] = pts + 4 * idx[k];
+                d4[k] = pts + 4 * idx[k] + 2;
+            }
+            // every triple keeps its orientation (and is not collinear) under a homography that maps the quadrilateral properly
+            for (int a = 0; a < 4 && ok; ++a) {
+                const int i0 = a, i1 = (a + 1) & 3, i2 = (a + 2) & 3;
+                const double os = orient(s4[i0], s4[i1], s4[i2]), od = orient(d4[i0], d4[i1], d4[i2]);
+                ok = os * od > 0.0;
+            }
+            if (!ok) continue;
+            double H[9];
+            if (!homography_4pt(s4, d4, H)) continue;
+            int cnt = 0;
+            for (int i = 0; i < n; ++i) {
+                const double x = pts[4 * i], y = pts[4 * i + 1];
+                const double wq = H[6] * x + H[7] * y + 1.0;
+                const double ex = (H[0] * x + H[1] * y + H[2]) / wq - (double)pts[4 * i + 2];
+                const double ey = (H[3] * x + H[4] * y + H[5]) / wq - (double)pts[4 * i + 3];
+                cnt += (ex * ex + ey * ey <= thr2) ? 1 : 0;
+            }
+            if (cnt > my_count) {     // j ascends per thread: the first best stays
+                my_count = cnt;
+                my_index = j;
+                for (int q = 0; q < 9; ++q) my_h[q] = H[q];
+            }
+        }
+    }
+    win_count[tid] = my_count;
+    win_index[tid] = my_index;
+    __syncthreads();
+    for (int step = blockDim.x / 2; step > 0; step >>= 1) {
+        if (tid < step) {
+            const int oc = win_count[tid + step], oi = win_index[tid + step];
+            if (oc > win_count[tid] || (oc == win_count[tid] && oi < win_index[tid])) {
+                win_count[tid] = oc;
+                win_index[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const int w_count = win_count[0], w_index = win_index[0];
+    if (my_index == w_index && w_count >= 0)
+        for (int q = 0; q < 9; ++q) win_h[q] = my_h[q];
+    if (w_count < 0 && tid == 0)
+        for (int q = 0; q < 9; ++q) win_h[q] = (q % 4 == 0) ? 1.0 : 0.0;
+    __syncthreads();
+    if (tid < 9) best_h[(size_t)p * 9 + tid] = win_h[tid];
+    if (tid == 0) {
+        best_count[p] = w_count < 0 ? 0 : w_count;
+        best_index[p] = w_count < 0 ? -1 : w_index;
+    }
+    for (int i = tid; i < max_points; i += blockDim.x) {
+        uint8_t in = 0;
+        if (i < n && w_count >= 0) {
+            const double x = pts[4 * i], y = pts[4 * i + 1];
+            const double wq = win_h[6] * x + win_h[7] * y + 1.0;
+            const double ex = (win_h[0] * x + win_h[1] * y + win_h[2]) / wq - (double)pts[4 * i + 2];
+            const double ey = (win_h[3] * x + win_h[4] * y + win_h[5]) / wq - (double)pts[4 * i + 3];
+            in = (ex * ex + ey * ey <= thr2) ? 1 : 0;
+        }
+        mask[(size_t)p * max_points + i] = in;
+    }
+}
+
 }  // namespace
 
 struct vq_flow {
@@ -231,6 +462,9 @@ struct vq_flow {
     int* n_active = nullptr;
     int* iters_log = nullptr;              // [levels][warps][pairs]
     double* hinv_dev = nullptr;
+    unsigned* frame_max = nullptr;         // [max_pairs] bit pattern of the largest corner strength of a frame
+    void* match_dev = nullptr;             // RANSAC scratch (matches, winners, masks), grown on demand
+    size_t match_bytes = 0;
 };
 
 static void flow_free(vq_flow* f) {
@@ -248,6 +482,8 @@ static void flow_free(vq_flow* f) {
     if (f->n_active) (void)hipFree(f->n_active);
     if (f->iters_log) (void)hipFree(f->iters_log);
     if (f->hinv_dev) (void)hipFree(f->hinv_dev);
+    if (f->frame_max) (void)hipFree(f->frame_max);
+    if (f->match_dev) (void)hipFree(f->match_dev);
 }
 
 extern "C" {
@@ -322,6 +558,7 @@ int vq_flow_create(int32_t max_pairs, int32_t h, int32_t w, const vq_tvl1_params
     if ((e = hipMalloc((void**)&f->iters_log, (size_t)f->levels.size() * prm.warps * max_pairs * sizeof(int))) != hipSuccess)
         return bail("hipMalloc(log)", e);
     if ((e = hipMalloc((void**)&f->hinv_dev, (size_t)max_pairs * 9 * sizeof(double))) != hipSuccess) return bail("hipMalloc(homographies)", e);
+    if ((e = hipMalloc((void**)&f->frame_max, (size_t)max_pairs * sizeof(unsigned))) != hipSuccess) return bail("hipMalloc(state)", e);
     *out = f;
     return VQ_OK;
 }
@@ -479,6 +716,244 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
         if (flow_y_host) VQ_HIP(hipMemcpyAsync(flow_y_host, f->img_dev[1], (size_t)full, hipMemcpyDeviceToHost, st));
     }
     VQ_HIP(hipStreamSynchronize(st));
+    return VQ_OK;
+}
+
+}  // extern "C"
+
+// ---- camera-motion estimation -------------------------------------------------------------------------------------------
+
+namespace {
+
+// cv::goodFeaturesToTrack's selection on the host: candidates above quality * max, strongest first (equal strengths: the later
+// pixel first, as cv's pointer comparison does), accepted unless a kept corner lies closer than min_distance (cell grid).
+int select_corners(const float* peaks, int h, int w, float top, int max_corners, float quality, float min_distance, float* out_xy) {
+    const float thresh = top * quality;
+    std::vector<int> cand;
+    for (int i = 0; i < h * w; ++i)
+        if (peaks[i] > thresh && peaks[i] != 0.f) cand.push_back(i);
+    std::sort(cand.begin(), cand.end(), [&](int a, int b) { return peaks[a] > peaks[b] || (peaks[a] == peaks[b] && a > b); });
+    int kept = 0;
+    if (min_distance >= 1.f) {
+        const int cell = (int)std::nearbyint(min_distance);
+        const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
+        std::vector<int> head((size_t)gw * gh, -1), next, pix;      // per cell: chain of kept corners (indices into pix)
+        const float md2 = min_distance * min_distance;
+        for (int i : cand) {
+            const int y = i / w, x = i - y * w;
+            const int cx = x / cell, cy = y / cell;
+            bool good = true;
+            for (int yy = std::max(cy - 1, 0); yy <= std::min(cy + 1, gh - 1) && good; ++yy)
+                for (int xx = std::max(cx - 1, 0); xx <= std::min(cx + 1, gw - 1) && good; ++xx)
+                    for (int q = head[(size_t)yy * gw + xx]; q >= 0; q = next[q]) {
+                        const int j = pix[q];
+                        const float dx = (float)(x - j % w), dy = (float)(y - j / w);
+                        if (dx * dx + dy * dy < md2) {
+                            good = false;
+                            break;
+                        }
+                    }
+            if (!good) continue;
+            next.push_back(head[(size_t)cy * gw + cx]);
+            pix.push_back(i);
+            head[(size_t)cy * gw + cx] = (int)pix.size() - 1;
+            out_xy[2 * kept] = (float)x;
+            out_xy[2 * kept + 1] = (float)y;
+            if (++kept == max_corners) break;
+        }
+    } else {
+        for (int i : cand) {
+            out_xy[2 * kept] = (float)(i % w);
+            out_xy[2 * kept + 1] = (float)(i / w);
+            if (++kept == max_corners) break;
+        }
+    }
+    return kept;
+}
+
+bool solve_dense(std::vector<double>& A, std::vector<double>& b, int n) {   // Gaussian elimination, partial pivoting; b <- solution
+    for (int c = 0; c < n; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < n; ++r)
+            if (std::fabs(A[(size_t)r * n + c]) > std::fabs(A[(size_t)piv * n + c])) piv = r;
+        if (std::fabs(A[(size_t)piv * n + c]) < 1e-300) return false;
+        if (piv != c) {
+            for (int q = 0; q < n; ++q) std::swap(A[(size_t)c * n + q], A[(size_t)piv * n + q]);
+            std::swap(b[c], b[piv]);
+        }
+        for (int r = c + 1; r < n; ++r) {
+            const double f = A[(size_t)r * n + c] / A[(size_t)c * n + c];
+            for (int q = c; q < n; ++q) A[(size_t)r * n + q] -= f * A[(size_t)c * n + q];
+            b[r] -= f * b[c];
+        }
+    }
+    for (int c = n - 1; c >= 0; --c) {
+        double v = b[c];
+        for (int q = c + 1; q < n; ++q) v -= A[(size_t)c * n + q] * b[q];
+        b[c] = v / A[(size_t)c * n + c];
+    }
+    return true;
+}
+
+// Least-squares homography (h33 = 1 in normalised coordinates) over the inliers: Hartley normalisation of both point sets,
+// normal equations of the 2k x 8 system in fp64, de-normalised and scaled to H[8] = 1.
+bool refit_homography(const float* src, const float* dst, const uint8_t* mask, int n, double* H) {
+    int k = 0;
+    double cs[2] = {0, 0}, cd[2] = {0, 0};
+    for (int i = 0; i < n; ++i)
+        if (mask[i]) {
+            cs[0] += src[2 * i];
+            cs[1] += src[2 * i + 1];
+            cd[0] += dst[2 * i];
+            cd[1] += dst[2 * i + 1];
+            ++k;
+        }
+    if (k < 4) return false;
+    for (int q = 0; q < 2; ++q) {
+        cs[q] /= k;
+        cd[q] /= k;
+    }
+    double ms = 0, md = 0;
+    for (int i = 0; i < n; ++i)
+        if (mask[i]) {
+            ms += std::sqrt((src[2 * i] - cs[0]) * (src[2 * i] - cs[0]) + (src[2 * i + 1] - cs[1]) * (src[2 * i + 1] - cs[1]));
+            md += std::sqrt((dst[2 * i] - cd[0]) * (dst[2 * i] - cd[0]) + (dst[2 * i + 1] - cd[1]) * (dst[2 * i + 1] - cd[1]));
+        }
+    if (ms <= 0 || md <= 0) return false;
+    const double ss = std::sqrt(2.0) * k / ms, sd = std::sqrt(2.0) * k / md;
+    std::vector<double> N(64, 0.0), r(8, 0.0);
+    for (int i = 0; i < n; ++i) {
+        if (!mask[i]) continue;
+        const double x = (src[2 * i] - cs[0]) * ss, y = (src[2 * i + 1] - cs[1]) * ss;
+        const double u = (dst[2 * i] - cd[0]) * sd, v = (dst[2 * i + 1] - cd[1]) * sd;
+        const double r0[8] = {x, y, 1, 0, 0, 0, -u * x, -u * y}, r1[8] = {0, 0, 0, x, y, 1, -v * x, -v * y};
+        for (int a = 0; a < 8; ++a) {
+            for (int b = 0; b < 8; ++b) N[a * 8 + b] += r0[a] * r0[b] + r1[a] * r1[b];
+            r[a] += r0[a] * u + r1[a] * v;
+        }
+    }
+    if (!solve_dense(N, r, 8)) return false;
+    const double Hn[9] = {r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], 1.0};
+    // H = Td^-1 Hn Ts with Ts = [ss 0 -ss cs0; 0 ss -ss cs1; 0 0 1], Td^-1 = [1/sd 0 cd0; 0 1/sd cd1; 0 0 1]
+    double M[9];
+    for (int a = 0; a < 3; ++a) {
+        M[a * 3] = Hn[a * 3] * ss;
+        M[a * 3 + 1] = Hn[a * 3 + 1] * ss;
+        M[a * 3 + 2] = -Hn[a * 3] * ss * cs[0] - Hn[a * 3 + 1] * ss * cs[1] + Hn[a * 3 + 2];
+    }
+    double G[9];
+    for (int q = 0; q < 3; ++q) {
+        G[q] = M[q] / sd + cd[0] * M[6 + q];
+        G[3 + q] = M[3 + q] / sd + cd[1] * M[6 + q];
+        G[6 + q] = M[6 + q];
+    }
+    if (std::fabs(G[8]) < 1e-300) return false;
+    for (int q = 0; q < 9; ++q) H[q] = G[q] / G[8];
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vq_flow_good_features(vq_flow* f, const uint8_t* frames, int32_t frames_on_device, int32_t n, int32_t max_corners, float quality,
+                          float min_distance, float* corners_host, int32_t* counts_host, void* hip_stream) {
+    VQ_REQUIRE(f && frames && corners_host && counts_host, "NULL argument");
+    VQ_REQUIRE(n > 0 && n <= f->max_pairs, "n %d outside (0,%d]", n, f->max_pairs);
+    VQ_REQUIRE(max_corners > 0 && quality > 0.f && quality < 1.f && min_distance >= 0.f, "corner parameters out of range");
+    std::lock_guard<std::mutex> lk(f->mu);
+    DeviceGuard g(f->device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int h = f->h, w = f->w;
+    const int64_t full = (int64_t)n * h * w;
+    const uint8_t* d = frames;
+    if (!frames_on_device) {
+        VQ_HIP(hipMemcpyAsync(f->frames_dev[0], frames, (size_t)full, hipMemcpyHostToDevice, st));
+        d = f->frames_dev[0];
+    }
+    float *strength = f->plane[0], *peaks = f->plane[1];
+    VQ_HIP(hipMemsetAsync(f->frame_max, 0, (size_t)n * sizeof(unsigned), st));
+    corner_strength_kernel<<<dim3((unsigned)cdiv((int64_t)h * w, 256), (unsigned)n), 256, 0, st>>>(d, strength, f->frame_max, n, h, w);
+    corner_peaks_kernel<<<cdiv(full, 256), 256, 0, st>>>(strength, peaks, n, h, w);
+    VQ_CHECK_LAUNCH();
+    std::vector<float> host((size_t)full);
+    std::vector<unsigned> top((size_t)n);
+    VQ_HIP(hipMemcpyAsync(host.data(), peaks, (size_t)full * sizeof(float), hipMemcpyDeviceToHost, st));
+    VQ_HIP(hipMemcpyAsync(top.data(), f->frame_max, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    VQ_HIP(hipStreamSynchronize(st));
+    // the selection is per frame and sequential inside a frame: frames are spread over host threads
+    const int workers = std::max(1, std::min<int>({n, 16, (int)std::thread::hardware_concurrency()}));
+    auto work = [&](int first) {
+        for (int p = first; p < n; p += workers) {
+            float t;
+            memcpy(&t, &top[p], sizeof t);
+            counts_host[p] = select_corners(host.data() + (size_t)p * h * w, h, w, t, max_corners, quality, min_distance,
+                                            corners_host + (size_t)p * max_corners * 2);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int k = 1; k < workers; ++k) pool.emplace_back(work, k);
+    work(0);
+    for (std::thread& th : pool) th.join();
+    return VQ_OK;
+}
+
+int vq_flow_ransac_homography(vq_flow* f, const float* src_host, const float* dst_host, const int32_t* counts_host, int32_t n,
+                              int32_t max_points, float threshold, int32_t hypotheses, uint32_t seed, int32_t refit, double* h_host,
+                              int32_t* inliers_host, int32_t* winner_host, uint8_t* mask_host, void* hip_stream) {
+    VQ_REQUIRE(f && src_host && dst_host && counts_host && h_host && inliers_host, "NULL argument");
+    VQ_REQUIRE(n > 0 && max_points >= 4 && max_points <= 8192 && hypotheses > 0 && hypotheses <= (1 << 20) && threshold > 0.f,
+               "RANSAC parameters out of range (at most 8192 matches per pair)");
+    for (int p = 0; p < n; ++p) VQ_REQUIRE(counts_host[p] >= 0 && counts_host[p] <= max_points, "pair %d: %d matches of at most %d", p, counts_host[p], max_points);
+    std::lock_guard<std::mutex> lk(f->mu);
+    DeviceGuard g(f->device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t pts_b = (size_t)n * max_points * 2 * sizeof(float);
+    const size_t need = 2 * pts_b + (size_t)n * (3 * sizeof(int) + 9 * sizeof(double)) + (size_t)n * max_points + 64;
+    if (need > f->match_bytes) {
+        if (f->match_dev) (void)hipFree(f->match_dev);
+        f->match_dev = nullptr;
+        f->match_bytes = 0;
+        VQ_HIP(hipMalloc(&f->match_dev, need));
+        f->match_bytes = need;
+    }
+    char* base = (char*)f->match_dev;
+    double* h_dev = (double*)base;                                   // 8-byte aligned things first
+    float* src_dev = (float*)(base + (size_t)n * 9 * sizeof(double));
+    float* dst_dev = (float*)((char*)src_dev + pts_b);
+    int* cnt_dev = (int*)((char*)dst_dev + pts_b);
+    int* best_dev = cnt_dev + n;
+    int* win_dev = best_dev + n;
+    uint8_t* mask_dev = (uint8_t*)(win_dev + n);
+    VQ_HIP(hipMemcpyAsync(src_dev, src_host, pts_b, hipMemcpyHostToDevice, st));
+    VQ_HIP(hipMemcpyAsync(dst_dev, dst_host, pts_b, hipMemcpyHostToDevice, st));
+    VQ_HIP(hipMemcpyAsync(cnt_dev, counts_host, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+    const size_t lds = (size_t)max_points * 4 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_homography_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16));
+        attr_set = true;
+    }
+    ransac_homography_kernel<<<n, 256, lds, st>>>(src_dev, dst_dev, cnt_dev, max_points, hypotheses, seed, (double)threshold * (double)threshold,
+                                                  h_dev, best_dev, win_dev, mask_dev);
+    VQ_CHECK_LAUNCH();
+    std::vector<uint8_t> mask((size_t)n * max_points);
+    std::vector<int> win((size_t)n);
+    VQ_HIP(hipMemcpyAsync(h_host, h_dev, (size_t)n * 9 * sizeof(double), hipMemcpyDeviceToHost, st));
+    VQ_HIP(hipMemcpyAsync(inliers_host, best_dev, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st));
+    VQ_HIP(hipMemcpyAsync(win.data(), win_dev, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st));
+    VQ_HIP(hipMemcpyAsync(mask.data(), mask_dev, mask.size(), hipMemcpyDeviceToHost, st));
+    VQ_HIP(hipStreamSynchronize(st));
+    if (refit)
+        for (int p = 0; p < n; ++p)
+            if (inliers_host[p] >= 4) {
+                double H[9];
+                if (refit_homography(src_host + (size_t)p * max_points * 2, dst_host + (size_t)p * max_points * 2, mask.data() + (size_t)p * max_points,
+                                     counts_host[p], H))
+                    memcpy(h_host + (size_t)p * 9, H, sizeof H);
+            }
+    if (winner_host) memcpy(winner_host, win.data(), (size_t)n * sizeof(int));
+    if (mask_host) memcpy(mask_host, mask.data(), mask.size());
     return VQ_OK;
 }
 

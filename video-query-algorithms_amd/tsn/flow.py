@@ -5,8 +5,10 @@ The reference gets its ``flow_x_NNNNN.jpg`` / ``flow_y_NNNNN.jpg`` frames from a
 clips (:78-128, ``frames.clip_plan``).  ``Tvl1Flow`` is the handle over ``vq_flow_*`` (csrc/vq_flow.hip): batches of
 grey frame pairs in, fp32 flow fields and / or the 8-bit flow images out.  Parity is unpinned (no binary, no frames, no
 flow images in the reference); the kernels follow oracle/tvl1_oracle.py, the published algorithm with OpenCV's defaults.
-The SURF + RANSAC homography of dense_flow's "warp" step is not built -- pass ``homographies`` to compensate a known
-camera motion.
+``warped`` adds the camera-motion compensation of dense_flow's "warp" step in its flow-match form (improved dense
+trajectories): Shi-Tomasi corners of the first frame moved by the first-pass flow, a RANSAC homography over those
+matches, the second frame warped back by it, the flow computed again.  The SURF matches the binary merges into the same
+RANSAC are not built.
 """
 from __future__ import annotations
 
@@ -72,6 +74,73 @@ class Tvl1Flow:
         for i in range(0, frames.shape[0] - 1, self.max_pairs):
             j = min(i + self.max_pairs, frames.shape[0] - 1)
             r = self.flow(frames[i:j], frames[i + 1:j + 1], fields=False)
+            fx.append(r["flow_x"])
+            fy.append(r["flow_y"])
+        return np.concatenate(fx), np.concatenate(fy)
+
+    # ---- camera-motion compensation ("warp"): corners -> flow matches -> RANSAC homography -> second pass
+    MAX_CORNERS, QUALITY, MIN_DISTANCE = 1000, 0.001, 3.0     # dense_flow's MatchFromFlow
+    RANSAC_THRESHOLD, MIN_MATCHES, MIN_INLIERS = 1.0, 50, 25  # findHomography(..., RANSAC, 1) and its two guards
+
+    def good_features(self, frames: np.ndarray, max_corners: int = MAX_CORNERS, quality: float = QUALITY,
+                      min_distance: float = MIN_DISTANCE):
+        """uint8 [n, h, w] -> (corners float32 [n, max_corners, 2] as (x, y), counts int32 [n]); strongest first."""
+        f = np.ascontiguousarray(frames, dtype=np.uint8)
+        if f.ndim != 3 or f.shape[1:] != (self.h, self.w):
+            raise ValueError("frames must be [n, %d, %d] uint8" % (self.h, self.w))
+        n = f.shape[0]
+        corners = np.zeros((n, int(max_corners), 2), dtype=np.float32)
+        counts = np.zeros(n, dtype=np.int32)
+        call("vq_flow_good_features", self._h, f.ctypes.data_as(C.c_void_p), 0, n, int(max_corners), float(quality), float(min_distance),
+             corners.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), None)
+        return corners, counts
+
+    def ransac_homography(self, src: np.ndarray, dst: np.ndarray, counts: np.ndarray, threshold: float = RANSAC_THRESHOLD,
+                          hypotheses: int = 512, seed: int = 0, refit: bool = True):
+        """Match sets src -> dst (float32 [n, max_points, 2], counts [n]) -> dict(H [n,3,3], inliers [n], winner [n],
+        mask [n, max_points])."""
+        a = np.ascontiguousarray(src, dtype=np.float32)
+        b = np.ascontiguousarray(dst, dtype=np.float32)
+        c = np.ascontiguousarray(counts, dtype=np.int32)
+        if a.shape != b.shape or a.ndim != 3 or a.shape[2] != 2 or c.shape != (a.shape[0],):
+            raise ValueError("src / dst must be [n, max_points, 2] and counts [n]")
+        n, mp = a.shape[0], a.shape[1]
+        out = {"H": np.zeros((n, 3, 3)), "inliers": np.zeros(n, np.int32), "winner": np.zeros(n, np.int32), "mask": np.zeros((n, mp), np.uint8)}
+        call("vq_flow_ransac_homography", self._h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p),
+             n, mp, float(threshold), int(hypotheses), int(seed) & 0xFFFFFFFF, int(bool(refit)), out["H"].ctypes.data_as(C.c_void_p),
+             out["inliers"].ctypes.data_as(C.c_void_p), out["winner"].ctypes.data_as(C.c_void_p), out["mask"].ctypes.data_as(C.c_void_p), None)
+        return out
+
+    def camera_motion(self, frames0: np.ndarray, u1: np.ndarray, u2: np.ndarray, seed: int = 0, hypotheses: int = 512):
+        """Homography frames0 -> frames1 per pair from corners of frames0 moved by the flow (u1, u2); identity where the
+        guards of dense_flow fail (<= 50 matches or <= 25 inliers).  -> (H [n,3,3], matches [n], inliers [n])."""
+        corners, counts = self.good_features(frames0)
+        n = corners.shape[0]
+        xi = np.clip(np.rint(corners[..., 0]).astype(np.int64), 0, self.w - 1)
+        yi = np.clip(np.rint(corners[..., 1]).astype(np.int64), 0, self.h - 1)
+        pair = np.arange(n)[:, None]
+        moved = np.stack([xi.astype(np.float32) + u1[pair, yi, xi], yi.astype(np.float32) + u2[pair, yi, xi]], axis=-1)
+        r = self.ransac_homography(corners, moved, counts, seed=seed, hypotheses=hypotheses)
+        H = r["H"].copy()
+        H[(counts <= self.MIN_MATCHES) | (r["inliers"] <= self.MIN_INLIERS)] = np.eye(3)
+        return H, counts, r["inliers"]
+
+    def warped(self, frames0: np.ndarray, frames1: np.ndarray, seed: int = 0, images: bool = True, fields: bool = False):
+        """The warped flow of extract_warp_gpu (flow-match branch): first-pass flow -> camera homography -> frames1 warped
+        back by it -> flow again.  Returns flow()'s dict plus ``H`` (frames0 -> frames1), ``matches`` and ``inliers``."""
+        first = self.flow(frames0, frames1, images=False, fields=True)
+        H, matches, inliers = self.camera_motion(frames0, first["u1"], first["u2"], seed=seed)
+        # flow(homographies=G) shows the second frame as out(x) = frame1(G^-1 x); the compensated frame is frame1(H x)
+        out = self.flow(frames0, frames1, homographies=np.linalg.inv(H), images=images, fields=fields)
+        out.update(H=H, matches=matches, inliers=inliers)
+        return out
+
+    def warped_consecutive(self, frames: np.ndarray, seed: int = 0):
+        """Grey frames [n + 1, h, w] -> (flow_x, flow_y) uint8 [n, h, w]: the files extract_warp_gpu -s 1 writes."""
+        fx, fy = [], []
+        for i in range(0, frames.shape[0] - 1, self.max_pairs):
+            j = min(i + self.max_pairs, frames.shape[0] - 1)
+            r = self.warped(frames[i:j], frames[i + 1:j + 1], seed=seed + i)
             fx.append(r["flow_x"])
             fy.append(r["flow_y"])
         return np.concatenate(fx), np.concatenate(fy)
