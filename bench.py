@@ -370,6 +370,72 @@ def cpu_baseline_sim(db, row0):
     return out
 
 
+def bench_flow(device_index, with_cpu):
+    """The step two in front of hot path A: TV-L1 flow of a batch of 340 x 256 grey frame pairs -- the
+    size the TSN pipeline resizes to -- plain and camera-motion compensated ("warped"), through the Python handle (frames go
+    in and 8-bit flow images come out over PCIe: 22 MB per batch, inside the timing).  Synthetic frames: a smooth texture that
+    moves by a different sub-pixel translation per pair."""
+    from video_query_algorithms_amd.tsn.flow import Tvl1Flow
+    n, h, w = 64, 256, 340
+    rng = np.random.default_rng(4)
+    f0 = np.empty((n, h, w), np.uint8)
+    f1 = np.empty((n, h, w), np.uint8)
+    for k in range(n):
+        t = np.random.default_rng(k % 8).random((h + 64, w + 64))
+        for _ in range(6):
+            t = (t + np.roll(t, 1, 0) + np.roll(t, -1, 0) + np.roll(t, 1, 1) + np.roll(t, -1, 1)) / 5.0
+        t = (t - t.min()) / (t.max() - t.min()) * 255.0
+        dx, dy = rng.uniform(-5, 5), rng.uniform(-3, 3)
+        ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+        x, y = xs + 32 - dx, ys + 32 - dy
+        x0, y0 = np.floor(x).astype(int), np.floor(y).astype(int)
+        fx, fy = x - x0, y - y0
+        moved = t[y0, x0] * (1 - fx) * (1 - fy) + t[y0, x0 + 1] * fx * (1 - fy) + t[y0 + 1, x0] * (1 - fx) * fy + t[y0 + 1, x0 + 1] * fx * fy
+        f0[k], f1[k] = np.rint(t[32:32 + h, 32:32 + w]), np.rint(moved)
+    m = Tvl1Flow(n, h, w, device=device_index)
+    m.flow(f0, f1, fields=False)
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = m.flow(f0, f1, fields=False, iterations=True)
+    dt = (time.perf_counter() - t0) / reps
+    its = r["iters"]                                              # [levels, warps, pairs], coarsest level first
+    px = np.array([a * b for a, b in m.levels[::-1]], dtype=np.float64)
+    pixel_iters = float((its.sum(axis=1) * px[:, None]).sum())
+    # algorithmic bytes of one pixel-iteration: the primal step reads rho_c, I1wx, I1wy, |grad|^2, u1, u2, p11..p22 and writes
+    # u1, u2; the dual step reads u1, u2, p11..p22 and writes p11..p22 -- 22 floats (neighbour reads are cache hits)
+    gbs = pixel_iters * 22 * 4 / dt / 1e9
+    m.warped(f0, f1)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        wr = m.warped(f0, f1)
+    dw = (time.perf_counter() - t0) / reps
+    out = {"metric": "frame pairs/sec TV-L1 flow (340x256, OpenCV default parameters)", "value": n / dt, "unit": "pairs/s",
+           "batch_pairs": n, "ms_per_batch": dt * 1e3, "mean_inner_iterations_per_warp": float(its.mean()),
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                        "kernel": "tvl1_primal_kernel + tvl1_dual_kernel (one pair of launches per inner iteration)",
+                        "note": "88 algorithmic bytes per pixel-iteration x %.3g pixel-iterations actually run per batch; wall time "
+                                "of the whole call (pyramids, warps, PCIe, the host's convergence polls) -- not a per-kernel "
+                                "HIP-event figure" % pixel_iters},
+           "warped": {"value": n / dw, "unit": "pairs/s", "ms_per_batch": dw * 1e3, "mean_corners": float(wr["matches"].mean()),
+                      "mean_inliers": float(wr["inliers"].mean()),
+                      "note": "first-pass flow + corners + RANSAC homography + second-pass flow on the compensated frame"},
+           "parity": "unpinned (third-party binary absent from the reference); kernels vs oracle/tvl1_oracle.py and oracle/warp_oracle.py "
+                     "in tests/test_flow_gpu.py, tests/test_warp_gpu.py"}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle"))
+        import tvl1_oracle
+        t0 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t0 < 4.0 and k < n:
+            tvl1_oracle.tvl1_flow(f0[k], f1[k])
+            k += 1
+        out["cpu_baseline"] = {"value": k / (time.perf_counter() - t0), "unit": "pairs/s", "cores": 1, "kind": "port",
+                               "sample": "%d of the %d pairs through oracle/tvl1_oracle.py (numpy, one thread)" % (k, n)}
+    m.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -377,6 +443,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--skip-sim", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-flow", action="store_true")
     ap.add_argument("--profile-only", action="store_true",
                     help="for rocprofv3 comparisons: every forward of the process runs like the timed region (one stream, "
                          "VQ_TSN_SPLIT=1) and the un-profiled production-mode pass is skipped")
@@ -455,6 +522,8 @@ def main():
             sim["cpu_baseline"] = cpu_baseline_sim(db, row0)
         out["similarity"] = sim
         db.close()
+    if rank == 0 and world == 1 and not args.skip_flow and not args.profile_only:
+        out["flow"] = bench_flow(local_rank, not args.skip_cpu)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
