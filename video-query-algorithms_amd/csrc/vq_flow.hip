@@ -83,7 +83,7 @@ __device__ __forceinline__ float sample_bilinear(const float* __restrict__ a, in
     return top * (1.0f - wy) + bot * wy;
 }
 
-struct PairState {
+struct alignas(128) PairState {   // one cache line per pair: the error sums of different pairs never contend for a line
     double err;          // sum of squared primal updates of the iteration in flight
     int stop_iter;       // iterations >= stop_iter of the current warp do not run (INT_MAX while the inner loop is live)
     int iters;           // inner iterations run in the current warp
@@ -94,9 +94,10 @@ constexpr int kNoStop = 0x7FFFFFFF;
 __global__ void tvl1_warp_kernel(const float* __restrict__ i0, const float* __restrict__ i1, const float* __restrict__ i1x,
                                  const float* __restrict__ i1y, const float* __restrict__ u1, const float* __restrict__ u2,
                                  float* __restrict__ i1wx, float* __restrict__ i1wy, float* __restrict__ grad, float* __restrict__ rho_c,
-                                 PairState* __restrict__ st, int n, int h, int w) {
+                                 PairState* __restrict__ st, int* __restrict__ n_active, int n, int h, int w) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n * h * w) return;
+    if (i == 0) *n_active = n;       // every pair starts the warp's inner loop live
     const int x = (int)(i % w), y = (int)((i / w) % h);
     const int64_t p = i / ((int64_t)h * w), base = p * (int64_t)h * w;
     const float a = u1[i], b = u2[i];
@@ -115,6 +116,12 @@ __global__ void tvl1_warp_kernel(const float* __restrict__ i0, const float* __re
     }
 }
 
+// End of a warp: the inner iterations each pair ran go to the log (read by the host once, after the last level).
+__global__ void log_iters_kernel(const PairState* __restrict__ st, int* __restrict__ log, int n) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) log[p] = st[p].iters;
+}
+
 struct IterArgs {
     const float *i1wx, *i1wy, *grad, *rho_c;
     float *u1, *u2, *p11, *p12, *p21, *p22;
@@ -123,6 +130,20 @@ struct IterArgs {
     int k;               // index of this inner iteration inside the warp
     float l_t, theta, taut;
 };
+
+// Sum of `local` over the 256 threads of a block added to *dst with ONE atomic (the per-wave atomics of 64+ blocks on one
+// address used to cost more than the whole stencil: fp64 atomics on a line are served one after the other).
+__device__ __forceinline__ void block_add(double* dst, double local) {
+    __shared__ double part[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double sum = (part[0] + part[1]) + (part[2] + part[3]);
+        if (sum != 0.0) atomicAdd(dst, sum);
+    }
+}
 
 // Primal step of one pair per blockIdx.y; blockIdx.x strides over its pixels.
 __global__ __launch_bounds__(256) void tvl1_primal_kernel(IterArgs a) {
@@ -159,9 +180,7 @@ __global__ __launch_bounds__(256) void tvl1_primal_kernel(IterArgs a) {
         a.u1[g] = n1;
         a.u2[g] = n2;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&a.st[p].err, local);
+    block_add(&a.st[p].err, local);
 }
 
 // Dual step.  Its first thread also closes the iteration: the squared update of the primal step just finished (complete: it
@@ -184,6 +203,116 @@ __global__ __launch_bounds__(256) void tvl1_dual_kernel(IterArgs a, double eps2,
         a.p12[g] = (a.p12[g] + a.taut * u1y) / ng1;
         a.p21[g] = (a.p21[g] + a.taut * u2x) / ng2;
         a.p22[g] = (a.p22[g] + a.taut * u2y) / ng2;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const double mean = a.st[p].err / (double)hw;
+        a.st[p].err = 0.0;
+        a.st[p].iters = a.k + 1;
+        if (!(mean > eps2) || a.k + 1 >= max_iters) {
+            a.st[p].stop_iter = a.k + 1;
+            atomicSub(n_active, 1);
+        }
+    }
+}
+
+// Row-vector forms of the two iteration kernels for levels whose width is a multiple of 4 (340 and 272 of the default
+// pyramid: 3/4 of all pixel-iterations): a thread owns 4 consecutive pixels of a row, every plane moves as 16-byte
+// accesses and the row / column decode happens once per 4 pixels.  Per pixel the operations and their order are those of
+// the scalar kernels above, so the fields are the same bits whichever form a level takes.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void tvl1_primal_kernel4(IterArgs a) {
+    const int p = blockIdx.y;
+    if (a.st[p].stop_iter <= a.k) return;
+    const int hw = a.h * a.w;
+    double local = 0.0;
+    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4; i < hw; i += gridDim.x * blockDim.x * 4) {
+        const int x0 = i % a.w, y = i / a.w;
+        const int64_t g = (int64_t)p * hw + i;
+        const floatx4 ux = *reinterpret_cast<const floatx4*>(a.u1 + g), uy = *reinterpret_cast<const floatx4*>(a.u2 + g);
+        const floatx4 gx = *reinterpret_cast<const floatx4*>(a.i1wx + g), gy = *reinterpret_cast<const floatx4*>(a.i1wy + g);
+        const floatx4 gr = *reinterpret_cast<const floatx4*>(a.grad + g), rc = *reinterpret_cast<const floatx4*>(a.rho_c + g);
+        const floatx4 q11 = *reinterpret_cast<const floatx4*>(a.p11 + g), q12 = *reinterpret_cast<const floatx4*>(a.p12 + g);
+        const floatx4 q21 = *reinterpret_cast<const floatx4*>(a.p21 + g), q22 = *reinterpret_cast<const floatx4*>(a.p22 + g);
+        floatx4 up12 = {0.f, 0.f, 0.f, 0.f}, up22 = {0.f, 0.f, 0.f, 0.f};
+        if (y > 0) {
+            up12 = *reinterpret_cast<const floatx4*>(a.p12 + g - a.w);
+            up22 = *reinterpret_cast<const floatx4*>(a.p22 + g - a.w);
+        }
+        float left11 = 0.f, left21 = 0.f;
+        if (x0 > 0) {
+            left11 = a.p11[g - 1];
+            left21 = a.p21[g - 1];
+        }
+        floatx4 n1v, n2v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float rho = rc[e] + (gx[e] * ux[e] + gy[e] * uy[e]);
+            float d1, d2;
+            if (rho < -a.l_t * gr[e]) {
+                d1 = a.l_t * gx[e];
+                d2 = a.l_t * gy[e];
+            } else if (rho > a.l_t * gr[e]) {
+                d1 = -a.l_t * gx[e];
+                d2 = -a.l_t * gy[e];
+            } else if (gr[e] > kGradIsZero) {
+                const float fi = -rho / gr[e];
+                d1 = fi * gx[e];
+                d2 = fi * gy[e];
+            } else {
+                d1 = d2 = 0.0f;
+            }
+            const float l11 = e == 0 ? left11 : q11[e > 0 ? e - 1 : 0], l21 = e == 0 ? left21 : q21[e > 0 ? e - 1 : 0];
+            const bool first = x0 + e == 0;
+            const float div1 = (first ? q11[e] : q11[e] - l11) + (y > 0 ? q12[e] - up12[e] : q12[e]);
+            const float div2 = (first ? q21[e] : q21[e] - l21) + (y > 0 ? q22[e] - up22[e] : q22[e]);
+            const float n1 = (ux[e] + d1) + a.theta * div1, n2 = (uy[e] + d2) + a.theta * div2;
+            const float err = (n1 - ux[e]) * (n1 - ux[e]) + (n2 - uy[e]) * (n2 - uy[e]);
+            local += (double)err;
+            n1v[e] = n1;
+            n2v[e] = n2;
+        }
+        *reinterpret_cast<floatx4*>(a.u1 + g) = n1v;
+        *reinterpret_cast<floatx4*>(a.u2 + g) = n2v;
+    }
+    block_add(&a.st[p].err, local);
+}
+
+__global__ __launch_bounds__(256) void tvl1_dual_kernel4(IterArgs a, double eps2, int max_iters, int* n_active) {
+    const int p = blockIdx.y;
+    if (a.st[p].stop_iter <= a.k) return;
+    const int hw = a.h * a.w;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i < hw) {
+        const int x0 = i % a.w, y = i / a.w;
+        const int64_t g = (int64_t)p * hw + i;
+        const floatx4 c1 = *reinterpret_cast<const floatx4*>(a.u1 + g), c2 = *reinterpret_cast<const floatx4*>(a.u2 + g);
+        const bool right = x0 + 4 < a.w, below = y + 1 < a.h;
+        const float r1 = right ? a.u1[g + 4] : 0.f, r2 = right ? a.u2[g + 4] : 0.f;
+        floatx4 b1 = c1, b2 = c2;
+        if (below) {
+            b1 = *reinterpret_cast<const floatx4*>(a.u1 + g + a.w);
+            b2 = *reinterpret_cast<const floatx4*>(a.u2 + g + a.w);
+        }
+        floatx4 q11 = *reinterpret_cast<const floatx4*>(a.p11 + g), q12 = *reinterpret_cast<const floatx4*>(a.p12 + g);
+        floatx4 q21 = *reinterpret_cast<const floatx4*>(a.p21 + g), q22 = *reinterpret_cast<const floatx4*>(a.p22 + g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool has_right = e < 3 || right;
+            const float n1 = e < 3 ? c1[e < 3 ? e + 1 : 3] : r1, n2 = e < 3 ? c2[e < 3 ? e + 1 : 3] : r2;
+            const float u1x = has_right ? n1 - c1[e] : 0.0f, u1y = below ? b1[e] - c1[e] : 0.0f;
+            const float u2x = has_right ? n2 - c2[e] : 0.0f, u2y = below ? b2[e] - c2[e] : 0.0f;
+            const float ng1 = 1.0f + a.taut * sqrtf(u1x * u1x + u1y * u1y);
+            const float ng2 = 1.0f + a.taut * sqrtf(u2x * u2x + u2y * u2y);
+            q11[e] = (q11[e] + a.taut * u1x) / ng1;
+            q12[e] = (q12[e] + a.taut * u1y) / ng1;
+            q21[e] = (q21[e] + a.taut * u2x) / ng2;
+            q22[e] = (q22[e] + a.taut * u2y) / ng2;
+        }
+        *reinterpret_cast<floatx4*>(a.p11 + g) = q11;
+        *reinterpret_cast<floatx4*>(a.p12 + g) = q12;
+        *reinterpret_cast<floatx4*>(a.p21 + g) = q21;
+        *reinterpret_cast<floatx4*>(a.p22 + g) = q22;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const double mean = a.st[p].err / (double)hw;
@@ -461,6 +590,8 @@ struct vq_flow {
     PairState* st = nullptr;
     int* n_active = nullptr;
     int* iters_log = nullptr;              // [levels][warps][pairs]
+    int* live_host = nullptr;              // pinned: the two most recent polls of n_active
+    hipEvent_t poll_ev[2] = {nullptr, nullptr};
     double* hinv_dev = nullptr;
     unsigned* frame_max = nullptr;         // [max_pairs] bit pattern of the largest corner strength of a frame
     void* match_dev = nullptr;             // RANSAC scratch (matches, winners, masks), grown on demand
@@ -481,6 +612,9 @@ static void flow_free(vq_flow* f) {
     if (f->st) (void)hipFree(f->st);
     if (f->n_active) (void)hipFree(f->n_active);
     if (f->iters_log) (void)hipFree(f->iters_log);
+    if (f->live_host) (void)hipHostFree(f->live_host);
+    for (hipEvent_t e : f->poll_ev)
+        if (e) (void)hipEventDestroy(e);
     if (f->hinv_dev) (void)hipFree(f->hinv_dev);
     if (f->frame_max) (void)hipFree(f->frame_max);
     if (f->match_dev) (void)hipFree(f->match_dev);
@@ -557,6 +691,9 @@ int vq_flow_create(int32_t max_pairs, int32_t h, int32_t w, const vq_tvl1_params
     if ((e = hipMalloc((void**)&f->n_active, sizeof(int))) != hipSuccess) return bail("hipMalloc(state)", e);
     if ((e = hipMalloc((void**)&f->iters_log, (size_t)f->levels.size() * prm.warps * max_pairs * sizeof(int))) != hipSuccess)
         return bail("hipMalloc(log)", e);
+    if ((e = hipHostMalloc((void**)&f->live_host, 2 * sizeof(int))) != hipSuccess) return bail("hipHostMalloc(poll)", e);
+    for (hipEvent_t& ev : f->poll_ev)
+        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc((void**)&f->hinv_dev, (size_t)max_pairs * 9 * sizeof(double))) != hipSuccess) return bail("hipMalloc(homographies)", e);
     if ((e = hipMalloc((void**)&f->frame_max, (size_t)max_pairs * sizeof(unsigned))) != hipSuccess) return bail("hipMalloc(state)", e);
     *out = f;
@@ -670,30 +807,39 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
         a.theta = P.theta;
         a.taut = (float)((double)P.tau / (double)P.theta);
         const dim3 grid((unsigned)std::min(cdiv((int64_t)L.h * L.w, 256), 64), (unsigned)n_pairs);
+        // rows of a multiple of 4 pixels (and plane bases 16-byte aligned: hw is then a multiple of 4 too): the row-vector kernels
+        const bool vec = L.w % 4 == 0;
+        const dim3 grid4((unsigned)cdiv((int64_t)L.h * L.w / 4, 256), (unsigned)n_pairs);
+        const dim3 grid4p(std::min(grid4.x, 32u), (unsigned)n_pairs);      // primal: few blocks per pair = few atomics on its error sum
         for (int wp = 0; wp < P.warps; ++wp) {
-            tvl1_warp_kernel<<<cdiv(tot, 256), 256, 0, st>>>(i0, i1, i1x, i1y, u1, u2, i1wx, i1wy, grad, rho_c, f->st, n_pairs, L.h, L.w);
-            int live = n_pairs;
-            VQ_HIP(hipMemcpyAsync(f->n_active, &live, sizeof(int), hipMemcpyHostToDevice, st));
-            VQ_HIP(hipStreamSynchronize(st));
-            // converged pairs switch themselves off on the device; the host only looks every `chunk` iterations
-            for (int it = 0; it < P.iterations && live > 0;) {
+            tvl1_warp_kernel<<<cdiv(tot, 256), 256, 0, st>>>(i0, i1, i1x, i1y, u1, u2, i1wx, i1wy, grad, rho_c, f->st, f->n_active, n_pairs, L.h, L.w);
+            // Converged pairs switch themselves off on the device (their workgroups exit at once).  The host polls the number
+            // of live pairs once per chunk of iterations, one chunk BEHIND what it has queued: the stream never runs dry while
+            // the host waits, at the price of at most one chunk of empty launches after the last pair has stopped.
+            int chunk_no = 0;
+            for (int it = 0; it < P.iterations; ++chunk_no) {
                 const int chunk = std::min(P.iterations - it, it < 16 ? 8 : 16);
                 for (int k = 0; k < chunk; ++k) {
                     a.k = it + k;
-                    tvl1_primal_kernel<<<grid, 256, 0, st>>>(a);
-                    tvl1_dual_kernel<<<grid, 256, 0, st>>>(a, eps2, P.iterations, f->n_active);
+                    if (vec) {
+                        tvl1_primal_kernel4<<<grid4p, 256, 0, st>>>(a);
+                        tvl1_dual_kernel4<<<grid4, 256, 0, st>>>(a, eps2, P.iterations, f->n_active);
+                    } else {
+                        tvl1_primal_kernel<<<grid, 256, 0, st>>>(a);
+                        tvl1_dual_kernel<<<grid, 256, 0, st>>>(a, eps2, P.iterations, f->n_active);
+                    }
                 }
                 VQ_CHECK_LAUNCH();
                 it += chunk;
-                VQ_HIP(hipMemcpyAsync(&live, f->n_active, sizeof(int), hipMemcpyDeviceToHost, st));
-                VQ_HIP(hipStreamSynchronize(st));
+                VQ_HIP(hipMemcpyAsync(f->live_host + (chunk_no & 1), f->n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+                VQ_HIP(hipEventRecord(f->poll_ev[chunk_no & 1], st));
+                if (chunk_no > 0) {
+                    VQ_HIP(hipEventSynchronize(f->poll_ev[(chunk_no - 1) & 1]));
+                    if (f->live_host[(chunk_no - 1) & 1] == 0) break;
+                }
             }
-            if (iters_host) {
-                std::vector<PairState> hs((size_t)n_pairs);
-                VQ_HIP(hipMemcpyAsync(hs.data(), f->st, hs.size() * sizeof(PairState), hipMemcpyDeviceToHost, st));
-                VQ_HIP(hipStreamSynchronize(st));
-                for (int p = 0; p < n_pairs; ++p) iters_host[((size_t)(nl - 1 - s) * P.warps + wp) * n_pairs + p] = hs[p].iters;
-            }
+            if (iters_host)
+                log_iters_kernel<<<cdiv(n_pairs, 256), 256, 0, st>>>(f->st, f->iters_log + ((size_t)(nl - 1 - s) * P.warps + wp) * n_pairs, n_pairs);
         }
         if (s > 0) {          // to the next finer level: bilinear resize, flow values divided by the scale step
             const Level& F = f->levels[s - 1];
@@ -706,6 +852,8 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
             VQ_CHECK_LAUNCH();
         }
     }
+    if (iters_host)
+        VQ_HIP(hipMemcpyAsync(iters_host, f->iters_log, (size_t)nl * P.warps * n_pairs * sizeof(int), hipMemcpyDeviceToHost, st));
     if (u1_host) VQ_HIP(hipMemcpyAsync(u1_host, u1, (size_t)full * sizeof(float), hipMemcpyDeviceToHost, st));
     if (u2_host) VQ_HIP(hipMemcpyAsync(u2_host, u2, (size_t)full * sizeof(float), hipMemcpyDeviceToHost, st));
     if (flow_x_host || flow_y_host) {
