@@ -66,7 +66,8 @@ CONV_CASES = [
 @pytest.mark.parametrize("tile", [None, "128x128", "128x96", "128x64", "128x32", "64x64", "64x128",
                                   "128x128x16", "128x96x16", "128x64x16", "128x32x16", "64x64x16", "64x128x16",
                                   "128x128x32x1", "128x96x32x1", "128x64x32x1", "128x32x32x1", "64x64x32x1", "64x128x32x1",
-                                  "128x128x16x1", "128x96x16x1", "128x64x16x1", "128x32x16x1", "64x64x16x1", "64x128x16x1"])
+                                  "128x128x16x1", "128x96x16x1", "128x64x16x1", "128x32x16x1", "64x64x16x1", "64x128x16x1",
+                                  "32x128", "32x128x16", "32x128x32x1", "32x128x16x1"])
 def test_conv_bn_relu_layer(tsn, monkeypatch, cin, h, cout, k, s, p, n, tile):
     bi, net = tsn
     if tile:
@@ -88,6 +89,31 @@ def test_conv_bn_relu_layer(tsn, monkeypatch, cin, h, cout, k, s, p, n, tile):
     assert (got >= 0).all()
     assert np.abs(ps - want["gp"].reshape(n, -1)).max() <= tol
     m.close()
+
+
+def test_every_direct_tiling_gives_the_same_bits(tsn, monkeypatch):
+    """The tiling of a direct convolution is chosen per layer and batch size by timing: it must never change a result bit
+    (every tiling sums an output element's K terms in the same order).  A stride-2 3x3 layer with a ragged M and N edge
+    and a poisoned slot, under every tiling the table holds."""
+    bi, net = tsn
+    monkeypatch.setenv("VQ_TSN_POISON", "1")
+    g = _mini(bi, 128, 14, 14, 160, 3, 2, 1)
+    w = net.synthetic_weights(g, seed=9)
+    crops = np.random.default_rng(3).integers(0, 256, (5, 14, 14, 128), dtype=np.uint8)
+    mean = np.full(128, 117.0, np.float32)
+    seen = None
+    for bm, bn in ((128, 128), (128, 96), (128, 64), (64, 128), (64, 64), (128, 32), (32, 128)):
+        for bk in (32, 16):
+            for pipe in (0, 1):
+                monkeypatch.setenv("VQ_TSN_TILE", "%dx%dx%dx%d" % (bm, bn, bk, pipe))
+                m = net.TsnNet(g, w, max_crops=5, feature_blob="gp")
+                m.forward(crops, 1, mean)
+                got = m.read_blob("c_bn", 5)
+                m.close()
+                assert np.isfinite(got).all(), (bm, bn, bk, pipe)
+                if seen is None:
+                    seen = got
+                assert (got == seen).all(), (bm, bn, bk, pipe)
 
 
 WINO_CASES = [

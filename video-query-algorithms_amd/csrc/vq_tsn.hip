@@ -770,8 +770,10 @@ static int launch_conv_t(vq_tsn* net, ConvArgs& a) {
 static const ConvTile kTiles[] = {
     {128, 128, 32, 0}, {128, 128, 16, 0}, {128, 96, 32, 0}, {128, 96, 16, 0}, {128, 64, 32, 0}, {128, 64, 16, 0},
     {64, 128, 32, 0},  {64, 128, 16, 0},  {64, 64, 32, 0},  {64, 64, 16, 0},  {128, 32, 32, 0}, {128, 32, 16, 0},
+    {32, 128, 32, 0},  {32, 128, 16, 0},
     {128, 128, 32, 1}, {128, 128, 16, 1}, {128, 96, 32, 1}, {128, 96, 16, 1}, {128, 64, 32, 1}, {128, 64, 16, 1},
-    {64, 128, 32, 1},  {64, 128, 16, 1},  {64, 64, 32, 1},  {64, 64, 16, 1},  {128, 32, 32, 1}, {128, 32, 16, 1}};
+    {64, 128, 32, 1},  {64, 128, 16, 1},  {64, 64, 32, 1},  {64, 64, 16, 1},  {128, 32, 32, 1}, {128, 32, 16, 1},
+    {32, 128, 32, 1},  {32, 128, 16, 1}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 
 template <int BM, int BN, int WM, int WN, int BK, bool SMALL>
@@ -796,13 +798,13 @@ static int launch_conv_pipe(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
     if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_) return launch_conv_pipe_t<BM_, BN_, WM_, WN_, BK_, SMALL>(net, a);
     P_(128, 128, 2, 2, 32) P_(128, 128, 2, 2, 16) P_(128, 96, 4, 1, 32) P_(128, 96, 4, 1, 16) P_(128, 64, 2, 2, 32)
     P_(128, 64, 2, 2, 16) P_(64, 128, 2, 2, 32) P_(64, 128, 2, 2, 16) P_(64, 64, 2, 2, 32) P_(64, 64, 2, 2, 16)
-    P_(128, 32, 4, 1, 32) P_(128, 32, 4, 1, 16)
+    P_(128, 32, 4, 1, 32) P_(128, 32, 4, 1, 16) P_(32, 128, 1, 4, 32) P_(32, 128, 1, 4, 16)
 #undef P_
     return fail(VQ_E_INVALID, "no pipelined kernel for tile %dx%dx%d", t.bm, t.bn, t.bk);
 }
 
 // The pooled loader keeps 8 extra window taps per staged chunk in registers: tilings that stage at most two chunks per thread.
-static bool pool_tile_ok(const ConvTile& t) { return !t.pipe && (t.bk == 16 || t.bm == 64); }
+static bool pool_tile_ok(const ConvTile& t) { return !t.pipe && t.bm >= 64 && (t.bk == 16 || t.bm == 64); }
 
 template <int BM, int BN, int WM, int WN, int BK>
 static int launch_conv_pool_t(vq_tsn* net, ConvArgs& a) {
@@ -835,7 +837,7 @@ static int launch_conv(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
     if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_) return launch_conv_t<BM_, BN_, WM_, WN_, BK_, SMALL>(net, a);
     T_(128, 128, 2, 2, 32) T_(128, 128, 2, 2, 16) T_(128, 96, 4, 1, 32) T_(128, 96, 4, 1, 16) T_(128, 64, 2, 2, 32)
     T_(128, 64, 2, 2, 16) T_(64, 128, 2, 2, 32) T_(64, 128, 2, 2, 16) T_(64, 64, 2, 2, 32) T_(64, 64, 2, 2, 16)
-    T_(128, 32, 4, 1, 32) T_(128, 32, 4, 1, 16)
+    T_(128, 32, 4, 1, 32) T_(128, 32, 4, 1, 16) T_(32, 128, 1, 4, 32) T_(32, 128, 1, 4, 16)
 #undef T_
     return fail(VQ_E_INVALID, "no kernel for tile %dx%dx%d", t.bm, t.bn, t.bk);
 }
