@@ -17,6 +17,7 @@ OUT = os.path.join(HERE, "libvqamd.so")
 # 128x64 tile's loop) -- VALU work that comes straight out of the fp32 matrix pipe's time.
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Wall", "-Wno-unused-result",
          "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc")]
+FLAGS += os.environ.get("VQ_EXTRA_HIPCC_FLAGS", "").split()     # experiments (e.g. -DVQ_WINO_SKEW=1); empty for the product
 
 
 def _stale():
