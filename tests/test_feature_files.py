@@ -163,6 +163,107 @@ def test_caffemodel_round_trip(tmp_path):
         caffemodel.weights_from_caffemodel(str(tmp_path / "bad.caffemodel"), g)
 
 
+def test_caffemodel_reader_against_the_protobuf_library(tmp_path):
+    """The same reader against bytes produced by google.protobuf's own encoder from a schema of the NetParameter subset
+    (field numbers as in BVLC caffe.proto, from memory -- the reference ships neither caffe.proto nor a .caffemodel), with
+    the things a real file has and our writer does not produce: fields the reader must skip (bottom / top / phase / a
+    nested convolution_param / blob diff), an un-packed repeated float, double_data, the legacy 4-d shape, V1 layers."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    from video_query_algorithms_amd.tsn import caffemodel
+    F = descriptor_pb2.FieldDescriptorProto
+    fd = descriptor_pb2.FileDescriptorProto(name="caffe_subset.proto", package="caffe_subset", syntax="proto2")
+
+    def msg(name, fields):
+        m = fd.message_type.add(name=name)
+        for fname, num, ftype, label, extra in fields:
+            f = m.field.add(name=fname, number=num, type=ftype, label=label)
+            if "type_name" in extra:
+                f.type_name = ".caffe_subset." + extra["type_name"]
+            if "packed" in extra:
+                f.options.packed = extra["packed"]
+    OPT, REP = F.LABEL_OPTIONAL, F.LABEL_REPEATED
+    msg("BlobShape", [("dim", 1, F.TYPE_INT64, REP, {"packed": True})])
+    msg("BlobProto", [("shape", 7, F.TYPE_MESSAGE, OPT, {"type_name": "BlobShape"}), ("data", 5, F.TYPE_FLOAT, REP, {"packed": True}),
+                      ("diff", 6, F.TYPE_FLOAT, REP, {"packed": True}), ("double_data", 8, F.TYPE_DOUBLE, REP, {"packed": True}),
+                      ("num", 1, F.TYPE_INT32, OPT, {}), ("channels", 2, F.TYPE_INT32, OPT, {}), ("height", 3, F.TYPE_INT32, OPT, {}),
+                      ("width", 4, F.TYPE_INT32, OPT, {})])
+    msg("LooseBlob", [("shape", 7, F.TYPE_MESSAGE, OPT, {"type_name": "BlobShape"}), ("data", 5, F.TYPE_FLOAT, REP, {"packed": False})])
+    msg("ConvParam", [("num_output", 1, F.TYPE_UINT32, OPT, {}), ("kernel_size", 4, F.TYPE_UINT32, REP, {})])
+    msg("LayerParameter", [("name", 1, F.TYPE_STRING, OPT, {}), ("type", 2, F.TYPE_STRING, OPT, {}), ("bottom", 3, F.TYPE_STRING, REP, {}),
+                           ("top", 4, F.TYPE_STRING, REP, {}), ("phase", 10, F.TYPE_INT32, OPT, {}),
+                           ("blobs", 7, F.TYPE_MESSAGE, REP, {"type_name": "BlobProto"}),
+                           ("convolution_param", 106, F.TYPE_MESSAGE, OPT, {"type_name": "ConvParam"})])
+    msg("LooseLayer", [("name", 1, F.TYPE_STRING, OPT, {}), ("type", 2, F.TYPE_STRING, OPT, {}),
+                       ("blobs", 7, F.TYPE_MESSAGE, REP, {"type_name": "LooseBlob"})])
+    msg("V1LayerParameter", [("name", 4, F.TYPE_STRING, OPT, {}), ("type", 5, F.TYPE_INT32, OPT, {}),
+                             ("blobs", 6, F.TYPE_MESSAGE, REP, {"type_name": "BlobProto"})])
+    msg("NetParameter", [("name", 1, F.TYPE_STRING, OPT, {}), ("layers", 2, F.TYPE_MESSAGE, REP, {"type_name": "V1LayerParameter"}),
+                         ("layer", 100, F.TYPE_MESSAGE, REP, {"type_name": "LayerParameter"})])
+    msg("LooseNet", [("layer", 100, F.TYPE_MESSAGE, REP, {"type_name": "LooseLayer"})])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    cls = {n: message_factory.GetMessageClass(pool.FindMessageTypeByName("caffe_subset." + n)) for n in ("NetParameter", "LooseNet")}
+
+    rng = np.random.default_rng(17)
+    W = rng.standard_normal((8, 3, 3, 3)).astype(np.float32)
+    bn = [rng.standard_normal(8).astype(np.float32) for _ in range(4)]
+    net = cls["NetParameter"](name="subset")
+    data_layer = net.layer.add(name="data", type="Input")
+    data_layer.top.append("data")                                              # no blobs: not reported
+    conv = net.layer.add(name="conv1", type="Convolution", phase=1)
+    conv.bottom.append("data")
+    conv.top.append("conv1")
+    conv.convolution_param.num_output = 8
+    conv.convolution_param.kernel_size.append(3)
+    b = conv.blobs.add()
+    b.shape.dim.extend(W.shape)
+    b.data.extend(W.ravel().tolist())
+    b.diff.extend([0.0] * 5)                                                   # skipped
+    b2 = conv.blobs.add()
+    b2.shape.dim.append(8)
+    b2.double_data.extend(np.arange(8, dtype=np.float64).tolist())             # bias stored as doubles
+    bnl = net.layer.add(name="conv1_bn", type="BN")
+    for a in bn:
+        q = bnl.blobs.add(num=1, channels=8, height=1, width=1)                # legacy 4-d shape
+        q.data.extend(a.tolist())
+    v1 = net.layers.add(name="old_ip", type=14)
+    q = v1.blobs.add(num=1, channels=1, height=2, width=3)
+    q.data.extend([0.5, 1.5, 2.5, 3.5, 4.5, 5.5])
+    (tmp_path / "lib.caffemodel").write_bytes(net.SerializeToString())
+    r = caffemodel.read_caffemodel(str(tmp_path / "lib.caffemodel"))
+    assert set(r) == {"conv1", "conv1_bn", "old_ip"}
+    assert r["conv1"]["type"] == "Convolution" and (r["conv1"]["blobs"][0] == W).all() and r["conv1"]["blobs"][0].shape == W.shape
+    assert r["conv1"]["blobs"][1].tolist() == list(range(8))
+    assert all(r["conv1_bn"]["blobs"][i].shape == (1, 8, 1, 1) and (r["conv1_bn"]["blobs"][i].ravel() == bn[i]).all() for i in range(4))
+    assert r["old_ip"]["type"] == 14 and r["old_ip"]["blobs"][0].shape == (1, 1, 2, 3)
+    # the same weights with the float field written element by element (what an encoder without [packed = true] emits)
+    loose = cls["LooseNet"]()
+    ll = loose.layer.add(name="conv1", type="Convolution")
+    lb = ll.blobs.add()
+    lb.shape.dim.extend(W.shape)
+    lb.data.extend(W.ravel().tolist())
+    raw = loose.SerializeToString()
+    assert len(raw) > 5 * W.size                                               # really one tag per element
+    (tmp_path / "loose.caffemodel").write_bytes(raw)
+    r2 = caffemodel.read_caffemodel(str(tmp_path / "loose.caffemodel"))
+    assert (r2["conv1"]["blobs"][0] == W).all()
+    # and our own writer is readable by the library's decoder
+    from video_query_algorithms_amd.tsn import bn_inception as bi
+    from video_query_algorithms_amd.tsn.net import synthetic_weights
+    g = bi.parse_prototxt('''name: "t" input: "data" input_dim: 1 input_dim: 3 input_dim: 8 input_dim: 8
+      layer { name: "c" type: "Convolution" bottom: "data" top: "c" convolution_param { num_output: 32 pad: 1 kernel_size: 3 } }
+      layer { name: "c_bn" type: "BN" bottom: "c" top: "c_bn" }
+      layer { name: "r" type: "ReLU" bottom: "c_bn" top: "c_bn" }
+      layer { name: "gp" type: "Pooling" bottom: "c_bn" top: "gp" pooling_param { pool: AVE kernel_size: 8 stride: 1 } }''')
+    w = synthetic_weights(g, seed=1)
+    caffemodel.write_caffemodel(str(tmp_path / "ours.caffemodel"), g, w)
+    back = cls["NetParameter"]()
+    back.ParseFromString((tmp_path / "ours.caffemodel").read_bytes())
+    by_name = {l.name: l for l in back.layer}
+    assert list(by_name["c"].blobs[0].shape.dim) == [32, 3, 3, 3]
+    assert (np.array(by_name["c"].blobs[0].data, dtype=np.float32) == w["c"]["W"].ravel()).all() and len(by_name["c_bn"].blobs) == 4
+
+
 def test_feature_store_round_trip_and_csv_tree_import(tmp_path):
     """feature_store: the [N,S,E,D] block + ids + presence mask on disk; import of a data/features CSV tree with a
     missing file (one stream of one split of one video) and clips that only some files hold."""

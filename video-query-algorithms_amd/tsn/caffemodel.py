@@ -62,7 +62,7 @@ def _blob(buf) -> np.ndarray:
     buf = bytes(buf)
     shape: List[int] = []
     legacy = {}
-    data = None
+    chunks: List[np.ndarray] = []        # a repeated field may arrive packed, element by element, or as several packed runs
     for num, wt, val in _fields(buf):
         if num == 7 and wt == 2:                                   # BlobShape
             for n2, w2, v2 in _fields(bytes(val)):
@@ -73,14 +73,13 @@ def _blob(buf) -> np.ndarray:
                         shape.append(d)
                 elif n2 == 1 and w2 == 0:
                     shape.append(v2)
-        elif num == 5:                                             # data
-            data = np.frombuffer(bytes(val), dtype="<f4") if wt == 2 else np.frombuffer(val, dtype="<f4")
-        elif num == 8 and wt == 2:
-            data = np.frombuffer(bytes(val), dtype="<f8").astype(np.float32)
+        elif num == 5 and wt in (2, 5):                            # data: packed run, or one fixed32 element
+            chunks.append(np.frombuffer(bytes(val), dtype="<f4"))
+        elif num == 8 and wt in (2, 1):                            # double_data
+            chunks.append(np.frombuffer(bytes(val), dtype="<f8").astype(np.float32))
         elif num in (1, 2, 3, 4) and wt == 0:
             legacy[num] = val
-    if data is None:
-        data = np.zeros(0, dtype=np.float32)
+    data = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.float32)
     if not shape and legacy:
         shape = [legacy.get(i, 1) for i in (1, 2, 3, 4)]
     return np.array(data, dtype=np.float32).reshape(shape) if shape else np.array(data, dtype=np.float32)
