@@ -59,6 +59,8 @@ CONV_CASES = [
     (3, 32, 64, 7, 2, 3, 2),                  # stem, RGB (small-Cin path, K = 147 -> 224 padded)
     (10, 32, 64, 7, 2, 3, 2),                 # stem, flow stack
     (32, 9, 32, 3, 1, 1, 1),                  # tiny: single partial tile
+    (1024, 7, 128, 1, 1, 0, 3),               # 5b/pool_proj: 7x7 map, K = 1024 -> two K slices + combine pass
+    (256, 14, 256, 3, 2, 1, 2),               # 4e/double_3x3_2: 7x7 output, K = 2304 -> four K slices, slices start mid-tap
 ]
 
 
@@ -89,6 +91,35 @@ def test_conv_bn_relu_layer(tsn, monkeypatch, cin, h, cout, k, s, p, n, tile):
     assert (got >= 0).all()
     assert np.abs(ps - want["gp"].reshape(n, -1)).max() <= tol
     m.close()
+
+
+def test_k_split_is_a_property_of_the_layer_not_of_the_batch(tsn, monkeypatch):
+    """The 7x7-map layers with long K run as K slices + a combine pass (a different summation order than one chain, so
+    it must apply to a layer at EVERY batch size).  Split and unsplit agree to rounding; with the split on, a crop's
+    output is the same bits alone, in a batch, and in a batch cut into sub-batches on two streams."""
+    bi, net = tsn
+    g = _mini(bi, 256, 14, 14, 256, 3, 2, 1)
+    w = net.synthetic_weights(g, seed=4)
+    crops = np.random.default_rng(6).integers(0, 256, (9, 14, 14, 256), dtype=np.uint8)
+    mean = np.full(256, 120.0, np.float32)
+    outs = {}
+    for sk in ("0", "1"):
+        monkeypatch.setenv("VQ_TSN_SPLITK", sk)
+        m = net.TsnNet(g, w, max_crops=9, feature_blob="gp")
+        m.forward(crops, 1, mean)
+        outs[sk] = m.read_blob("c_bn", 9)
+        if sk == "1":
+            for lo, hi in ((0, 1), (3, 8), (8, 9)):
+                m.forward(crops[lo:hi], 1, mean)
+                assert (m.read_blob("c_bn", hi - lo) == outs[sk][lo:hi]).all(), (lo, hi)
+            monkeypatch.setenv("VQ_TSN_SPLIT", "1")
+            m1 = net.TsnNet(g, w, max_crops=9, feature_blob="gp")
+            m1.forward(crops, 1, mean)
+            assert (m1.read_blob("c_bn", 9) == outs[sk]).all()
+            m1.close()
+        m.close()
+    assert not (outs["0"] == outs["1"]).all()                                   # the split really is another order ...
+    assert np.abs(outs["0"] - outs["1"]).max() <= 2e-6 * np.abs(outs["0"]).max()  # ... of the same sum
 
 
 def test_every_direct_tiling_gives_the_same_bits(tsn, monkeypatch):

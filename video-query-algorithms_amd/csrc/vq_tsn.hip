@@ -96,6 +96,9 @@ struct ConvArgs {
                          // clipped at the image edge) of the H x W source instead of a pixel; Ho x Wo is the pooled size
     int tiles_m, tiles_n;
     unsigned in_bytes, w_bytes;   // extents for the buffer descriptors (out-of-range offsets read as zero)
+    int ksplit;          // > 1: the grid is ksplit x tiles; slice ks sums K floats [ks * k_per, (ks + 1) * k_per) only and stores
+    int k_per;           // its raw partial sums (zero bias, no ReLU) through segs[ks * seg_stride ..] into a scratch plane;
+    int seg_stride;      // splitk_combine_kernel adds the planes in slice order, then bias and ReLU.  Aligned Cin only.
 };
 
 constexpr int KPAD = 32;       // weights are packed [Cout][Kp] with Kp a multiple of 32
@@ -159,7 +162,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     ConvSmem<BM, BN, BK>& sm = *reinterpret_cast<ConvSmem<BM, BN, BK>*>(smem_raw);
 
     const int tid = threadIdx.x;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int n_tiles = a.tiles_m * a.tiles_n;
+    const int ks = a.ksplit > 1 ? (int)blockIdx.x / n_tiles : 0;            // K slice of this workgroup (uniform)
+    const int kbeg = ks * a.k_per;
+    const int tile = xcd_remap(blockIdx.x - ks * n_tiles, n_tiles);
     const int m0 = (tile / a.tiles_n) * BM;
     const int n0 = (tile % a.tiles_n) * BN;
 
@@ -198,13 +204,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         b_col[i] = c % CPR;
         const int n = n0 + b_row[i];
         b_ok[i] = n < a.Cout && b_row[i] < BN;
-        b_ptr[i] = a.w + (size_t)(b_ok[i] ? n : 0) * a.Kp + b_col[i] * 4;
+        b_ptr[i] = a.w + (size_t)(b_ok[i] ? n : 0) * a.Kp + b_col[i] * 4 + kbeg;
     }
 
     floatx4 ra[NA], rb[NB];   // ext-vector values (a HIP float4 struct copy becomes a memcpy the optimiser leaves in scratch)
     constexpr int PT = POOL ? 8 : 1;
     floatx4 rp[NA][PT];       // POOL: the other window taps, in flight under the MFMAs; folded into ra when the tile is stored
     int kh = 0, kw = 0, c0 = 0;   // aligned mode: walk (tap, channel chunk) without divisions
+    if (!SMALL_CIN && kbeg > 0) {  // a later K slice starts its walk in the middle
+        const int tap0 = kbeg / a.Cin;
+        c0 = kbeg - tap0 * a.Cin;
+        kh = tap0 / a.kw;
+        kw = tap0 - kh * a.kw;
+    }
     // Every lane always issues its loads: lanes that fall into the zero padding (or past M / Cout) read the
     // zero page instead, so there is no branch and no exec-mask juggling around the global loads.
     // (Macros, not lambdas: by-reference captures of the staging arrays ended up in scratch memory.)
@@ -285,10 +297,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const int nb_ = n0 + wn * (BN / WN) + 32 * j;
         const int n = nb_ + (lane & 7) * 4;
         bias_v[j] = *reinterpret_cast<const floatx4*>(a.bias + (n < a.Cout ? n : 0));
-        seg_v[j] = a.segs[nb_ < a.Cout ? nb_ >> 5 : 0];
+        seg_v[j] = a.segs[ks * a.seg_stride + (nb_ < a.Cout ? nb_ >> 5 : 0)];
     }
 
-    const int nk = a.Kp / BK;
+    const int nk = (a.ksplit > 1 ? a.k_per : a.Kp) / BK;
     VQ_LOAD_TILES(0)
     VQ_STORE_TILES(0)
     __syncthreads();
@@ -350,7 +362,10 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     ConvSmem<BM, BN, BK>& sm = *reinterpret_cast<ConvSmem<BM, BN, BK>*>(smem_raw);
 
     const int tid = threadIdx.x;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int n_tiles = a.tiles_m * a.tiles_n;
+    const int ks = a.ksplit > 1 ? (int)blockIdx.x / n_tiles : 0;            // K slice of this workgroup (uniform)
+    const int kbeg = ks * a.k_per;
+    const int tile = xcd_remap(blockIdx.x - ks * n_tiles, n_tiles);
     const int m0 = (tile / a.tiles_n) * BM;
     const int n0 = (tile % a.tiles_n) * BN;
 
@@ -392,7 +407,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         b_row[i] = c / CPR;
         b_col[i] = c % CPR;
         const int n = n0 + b_row[i];
-        b_off[i] = (n < a.Cout && b_row[i] < BN) ? (unsigned)((n * a.Kp + b_col[i] * 4) * 4) : 0xFFFFFFFFu;
+        b_off[i] = (n < a.Cout && b_row[i] < BN) ? (unsigned)((n * a.Kp + b_col[i] * 4 + kbeg) * 4) : 0xFFFFFFFFu;
     }
 
     floatx4 ra[2][NA], rb[2][NB];   // two staging sets: tile kc+1 waits in one while tile kc+2 is fetched into the other
@@ -403,8 +418,17 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     // the hardware range check accounts for.  The VALU and the matrix pipe share issue bandwidth
     // (tools/ubench/mfma_coissue.hip), so the steady state of the K loop carries no address arithmetic at all.
     unsigned a_voff[NA];
+    if (!SMALL_CIN && kbeg > 0) {   // a later K slice starts its walk in the middle
+        tap = kbeg / a.Cin;
+        c0 = kbeg - tap * a.Cin;
+        kh = tap / a.kw;
+        kw = tap - kh * a.kw;
+    }
+    {
+        const int tap_pix0 = ((kh * a.W + kw) * a.Cs_in) * 4;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) a_voff[i] = (a_mask[i] & 1ull) ? (unsigned)a_off[i] : 0xFFFFFFFFu;
+        for (int i = 0; i < NA; ++i) a_voff[i] = ((a_mask[i] >> tap) & 1ull) ? (unsigned)(a_off[i] + tap_pix0) : 0xFFFFFFFFu;
+    }
     const unsigned cpt = (unsigned)a.Cin >> 2, inv_cpt = 65536u / cpt + 1u, inv_k = 65536u / (unsigned)a.kw + 1u;   // small-Cin decode
 
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -424,7 +448,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         const int nb_ = n0 + wn * (BN / WN) + 32 * j;
         const int n = nb_ + (lane & 7) * 4;
         bias_v[j] = *reinterpret_cast<const floatx4*>(a.bias + (n < a.Cout ? n : 0));
-        seg_v[j] = a.segs[nb_ < a.Cout ? nb_ >> 5 : 0];
+        seg_v[j] = a.segs[ks * a.seg_stride + (nb_ < a.Cout ? nb_ >> 5 : 0)];
     }
 
 // Small-Cin mode (the 7x7 stem: Cin padded to 4 or 12): a 32-wide K-step spans several taps, so every staged
@@ -521,7 +545,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         }                                                                                                      \
     }
 
-    const int nk = a.Kp / BK;
+    const int nk = (a.ksplit > 1 ? a.k_per : a.Kp) / BK;
     _Pragma("unroll") for (int i = 0; i < NG; ++i) VQ_G_LOAD(i, 0, 0)
     _Pragma("unroll") for (int i = 0; i < NG; ++i) VQ_G_STORE(i, 0, 0)
     if (nk > 1) {
@@ -615,6 +639,28 @@ __global__ void gavgpool_kernel(const float* __restrict__ in, float* __restrict_
     out[(size_t)img * Cs_out + coff_out + c] = acc / (float)HW;
 }
 
+// Second half of a convolution that was split over K (the 7x7-map layers with long K chains: at M = 49 x crops there
+// are fewer output tiles than compute units, and one wave per SIMD cannot hide its own load latency): the slices' partial
+// sums are added in slice order, then bias and ReLU -- a fixed order for every batch size and tiling, so the rule "which
+// layers are split" (layer geometry only) keeps the features independent of how crops are batched.
+__global__ void splitk_combine_kernel(const float* __restrict__ part, int ksplit, size_t slice_stride, int M, int Cout,
+                                      const float* __restrict__ bias, int relu, float* __restrict__ out, int Cs_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = Cout / 4;
+    if (i >= (int64_t)M * c4) return;
+    const int m = (int)(i / c4), n = (int)(i - (int64_t)m * c4) * 4;
+    floatx4 v = *reinterpret_cast<const floatx4*>(part + (size_t)m * Cout + n);
+    for (int q = 1; q < ksplit; ++q) v += *reinterpret_cast<const floatx4*>(part + q * slice_stride + (size_t)m * Cout + n);
+    v += *reinterpret_cast<const floatx4*>(bias + n);
+    if (relu) {
+        v[0] = fmaxf(v[0], 0.f);
+        v[1] = fmaxf(v[1], 0.f);
+        v[2] = fmaxf(v[2], 0.f);
+        v[3] = fmaxf(v[3], 0.f);
+    }
+    *reinterpret_cast<floatx4*>(out + (size_t)m * Cs_out + n) = v;
+}
+
 // global average pool + segment consensus in one pass: a snippet's global_pool value is formed exactly
 // like gavgpool_kernel does (sequential fp32 sum over h, w, then / (H*W)) and stored as the per-snippet blob
 // (calcSig_wOF.py:95,112); the T values of a clip meet in LDS and are summed in fp64 in numpy's axis-0 order
@@ -703,6 +749,11 @@ struct vq_tsn {
     float* zeros = nullptr;               // 256 bytes of zeros (load target of masked lanes)
     ConvSeg* seg_table = nullptr;         // destination tables of all conv layers, back to back
     std::vector<int> seg_table_off;       // per layer: first entry
+    std::vector<int> ksplit;              // per layer: K slices of a direct convolution (1 = not split; layer geometry only)
+    float* split_scratch = nullptr;       // [slice][max_crops * Ho * Wo][Cout] partial sums of the split layer in flight
+    size_t split_slice_floats = 0;        // floats between slices (= max_crops * split_crop_floats)
+    size_t split_crop_floats = 0;         // scratch floats one crop owns per slice: largest Ho*Wo*Cout of a split layer + one row of slack
+    float* zero_bias = nullptr;           // zeros for the slices' epilogues (the bias is added once, by the combine pass)
     float* blob = nullptr;                // weights + biases
     int64_t blob_floats = 0;
     int feature_slot = -1, D = 0;
@@ -743,6 +794,8 @@ static void tsn_free(vq_tsn* net) {
     if (net->blob) (void)hipFree(net->blob);
     if (net->zeros) (void)hipFree(net->zeros);
     if (net->seg_table) (void)hipFree(net->seg_table);
+    if (net->split_scratch) (void)hipFree(net->split_scratch);
+    if (net->zero_bias) (void)hipFree(net->zero_bias);
     if (net->crops_dev) (void)hipFree(net->crops_dev);
     if (net->mean_dev) (void)hipFree(net->mean_dev);
     if (net->feat_dev) (void)hipFree(net->feat_dev);
@@ -759,7 +812,7 @@ static int launch_conv_t(vq_tsn* net, ConvArgs& a) {
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    VQ_LAUNCH(kern, a.tiles_m * a.tiles_n, 256, lds, net->ls, net->ev_start, net->ev_stop, a);
+    VQ_LAUNCH(kern, a.tiles_m * a.tiles_n * a.ksplit, 256, lds, net->ls, net->ev_start, net->ev_stop, a);
     VQ_CHECK_LAUNCH();
     return VQ_OK;
 }
@@ -787,7 +840,7 @@ static int launch_conv_pipe_t(vq_tsn* net, ConvArgs& a) {
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    VQ_LAUNCH(kern, a.tiles_m * a.tiles_n, 256, lds, net->ls, net->ev_start, net->ev_stop, a);
+    VQ_LAUNCH(kern, a.tiles_m * a.tiles_n * a.ksplit, 256, lds, net->ls, net->ev_start, net->ev_stop, a);
     VQ_CHECK_LAUNCH();
     return VQ_OK;
 }
@@ -893,6 +946,9 @@ static void fill_conv_args(vq_tsn* net, int li, int n_crops, ConvArgs& a) {
     a.relu = L.relu;
     a.pool_k = L.pre_pool_k;
     a.pool_s = L.pre_pool_stride;
+    a.ksplit = 1;
+    a.k_per = 0;
+    a.seg_stride = 0;
     a.tiles_m = a.tiles_n = 0;
     a.in_bytes = (unsigned)((size_t)n_crops * ts.h * ts.w * ts.c * sizeof(float));   // < 2^31: LaunchItem::max_crops
     a.w_bytes = (unsigned)((size_t)L.cout * a.Kp * sizeof(float));
@@ -919,6 +975,32 @@ static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
         return launch_conv_pool(net, a, t);
     }
     const bool small = (a.Cin % kTiles[tile_idx].bk) != 0;
+    if (net->ksplit[li] > 1) {
+        // K slices into the scratch planes (zero bias, no ReLU: the slice tables say so), then the combine pass into the
+        // layer's destination.  The profiling events bracket the pair.
+        const hipEvent_t e0 = net->ev_start, e1 = net->ev_stop;
+        a.ksplit = net->ksplit[li];
+        a.k_per = a.Kp / a.ksplit;
+        a.seg_stride = (L.cout + 31) / 32;
+        a.bias = net->zero_bias;
+        // Sub-batches of one forward run on separate streams and may be at DIFFERENT split layers at the same moment: every
+        // crop owns a fixed stretch of each scratch plane (split_crop_floats, room for the largest split layer), and a
+        // launch writes its [M][Cout] partial sums at the first whole row inside the stretch of its first crop.
+        a.out_row0 = (int)cdiv((int64_t)net->crop_off * (int64_t)net->split_crop_floats, (int64_t)L.cout);
+        net->ev_stop = nullptr;
+        int rc = kTiles[tile_idx].pipe == 1 ? launch_conv_pipe<false>(net, a, kTiles[tile_idx]) : launch_conv<false>(net, a, kTiles[tile_idx]);
+        net->ev_stop = e1;
+        if (rc != VQ_OK) return rc;
+        net->ev_start = nullptr;
+        const vq_tensor_desc& td = net->tensors[L.dst];
+        float* out = net->slots[L.dst] + (size_t)net->crop_off * td.h * td.w * td.c + L.dst_coff;
+        const int64_t work = (int64_t)a.M * (L.cout / 4);
+        VQ_LAUNCH(splitk_combine_kernel, (unsigned)cdiv(work, 256), 256, 0, net->ls, net->ev_start, net->ev_stop,
+                  net->split_scratch + (size_t)a.out_row0 * L.cout, a.ksplit, net->split_slice_floats, a.M, L.cout, net->blob + L.b_off, L.relu, out, td.c);
+        net->ev_start = e0;
+        VQ_CHECK_LAUNCH();
+        return VQ_OK;
+    }
     if (kTiles[tile_idx].pipe == 1) return small ? launch_conv_pipe<true>(net, a, kTiles[tile_idx]) : launch_conv_pipe<false>(net, a, kTiles[tile_idx]);
     return small ? launch_conv<true>(net, a, kTiles[tile_idx]) : launch_conv<false>(net, a, kTiles[tile_idx]);
 }
@@ -1373,6 +1455,39 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
     if (e != hipSuccess) return bail("hipMalloc(weights)", e);
     e = hipMemcpy(net->blob, blob_host, (size_t)blob_floats * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) return bail("hipMemcpy(weights)", e);
+    {   // Which direct convolutions run split over K: single-destination layers with aligned channels on maps of at most
+        // 7 x 7 (M = 49 x crops: at any usual batch fewer output tiles than the chip has room for, each a long serial K chain
+        // on one wave per SIMD), cut into slices of at least 16 K-steps of 32 -- at most 4 slices.  On the 14 x 14 maps the
+        // same cut LOSES (3c/3x3 0.058 -> 0.076 ms at 96 crops: enough tiles already, the scratch round trip costs more).
+        // A function of the layer alone -- never of the batch actually run -- so a crop's features do not depend on the batch
+        // it travels in.  VQ_TSN_SPLITK=0 turns it off (A/B measurements).
+        net->ksplit.assign(n_layers, 1);
+        const char* sk = getenv("VQ_TSN_SPLITK");
+        size_t scratch = 0;
+        int max_cout = 4;
+        for (int i = 0; i < n_layers && !(sk && atoi(sk) == 0); ++i) {
+            const vq_layer_desc& L = layers[i];
+            const vq_tensor_desc& td = tensors[L.dst];
+            if (L.op != VQ_OP_CONV || L.seg_count > 0 || L.pre_pool_k > 0 || L.cin % KPAD != 0 || td.h * td.w > 49) continue;
+            const int steps = L.k * L.k * L.cin / KPAD;
+            int ks = std::min(4, steps / 16);
+            while (ks > 1 && steps % ks != 0) --ks;
+            if (ks <= 1) continue;
+            net->ksplit[i] = ks;
+            scratch = std::max(scratch, (size_t)td.h * td.w * L.cout);
+            max_cout = std::max(max_cout, L.cout);
+        }
+        if (scratch > 0) {
+            net->split_crop_floats = scratch + (size_t)max_cout;
+            net->split_slice_floats = (size_t)max_crops * net->split_crop_floats;
+            e = hipMalloc((void**)&net->split_scratch, net->split_slice_floats * 4 * sizeof(float));      // up to 4 slices
+            if (e != hipSuccess) return bail("hipMalloc(split-K scratch)", e);
+            e = hipMalloc((void**)&net->zero_bias, (size_t)max_cout * sizeof(float));
+            if (e != hipSuccess) return bail("hipMalloc(zero bias)", e);
+            e = hipMemset(net->zero_bias, 0, (size_t)max_cout * sizeof(float));
+            if (e != hipSuccess) return bail("hipMemset(zero bias)", e);
+        }
+    }
     {   // destination tables: one entry per 32 output columns of every convolution
         std::vector<ConvSeg> table;
         net->seg_table_off.assign(n_layers, 0);
@@ -1380,6 +1495,12 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
             const vq_layer_desc& L = layers[i];
             if (L.op != VQ_OP_CONV) continue;
             net->seg_table_off[i] = (int)table.size();
+            if (net->ksplit[i] > 1) {       // slice q of a split layer writes plane q of the scratch, raw
+                for (int q = 0; q < net->ksplit[i]; ++q)
+                    for (int b = 0; b < (L.cout + 31) / 32; ++b)
+                        table.push_back(ConvSeg{net->split_scratch + (size_t)q * net->split_slice_floats, L.cout, 0});
+                continue;
+            }
             if (L.seg_count > 0) {
                 int col0 = 0;
                 for (int q = 0; q < L.seg_count; ++q) {
