@@ -161,6 +161,10 @@ def bench_tsn(args, rank, world, device, stream):
             "effective_tflops": conv_flops / conv_ms / 1e9, "effective_frac": conv_flops / conv_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS,
             "launches_per_step": conv_launches, "all_launches_per_step": int(n_items), "avg_launch_ms": conv_ms / conv_launches,
             "conv_ms_per_step": conv_ms, "other_kernels_ms_per_step": float(ms_layers[~in_conv_launch].sum()),
+            # the pooling layers that ride in Winograd launches take part of those launches' time (their share by workgroup
+            # count); pool1 inside conv2/3x3_reduce's loader cannot be separated and stays in
+            "pooling_share_of_conv_launches_ms": float(ms_layers[in_conv_launch & ~conv].sum()),
+            "frac_without_pooling_share": executed / float(ms_layers[conv].sum()) / 1e9 / PEAK_FP32_MFMA_TFLOPS,
             "flops_per_step": conv_flops, "executed_flops_per_step": executed, "profiled_steps": cdiv(args.steps, PROFILE_EVERY),
             "families": fam,
             "note": "achieved/frac = MFMA FLOPs the matrix pipe EXECUTED (K / tile padding included; Winograd layers issue 16 of the 36 "
