@@ -166,6 +166,22 @@ int vq_resize_crop(const uint8_t* frames, int32_t frames_on_device, int32_t n, i
                    int32_t resize_w, int32_t resize_h, int32_t crop, uint8_t* crops_dev, int32_t dst_channels,
                    int32_t dst_channel0, int32_t device, void* hip_stream);
 
+/* JPEG decode, the step in front of vq_resize_crop: replaces cv2.imread(img_NNNNN.jpg, IMREAD_COLOR) and
+ * cv2.imread(flow_{x,y}_NNNNN.jpg, IMREAD_GRAYSCALE) at calcSig_wOF.py:92,105-106 for the baseline JPEG files
+ * build_wof_clips.py:46,70-73 writes.  Entropy decoding (ITU-T T.81 F.2.2) runs on host threads, one frame each; the
+ * integer "islow" IDCT, libjpeg's fancy h2v2 / h2v1 chroma upsampling and its fixed-point YCbCr -> RGB run on the device for
+ * the whole batch -- the same bits libjpeg(-turbo), and therefore cv2.imread, produces (oracle/jpeg_oracle.py, pinned against
+ * Pillow's libjpeg-turbo).  n files of ONE size h x w; color != 0: [n][h][w][3] B,G,R; color == 0: [n][h][w] (the Y plane,
+ * as cv2's grey read of a colour file).  out_host (optional) receives the frames; *out_dev (optional) is set to the
+ * handle's device copy, valid until the next call -- pass it to vq_resize_crop(frames_on_device = 1).
+ * Progressive / arithmetic / 12-bit / multi-scan / CMYK files: VQ_E_UNSUPPORTED. */
+typedef struct vq_jpeg vq_jpeg;
+int vq_jpeg_info(const uint8_t* data, int64_t size, int32_t* h, int32_t* w, int32_t* components);
+int vq_jpeg_create(int32_t max_frames, int32_t max_h, int32_t max_w, int32_t device, vq_jpeg** out);
+int vq_jpeg_destroy(vq_jpeg* jpeg);
+int vq_jpeg_decode(vq_jpeg* jpeg, const uint8_t* const* files, const int64_t* sizes, int32_t n, int32_t color, int32_t h, int32_t w,
+                   uint8_t* out_host, uint8_t** out_dev, void* hip_stream);
+
 enum {
     VQ_OP_CONV = 1,
     VQ_OP_MAXPOOL = 2,

@@ -1,0 +1,86 @@
+"""GPU: the JPEG decoder (csrc/vq_jpeg.hip: Huffman decoding on host threads in the library, IDCT / upsampling / colour on the
+device) against oracle/jpeg_oracle.py and against libjpeg-turbo itself (through Pillow) -- bit for bit.  This is the ingest
+step with a REAL pin: cv2.imread (calcSig_wOF.py:92,105-106) decodes with the same library at the same defaults."""
+import io
+
+import numpy as np
+import pytest
+
+import jpeg_oracle as jo
+from test_jpeg_oracle import encode, picture, pil_bgr
+
+pytestmark = pytest.mark.gpu
+Image = pytest.importorskip("PIL.Image")
+
+
+@pytest.fixture(scope="module")
+def jpeg(gpu):
+    from video_query_algorithms_amd.tsn import jpeg
+    return jpeg
+
+
+@pytest.mark.parametrize("h,w", [(48, 64), (37, 53), (8, 8), (1, 1), (31, 3), (9, 5), (256, 340)])
+def test_batches_of_mixed_layouts_equal_libjpeg(jpeg, h, w):
+    files = []
+    for k, (sub, q) in enumerate(((2, 95), (1, 80), (0, 60), (2, 30))):
+        files.append(encode(picture(h, w, 10 * k + h), quality=q, subsampling=sub))
+    files.append(encode(picture(h, w, 77)[:, :, 1], quality=88))                  # a one-component file in the same batch
+    files.append(encode(picture(h, w, 5), quality=85, subsampling=2, optimize=True))
+    if h * w > 64:
+        files.append(encode(picture(h, w, 6), quality=85, subsampling=2, restart_marker_blocks=2))
+    dec = jpeg.JpegDecoder(8, h, w)
+    got = dec.decode(files, color=True)
+    grey = dec.decode(files, color=False)
+    assert got.shape == (len(files), h, w, 3) and grey.shape == (len(files), h, w)
+    for i, data in enumerate(files):
+        assert jpeg.info(data)[:2] == (h, w)
+        assert (got[i] == jo.decode(data, color=True)).all(), i
+        assert (got[i] == pil_bgr(data)).all(), i                                 # libjpeg-turbo's own pixels
+        assert (grey[i] == jo.decode(data, color=False)).all(), i
+    # one file at a time gives the same pixels as inside the batch
+    assert (dec.decode(files[1:2])[0] == got[1]).all()
+    dec.close()
+
+
+def test_a_clip_of_video_frames_and_the_device_hand_over(jpeg):
+    """96 frames of 340 x 256 (cv2.imwrite defaults: quality 95, 4:2:0) decoded in one call; the decoder's device copy goes
+    straight into vq_resize_crop and gives the crops the host path gives."""
+    import ctypes as C
+
+    import torch
+    from video_query_algorithms_amd import _lib
+    from video_query_algorithms_amd.tsn import frames
+    rng = np.random.default_rng(2)
+    base = picture(256, 340, 4).astype(np.int16)
+    files = [encode(np.clip(base + rng.integers(-20, 20, base.shape), 0, 255).astype(np.uint8), quality=95, subsampling=2) for _ in range(96)]
+    dec = jpeg.JpegDecoder(96, 256, 340)
+    got = dec.decode(files)
+    for i in (0, 41, 95):
+        assert (got[i] == pil_bgr(files[i])).all()
+    dev, (n, h, w) = dec.decode_to_device(files)
+    crops = torch.empty((n, 224, 224, 3), dtype=torch.uint8, device="cuda")
+    _lib.call("vq_resize_crop", C.c_void_p(dev), 1, n, h, w, 3, 340, 256, 224, C.c_void_p(crops.data_ptr()), 3, 0, 0, None)
+    torch.cuda.synchronize()
+    want = np.stack([frames.crop0(got[i], (340, 256), 224) for i in (0, 95)])
+    assert (crops.cpu().numpy()[[0, 95]] == want).all()
+    dec.close()
+
+
+def test_what_is_refused(jpeg):
+    from video_query_algorithms_amd import VqError
+    dec = jpeg.JpegDecoder(2, 32, 32)
+    good = encode(picture(32, 32, 1), quality=90)
+    with pytest.raises(VqError, match="progressive"):
+        dec.decode([encode(picture(32, 32, 2), progressive=True)])
+    with pytest.raises(VqError, match="not a JPEG"):
+        dec.decode([b"\x89PNG\r\n\x1a\n0000"])
+    with pytest.raises(VqError, match="decodes 32x32"):
+        dec.decode([good, encode(picture(16, 32, 3), quality=90)])
+    with pytest.raises(VqError):
+        dec.decode([good[:len(good) // 3]])                                       # cut inside the headers
+    cut = dec.decode([good[:len(good) - 40]])                                     # cut inside the scan: the missing blocks decode from zero bits
+    assert cut.shape == (1, 32, 32, 3)
+    with pytest.raises(VqError, match="outside"):
+        dec.decode([good, good, good])
+    assert (dec.decode([good])[0] == pil_bgr(good)).all()                          # the handle survives all of it
+    dec.close()

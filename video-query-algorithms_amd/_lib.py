@@ -90,6 +90,9 @@ SIGNATURES = {
     "vq_flow_create": [_I32, _I32, _I32, C.POINTER(Tvl1Params), _I32, _PP], "vq_flow_destroy": [_P],
     "vq_flow_levels": [_P, _pI32, _pI32, _I32],
     "vq_flow_tvl1": [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P],
+    "vq_jpeg_info": [_P, _I64, _pI32, _pI32, _pI32],
+    "vq_jpeg_create": [_I32, _I32, _I32, _I32, _PP], "vq_jpeg_destroy": [_P],
+    "vq_jpeg_decode": [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P],
     "vq_flow_good_features": [_P, _P, _I32, _I32, _I32, C.c_float, C.c_float, _P, _P, _P],
     "vq_flow_ransac_homography": [_P, _P, _P, _P, _I32, _I32, C.c_float, _I32, C.c_uint32, _I32, _P, _P, _P, _P, _P],
     "vq_comm_unique_id": [_P], "vq_comm_init": [_I32, _I32, _P, _I32, _PP], "vq_comm_destroy": [_P],

@@ -8,7 +8,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = ["csrc/vq_sim.hip", "csrc/vq_tsn.hip", "csrc/vq_wino.hip", "csrc/vq_boot.hip", "csrc/vq_frames.hip", "csrc/vq_comm.hip", "csrc/vq_flow.hip"]
+SOURCES = ["csrc/vq_sim.hip", "csrc/vq_tsn.hip", "csrc/vq_wino.hip", "csrc/vq_boot.hip", "csrc/vq_frames.hip", "csrc/vq_comm.hip", "csrc/vq_flow.hip",
+           "csrc/vq_jpeg.hip"]
 HEADERS = ["csrc/vq_common.h", "csrc/vq_tsn_kernels.h", "../include/vq_amd.h"]
 OUT = os.path.join(HERE, "libvqamd.so")
 # -ffp-contract=off: score arithmetic must round like the reference's numpy scalars; FMAs are explicit

@@ -1,0 +1,73 @@
+"""Baseline JPEG decoding of a batch of equally sized frames: Huffman decoding on host threads inside the library,
+IDCT / chroma upsampling / colour transform on the GPU (csrc/vq_jpeg.hip).
+
+Replaces ``cv2.imread(..., IMREAD_COLOR)`` / ``cv2.imread(..., IMREAD_GRAYSCALE)`` of the reference's frame loops
+(src/features_GPU_compute/calcSig_wOF.py:92,105-106) for the files its frame preparation writes; the pixels are the ones
+libjpeg(-turbo) produces (oracle/jpeg_oracle.py, pinned bit for bit against Pillow's libjpeg-turbo).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence, Tuple, Union
+
+import numpy as np
+
+from .. import _lib
+from .._lib import call
+
+
+def info(data: bytes) -> Tuple[int, int, int]:
+    """(height, width, components) of a JPEG file's frame header."""
+    h, w, c = C.c_int32(), C.c_int32(), C.c_int32()
+    call("vq_jpeg_info", data, len(data), C.byref(h), C.byref(w), C.byref(c))
+    return h.value, w.value, c.value
+
+
+class JpegDecoder:
+    def __init__(self, max_frames: int, max_h: int, max_w: int, device: int = 0):
+        self.max_frames, self.max_h, self.max_w, self.device = int(max_frames), int(max_h), int(max_w), int(device)
+        self._h = C.c_void_p()
+        call("vq_jpeg_create", self.max_frames, self.max_h, self.max_w, self.device, C.byref(self._h))
+
+    def _submit(self, files: Sequence[Union[bytes, str]], color: bool, out_host, want_dev: bool):
+        blobs: List[bytes] = []
+        for f in files:
+            if isinstance(f, (bytes, bytearray, memoryview)):
+                blobs.append(bytes(f))
+            else:
+                with open(f, "rb") as fh:
+                    blobs.append(fh.read())
+        n = len(blobs)
+        if n == 0:
+            raise ValueError("no files")
+        h, w, _ = info(blobs[0])
+        ptrs = (C.c_char_p * n)(*blobs)
+        sizes = (C.c_int64 * n)(*[len(b) for b in blobs])
+        dev = C.c_void_p()
+        host = None
+        if out_host:
+            host = np.empty((n, h, w, 3) if color else (n, h, w), dtype=np.uint8)
+        call("vq_jpeg_decode", self._h, ptrs, sizes, n, int(bool(color)), h, w, host.ctypes.data_as(C.c_void_p) if host is not None else None,
+             C.byref(dev) if want_dev else None, None)
+        return host, dev.value, (n, h, w)
+
+    def decode(self, files: Sequence[Union[bytes, str]], color: bool = True) -> np.ndarray:
+        """File contents or paths -> uint8 [n, h, w, 3] (B, G, R: cv2 order) or [n, h, w] (grey: the Y plane)."""
+        return self._submit(files, color, True, False)[0]
+
+    def decode_to_device(self, files: Sequence[Union[bytes, str]], color: bool = True):
+        """-> (device pointer of [n, h, w, 3 | 1] uint8, (n, h, w)); the memory belongs to the decoder and is valid until
+        its next call -- feed it to ``vq_resize_crop(frames_on_device=1)``."""
+        _, dev, shape = self._submit(files, color, False, True)
+        return dev, shape
+
+    def close(self):
+        if self._h:
+            _lib.load().vq_jpeg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
