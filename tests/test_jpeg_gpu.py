@@ -10,7 +10,11 @@ import jpeg_oracle as jo
 from test_jpeg_oracle import encode, picture, pil_bgr
 
 pytestmark = pytest.mark.gpu
-Image = pytest.importorskip("PIL.Image")
+try:
+    from PIL import Image
+except ImportError:
+    Image = None
+needs_pil = pytest.mark.skipif(Image is None, reason="Pillow not installed (the committed fixtures still run)")
 
 
 @pytest.fixture(scope="module")
@@ -19,6 +23,7 @@ def jpeg(gpu):
     return jpeg
 
 
+@needs_pil
 @pytest.mark.parametrize("h,w", [(48, 64), (37, 53), (8, 8), (1, 1), (31, 3), (9, 5), (256, 340)])
 def test_batches_of_mixed_layouts_equal_libjpeg(jpeg, h, w):
     files = []
@@ -42,6 +47,7 @@ def test_batches_of_mixed_layouts_equal_libjpeg(jpeg, h, w):
     dec.close()
 
 
+@needs_pil
 def test_a_clip_of_video_frames_and_the_device_hand_over(jpeg):
     """96 frames of 340 x 256 (cv2.imwrite defaults: quality 95, 4:2:0) decoded in one call; the decoder's device copy goes
     straight into vq_resize_crop and gives the crops the host path gives."""
@@ -66,6 +72,7 @@ def test_a_clip_of_video_frames_and_the_device_hand_over(jpeg):
     dec.close()
 
 
+@needs_pil
 def test_what_is_refused(jpeg):
     from video_query_algorithms_amd import VqError
     dec = jpeg.JpegDecoder(2, 32, 32)
@@ -84,3 +91,48 @@ def test_what_is_refused(jpeg):
         dec.decode([good, good, good])
     assert (dec.decode([good])[0] == pil_bgr(good)).all()                          # the handle survives all of it
     dec.close()
+
+
+@needs_pil
+def test_cli_on_a_jpeg_frame_tree_device_decode_equals_host_decode(jpeg, tmp_path):
+    """calcSig_wOF.py on img_/flow_x_/flow_y_ .jpg files as build_wof_clips.py leaves them: --device_jpeg (library decoder,
+    frames never on the host) writes the same CSV bytes as the default path (host libjpeg through Pillow, resize on the GPU)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_tsn_gpu import _write_protos
+    from video_query_algorithms_amd import calcSig_wOF
+    from video_query_algorithms_amd.tsn import bn_inception as bi
+    root = tmp_path / "frames"
+    rng = np.random.default_rng(11)
+    for clip, n in (("clip_0001", 8), ("clip_0002", 11), ("clip_0003", 6)):
+        d = root / "vid" / clip
+        d.mkdir(parents=True)
+        for i in range(1, n + 1):
+            (d / ("img_%05d.jpg" % i)).write_bytes(encode(picture(256, 340, int(rng.integers(1 << 30))), quality=95, subsampling=2))
+            for p in ("flow_x", "flow_y"):
+                (d / ("%s_%05d.jpg" % (p, i))).write_bytes(encode(picture(256, 340, int(rng.integers(1 << 30)))[:, :, 0], quality=95))
+    protos = _write_protos(bi, tmp_path)
+    outs = {}
+    for tag, extra in (("host", []), ("device", ["--device_jpeg"])):
+        out_dir = tmp_path / ("features_" + tag)
+        rc = calcSig_wOF.main([str(root), protos["rgb"], "synthetic:2", protos["flow"], "synthetic:5", "--num_frame_per_video", "3",
+                               "--outFeatures_dir", str(out_dir), "--modelname", "UCF101_split1", "--batch_clips", "2"] + extra)
+        assert rc == 0
+        outs[tag] = {f: (out_dir / "vid" / "UCF101_split1" / f).read_bytes()
+                     for f in ("rgb_global_pool_features.csv", "warped_optical_flow_global_pool_features.csv")}
+    assert outs["host"] == outs["device"]
+    assert outs["host"]["rgb_global_pool_features.csv"].count(b"\n") == 4                # header + three clips
+
+
+def test_committed_libjpeg_fixtures(jpeg):
+    """tests/golden/jpeg (files + the pixels libjpeg-turbo decoded them to): the decoder reproduces them on the device."""
+    import glob
+    import os
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg")
+    for path in sorted(glob.glob(os.path.join(root, "*.jpg"))):
+        want = np.load(path[:-4] + ".npy")
+        dec = jpeg.JpegDecoder(1, want.shape[0], want.shape[1])
+        assert (dec.decode([path], color=want.ndim == 3)[0] == want).all(), path
+        dec.close()

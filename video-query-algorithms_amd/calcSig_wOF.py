@@ -57,6 +57,9 @@ def build_parser():
     parser.add_argument('--batch_clips', type=int, default=32, help='clips per forward pass')
     parser.add_argument('--host_resize', action='store_true',
                         help='resize + crop the frames on the host (numpy) instead of on the GPU; same bytes either way')
+    parser.add_argument('--device_jpeg', action='store_true',
+                        help='decode the .jpg frames with the library (Huffman on host threads, IDCT / upsampling / colour on the '
+                             'GPU; the pixels libjpeg gives cv2.imread) and resize them where they land -- no host image library')
     parser.add_argument('--number_format', choices=('repr', 'g12'), default='repr',
                         help="how str(numpy.float64) printed under the numpy the reference ran with: shortest round-trip "
                              "(numpy >= 1.14, lossless) or 12 significant digits (numpy < 1.14); the reference ships files of both kinds")
@@ -111,6 +114,7 @@ def main(argv=None, net_factory=None):
                  {'modality': 'flow', 'mode': 'warped_optical_flow', 'net_proto': args.net_proto_flow,
                   'net_weights': args.net_weights_flow, 'cnt_indexer': 2, 'stack_depth': 5}]   # calcSig_wOF.py:185-189
     nets = {}
+    device_jpeg = args.device_jpeg and args.frame_ext.lower() in ('.jpg', '.jpeg') and not args.host_resize
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=max(1, args.num_worker))
     for video_path in sorted(glob.glob(frame_path + '*/')):                            # calcSig_wOF.py:193-195
@@ -129,9 +133,9 @@ def main(argv=None, net_factory=None):
                 frame_cnt = f_info[s['cnt_indexer']][vid]
                 ticks = frames.frame_ticks(frame_cnt, T, s['stack_depth'])
                 if s['modality'] == 'rgb':
-                    load = frames.load_rgb_snippets if args.host_resize else frames.load_rgb_frames
+                    load = frames.load_rgb_jpegs if device_jpeg else frames.load_rgb_snippets if args.host_resize else frames.load_rgb_frames
                     return load(f_info[0][vid], ticks, args.rgb_prefix, args.frame_ext)
-                load = frames.load_flow_snippets if args.host_resize else frames.load_flow_frames
+                load = frames.load_flow_jpegs if device_jpeg else frames.load_flow_snippets if args.host_resize else frames.load_flow_frames
                 return load(f_info[0][vid], ticks, frame_cnt, s['stack_depth'], args.flow_x_prefix, args.flow_y_prefix, args.frame_ext)
 
             # --num_worker decoder threads (the reference runs that many worker PROCESSES, each with its own net,
@@ -145,7 +149,9 @@ def main(argv=None, net_factory=None):
                     print('video {} for {} modality done'.format(vid, s['modality']))
                 if crops:
                     on_gpu = world > 1                   # blocks that will be all-gathered never visit the host
-                    if args.host_resize:
+                    if device_jpeg:                      # lists of undecoded files: decoded, resized and cropped on the GPU
+                        mine.append(net.extract_clips_from_jpegs([f for c in crops for f in c], T, on_device=on_gpu))
+                    elif args.host_resize:
                         mine.append(net.extract_clips(np.concatenate(crops, axis=0), T, on_device=on_gpu))
                     elif len({c.shape[1:] for c in crops}) == 1:
                         mine.append(net.extract_clips_from_frames(np.concatenate(crops, axis=0), T, on_device=on_gpu))   # resize + crop on the GPU

@@ -122,6 +122,66 @@ class CaffeNet:
                      crop, C.c_void_p(out.data_ptr()), self._channels, k, self._model.device, C.c_void_p(stream))
         return out
 
+    def crops_from_jpegs(self, files, frame_size=(340, 256), crop=224):
+        """JPEG file contents -> device crops (torch uint8 [n, crop, crop, C]) without the frames ever visiting the host:
+        entropy decoding on the library's host threads, IDCT / upsampling / colour on the device (tsn/jpeg.py), resize +
+        crop 0 straight from the decoder's device buffer.  RGB net: n files; flow net: n * C files in stack order per
+        snippet (x0, y0, x1, y1, ...).  The pixels are libjpeg's (what cv2.imread returns), bit for bit."""
+        import ctypes as C
+        import torch
+        from .._lib import call
+        from . import jpeg
+        ch = self._channels
+        per_snip = 1 if ch == 3 else ch
+        if len(files) % per_snip:
+            raise ValueError("flow net: %d files is not a multiple of the %d planes of a snippet" % (len(files), ch))
+        n = len(files) // per_snip
+        dev = torch.device("cuda", self._model.device)
+        out = torch.empty((n, crop, crop, ch), dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        h, w, _ = jpeg.info(files[0])
+        cap = 256
+        dec = getattr(self, "_jpeg", None)
+        if dec is None or dec.max_h < h or dec.max_w < w:
+            if dec is not None:
+                dec.close()
+            dec = self._jpeg = jpeg.JpegDecoder(cap, h, w, self._model.device)
+        if ch == 3:
+            for i in range(0, n, cap):
+                ptr, (m, _, _) = dec.decode_to_device(files[i:i + cap], color=True)
+                call("vq_resize_crop", C.c_void_p(ptr), 1, m, h, w, 3, frame_size[0], frame_size[1], crop,
+                     C.c_void_p(out[i:i + m].data_ptr()), 3, 0, self._model.device, C.c_void_p(stream))
+                torch.cuda.current_stream(dev).synchronize()          # the decoder's buffer is reused by its next call
+        else:
+            for k in range(ch):                                       # plane k of every snippet: contiguous grey frames
+                plane_files = files[k::ch]
+                for i in range(0, n, cap):
+                    ptr, (m, _, _) = dec.decode_to_device(plane_files[i:i + cap], color=False)
+                    call("vq_resize_crop", C.c_void_p(ptr), 1, m, h, w, 1, frame_size[0], frame_size[1], crop,
+                         C.c_void_p(out[i:i + m].data_ptr()), ch, k, self._model.device, C.c_void_p(stream))
+                    torch.cuda.current_stream(dev).synchronize()
+        return out
+
+    def extract_clips_from_jpegs(self, files, T: int, frame_size=(340, 256), on_device: bool = False):
+        """JPEG file contents of B*T snippets (flow: * C planes) -> consensus features [B, D]; see crops_from_jpegs."""
+        import torch
+        per_snip = 1 if self._channels == 3 else self._channels
+        per = (self._model.max_crops // T) * T
+        if per == 0:
+            raise ValueError("max_crops (%d) is smaller than T (%d)" % (self._model.max_crops, T))
+        dev = torch.device("cuda", self._model.device)
+        out = []
+        for i in range(0, len(files) // per_snip, per):
+            crops = self.crops_from_jpegs(files[i * per_snip:(i + per) * per_snip], frame_size)
+            torch.cuda.current_stream(dev).synchronize()
+            nb = crops.shape[0]
+            self._model.forward_device(crops.data_ptr(), nb, T, self._mean)
+            if on_device:
+                out.append(self._model.features_tensor(nb // T).clone())
+            else:
+                out.append(self._model.read_features(np.empty((nb // T, self._model.feature_dim), dtype=np.float64)))
+        return torch.cat(out, dim=0) if on_device else np.concatenate(out, axis=0)
+
     def extract_clips_from_frames(self, frames_: np.ndarray, T: int, frame_size=(340, 256), on_device: bool = False):
         """Decoded frames of B*T snippets -> consensus features [B, D]: resize + crop 0 on the device, then the
         batched forward on the resident crops (no host-side image processing at all).  ``on_device``: see extract_clips."""
@@ -147,4 +207,7 @@ class CaffeNet:
         return self._model.feature_dim
 
     def close(self):
+        if getattr(self, "_jpeg", None) is not None:
+            self._jpeg.close()
+            self._jpeg = None
         self._model.close()

@@ -8,7 +8,8 @@ Appendix B -- those parts are "parity unpinned"):
   * ``flow_stack_indices``   -> the 5 flow frames of a snippet                       (calcSig_wOF.py:104)
   * ``crop0``                -> resize to 340x256 and keep the top-left 224x224 crop: the only one of the 10
                                 over-sampled crops whose feature the reference keeps (calcSig_wOF.py:94-95)
-Image decoding uses cv2 when present, else PIL, else the built-in PPM/PGM/NPY reader (this image has neither).
+Image decoding on the host uses cv2 when present, else PIL, else the built-in PPM/PGM/NPY reader; ``load_*_jpegs`` hand the
+undecoded JPEG files to the library's own decoder instead (tsn/jpeg.py: same pixels as libjpeg, no host image library).
 """
 from __future__ import annotations
 
@@ -108,7 +109,11 @@ def imread(path: str, color: bool) -> np.ndarray:
     try:
         from PIL import Image
         im = Image.open(path)
-        return np.asarray(im.convert('RGB'))[:, :, ::-1].copy() if color else np.asarray(im.convert('L'))
+        if color:
+            return np.asarray(im.convert('RGB'))[:, :, ::-1].copy()
+        if im.format == 'JPEG' and im.mode != 'L':
+            im.draft('L', im.size)      # libjpeg's own grayscale output (the Y plane), as cv2.IMREAD_GRAYSCALE gets it
+        return np.asarray(im.convert('L'))
     except ImportError:
         raise ImportError("no JPEG decoder in this environment (cv2 / PIL missing); use .ppm/.pgm/.npy frames "
                           "(--frame_ext) or install one")
@@ -166,6 +171,27 @@ def load_flow_frames(clip_dir: str, ticks: List[int], frame_cnt: int, stk_depth=
             planes.append(imread(os.path.join(clip_dir, '{}{:05d}{}'.format(flow_y_prefix, idx, ext)), False))
         out.append(np.stack(planes))
     return np.stack(out)
+
+
+def _read_file(path: str) -> bytes:
+    with open(path, 'rb') as f:
+        return f.read()
+
+
+def load_rgb_jpegs(clip_dir: str, ticks: List[int], rgb_prefix='img_', ext='.jpg') -> List[bytes]:
+    """The JPEG FILES of the snippets, undecoded (the library decodes them: tsn/jpeg.py)."""
+    return [_read_file(os.path.join(clip_dir, '{}{:05d}{}'.format(rgb_prefix, t, ext))) for t in ticks]
+
+
+def load_flow_jpegs(clip_dir: str, ticks: List[int], frame_cnt: int, stk_depth=5, flow_x_prefix='flow_x_', flow_y_prefix='flow_y_',
+                    ext='.jpg') -> List[bytes]:
+    """The x / y flow JPEG files of every snippet in stack order (x0, y0, x1, y1, ...), undecoded."""
+    out = []
+    for tick in ticks:
+        for idx in flow_stack_indices(tick, frame_cnt, stk_depth):
+            out.append(_read_file(os.path.join(clip_dir, '{}{:05d}{}'.format(flow_x_prefix, idx, ext))))
+            out.append(_read_file(os.path.join(clip_dir, '{}{:05d}{}'.format(flow_y_prefix, idx, ext))))
+    return out
 
 
 def load_rgb_snippets(clip_dir: str, ticks: List[int], rgb_prefix='img_', ext='.jpg') -> np.ndarray:
