@@ -1,0 +1,79 @@
+"""The drop-in for the reference's frame preparation command line (src/features_GPU_compute/build_wof_clips.py): clip
+regrouping and grey conversion on the CPU, the whole command on the GPU (flow parity is unpinned: third-party binary)."""
+import os
+
+import numpy as np
+import pytest
+
+
+def _touch_frames(d, n, ext=".jpg"):
+    os.makedirs(d)
+    for i in range(1, n + 1):
+        for kind in ("img", "flow_x", "flow_y"):
+            with open(os.path.join(d, "%s_%05d%s" % (kind, i, ext)), "wb") as f:
+                f.write(b"%s %d" % (kind.encode(), i))
+
+
+def test_create_clip_follows_the_reference_rules(tmp_path):
+    """build_wof_clips.py:78-128: int(n / frames_per_clip) full clips, frames renumbered from 1 inside each clip; the rest becomes
+    one more clip when it lasts >= 2 s, else it is deleted."""
+    import video_query_algorithms_amd  # noqa: F401
+    from video_query_algorithms_amd import build_wof_clips as bw
+    out = tmp_path / "out"
+    _touch_frames(str(out / "vidA"), 3 * 150 + 40)          # 40 >= 2 * 15: a fourth, short clip
+    _touch_frames(str(out / "vidB"), 150 + 20)              # 20 < 30: the tail is dropped
+    _touch_frames(str(out / "vidC"), 12, ext=".ppm")        # shorter than 2 s: nothing survives
+    assert bw.create_clip("/videos/vidA.mp4", str(out)) == 4
+    assert bw.create_clip("/videos/vidB.mp4", str(out)) == 1
+    assert bw.create_clip(str(tmp_path / "src" / "vidC"), str(out)) == 0
+    a = out / "vidA"
+    assert sorted(os.listdir(a)) == ["clip_0001", "clip_0002", "clip_0003", "clip_0004"]
+    assert len(os.listdir(a / "clip_0002")) == 450 and len(os.listdir(a / "clip_0004")) == 120
+    assert (a / "clip_0002" / "flow_y_00001.jpg").read_bytes() == b"flow_y 151"          # frame 151 is frame 1 of clip 2
+    assert (a / "clip_0004" / "img_00040.jpg").read_bytes() == b"img 490"
+    assert sorted(os.listdir(out / "vidB")) == ["clip_0001"] and len(os.listdir(out / "vidB" / "clip_0001")) == 450
+    assert os.listdir(out / "vidC") == []
+    # what calcSig_wOF.py's parse_directory then sees
+    from video_query_algorithms_amd.tsn import frames
+    d, rgb, flow = frames.parse_directory(str(a))
+    assert rgb == {"clip_0001": 150, "clip_0002": 150, "clip_0003": 150, "clip_0004": 40} and flow == rgb
+
+
+def test_grey_conversion_is_cv2s_fixed_point_rule():
+    import video_query_algorithms_amd  # noqa: F401
+    from video_query_algorithms_amd.build_wof_clips import bgr_to_grey
+    px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 200, 90]]], np.uint8)      # B, G, R
+    assert bgr_to_grey(px).tolist() == [[255, 0, 29, 150, 76, int((10 * 1868 + 200 * 9617 + 90 * 4899 + 8192) >> 14)]]
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    ref = np.rint(0.114 * img[..., 0] + 0.587 * img[..., 1] + 0.299 * img[..., 2])
+    assert np.abs(bgr_to_grey(img).astype(int) - ref).max() <= 1
+
+
+@pytest.mark.gpu
+def test_command_line_on_a_frame_directory(gpu, tmp_path):
+    """A 'video' given as a directory of its frames (no cv2 here): a panning texture, 41 frames -> 40 img / flow_x / flow_y
+    triples -> with --fps 5 --clip_time 3: two clips of 15 and a 10-frame (= 2 s) third one; the warped flow of a pure pan is
+    mid-grey; the tree is what calcSig_wOF.py reads."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_warp_oracle import analytic_pair
+    from video_query_algorithms_amd import build_wof_clips as bw
+    from video_query_algorithms_amd.tsn import frames
+    src = tmp_path / "src" / "pan"
+    src.mkdir(parents=True)
+    for t in range(41):
+        H = np.array([[1, 0, 1.5 * t], [0, 1, -0.5 * t], [0, 0, 1.0]])
+        g = analytic_pair(96, 128, H, seed=3)[1]
+        frames.write_pnm(str(src / ("frame_%05d.ppm" % t)), np.repeat(g[:, :, None], 3, 2))
+    out = tmp_path / "out"
+    assert bw.main([str(tmp_path / "src"), str(out), "--fps", "5", "--clip_time", "3", "--max_pairs", "16"]) == 0
+    d, rgb, flow = frames.parse_directory(str(out / "pan"))
+    assert rgb == {"clip_0001": 15, "clip_0002": 15, "clip_0003": 10} and flow == rgb
+    ext = os.path.splitext(os.listdir(out / "pan" / "clip_0001")[0])[1]
+    fx = frames.imread(str(out / "pan" / "clip_0002" / ("flow_x_00003" + ext)), False)
+    fy = frames.imread(str(out / "pan" / "clip_0002" / ("flow_y_00003" + ext)), False)
+    assert fx.shape == (96, 128) and abs(int(np.median(fx[16:-16, 16:-16])) - 128) <= 2 and abs(int(np.median(fy[16:-16, 16:-16])) - 128) <= 2
+    img = frames.imread(str(out / "pan" / "clip_0001" / ("img_00001" + ext)), True)
+    want = frames.imread(str(src / "frame_00001.ppm"), True)                   # the initial frame is skipped: img 1 = frame 1
+    assert img.shape == (96, 128, 3) and np.abs(img.astype(int) - want.astype(int)).max() <= (12 if ext == ".jpg" else 0)

@@ -1,0 +1,181 @@
+"""Frame / warped-optical-flow preparation: the drop-in for the reference's ``build_wof_clips.py`` command line.
+
+Reference: src/features_GPU_compute/build_wof_clips.py -- per video it (1) shells out to the third-party
+``extract_warp_gpu -b 20 -t 1 -s 1`` for ``flow_x_NNNNN.jpg`` / ``flow_y_NNNNN.jpg`` (:55-76), (2) dumps the RGB frames with
+cv2, skipping the first one, as ``img_NNNNN.jpg`` (:24-53), (3) regroups everything into ``clip_NNNN`` directories of
+``clip_time * fps`` frames, keeping a shorter last clip if it lasts at least 2 s (:78-128).  Same positional arguments and
+flags (:132-152); ``--df_path`` and ``--out_format`` are accepted and ignored (there is no external binary; output is
+always directories).
+
+What runs where: the flow is ``Tvl1Flow.warped_consecutive`` (csrc/vq_flow.hip: TV-L1, camera motion from corners moved by
+the first-pass flow, second pass; the SURF matches the binary also uses are not built -- parity unpinned either way, the
+binary is not in the reference tree).  Grey conversion follows cv2's 8-bit BGR2GRAY fixed-point rule.  Files are written
+with cv2 or Pillow at cv2.imwrite's default JPEG quality (95), or as .ppm / .pgm when neither is importable
+(``calcSig_wOF.py --frame_ext .ppm`` reads those).
+
+Video decoding needs cv2 (``VideoCapture``); where it is missing (this image), a "video" may be a directory
+``<src_dir>/<name>/`` of ALL its frames in order (``frame_00000.jpg`` ..., any extension ``tsn/frames.imread`` reads): frame
+0 plays the part of the initial frame the reference skips, so ``img_00001`` is the second frame and ``flow_x_00001`` the flow
+from the first to the second, exactly the numbering the reference's two passes produce.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import os
+import sys
+
+if __package__ in (None, ""):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import video_query_algorithms_amd  # noqa: F401  (registers the package under its importable name)
+    from video_query_algorithms_amd.tsn import frames as frames_mod
+    from video_query_algorithms_amd.tsn.flow import Tvl1Flow
+else:
+    from .tsn import frames as frames_mod
+    from .tsn.flow import Tvl1Flow
+
+import numpy as np
+
+
+def bgr_to_grey(frame: np.ndarray) -> np.ndarray:
+    """cv2.cvtColor(frame, COLOR_BGR2GRAY) for uint8: (B * 1868 + G * 9617 + R * 4899 + 8192) >> 14."""
+    f = frame.astype(np.int32)
+    return ((f[..., 0] * 1868 + f[..., 1] * 9617 + f[..., 2] * 4899 + 8192) >> 14).astype(np.uint8)
+
+
+def _writer():
+    """(extension, write(path_without_ext, image)) for the best image writer available."""
+    try:
+        import cv2
+        return ".jpg", lambda p, img: cv2.imwrite(p + ".jpg", img)
+    except ImportError:
+        pass
+    try:
+        from PIL import Image
+
+        def save(p, img):
+            im = Image.fromarray(img if img.ndim == 2 else np.ascontiguousarray(img[:, :, ::-1]))
+            if img.ndim == 3:
+                im.save(p + ".jpg", "JPEG", quality=95, subsampling=2)         # cv2.imwrite's defaults: quality 95, 4:2:0
+            else:
+                im.save(p + ".jpg", "JPEG", quality=95)
+        return ".jpg", save
+    except ImportError:
+        return ".ppm", lambda p, img: frames_mod.write_pnm(p + ".ppm", img)
+
+
+def read_video(path: str, new_size=(0, 0)) -> np.ndarray:
+    """All frames of a video as BGR uint8 [n, h, w, 3]: a video file through cv2.VideoCapture, or a directory of frames."""
+    if os.path.isdir(path):
+        names = sorted(n for n in os.listdir(path) if os.path.splitext(n)[1].lower() in (".jpg", ".jpeg", ".ppm", ".pnm", ".npy", ".png"))
+        if not names:
+            raise IOError("no frames in " + path)
+        out = [frames_mod.imread(os.path.join(path, n), True) for n in names]
+    else:
+        try:
+            import cv2
+        except ImportError:
+            raise ImportError("decoding %s needs cv2.VideoCapture; without cv2 give a directory of the video's frames instead" % path)
+        video = cv2.VideoCapture(path)
+        out = []
+        while True:
+            ret, frame = video.read()
+            if not ret:
+                break
+            out.append(frame)
+    if new_size != (0, 0):
+        out = [frames_mod.resize_bilinear(f, new_size) for f in out]
+    return np.stack(out)
+
+
+def process_video(vid_path: str, out_path: str, flow, new_size=(0, 0), seed: int = 0) -> int:
+    """Steps (1) and (2) for one video: ``img_NNNNN`` for frames 1.., ``flow_x/y_NNNNN`` for the flow (k-1 -> k).  Returns
+    the number of frames written."""
+    return _process_frames(vid_path, out_path, read_video(vid_path, new_size), flow, seed)
+
+
+def _process_frames(vid_path: str, out_path: str, frames: np.ndarray, flow, seed: int = 0) -> int:
+    vid_name = os.path.basename(os.path.normpath(vid_path)).split('.')[0]
+    out_full_path = os.path.join(out_path, vid_name)
+    os.makedirs(out_full_path, exist_ok=True)
+    if frames.shape[0] < 2:
+        return 0
+    ext, write = _writer()
+    grey = np.stack([bgr_to_grey(f) for f in frames])
+    if grey.shape[1:] != (flow.h, flow.w):
+        raise ValueError("%s: frames are %dx%d, the flow workspace %dx%d" % (vid_name, grey.shape[2], grey.shape[1], flow.w, flow.h))
+    fx, fy = flow.warped_consecutive(grey, seed=seed)
+    for k in range(1, frames.shape[0]):
+        write('{}/img_{:05d}'.format(out_full_path, k), frames[k])             # the reference skips the initial frame (:34)
+        write('{}/flow_x_{:05d}'.format(out_full_path, k), fx[k - 1])
+        write('{}/flow_y_{:05d}'.format(out_full_path, k), fy[k - 1])
+    return frames.shape[0] - 1
+
+
+def create_clip(vid_path: str, out_path: str, frames_per_clip: int = 150, frames_per_second: int = 15) -> int:
+    """Step (3), build_wof_clips.py:78-128: move the frames of one video into clip_NNNN directories.  Returns the clips made."""
+    vid_name = os.path.basename(os.path.normpath(vid_path)).split('.')[0]
+    out_video_path = os.path.join(out_path, vid_name)
+    rgb = sorted(glob.glob(os.path.join(out_video_path, 'img_*')))
+    if not rgb:
+        return 0
+    ext = os.path.splitext(rgb[0])[1]
+    plan, dropped = frames_mod.clip_plan(len(rgb), frames_per_clip, frames_per_second)
+    kinds = ('img', 'flow_x', 'flow_y')
+    for clip, first, last in plan:
+        clip_dir = os.path.join(out_video_path, 'clip_{:04d}'.format(clip))
+        os.mkdir(clip_dir)
+        for iframe in range(first, last + 1):
+            for kind in kinds:
+                os.replace(os.path.join(out_video_path, '{}_{:05d}{}'.format(kind, iframe, ext)),
+                           os.path.join(clip_dir, '{}_{:05d}{}'.format(kind, iframe - first + 1, ext)))
+    for iframe in range(len(rgb) - dropped + 1, len(rgb) + 1):                 # a tail shorter than 2 s is deleted (:123-126)
+        for kind in kinds:
+            os.remove(os.path.join(out_video_path, '{}_{:05d}{}'.format(kind, iframe, ext)))
+    return len(plan)
+
+
+def main(argv=None) -> int:
+    parser = argparse.ArgumentParser(description="Extract rgb and warped optical flow frames")
+    parser.add_argument("src_dir", help="directory with video files")
+    parser.add_argument("out_dir")
+    parser.add_argument("--fps", type=int, default=15, help="frames per second, default = 15")
+    parser.add_argument("--clip_time", type=int, default=10, help="clip time in seconds, default = 10")
+    parser.add_argument("--num_worker", type=int, default=16, help="CPU workers, default=16")
+    parser.add_argument("--df_path", type=str, default='./lib/dense_flow/', help='accepted for compatibility; no external toolbox is used')
+    parser.add_argument("--out_format", type=str, default='dir', choices=['dir', 'zip'], help='format of output, default=dir')
+    parser.add_argument("--ext", type=str, default='mp4', choices=['avi', 'mp4'], help='video file extensions, default = mp4')
+    parser.add_argument("--new_width", type=int, default=0, help='resize image width')
+    parser.add_argument("--new_height", type=int, default=0, help='resize image height')
+    parser.add_argument("--num_gpu", type=int, default=1, help='number of GPU, default = 1')
+    parser.add_argument("--starting_gpu", type=int, default=0, help='ID of first GPU to use, default = 0')
+    parser.add_argument("--max_pairs", type=int, default=64, help='frame pairs per flow batch on the GPU (not in the reference)')
+    args = parser.parse_args(argv)
+    new_size = (args.new_width, args.new_height)
+    assert new_size == (0, 0) or (new_size[0] != 0 and new_size[1] != 0)
+    if args.out_format != 'dir':
+        raise SystemExit("only --out_format dir is produced")
+    os.makedirs(args.out_dir, exist_ok=True)
+    vid_list = sorted(glob.glob(args.src_dir + '/*.' + args.ext))
+    if not vid_list:                                                            # frame directories stand in for video files
+        vid_list = sorted(d for d in glob.glob(args.src_dir + '/*') if os.path.isdir(d))
+    print("number of videos found = {}".format(len(vid_list)))
+    flows = {}                                                                  # (h, w) -> flow workspace
+    device = args.starting_gpu
+    for vid_id, vid_path in enumerate(vid_list):
+        frames = read_video(vid_path, new_size)
+        h, w = frames.shape[1:3]
+        if (h, w) not in flows:
+            flows[(h, w)] = Tvl1Flow(args.max_pairs, h, w, device=device)
+        n = _process_frames(vid_path, args.out_dir, frames, flows[(h, w)], seed=vid_id)
+        print('warp + rgb for {} {} done ({} frames)'.format(vid_id, os.path.basename(os.path.normpath(vid_path)), n))
+        sys.stdout.flush()
+    for vid_path in vid_list:                                                   # build_wof_clips.py:188-191
+        create_clip(vid_path, args.out_dir, frames_per_clip=args.clip_time * args.fps, frames_per_second=args.fps)
+    for f in flows.values():
+        f.close()
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
