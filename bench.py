@@ -440,6 +440,47 @@ def bench_flow(device_index, with_cpu):
     return out
 
 
+def bench_jpeg(device_index):
+    """Frame ingest in front of hot path A: a batch of 340 x 256, 4:2:0, quality-95 JPEG frames (cv2.imwrite's defaults)
+    decoded into device memory -- Huffman decoding on the library's host threads, IDCT / upsampling / colour on the GPU.
+    Needs Pillow to MAKE the test files (and to time libjpeg-turbo beside it); absent -> the section is skipped."""
+    try:
+        import io
+        from PIL import Image
+    except ImportError:
+        return None
+    from video_query_algorithms_amd.tsn.jpeg import JpegDecoder
+    n, h, w = 256, 256, 340
+    rng = np.random.default_rng(9)
+    ys, xs = np.mgrid[0:h, 0:w]
+    base = np.stack([127 + 100 * np.sin(xs / 7.0) + 20 * np.cos(ys / 3.0), 127 + 90 * np.cos(ys / 9.0) + 30 * np.sin(xs / 2.5),
+                     127 + 80 * np.sin((xs + ys) / 11.0)], -1)
+    files = []
+    for _ in range(n):
+        buf = io.BytesIO()
+        Image.fromarray(np.clip(base + rng.normal(0, 12, base.shape), 0, 255).astype(np.uint8)).save(buf, "JPEG", quality=95, subsampling=2)
+        files.append(buf.getvalue())
+    dec = JpegDecoder(n, h, w, device_index)
+    dec.decode_to_device(files)
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dec.decode_to_device(files)
+    dt = (time.perf_counter() - t0) / reps
+    got = dec.decode(files[:4])
+    same = all((got[i] == np.asarray(Image.open(io.BytesIO(files[i])).convert("RGB"))[:, :, ::-1]).all() for i in range(4))
+    t0 = time.perf_counter()
+    for f in files[:64]:
+        np.asarray(Image.open(io.BytesIO(f)).convert("RGB"))
+    dp = (time.perf_counter() - t0) / 64
+    dec.close()
+    return {"metric": "JPEG frames/sec decoded into device memory (340x256, 4:2:0, quality 95)", "value": n / dt, "unit": "frames/s",
+            "batch_frames": n, "ms_per_batch": dt * 1e3, "mean_file_kb": sum(len(f) for f in files) / n / 1024,
+            "host_threads": min(16, os.cpu_count() or 1), "bit_identical_to_libjpeg_turbo": bool(same),
+            "cpu_baseline": {"value": 1.0 / dp, "unit": "frames/s", "cores": 1, "kind": "reference",
+                             "sample": "64 of the files through Pillow's libjpeg-turbo (the library cv2.imread decodes with), one thread"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -528,6 +569,9 @@ def main():
         db.close()
     if rank == 0 and world == 1 and not args.skip_flow and not args.profile_only:
         out["flow"] = bench_flow(local_rank, not args.skip_cpu)
+        jp = bench_jpeg(local_rank)
+        if jp:
+            out["jpeg"] = jp
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
