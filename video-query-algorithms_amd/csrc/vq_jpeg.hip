@@ -571,12 +571,14 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
             if (f.qt_present[t]) memcpy(&qts[((size_t)i * 4 + t) * 64], f.qt[t], 64 * sizeof(uint16_t));
     }
     // ---- entropy decoding: one frame per host thread
-    memset(j->coef_host, 0, blocks * 64 * sizeof(int16_t));
     const int workers = std::max(1, std::min<int>({n, 16, (int)std::thread::hardware_concurrency()}));
     std::vector<int> status((size_t)n, VQ_OK);
     std::vector<std::string> message((size_t)n);
     auto work = [&](int first) {
         for (int i = first; i < n; i += workers) {
+            // the frame's blocks start from zero (only non-zero coefficients are written): cleared here, by the frame's own thread
+            const size_t b0 = comp_off[(size_t)i * 3], b1 = i + 1 < n ? comp_off[(size_t)(i + 1) * 3] : blocks;
+            memset(j->coef_host + b0 * 64, 0, (b1 - b0) * 64 * sizeof(int16_t));
             status[i] = decode_scan(files[i], (size_t)sizes[i], fr[i], j->coef_host, &comp_off[(size_t)i * 3]);
             if (status[i] != VQ_OK) message[i] = last_error_ref();       // thread-local message of this worker
         }
