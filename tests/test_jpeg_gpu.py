@@ -136,3 +136,33 @@ def test_committed_libjpeg_fixtures(jpeg):
         dec = jpeg.JpegDecoder(1, want.shape[0], want.shape[1])
         assert (dec.decode([path], color=want.ndim == 3)[0] == want).all(), path
         dec.close()
+
+
+@needs_pil
+def test_damaged_files_never_take_the_process_down(jpeg):
+    """600 random mutations (overwritten bytes, truncation, a 4-byte splice) of four valid files: every one is either decoded
+    to SOMETHING of the right shape or refused with VqError; the handle keeps working."""
+    from video_query_algorithms_amd import VqError
+    rng = np.random.default_rng(0)
+    dec = jpeg.JpegDecoder(2, 48, 64)
+    seeds = [encode(picture(48, 64, 1), quality=90, subsampling=2), encode(picture(48, 64, 2), quality=70, subsampling=1, restart_marker_blocks=2),
+             encode(picture(48, 64, 3)[:, :, 0], quality=85), encode(picture(48, 64, 4), quality=95, subsampling=0, optimize=True)]
+    decoded = refused = 0
+    for it in range(600):
+        base = bytearray(seeds[it % 4])
+        if it % 3 == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                base[int(rng.integers(2, len(base)))] = int(rng.integers(0, 256))
+        elif it % 3 == 1:
+            base = base[:int(rng.integers(4, len(base)))]
+        else:
+            p = int(rng.integers(2, len(base) - 8))
+            base[p:p + 4] = bytes(rng.integers(0, 256, 4, dtype=np.uint8))
+        try:
+            assert dec.decode([bytes(base)]).shape == (1, 48, 64, 3)
+            decoded += 1
+        except VqError:
+            refused += 1
+    assert decoded > 100 and refused > 100
+    assert (dec.decode([seeds[0]])[0] == pil_bgr(seeds[0])).all()
+    dec.close()
