@@ -57,7 +57,7 @@ def clip_plan(n_frames: int, frames_per_clip: int = 150, frames_per_second: int 
     """How ``create_clip`` cuts a video's frames into clips (src/features_GPU_compute/build_wof_clips.py:78-128):
     ``int(n / frames_per_clip)`` full clips of consecutive frames (1-based), then the remaining frames become one more,
     shorter clip if they last at least 2 seconds, else they are deleted.  Returns [(clip number, first frame, last frame)]
-    and the number of frames dropped.  (The optical flow itself -- warped TV-L1 from a third-party binary -- is out of scope.)"""
+    and the number of frames dropped.  (The flow frames themselves: tsn/flow.py; the whole command line: build_wof_clips.py.)"""
     nclips = int(n_frames / frames_per_clip)
     plan = [(n + 1, n * frames_per_clip + 1, (n + 1) * frames_per_clip) for n in range(nclips)]
     remaining = n_frames - nclips * frames_per_clip
