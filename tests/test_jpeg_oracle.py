@@ -85,3 +85,24 @@ def test_committed_fixtures_decoded_by_libjpeg_turbo():
         with open(path, "rb") as f:
             data = f.read()
         assert (jo.decode(data, color=want.ndim == 3) == want).all(), path
+
+
+def test_library_header_parser_without_a_gpu():
+    """vq_jpeg_info is host code: frame header of the committed fixtures, and the refusals, through the C ABI on the CPU."""
+    import glob
+    import os
+    import video_query_algorithms_amd as vqa
+    from video_query_algorithms_amd.tsn import jpeg
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg")
+    for path in sorted(glob.glob(os.path.join(root, "*.jpg"))):
+        want = np.load(path[:-4] + ".npy")
+        with open(path, "rb") as f:
+            data = f.read()
+        assert jpeg.info(data) == (want.shape[0], want.shape[1], 3 if want.ndim == 3 else 1), path
+        with pytest.raises(vqa.VqError):
+            jpeg.info(data[:20])
+    with pytest.raises(vqa.VqError, match="not a JPEG"):
+        jpeg.info(b"GIF89a" + b"\0" * 32)
+    if Image is not None:
+        with pytest.raises(vqa.VqError, match="progressive"):
+            jpeg.info(encode(picture(16, 16, 2), progressive=True))
