@@ -1,0 +1,46 @@
+"""The drop-in ``calcSig_wOF`` command line with a stand-in extractor, for the CPU tests of its process / sharding logic.
+
+There is no GPU in the build container and the product has no CPU fallback, so the per-stream extractor is replaced by a
+deterministic function of the decoded crops (the arithmetic of the real one is checked on the GPU, tests/test_tsn_gpu.py).
+Run as a script it IS the command line: the per-GPU children of the fan-out are started from this file again
+(``program=__file__``), exactly as the product starts them from calcSig_wOF.py."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class StandInNet:
+    """Looks like tsn.caffe_net.CaffeNet to the command line; the 'features' of a clip are a hash of its crops."""
+    feature_dim = 1024
+
+    def __init__(self, net_proto, net_weights, device_id=0, max_crops=96, feature_blob="global_pool"):
+        self.device, self.max_crops = device_id, max_crops
+        log = os.environ.get("STANDIN_DEVICE_LOG")
+        if log:                                            # which rank built a net on which device (one line per net)
+            with open(log + ".%s" % os.environ.get("RANK", "0"), "a") as f:
+                f.write("%d\n" % device_id)
+        if os.environ.get("STANDIN_FAIL_RANK") == os.environ.get("RANK", "0"):
+            raise RuntimeError("stand-in extractor told to fail on this rank")
+
+    @staticmethod
+    def _clip_feature(crops):
+        seed = int.from_bytes(hashlib.sha256(np.ascontiguousarray(crops).tobytes()).digest()[:8], "little")
+        return np.random.default_rng(seed).random(1024) * 10.0
+
+    def extract_clips(self, crops, T, on_device=False):
+        assert crops.shape[0] % T == 0 and crops.shape[0] <= self.max_crops
+        return np.stack([self._clip_feature(crops[i:i + T]) for i in range(0, crops.shape[0], T)])
+
+    def close(self):
+        pass
+
+
+if __name__ == "__main__":
+    from video_query_algorithms_amd import calcSig_wOF
+    sys.exit(calcSig_wOF.main(net_factory=StandInNet, program=os.path.abspath(__file__)))

@@ -77,3 +77,55 @@ def test_command_line_on_a_frame_directory(gpu, tmp_path):
     img = frames.imread(str(out / "pan" / "clip_0001" / ("img_00001" + ext)), True)
     want = frames.imread(str(src / "frame_00001.ppm"), True)                   # the initial frame is skipped: img 1 = frame 1
     assert img.shape == (96, 128, 3) and np.abs(img.astype(int) - want.astype(int)).max() <= (12 if ext == ".jpg" else 0)
+
+
+def _run_wof(argv, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("VQ_FANOUT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "tests", "_wof_standin.py")] + argv, env=env, timeout=timeout,
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+
+def _tree(out):
+    found = {}
+    for dirpath, _, files in os.walk(out):
+        for fn in files:
+            found[os.path.relpath(os.path.join(dirpath, fn), out)] = open(os.path.join(dirpath, fn), "rb").read()
+    return found
+
+
+def test_num_gpu_fans_out_one_process_per_gpu_and_the_files_do_not_change(tmp_path):
+    """build_wof_clips.py:66: worker i runs on GPU (i - 1) % NUM_GPU + START_GPU.  ``--num_gpu 3 --starting_gpu 2`` must put
+    one process on each of GPUs 2, 3, 4 (videos dealt round-robin) and write the same files as one GPU; a window size that
+    does not divide a video must not change them either; --new_width / --new_height resize the img_ frames only (the
+    reference hands the VIDEO to extract_warp_gpu, :70-73)."""
+    import video_query_algorithms_amd  # noqa: F401
+    from video_query_algorithms_amd.tsn import frames
+    rng = np.random.default_rng(4)
+    src = tmp_path / "src"
+    for v, (n, h, w) in enumerate([(13, 24, 32), (7, 24, 32), (12, 20, 28), (2, 24, 32), (9, 24, 32)]):
+        d = src / ("vid%d" % v)
+        d.mkdir(parents=True)
+        for t in range(n):
+            frames.write_pnm(str(d / ("frame_%05d.ppm" % t)), rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+    common = ["--fps", "2", "--clip_time", "2", "--new_width", "16", "--new_height", "12"]
+    one = tmp_path / "one"
+    r = _run_wof([str(src), str(one)] + common + ["--max_pairs", "64"], {"STANDIN_DEVICE_LOG": str(tmp_path / "dev1")})
+    assert r.returncode == 0, r.stdout
+    want = _tree(str(one))
+    assert "vid0/clip_0001/flow_x_00001.ppm" in want and "vid0/clip_0003/img_00004.ppm" in want       # 12 frames -> 3 clips of 4
+    assert frames.imread(str(one / "vid0" / "clip_0001" / "img_00001.ppm"), True).shape == (12, 16, 3)   # resized dump
+    assert frames.imread(str(one / "vid0" / "clip_0001" / "flow_x_00001.ppm"), False).shape == (24, 32)  # flow at video size
+    assert open(str(tmp_path / "dev1.0")).read().split("\n")[0] == "0 24 32"
+    fan = tmp_path / "fan"
+    r = _run_wof([str(src), str(fan)] + common + ["--max_pairs", "4", "--num_gpu", "3", "--starting_gpu", "2"],
+                 {"STANDIN_DEVICE_LOG": str(tmp_path / "dev3")})
+    assert r.returncode == 0, r.stdout
+    assert _tree(str(fan)) == want
+    for rank in range(3):
+        devs = {line.split()[0] for line in open(str(tmp_path / ("dev3.%d" % rank))).read().split("\n") if line}
+        assert devs == {str(2 + rank)}
+    assert r.stdout.count("number of videos found") == 1

@@ -6,7 +6,6 @@ There is no GPU here and the product has no CPU fallback, so the extractor is a 
 deterministic function of the decoded crops); the arithmetic of the real one is checked on the GPU
 (tests/test_tsn_gpu.py).  What this test pins is the control flow around it: ragged shards (7 clips over 2 ranks),
 batches that do not divide a shard, several videos, both streams, the ``--gpus`` -> device mapping."""
-import hashlib
 import os
 import socket
 import sys
@@ -18,24 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SEEN_DEVICES = "devices_%d.txt"
 
 
-class StandInNet:
-    """Looks like tsn.caffe_net.CaffeNet to the command line; the 'features' of a clip are a hash of its crops."""
-    feature_dim = 1024
-
-    def __init__(self, net_proto, net_weights, device_id=0, max_crops=96, feature_blob="global_pool"):
-        self.device, self.max_crops = device_id, max_crops
-
-    @staticmethod
-    def _clip_feature(crops):
-        seed = int.from_bytes(hashlib.sha256(np.ascontiguousarray(crops).tobytes()).digest()[:8], "little")
-        return np.random.default_rng(seed).random(1024) * 10.0
-
-    def extract_clips(self, crops, T, on_device=False):
-        assert crops.shape[0] % T == 0 and crops.shape[0] <= self.max_crops
-        return np.stack([self._clip_feature(crops[i:i + T]) for i in range(0, crops.shape[0], T)])
-
-    def close(self):
-        pass
+from _cli_standin import StandInNet  # noqa: E402
 
 
 def _make_tree(root):
@@ -43,7 +25,8 @@ def _make_tree(root):
     rng = np.random.default_rng(11)
     for video, clips in (("videoA", {"clip_0001": 6, "clip_0002": 7, "clip_0003": 6, "clip_0005": 9, "clip_0008": 6,
                                      "clip_0013": 6, "clip_0021": 8}),
-                         ("videoB", {"clip_0002": 6, "clip_0004": 6, "clip_0006": 6})):
+                         ("videoB", {"clip_0002": 6, "clip_0004": 6, "clip_0006": 6}),
+                         ("videoC", {"clip_0001": 7})):                 # fewer clips than ranks: a rank owns nothing
         for clip, n in clips.items():
             d = os.path.join(root, video, clip)
             os.makedirs(d)
@@ -53,11 +36,11 @@ def _make_tree(root):
                 frames.write_pnm(os.path.join(d, "flow_y_%05d.ppm" % i), rng.integers(0, 256, (24, 32), dtype=np.uint8))
 
 
-def _argv(frames_root, out_dir):
+def _argv(frames_root, out_dir, gpus=("4", "6"), workers="2"):
     return [frames_root, "rgb.prototxt", "ucf101_split1_tsn_rgb_bn_inception_wOF.caffemodel", "flow.prototxt",
             "ucf101_split1_tsn_flow_bn_inception_wOF.caffemodel", "--num_frame_per_video", "3", "--outFeatures_dir", out_dir,
-            "--modelname", "UCF101_split1", "--frame_ext", ".ppm", "--batch_clips", "2", "--num_worker", "2", "--host_resize",
-            "--gpus", "4", "6"]
+            "--modelname", "UCF101_split1", "--frame_ext", ".ppm", "--batch_clips", "2", "--num_worker", workers, "--host_resize",
+            "--gpus"] + list(gpus)
 
 
 def _rank(rank, world, port, frames_root, out_dir):
@@ -95,12 +78,10 @@ def test_two_rank_cli_writes_the_same_bytes_as_one_rank(tmp_path, monkeypatch):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
     one = str(tmp_path / "one")
-    assert calcSig_wOF.main(_argv(frames_root, one), net_factory=StandInNet) == 0
+    assert calcSig_wOF.main(_argv(frames_root, one), net_factory=StandInNet) == 0      # a caller's own extractor: no fan-out
     want = _tree_bytes(one)
-    assert sorted(want) == ["videoA/UCF101_split1/rgb_global_pool_features.csv",
-                            "videoA/UCF101_split1/warped_optical_flow_global_pool_features.csv",
-                            "videoB/UCF101_split1/rgb_global_pool_features.csv",
-                            "videoB/UCF101_split1/warped_optical_flow_global_pool_features.csv"]
+    assert sorted(want) == ["video%s/UCF101_split1/%s_global_pool_features.csv" % (v, m) for v in "ABC"
+                            for m in ("rgb", "warped_optical_flow")]
     rows = want["videoA/UCF101_split1/rgb_global_pool_features.csv"].decode().split("\n")
     assert [r.split(",")[0] for r in rows[1:-1]] == ["1", "2", "3", "5", "8", "13", "21"]     # calcSig_wOF.py:200
     with socket.socket() as sk:
@@ -113,3 +94,61 @@ def test_two_rank_cli_writes_the_same_bytes_as_one_rank(tmp_path, monkeypatch):
     # worker -> GPU map of calcSig_wOF.py:50-55: rank g of the node takes gpu_list[g % len]
     assert open(os.path.join(two, SEEN_DEVICES % 0)).read() == "4,4"          # one net per stream
     assert open(os.path.join(two, SEEN_DEVICES % 1)).read() == "6,6"
+
+
+def _run_cli(argv, env_extra, timeout=300):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "VQ_FANOUT_CHILD")}
+    env.update(VQ_DIST_BACKEND="gloo", **env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_cli_standin.py")] + argv, env=env, timeout=timeout,
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+
+def test_the_ensemble_scripts_own_command_line_fans_out_over_the_gpus_it_names(tmp_path):
+    """calcSig_wOF_ensemble.sh:13-19 runs ``python calcSig_wOF.py ... --num_worker 24 ... --gpus 0 1 ...`` with NO launcher;
+    the reference maps worker i to gpu_list[(i-1) % len] itself (calcSig_wOF.py:44-56, 204-210).  Spelled that way the
+    drop-in must start one process per GPU and write the byte-identical CSV tree of the one-GPU run -- here with 2 and with
+    4 GPUs named (videoC has ONE clip: with 4 ranks three of them own nothing of it, with 2 ranks one), and with a GPU
+    named twice (two workers share it: still one process on it)."""
+    frames_root = str(tmp_path / "frames")
+    _make_tree(frames_root)
+    one = str(tmp_path / "one")
+    r = _run_cli(_argv(frames_root, one, gpus=("0",), workers="24"), {})
+    assert r.returncode == 0, r.stdout
+    want = _tree_bytes(one)
+    assert len(want) == 6 and "one process per GPU" not in r.stdout
+    for gpus in (("0", "1"), ("3", "2", "1", "0"), ("5", "5", "7")):
+        out = str(tmp_path / ("fan%d" % len(gpus)))
+        log = str(tmp_path / ("devices%d" % len(gpus)))
+        r = _run_cli(_argv(frames_root, out, gpus=gpus, workers="24"), {"STANDIN_DEVICE_LOG": log})
+        assert r.returncode == 0, r.stdout
+        assert "one process per GPU" in r.stdout
+        assert _tree_bytes(out) == want
+        for rank, g in enumerate(dict.fromkeys(gpus)):       # rank i of the fan-out sits on the i-th DISTINCT GPU the workers reach
+            assert open("%s.%d" % (log, rank)).read().split() == [g, g]          # one net per stream, both on that GPU
+
+
+def test_workers_reach_only_the_gpus_the_reference_would_give_them(tmp_path):
+    """--num_worker 1 --gpus 0 1: the reference's only worker takes gpu_list[0] (calcSig_wOF.py:47-55): no fan-out.
+    --num_worker 3 --gpus 5 7 9 11: workers 1..3 -> GPUs 5, 7, 9."""
+    from video_query_algorithms_amd import fanout
+    assert fanout.worker_devices([0, 1], 1) == [0]
+    assert fanout.worker_devices([5, 7, 9, 11], 3) == [5, 7, 9]
+    assert fanout.worker_devices([0, 1, 2, 3, 4, 5, 6, 7], 24) == list(range(8))
+    assert fanout.worker_devices([2, 2, 3], 5) == [2, 3]
+    assert fanout.worker_devices(None, 4, visible=8) == [0, 1, 2, 3] and fanout.worker_devices(None, 24, visible=8) == list(range(8))
+    assert fanout.worker_devices(None, 1, visible=8) == [0]
+    frames_root = str(tmp_path / "frames")
+    _make_tree(frames_root)
+    r = _run_cli(_argv(frames_root, str(tmp_path / "o"), gpus=("0", "1"), workers="1"), {})
+    assert r.returncode == 0 and "one process per GPU" not in r.stdout
+
+
+def test_a_failing_rank_fails_the_command(tmp_path):
+    """The reference aborts on any exception in a worker (calcSig_wOF.py:51,72,220); a child of the fan-out that dies must
+    end its peers (they would wait in the all-gather for ever) and give the command a non-zero exit code."""
+    frames_root = str(tmp_path / "frames")
+    _make_tree(frames_root)
+    r = _run_cli(_argv(frames_root, str(tmp_path / "o"), gpus=("0", "1"), workers="2"), {"STANDIN_FAIL_RANK": "1"}, timeout=120)
+    assert r.returncode != 0
+    assert "told to fail" in r.stdout

@@ -30,7 +30,9 @@ if __package__ in (None, ""):
     import video_query_algorithms_amd  # noqa: F401  (registers the package under its importable name)
     from video_query_algorithms_amd.tsn import frames as frames_mod
     from video_query_algorithms_amd.tsn.flow import Tvl1Flow
+    from video_query_algorithms_amd import fanout
 else:
+    from . import fanout
     from .tsn import frames as frames_mod
     from .tsn.flow import Tvl1Flow
 
@@ -64,52 +66,73 @@ def _writer():
         return ".ppm", lambda p, img: frames_mod.write_pnm(p + ".ppm", img)
 
 
-def read_video(path: str, new_size=(0, 0)) -> np.ndarray:
-    """All frames of a video as BGR uint8 [n, h, w, 3]: a video file through cv2.VideoCapture, or a directory of frames."""
+def iter_video(path: str):
+    """The frames of a video one by one as BGR uint8 [h, w, 3]: a video file through cv2.VideoCapture, or a directory of
+    frames.  Nothing is kept: a 10-minute video never sits in host memory as a whole."""
     if os.path.isdir(path):
         names = sorted(n for n in os.listdir(path) if os.path.splitext(n)[1].lower() in (".jpg", ".jpeg", ".ppm", ".pnm", ".npy", ".png"))
         if not names:
             raise IOError("no frames in " + path)
-        out = [frames_mod.imread(os.path.join(path, n), True) for n in names]
-    else:
-        try:
-            import cv2
-        except ImportError:
-            raise ImportError("decoding %s needs cv2.VideoCapture; without cv2 give a directory of the video's frames instead" % path)
-        video = cv2.VideoCapture(path)
-        out = []
-        while True:
-            ret, frame = video.read()
-            if not ret:
-                break
-            out.append(frame)
-    if new_size != (0, 0):
-        out = [frames_mod.resize_bilinear(f, new_size) for f in out]
-    return np.stack(out)
+        for n in names:
+            yield frames_mod.imread(os.path.join(path, n), True)
+        return
+    try:
+        import cv2
+    except ImportError:
+        raise ImportError("decoding %s needs cv2.VideoCapture; without cv2 give a directory of the video's frames instead" % path)
+    video = cv2.VideoCapture(path)
+    while True:
+        ret, frame = video.read()
+        if not ret:
+            break
+        yield frame
 
 
-def process_video(vid_path: str, out_path: str, flow, new_size=(0, 0), seed: int = 0) -> int:
-    """Steps (1) and (2) for one video: ``img_NNNNN`` for frames 1.., ``flow_x/y_NNNNN`` for the flow (k-1 -> k).  Returns
-    the number of frames written."""
-    return _process_frames(vid_path, out_path, read_video(vid_path, new_size), flow, seed)
+def read_video(path: str) -> np.ndarray:
+    """All frames of a (short) video as BGR uint8 [n, h, w, 3]."""
+    return np.stack(list(iter_video(path)))
 
 
-def _process_frames(vid_path: str, out_path: str, frames: np.ndarray, flow, seed: int = 0) -> int:
+def process_video(vid_path: str, out_path: str, flow_for, new_size=(0, 0), seed: int = 0, max_pairs: int = 64) -> int:
+    """Steps (1) and (2) for one video: ``img_NNNNN`` for frames 1.. (resized to ``new_size`` when given, as the reference's
+    dump_frames does, build_wof_clips.py:40-42), ``flow_x/y_NNNNN`` for the warped flow (k-1 -> k) of the frames AS DECODED
+    (the reference hands the video file itself to extract_warp_gpu, :70-73: the flow never sees --new_width / --new_height).
+    The video streams through in windows of ``max_pairs`` frame pairs.  ``flow_for(h, w)`` gives the flow workspace for a
+    frame size.  Returns the number of frames written."""
     vid_name = os.path.basename(os.path.normpath(vid_path)).split('.')[0]
     out_full_path = os.path.join(out_path, vid_name)
     os.makedirs(out_full_path, exist_ok=True)
-    if frames.shape[0] < 2:
-        return 0
     ext, write = _writer()
-    grey = np.stack([bgr_to_grey(f) for f in frames])
-    if grey.shape[1:] != (flow.h, flow.w):
-        raise ValueError("%s: frames are %dx%d, the flow workspace %dx%d" % (vid_name, grey.shape[2], grey.shape[1], flow.w, flow.h))
-    fx, fy = flow.warped_consecutive(grey, seed=seed)
-    for k in range(1, frames.shape[0]):
-        write('{}/img_{:05d}'.format(out_full_path, k), frames[k])             # the reference skips the initial frame (:34)
-        write('{}/flow_x_{:05d}'.format(out_full_path, k), fx[k - 1])
-        write('{}/flow_y_{:05d}'.format(out_full_path, k), fy[k - 1])
-    return frames.shape[0] - 1
+    flow = None
+    window, greys = [], []                  # frames k0 .. of the current window; greys[0] is the last frame of the one before
+    done = 0                                # frame pairs written so far
+
+    def flush():
+        nonlocal done
+        if len(greys) < 2:
+            return
+        fx, fy = flow.warped_consecutive(np.stack(greys), seed=seed + done)
+        for j, frame in enumerate(window):
+            k = done + j + 1
+            write('{}/img_{:05d}'.format(out_full_path, k), frame if new_size == (0, 0) else frames_mod.resize_bilinear(frame, new_size))
+            write('{}/flow_x_{:05d}'.format(out_full_path, k), fx[j])
+            write('{}/flow_y_{:05d}'.format(out_full_path, k), fy[j])
+        done += len(window)
+
+    for i, frame in enumerate(iter_video(vid_path)):
+        g = bgr_to_grey(frame)
+        if flow is None:
+            flow = flow_for(g.shape[0], g.shape[1])
+        elif g.shape != (flow.h, flow.w):
+            raise ValueError("%s: frame %d is %dx%d, the first one %dx%d" % (vid_name, i, g.shape[1], g.shape[0], flow.w, flow.h))
+        greys.append(g)
+        if i > 0:                                                              # the reference skips the initial frame (:34)
+            window.append(frame)
+        if len(window) == max_pairs:
+            flush()
+            window, greys = [], [g]
+    flush()
+    return done
 
 
 def create_clip(vid_path: str, out_path: str, frames_per_clip: int = 150, frames_per_second: int = 15) -> int:
@@ -135,7 +158,7 @@ def create_clip(vid_path: str, out_path: str, frames_per_clip: int = 150, frames
     return len(plan)
 
 
-def main(argv=None) -> int:
+def main(argv=None, program=None) -> int:
     parser = argparse.ArgumentParser(description="Extract rgb and warped optical flow frames")
     parser.add_argument("src_dir", help="directory with video files")
     parser.add_argument("out_dir")
@@ -147,9 +170,10 @@ def main(argv=None) -> int:
     parser.add_argument("--ext", type=str, default='mp4', choices=['avi', 'mp4'], help='video file extensions, default = mp4')
     parser.add_argument("--new_width", type=int, default=0, help='resize image width')
     parser.add_argument("--new_height", type=int, default=0, help='resize image height')
-    parser.add_argument("--num_gpu", type=int, default=1, help='number of GPU, default = 1')
+    parser.add_argument("--num_gpu", type=int, default=1, help='number of GPU, default = 1 (one process per GPU, videos dealt round-robin)')
     parser.add_argument("--starting_gpu", type=int, default=0, help='ID of first GPU to use, default = 0')
     parser.add_argument("--max_pairs", type=int, default=64, help='frame pairs per flow batch on the GPU (not in the reference)')
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = parser.parse_args(argv)
     new_size = (args.new_width, args.new_height)
     assert new_size == (0, 0) or (new_size[0] != 0 and new_size[1] != 0)
@@ -159,18 +183,28 @@ def main(argv=None) -> int:
     vid_list = sorted(glob.glob(args.src_dir + '/*.' + args.ext))
     if not vid_list:                                                            # frame directories stand in for video files
         vid_list = sorted(d for d in glob.glob(args.src_dir + '/*') if os.path.isdir(d))
-    print("number of videos found = {}".format(len(vid_list)))
+    if not fanout.is_child():
+        print("number of videos found = {}".format(len(vid_list)))
+    if args.num_gpu > 1 and not fanout.is_child():
+        # the reference spreads its workers over the GPUs (worker i -> (i - 1) % NUM_GPU + START_GPU, build_wof_clips.py:66);
+        # here: one fresh process per GPU, started before this one makes any GPU call, videos dealt round-robin
+        envs = [{"VQ_FANOUT_RANK": str(i), "VQ_FANOUT_WORLD": str(args.num_gpu)} for i in range(args.num_gpu)]
+        return fanout.run_children(program or os.path.abspath(__file__), argv, envs)
+    rank, world = int(os.environ.get("VQ_FANOUT_RANK", "0")), int(os.environ.get("VQ_FANOUT_WORLD", "1"))
+    device = args.starting_gpu + rank
     flows = {}                                                                  # (h, w) -> flow workspace
-    device = args.starting_gpu
-    for vid_id, vid_path in enumerate(vid_list):
-        frames = read_video(vid_path, new_size)
-        h, w = frames.shape[1:3]
+
+    def flow_for(h, w):
         if (h, w) not in flows:
             flows[(h, w)] = Tvl1Flow(args.max_pairs, h, w, device=device)
-        n = _process_frames(vid_path, args.out_dir, frames, flows[(h, w)], seed=vid_id)
+        return flows[(h, w)]
+
+    mine = [(vid_id, vid_path) for vid_id, vid_path in enumerate(vid_list) if vid_id % world == rank]
+    for vid_id, vid_path in mine:                                               # the seed is the video's GLOBAL index: the
+        n = process_video(vid_path, args.out_dir, flow_for, new_size, seed=vid_id, max_pairs=args.max_pairs)   # files do not depend on --num_gpu
         print('warp + rgb for {} {} done ({} frames)'.format(vid_id, os.path.basename(os.path.normpath(vid_path)), n))
         sys.stdout.flush()
-    for vid_path in vid_list:                                                   # build_wof_clips.py:188-191
+    for _, vid_path in mine:                                                    # build_wof_clips.py:188-191
         create_clip(vid_path, args.out_dir, frames_per_clip=args.clip_time * args.fps, frames_per_second=args.fps)
     for f in flows.values():
         f.close()

@@ -8,6 +8,12 @@ network in one pass instead of one 10-crop forward per snippet (only crop 0 was 
 are all-gathered over RCCL (from device memory); rank 0 writes the files.  ``--num_worker`` sizes the pool of decoder
 threads (the reference's worker processes, calcSig_wOF.py:204-210).
 
+Started by plain ``python`` the way calcSig_wOF_ensemble.sh:13-19 spells it (``--num_worker 24 --gpus 0 1 2 3 4 5 6 7``, no
+launcher), the command line maps workers to GPUs as the reference does (worker i -> ``gpu_list[(i - 1) % len]``, :47-55) and,
+when that names more than one GPU, starts itself once per GPU as fresh child processes BEFORE making any GPU call
+(``fanout.py``): the children are the ranks of the sharded path above, the parent only waits and returns the first
+non-zero exit code.  The CSV tree is byte-identical to the one-GPU run.
+
     python calcSig_wOF.py frames/ rgb.prototxt rgb_weights.npz flow.prototxt flow_weights.npz \
         --outFeatures_dir features/ --modelname UCF101_split1 [--num_frame_per_video 25] [--gpus 0]
 """
@@ -27,7 +33,9 @@ if __package__ in (None, ""):
     from video_query_algorithms_amd.tsn.caffe_net import CaffeNet
     from video_query_algorithms_amd.tsn.feature_csv import write_features
     from video_query_algorithms_amd.shard import all_gather_rows, shard_range
+    from video_query_algorithms_amd import fanout
 else:
+    from . import fanout
     from .tsn import frames
     from .tsn.caffe_net import CaffeNet
     from .tsn.feature_csv import write_features
@@ -96,10 +104,37 @@ def _stack_rows(blocks, width):
     return torch.cat(blocks, dim=0)
 
 
-def main(argv=None, net_factory=None):
+def _fan_out(args, argv, program):
+    """The reference's worker -> GPU map (calcSig_wOF.py:47-55) as child processes, one per distinct GPU.  Returns the exit
+    code of the fan-out, or None when this process is to do the work itself (one GPU, a rank of a launcher, a child)."""
+    if "RANK" in os.environ or fanout.is_child() or program is None:
+        return None
+    devices = fanout.worker_devices(args.gpus, args.num_worker, None if args.gpus else fanout.visible_gpus())
+    if len(devices) < 2:
+        return None
+    per_rank = -(-max(1, args.num_worker) // len(devices))            # the decoder threads are shared out over the ranks
+    envs = fanout.rank_envs(len(devices), per_rank)
+    for e, g in zip(envs, devices):
+        e["VQ_FANOUT_WORKERS"] = str(per_rank)
+        e["VQ_FANOUT_DEVICE"] = str(g)
+    print('{} workers on GPUs {}: one process per GPU'.format(args.num_worker, devices), flush=True)
+    return fanout.run_children(program, argv, envs)
+
+
+def main(argv=None, net_factory=None, program=None):
     """``net_factory(net_proto, net_weights, device, max_crops=, feature_blob=)`` builds the per-stream extractor
-    (default: the HIP ``CaffeNet``; the CPU tests of the sharding logic pass a stand-in)."""
+    (default: the HIP ``CaffeNet``; the CPU tests of the sharding logic pass a stand-in).  ``program``: the script the
+    per-GPU children are started from (default: this file; a caller that passes its own ``net_factory`` names its own
+    script here, or gets no fan-out)."""
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = build_parser().parse_args(argv)
+    if program is None and net_factory is None:
+        program = os.path.abspath(__file__)
+    rc = _fan_out(args, argv, program)                                  # before ANY GPU call of this process
+    if rc is not None:
+        return rc
+    if fanout.is_child() and "VQ_FANOUT_WORKERS" in os.environ:
+        args.num_worker = int(os.environ["VQ_FANOUT_WORKERS"])
     net_factory = net_factory or CaffeNet
     if args.modelname is None:                                                         # calcSig_wOF.py:179-180
         args.modelname = args.net_weights_rgb.split('/')[-1][:-11] + '_' + args.net_weights_flow.split('/')[-1][:-11]
@@ -107,7 +142,15 @@ def main(argv=None, net_factory=None):
     gpu_list = args.gpus
     local = int(os.environ.get("LOCAL_RANK", "0"))
     device = gpu_list[local % len(gpu_list)] if gpu_list else local                    # calcSig_wOF.py:50-55
+    if fanout.is_child() and "VQ_FANOUT_DEVICE" in os.environ:                         # the GPU the parent mapped this rank to
+        device = int(os.environ["VQ_FANOUT_DEVICE"])
     rank, world = _join_world(device)
+    backend_device = None                                # where a rank's blocks must live for the collective (RCCL: its GPU)
+    if world > 1:
+        import torch.distributed as dist
+        if dist.get_backend() == "nccl":
+            import torch
+            backend_device = torch.device("cuda", device)
     frame_path = args.frame_path if args.frame_path[-1] == '/' else args.frame_path + '/'
     streamCNN = [{'modality': 'rgb', 'mode': 'rgb', 'net_proto': args.net_proto_rgb, 'net_weights': args.net_weights_rgb,
                   'cnt_indexer': 1, 'stack_depth': 1},
@@ -160,8 +203,10 @@ def main(argv=None, net_factory=None):
             local_feat = _stack_rows(mine, net.feature_dim)
             if world > 1:
                 import torch
-                if isinstance(local_feat, np.ndarray):
+                if isinstance(local_feat, np.ndarray):       # host blocks, or a rank that owns no clip of this video
                     local_feat = torch.from_numpy(np.ascontiguousarray(local_feat, dtype=np.float64))
+                if backend_device is not None and local_feat.device != backend_device:
+                    local_feat = local_feat.to(backend_device)
                 local_feat = all_gather_rows(local_feat, len(clip_list)).cpu().numpy()
             features[s['mode']] = local_feat
         numFeatures = features['rgb'].shape[1] if len(clip_list) else args.featureBlob_size
