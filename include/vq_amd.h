@@ -364,7 +364,10 @@ int vq_comm_info(vq_comm* comm, int32_t* rank, int32_t* world, int32_t* device);
  * for contiguous shards.  One all-gather on hip_stream, asynchronous. */
 int vq_allgather_features(vq_comm* comm, const void* block_dev, int64_t block_bytes, void* all_dev, void* hip_stream);
 /* Sharded scan: gathers the score slice of every rank's row shard (db's scores[n], zero-padded to slice_rows) into
- * all_scores_dev [world][slice_rows] fp64 on every rank -- N x 8 bytes cross xGMI, never the features. */
+ * all_scores_dev [world][slice_rows] fp64 on every rank -- N x 8 bytes cross xGMI, never the features.
+ * Stream contract: vq_db_scan only ENQUEUES on the database handle's stream (vq_db_set_stream); this call orders its copy
+ * of the scores behind that scan with an event, whatever hip_stream is, and the all-gather runs on hip_stream.  VQ_E_STATE
+ * when the handle holds no scores (no scan / rescore since the last query).  Takes the handle's lock for the copy. */
 int vq_allgather_scores(vq_comm* comm, vq_db* db, int64_t slice_rows, double* all_scores_dev, void* hip_stream);
 /* The 80 KB query block t[S][E][D] (or any small device buffer) from `root` to every rank, in place. */
 int vq_broadcast_query(vq_comm* comm, void* buf_dev, int64_t bytes, int32_t root, void* hip_stream);

@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 
@@ -106,3 +107,25 @@ def test_install_patches_exactly_the_hot_path_methods():
     for n in untouched:
         assert getattr(Ticket, n) is before[n]
     assert Ticket.feature_db is None
+
+
+def test_comm_group_without_rccl_reports_unsupported(tmp_path):
+    """A host without librccl (VQ_RCCL_LIB names the only candidate; here a file that does not exist): every vq_comm_* entry
+    point returns VQ_E_UNSUPPORTED with the loader's message -- no crash inside the library, no HIP call."""
+    import subprocess
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from video_query_algorithms_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "buf = C.create_string_buffer(128)\n"
+        "rc = lib.vq_comm_unique_id(buf)\n"
+        "msg = lib.vq_last_error().decode()\n"
+        "assert rc == -5, (rc, msg)\n"
+        "assert 'librccl not found' in msg and 'no_such_rccl' in msg, msg\n"
+        "h = C.c_void_p()\n"
+        "assert lib.vq_comm_init(0, 1, buf, 0, C.byref(h)) == -5\n"
+        "print('ok')\n" % ROOT)
+    env = dict(os.environ, VQ_RCCL_LIB=str(tmp_path / "no_such_rccl.so"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout

@@ -45,14 +45,18 @@ Rccl* rccl() {
     static std::once_flag once;
     std::call_once(once, [] {
         const char* env = getenv("VQ_RCCL_LIB");
-        // an already-mapped RCCL first (torch's), then the usual names
-        const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : {"librccl.so.1", "librccl.so"})
-            if (!r.so) r.so = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-        for (const char* n : names)
-            if (!r.so && n && *n) r.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (env && *env) {
+            r.so = dlopen(env, RTLD_NOW | RTLD_GLOBAL);          // an explicit library is the ONLY candidate
+        } else {
+            // an already-mapped RCCL first (torch's), then the usual names
+            for (const char* n : {"librccl.so.1", "librccl.so"})
+                if (!r.so) r.so = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+            for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+                if (!r.so) r.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        }
         if (!r.so) {
-            r.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
+            const char* e = dlerror();           // ONE call: dlerror() clears the message it returns
+            r.why = std::string("librccl not found: ") + (e ? e : "?");
             return;
         }
         r.get_unique_id = (get_unique_id_fn)dlsym(r.so, "ncclGetUniqueId");
@@ -155,19 +159,18 @@ int vq_allgather_scores(vq_comm* c, vq_db* db, int64_t slice_rows, double* all_s
     int rc = vq_db_shape(db, &n, &S, &E, &D, &dt);
     if (rc != VQ_OK) return rc;
     VQ_REQUIRE(slice_rows >= n, "slice_rows %lld smaller than this rank's %lld rows", (long long)slice_rows, (long long)n);
-    void* scores = nullptr;
-    rc = vq_db_scores_devptr(db, &scores);
-    if (rc != VQ_OK) return rc;
     VQ_RCCL_READY(r);
     std::lock_guard<std::mutex> lk(c->mu);
     DeviceGuard g(c->device);
     hipStream_t st = (hipStream_t)hip_stream;
     // every rank contributes slice_rows doubles: its own slice first lands in its slot of the result (the padding
     // rows beyond n are zero), then the all-gather runs IN PLACE on that slot (ncclAllGather allows
-    // sendbuff == recvbuff + rank * sendcount)
+    // sendbuff == recvbuff + rank * sendcount).  The copy is ordered behind the scan that produced the scores (the
+    // scan runs on the database handle's stream, which need not be hip_stream); VQ_E_STATE if there was no scan.
     double* mine = all_scores_dev + (int64_t)c->rank * slice_rows;
     VQ_HIP(hipMemsetAsync(mine, 0, (size_t)slice_rows * 8, st));
-    if (n) VQ_HIP(hipMemcpyAsync(mine, scores, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+    rc = db_copy_scores_ordered(db, mine, nullptr, st);
+    if (rc != VQ_OK) return rc;
     rc = r->all_gather(mine, all_scores_dev, (size_t)slice_rows * 8, kNcclInt8, c->comm, st);
     if (rc != 0) return rccl_fail(r, "ncclAllGather", rc);
     return VQ_OK;

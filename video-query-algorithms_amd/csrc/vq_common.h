@@ -65,4 +65,8 @@ int bootstrap_from_device_rows(const void* base_dev, int dtype, const std::vecto
                                const int32_t* n_invalid, int P, int D, double mu, hipStream_t stream, double* targets_host,
                                double* targets_dev_copy);
 
+// csrc/vq_sim.hip: copy the n scores of the last scan to dst_dev on `st`, ORDERED BEHIND that scan (which ran on the handle's
+// own stream): an event recorded on the handle's stream, waited for by `st`.  VQ_E_STATE without a scan.  Takes the handle's lock.
+int db_copy_scores_ordered(vq_db* db, double* dst_dev, int64_t* n_out, hipStream_t st);
+
 }  // namespace vq

@@ -680,6 +680,27 @@ static int db_free(vq_db* db) {
     return VQ_OK;
 }
 
+namespace vq {
+int db_copy_scores_ordered(vq_db* db, double* dst_dev, int64_t* n_out, hipStream_t st) {
+    VQ_REQUIRE(db && dst_dev, "NULL argument");
+    std::lock_guard<std::mutex> lk(db->mu);
+    if (!db->have_scores) return fail(VQ_E_STATE, "no scores: scan (or rescore) first");
+    DeviceGuard g(db->device);
+    if (n_out) *n_out = db->n;
+    if (!db->n) return VQ_OK;
+    if (st != db->stream) {                     // the scan was only ENQUEUED on db->stream: nothing else orders st behind it
+        hipEvent_t ev;
+        VQ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ev, db->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, ev, 0);
+        (void)hipEventDestroy(ev);              // destruction is deferred until the event has completed
+        if (e != hipSuccess) return fail(VQ_E_HIP, "ordering the score copy behind the scan failed: %s", hipGetErrorString(e));
+    }
+    VQ_HIP(hipMemcpyAsync(dst_dev, db->scores, (size_t)db->n * 8, hipMemcpyDeviceToDevice, st));
+    return VQ_OK;
+}
+}  // namespace vq
+
 extern "C" {
 
 const char* vq_last_error(void) { return last_error_ref().c_str(); }
