@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQ_ABI_VERSION 4
+#define VQ_ABI_VERSION 5
 
 enum {
     VQ_OK = 0,
@@ -156,14 +156,19 @@ int vq_db_min_score(vq_db* db, const int64_t* rows_host, int32_t L, double* min_
 typedef struct vq_tsn vq_tsn;
 
 /* Frame ingest (the step in front of vq_tsn_forward): n decoded frames [n][h][w][c] uint8 (host, or device if
- * frames_on_device) -> bilinear resize to resize_w x resize_h with half-pixel centres -> over-sample crop 0 (top-left
+ * frames_on_device) -> cv2.resize(frame, (resize_w, resize_h)), INTER_LINEAR -> over-sample crop 0 (top-left
  * crop x crop), written as channels [dst_channel0, dst_channel0 + c) of the device buffer crops_dev
  * [n][crop][crop][dst_channels] (so the 10 grey flow frames of a stack interleave into one 10-channel crop).
  * Replaces the resize/over-sample half of CaffeNet.predict_single_frame / predict_single_flow_stack(...,
- * frame_size=(340,256)) at calcSig_wOF.py:94,111.  Same bytes as tsn/frames.py:crop0 (fp64 arithmetic, round half to
- * even); parity with cv2's fixed-point uint8 path is unpinned. */
+ * frame_size=(340,256)) at calcSig_wOF.py:94,111.  rule: VQ_RESIZE_CV2_FIXED = the rule of the reference's dependency,
+ * OpenCV's uint8 path (float sample positions, 11-bit fixed-point weights, integer passes; same bytes as
+ * tsn/frames.py:resize_cv2_fixed and oracle/frames_oracle.py); VQ_RESIZE_EXACT = the same sampling grid with exact fp64
+ * weights, round half to even (tsn/frames.py:resize_exact).  A frame that already has the size is copied.  Both are
+ * restated without cv2 at hand: parity unpinned. */
+#define VQ_RESIZE_CV2_FIXED 0
+#define VQ_RESIZE_EXACT 1
 int vq_resize_crop(const uint8_t* frames, int32_t frames_on_device, int32_t n, int32_t h, int32_t w, int32_t c,
-                   int32_t resize_w, int32_t resize_h, int32_t crop, uint8_t* crops_dev, int32_t dst_channels,
+                   int32_t resize_w, int32_t resize_h, int32_t crop, int32_t rule, uint8_t* crops_dev, int32_t dst_channels,
                    int32_t dst_channel0, int32_t device, void* hip_stream);
 
 /* JPEG decode, the step in front of vq_resize_crop: replaces cv2.imread(img_NNNNN.jpg, IMREAD_COLOR) and

@@ -19,7 +19,7 @@ class StandInNet:
     """Looks like tsn.caffe_net.CaffeNet to the command line; the 'features' of a clip are a hash of its crops."""
     feature_dim = 1024
 
-    def __init__(self, net_proto, net_weights, device_id=0, max_crops=96, feature_blob="global_pool"):
+    def __init__(self, net_proto, net_weights, device_id=0, max_crops=96, feature_blob="global_pool", resize_rule="cv2"):
         self.device, self.max_crops = device_id, max_crops
         log = os.environ.get("STANDIN_DEVICE_LOG")
         if log:                                            # which rank built a net on which device (one line per net)

@@ -103,19 +103,46 @@ def test_parse_directory_and_image_io(tmp_path):
 
 
 def test_host_resize_equals_the_pixel_loop_oracle():
-    """tsn/frames.py (the --host_resize path) against oracle/frames_oracle.py, byte for byte; and how far the exact
-    bilinear weights are from cv2's 11-bit fixed-point rule as remembered (reported, at most one grey level; PARITY
-    UNPINNED -- no cv2 and no reference frames here)."""
+    """tsn/frames.py (the --host_resize path) against oracle/frames_oracle.py, byte for byte, under both rules: "cv2" (the
+    default: OpenCV's 11-bit fixed-point INTER_LINEAR as restated from memory of imgproc/resize.cpp -- what the reference's
+    dependency computes at calcSig_wOF.py:94,111) and "exact" (fp64 weights, the rule of rounds 1-2).  Down- and up-scaling,
+    colour and grey, odd sizes.  PARITY UNPINNED -- no cv2 and no reference frames here."""
     import frames_oracle as fo
     rng = np.random.default_rng(3)
-    for shape in ((360, 480, 3), (240, 320), (256, 340, 3), (97, 131)):
+    for shape in ((360, 480, 3), (240, 320), (256, 340, 3), (97, 131), (480, 854), (1080, 1920, 3), (200, 500)):
         img = rng.integers(0, 256, shape, dtype=np.uint8)
-        assert (frames.crop0(img) == fo.crop0(img)).all()
-    img = rng.integers(0, 256, (360, 480), dtype=np.uint8)
-    exact = frames.crop0(img)
+        small = dict(crop=40) if shape[0] > 400 else {}                # the scalar loops are slow: a corner of the big frames
+        assert (frames.crop0(img, **small) == fo.crop0(img, **small)).all()
+        assert (frames.crop0(img, rule="exact", **small) == fo.crop0(img, rule="exact", **small)).all()
+    # the whole resized frame (not only crop 0): right and bottom borders, where the taps are clamped / the rows clipped
+    img = rng.integers(0, 256, (45, 61), dtype=np.uint8)
     rows = img.tolist()
-    diff = [abs(fo.fixed_point_resize_pixel(rows, y, x, 256, 340, None) - int(exact[y, x])) for y in range(0, 224, 5) for x in range(0, 224, 5)]
-    assert max(diff) <= 1
+    for (w, h) in ((340, 256), (30, 20), (61, 90)):
+        got = frames.resize_bilinear(img, (w, h))
+        want = np.array([[fo.fixed_point_resize_pixel(rows, y, x, h, w, None) for x in range(w)] for y in range(h)], dtype=np.uint8)
+        assert (got == want).all()
+    # how far the two rules are apart: at most one grey level
+    img = rng.integers(0, 256, (360, 480), dtype=np.uint8)
+    d = np.abs(frames.crop0(img).astype(int) - frames.crop0(img, rule="exact").astype(int))
+    assert d.max() == 1 and 0.02 < (d > 0).mean() < 0.3
+
+
+def test_fixed_point_resize_known_answers():
+    """Facts about cv2.resize(INTER_LINEAR, uint8) that do not depend on the remembered source: an exact 2x reduction is the
+    rounded mean of each 2 x 2 block, ``(a + b + c + d + 2) >> 2`` (OpenCV itself switches to its INTER_AREA code for this
+    case because the two coincide); a constant image stays constant; the weights of every tap sum to 2048."""
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (64, 96, 3), dtype=np.uint8)
+    a = img.astype(int)
+    want = (a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2
+    assert (frames.resize_bilinear(img, (48, 32)) == want).all()
+    for v in (0, 1, 37, 254, 255):
+        assert (frames.resize_bilinear(np.full((100, 120), v, np.uint8), (340, 256)) == v).all()
+        assert (frames.resize_bilinear(np.full((700, 900), v, np.uint8), (340, 256)) == v).all()
+    for n_in, n_out in ((480, 256), (854, 340), (100, 256), (1080, 256), (3, 340)):
+        for clamp in (True, False):
+            s, w0, w1 = frames._cv2_linear_taps(n_in, n_out, clamp)
+            assert ((w0 + w1) == 2048).all() and (w0 >= 0).all() and (w1 >= 0).all()
 
 
 def test_resize_and_crop0():

@@ -65,7 +65,7 @@ def test_a_clip_of_video_frames_and_the_device_hand_over(jpeg):
         assert (got[i] == pil_bgr(files[i])).all()
     dev, (n, h, w) = dec.decode_to_device(files)
     crops = torch.empty((n, 224, 224, 3), dtype=torch.uint8, device="cuda")
-    _lib.call("vq_resize_crop", C.c_void_p(dev), 1, n, h, w, 3, 340, 256, 224, C.c_void_p(crops.data_ptr()), 3, 0, 0, None)
+    _lib.call("vq_resize_crop", C.c_void_p(dev), 1, n, h, w, 3, 340, 256, 224, 0, C.c_void_p(crops.data_ptr()), 3, 0, 0, None)
     torch.cuda.synchronize()
     want = np.stack([frames.crop0(got[i], (340, 256), 224) for i in (0, 95)])
     assert (crops.cpu().numpy()[[0, 95]] == want).all()
@@ -96,7 +96,10 @@ def test_what_is_refused(jpeg):
 @needs_pil
 def test_cli_on_a_jpeg_frame_tree_device_decode_equals_host_decode(jpeg, tmp_path):
     """calcSig_wOF.py on img_/flow_x_/flow_y_ .jpg files as build_wof_clips.py leaves them: --device_jpeg (library decoder,
-    frames never on the host) writes the same CSV bytes as the default path (host libjpeg through Pillow, resize on the GPU)."""
+    frames never on the host) writes the same CSV bytes as the default path (host libjpeg through Pillow, resize on the GPU)
+    and as --host_resize (host libjpeg, numpy resize): the frames are 480 x 360, so cv2's fixed-point resize rule runs on the
+    device, on the device behind the library's decoder, and on the host, and must agree to the bit in all three.
+    --exact_resize (the exact-weight rule) is a different function of the pixels: its files differ."""
     import os
     import sys
 
@@ -110,19 +113,20 @@ def test_cli_on_a_jpeg_frame_tree_device_decode_equals_host_decode(jpeg, tmp_pat
         d = root / "vid" / clip
         d.mkdir(parents=True)
         for i in range(1, n + 1):
-            (d / ("img_%05d.jpg" % i)).write_bytes(encode(picture(256, 340, int(rng.integers(1 << 30))), quality=95, subsampling=2))
+            (d / ("img_%05d.jpg" % i)).write_bytes(encode(picture(360, 480, int(rng.integers(1 << 30))), quality=95, subsampling=2))
             for p in ("flow_x", "flow_y"):
-                (d / ("%s_%05d.jpg" % (p, i))).write_bytes(encode(picture(256, 340, int(rng.integers(1 << 30)))[:, :, 0], quality=95))
+                (d / ("%s_%05d.jpg" % (p, i))).write_bytes(encode(picture(360, 480, int(rng.integers(1 << 30)))[:, :, 0], quality=95))
     protos = _write_protos(bi, tmp_path)
     outs = {}
-    for tag, extra in (("host", []), ("device", ["--device_jpeg"])):
+    for tag, extra in (("host", []), ("device", ["--device_jpeg"]), ("host_resize", ["--host_resize"]), ("exact", ["--exact_resize"])):
         out_dir = tmp_path / ("features_" + tag)
         rc = calcSig_wOF.main([str(root), protos["rgb"], "synthetic:2", protos["flow"], "synthetic:5", "--num_frame_per_video", "3",
                                "--outFeatures_dir", str(out_dir), "--modelname", "UCF101_split1", "--batch_clips", "2"] + extra)
         assert rc == 0
         outs[tag] = {f: (out_dir / "vid" / "UCF101_split1" / f).read_bytes()
                      for f in ("rgb_global_pool_features.csv", "warped_optical_flow_global_pool_features.csv")}
-    assert outs["host"] == outs["device"]
+    assert outs["host"] == outs["device"] == outs["host_resize"]
+    assert outs["exact"]["rgb_global_pool_features.csv"] != outs["host"]["rgb_global_pool_features.csv"]
     assert outs["host"]["rgb_global_pool_features.csv"].count(b"\n") == 4                # header + three clips
 
 

@@ -578,7 +578,9 @@ def test_device_resize_crop_against_the_pixel_loop_oracle(tsn, h, w):
     scalar-loop restatement of the resize + crop-0 step behind calcSig_wOF.py:94,111 -- byte for byte: RGB frames and
     the 10 interleaved grey planes of a flow stack; frames already at 340x256 pass through untouched.  The host path of
     the product (tsn/frames.py, used by --host_resize) is held to the same oracle in tests/test_feature_files.py.
-    cv2's own fixed-point uint8 path: PARITY UNPINNED (no cv2, no reference frames; frames_oracle docstring)."""
+    The default rule is cv2's own fixed-point uint8 path (oracle: fixed_point_resize_pixel) -- integer arithmetic, so the
+    device must equal it bit for bit; the exact-weight rule stays available (resize_rule="exact").  PARITY UNPINNED
+    against cv2 itself (no cv2, no reference frames; frames_oracle docstring)."""
     import frames_oracle as fo
     from video_query_algorithms_amd.tsn import caffe_net
     bi, net = tsn
@@ -587,9 +589,13 @@ def test_device_resize_crop_against_the_pixel_loop_oracle(tsn, h, w):
     cn = caffe_net.CaffeNet(g3, net.synthetic_weights(g3, seed=2), max_crops=4)
     rgb = rng.integers(0, 256, (3, h, w, 3), dtype=np.uint8)
     got = cn.crops_from_frames(rgb).cpu().numpy()
-    want = np.stack([fo.crop0(f) for f in rgb])
+    want = np.stack([fo.crop0(f) for f in rgb])              # = fixed_point_resize_pixel on every surviving pixel
     assert got.shape == (3, 224, 224, 3) and (got == want).all()
     cn.close()
+    ce = caffe_net.CaffeNet(g3, net.synthetic_weights(g3, seed=2), max_crops=4, resize_rule="exact")
+    got = ce.crops_from_frames(rgb[:1]).cpu().numpy()
+    assert (got[0] == fo.crop0(rgb[0], rule="exact")).all()
+    ce.close()
     g10 = bi.bn_inception(10)
     cf = caffe_net.CaffeNet(g10, net.synthetic_weights(g10, seed=2), max_crops=4)
     planes = rng.integers(0, 256, (2, 10, h, w), dtype=np.uint8)

@@ -65,6 +65,9 @@ def build_parser():
     parser.add_argument('--batch_clips', type=int, default=32, help='clips per forward pass')
     parser.add_argument('--host_resize', action='store_true',
                         help='resize + crop the frames on the host (numpy) instead of on the GPU; same bytes either way')
+    parser.add_argument('--exact_resize', action='store_true',
+                        help="resize with exact fp64 bilinear weights instead of cv2.resize's 11-bit fixed-point rule (the default, "
+                             "what the reference's dependency computes); differs by one grey level on about one pixel in eight")
     parser.add_argument('--device_jpeg', action='store_true',
                         help='decode the .jpg frames with the library (Huffman on host threads, IDCT / upsampling / colour on the '
                              'GPU; the pixels libjpeg gives cv2.imread) and resize them where they land -- no host image library')
@@ -122,7 +125,7 @@ def _fan_out(args, argv, program):
 
 
 def main(argv=None, net_factory=None, program=None):
-    """``net_factory(net_proto, net_weights, device, max_crops=, feature_blob=)`` builds the per-stream extractor
+    """``net_factory(net_proto, net_weights, device, max_crops=, feature_blob=, resize_rule=)`` builds the per-stream extractor
     (default: the HIP ``CaffeNet``; the CPU tests of the sharding logic pass a stand-in).  ``program``: the script the
     per-GPU children are started from (default: this file; a caller that passes its own ``net_factory`` names its own
     script here, or gets no fan-out)."""
@@ -157,6 +160,7 @@ def main(argv=None, net_factory=None, program=None):
                  {'modality': 'flow', 'mode': 'warped_optical_flow', 'net_proto': args.net_proto_flow,
                   'net_weights': args.net_weights_flow, 'cnt_indexer': 2, 'stack_depth': 5}]   # calcSig_wOF.py:185-189
     nets = {}
+    rule = "exact" if args.exact_resize else "cv2"
     device_jpeg = args.device_jpeg and args.frame_ext.lower() in ('.jpg', '.jpeg') and not args.host_resize
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=max(1, args.num_worker))
@@ -167,19 +171,21 @@ def main(argv=None, net_factory=None, program=None):
         features = {}
         for s in streamCNN:
             if s['modality'] not in nets:
-                nets[s['modality']] = net_factory(s['net_proto'], s['net_weights'], device,
-                                                  max_crops=args.batch_clips * T, feature_blob=args.featureBlob)
+                nets[s['modality']] = net_factory(s['net_proto'], s['net_weights'], device, max_crops=args.batch_clips * T,
+                                                  feature_blob=args.featureBlob, resize_rule=rule)
             net = nets[s['modality']]
             mine = []
+
+            host_rule = {'rule': rule} if args.host_resize else {}         # the host loaders resize; the others hand frames to the GPU
 
             def load_clip(vid, s=s):
                 frame_cnt = f_info[s['cnt_indexer']][vid]
                 ticks = frames.frame_ticks(frame_cnt, T, s['stack_depth'])
                 if s['modality'] == 'rgb':
                     load = frames.load_rgb_jpegs if device_jpeg else frames.load_rgb_snippets if args.host_resize else frames.load_rgb_frames
-                    return load(f_info[0][vid], ticks, args.rgb_prefix, args.frame_ext)
+                    return load(f_info[0][vid], ticks, args.rgb_prefix, args.frame_ext, **host_rule)
                 load = frames.load_flow_jpegs if device_jpeg else frames.load_flow_snippets if args.host_resize else frames.load_flow_frames
-                return load(f_info[0][vid], ticks, frame_cnt, s['stack_depth'], args.flow_x_prefix, args.flow_y_prefix, args.frame_ext)
+                return load(f_info[0][vid], ticks, frame_cnt, s['stack_depth'], args.flow_x_prefix, args.flow_y_prefix, args.frame_ext, **host_rule)
 
             # --num_worker decoder threads (the reference runs that many worker PROCESSES, each with its own net,
             # calcSig_wOF.py:204-210); the batch after the one on the GPU is decoded meanwhile

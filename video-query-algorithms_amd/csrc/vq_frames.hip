@@ -3,11 +3,14 @@
 // What it replaces (paths relative to the reference checkout): the resize + over-sample part of
 //   src/features_GPU_compute/calcSig_wOF.py:94,111   CaffeNet.predict_single_frame / predict_single_flow_stack(...,
 //                                                    frame_size=(340, 256))  ->  crop 0 (top-left 224 x 224, un-mirrored)
-// i.e. per frame: bilinear resize to 340 x 256 with half-pixel centres (the sampling grid of cv2.resize INTER_LINEAR),
-// then the top-left crop.  Only the crop x crop pixels that survive are computed.  The arithmetic is the fp64
-// restatement of tsn/frames.py:resize_bilinear operation for operation (contraction off), so host and device paths
-// give the same bytes; cv2's own uint8 path uses 11-bit fixed-point coefficients and may differ by one grey level --
-// "parity unpinned" for lack of cv2 and of the reference's frames (frames.py says the same).
+// i.e. per frame: cv2.resize(frame, (340, 256)) (INTER_LINEAR), then the top-left crop.  Only the crop x crop pixels that
+// survive are computed.  Two rules (vq_amd.h):
+//   VQ_RESIZE_CV2_FIXED (default of every caller)  OpenCV's own uint8 rule: float sample positions, 11-bit fixed-point weights,
+//       int32 horizontal pass, ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2 vertical pass -- integer
+//       arithmetic, so host (tsn/frames.py:resize_cv2_fixed), device and oracle (oracle/frames_oracle.py) agree bit for bit;
+//   VQ_RESIZE_EXACT  the same sampling grid with exact fp64 weights, rounded half to even (tsn/frames.py:resize_exact,
+//       operation for operation, contraction off).
+// Both restate cv2 from memory of imgproc/resize.cpp: "parity unpinned" for lack of cv2 and of the reference's frames.
 #include "vq_common.h"
 
 using namespace vq;
@@ -20,6 +23,41 @@ struct ResizeArgs {
     int64_t total;        // n * crop * crop
     int h, w, c, rw, rh, crop, dst_c, dst_c0;
 };
+
+// cv::resize INTER_LINEAR, 8-bit: tap position and weights of output coordinate d (frames.py:_cv2_linear_taps)
+__device__ inline void cv2_taps(int d, int n_in, int n_out, bool clamp_taps, int& s, int& w0, int& w1) {
+    const double scale = 1.0 / ((double)n_out / (double)n_in);
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    s = (int)floorf(f);
+    f = f - (float)s;
+    if (clamp_taps) {
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= n_in - 1) { f = 0.f; s = n_in - 1; }
+    }
+    w0 = (int)rintf((1.f - f) * 2048.f);          // cvRound: round half to even
+    w1 = (int)rintf(f * 2048.f);
+}
+
+__global__ void resize_crop_cv2_kernel(ResizeArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.total) return;
+    const int x = (int)(i % a.crop), y = (int)((i / a.crop) % a.crop);
+    const int64_t n = i / ((int64_t)a.crop * a.crop);
+    int sx, a0, a1, sy, b0, b1;
+    cv2_taps(x, a.w, a.rw, true, sx, a0, a1);
+    cv2_taps(y, a.h, a.rh, false, sy, b0, b1);      // along y the weights stay, the ROWS are clipped
+    const int x1 = min(sx + 1, a.w - 1);
+    const int y0 = min(max(sy, 0), a.h - 1), y1 = min(max(sy + 1, 0), a.h - 1);
+    const uint8_t* img = a.src + n * (int64_t)a.h * a.w * a.c;
+    uint8_t* out = a.dst + (n * a.crop * a.crop + (int64_t)y * a.crop + x) * a.dst_c + a.dst_c0;
+    for (int ch = 0; ch < a.c; ++ch) {
+        const int p00 = img[((int64_t)y0 * a.w + sx) * a.c + ch], p01 = img[((int64_t)y0 * a.w + x1) * a.c + ch];
+        const int p10 = img[((int64_t)y1 * a.w + sx) * a.c + ch], p11 = img[((int64_t)y1 * a.w + x1) * a.c + ch];
+        const int s0 = p00 * a0 + p01 * a1, s1 = p10 * a0 + p11 * a1;
+        const int v = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
+        out[ch] = (uint8_t)min(max(v, 0), 255);
+    }
+}
 
 __global__ void resize_crop_kernel(ResizeArgs a) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -52,11 +90,12 @@ __global__ void resize_crop_kernel(ResizeArgs a) {
 }  // namespace
 
 extern "C" int vq_resize_crop(const uint8_t* frames, int32_t frames_on_device, int32_t n, int32_t h, int32_t w, int32_t c,
-                              int32_t resize_w, int32_t resize_h, int32_t crop, uint8_t* crops_dev, int32_t dst_channels,
+                              int32_t resize_w, int32_t resize_h, int32_t crop, int32_t rule, uint8_t* crops_dev, int32_t dst_channels,
                               int32_t dst_channel0, int32_t device, void* stream) {
     VQ_REQUIRE(frames && crops_dev, "NULL argument");
     VQ_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0, "frames must be [n][h][w][c] with positive sizes");
     VQ_REQUIRE(resize_w >= crop && resize_h >= crop && crop > 0, "crop %d does not fit the %dx%d resized frame", crop, resize_w, resize_h);
+    VQ_REQUIRE(rule == VQ_RESIZE_CV2_FIXED || rule == VQ_RESIZE_EXACT, "unknown resize rule %d", rule);
     VQ_REQUIRE(dst_channel0 >= 0 && dst_channel0 + c <= dst_channels, "channels [%d,%d) outside the %d-channel crop buffer", dst_channel0,
                dst_channel0 + c, dst_channels);
     int ndev = 0;
@@ -88,7 +127,10 @@ extern "C" int vq_resize_crop(const uint8_t* frames, int32_t frames_on_device, i
     a.crop = crop;
     a.dst_c = dst_channels;
     a.dst_c0 = dst_channel0;
-    resize_crop_kernel<<<cdiv(a.total, 256), 256, 0, st>>>(a);
+    if (rule == VQ_RESIZE_CV2_FIXED && !(h == resize_h && w == resize_w))
+        resize_crop_cv2_kernel<<<cdiv(a.total, 256), 256, 0, st>>>(a);
+    else                                       // a frame that already has the size is copied by either rule (weights 1, 0)
+        resize_crop_kernel<<<cdiv(a.total, 256), 256, 0, st>>>(a);
     hipError_t le = hipGetLastError();
     if (staged) {
         (void)hipStreamSynchronize(st);

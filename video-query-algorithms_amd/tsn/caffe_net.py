@@ -51,7 +51,12 @@ class _NetView:
 
 
 class CaffeNet:
-    def __init__(self, net_proto, net_weights, device_id=0, max_crops=96, feature_blob="global_pool"):
+    def __init__(self, net_proto, net_weights, device_id=0, max_crops=96, feature_blob="global_pool", resize_rule="cv2"):
+        """resize_rule: "cv2" = OpenCV's fixed-point INTER_LINEAR, what the reference's ``cv2.resize(frame, (340, 256))``
+        computes (default); "exact" = exact fp64 bilinear weights (tsn/frames.py)."""
+        if resize_rule not in frames.RESIZE_RULES:
+            raise ValueError("resize_rule must be 'cv2' or 'exact'")
+        self._resize_rule = resize_rule
         self._graph = bn_inception.load_prototxt(net_proto) if isinstance(net_proto, str) else net_proto
         self._weights = load_weights(self._graph, net_weights) if isinstance(net_weights, str) else net_weights
         self._blob = feature_blob
@@ -62,13 +67,13 @@ class CaffeNet:
 
     # -- the reference's per-snippet interface ------------------------------------------------------------
     def predict_single_frame(self, frame, score_name=None, over_sample=True, frame_size=(340, 256)):
-        crop = frames.crop0(frame[0], frame_size)[None]                     # crop 0 of the 10-crop over-sample
+        crop = frames.crop0(frame[0], frame_size, rule=self._resize_rule)[None]                     # crop 0 of the 10-crop over-sample
         _, ps = self._model.forward(crop, 1, self._mean)
         self._net.blobs[self._blob] = _Blob(ps.reshape(1, -1, 1, 1))        # .data[0] is what calcSig reads
         return None
 
     def predict_single_flow_stack(self, frame, score_name=None, over_sample=True, frame_size=(340, 256)):
-        crop = np.stack([frames.crop0(f, frame_size) for f in frame], axis=-1)[None]
+        crop = np.stack([frames.crop0(f, frame_size, rule=self._resize_rule) for f in frame], axis=-1)[None]
         _, ps = self._model.forward(crop, 1, self._mean)
         self._net.blobs[self._blob] = _Blob(ps.reshape(1, -1, 1, 1))
         return None
@@ -111,7 +116,7 @@ class CaffeNet:
         if self._channels == 3:
             if f.shape[3] != 3:
                 raise ValueError("RGB frames must be [n,H,W,3]")
-            call("vq_resize_crop", f.ctypes.data_as(C.c_void_p), 0, n, f.shape[1], f.shape[2], 3, frame_size[0], frame_size[1], crop,
+            call("vq_resize_crop", f.ctypes.data_as(C.c_void_p), 0, n, f.shape[1], f.shape[2], 3, frame_size[0], frame_size[1], crop, frames.RESIZE_RULES[self._resize_rule],
                  C.c_void_p(out.data_ptr()), 3, 0, self._model.device, C.c_void_p(stream))
         else:
             if f.shape[1] != self._channels:
@@ -119,7 +124,7 @@ class CaffeNet:
             for k in range(self._channels):
                 plane = np.ascontiguousarray(f[:, k])
                 call("vq_resize_crop", plane.ctypes.data_as(C.c_void_p), 0, n, f.shape[2], f.shape[3], 1, frame_size[0], frame_size[1],
-                     crop, C.c_void_p(out.data_ptr()), self._channels, k, self._model.device, C.c_void_p(stream))
+                     crop, frames.RESIZE_RULES[self._resize_rule], C.c_void_p(out.data_ptr()), self._channels, k, self._model.device, C.c_void_p(stream))
         return out
 
     def crops_from_jpegs(self, files, frame_size=(340, 256), crop=224):
@@ -149,7 +154,7 @@ class CaffeNet:
         if ch == 3:
             for i in range(0, n, cap):
                 ptr, (m, _, _) = dec.decode_to_device(files[i:i + cap], color=True)
-                call("vq_resize_crop", C.c_void_p(ptr), 1, m, h, w, 3, frame_size[0], frame_size[1], crop,
+                call("vq_resize_crop", C.c_void_p(ptr), 1, m, h, w, 3, frame_size[0], frame_size[1], crop, frames.RESIZE_RULES[self._resize_rule],
                      C.c_void_p(out[i:i + m].data_ptr()), 3, 0, self._model.device, C.c_void_p(stream))
                 torch.cuda.current_stream(dev).synchronize()          # the decoder's buffer is reused by its next call
         else:
@@ -157,7 +162,7 @@ class CaffeNet:
                 plane_files = files[k::ch]
                 for i in range(0, n, cap):
                     ptr, (m, _, _) = dec.decode_to_device(plane_files[i:i + cap], color=False)
-                    call("vq_resize_crop", C.c_void_p(ptr), 1, m, h, w, 1, frame_size[0], frame_size[1], crop,
+                    call("vq_resize_crop", C.c_void_p(ptr), 1, m, h, w, 1, frame_size[0], frame_size[1], crop, frames.RESIZE_RULES[self._resize_rule],
                          C.c_void_p(out[i:i + m].data_ptr()), ch, k, self._model.device, C.c_void_p(stream))
                     torch.cuda.current_stream(dev).synchronize()
         return out

@@ -130,13 +130,55 @@ def write_pnm(path: str, img: np.ndarray):
             f.write(img.tobytes())
 
 
-def resize_bilinear(img: np.ndarray, size_wh: Tuple[int, int]) -> np.ndarray:
-    """Bilinear resize with half-pixel centres (the sampling grid of cv2.resize INTER_LINEAR; cv2 itself uses
-    11-bit fixed-point coefficients for uint8, so single values can differ by one grey level)."""
+RESIZE_CV2, RESIZE_EXACT = 0, 1            # include/vq_amd.h: VQ_RESIZE_CV2_FIXED / VQ_RESIZE_EXACT
+RESIZE_RULES = {"cv2": RESIZE_CV2, "exact": RESIZE_EXACT}
+
+
+def _cv2_linear_taps(n_in: int, n_out: int, clamp_taps: bool):
+    """Source index and the two 11-bit weights of every output position under cv::resize's INTER_LINEAR rule for 8-bit
+    images: ``scale = 1 / (n_out / n_in)`` in double, ``f = (float)((d + 0.5) * scale - 0.5)``, ``s = floor(f)``, ``f -= s``
+    in float, weights ``cvRound((1.f - f) * 2048)`` and ``cvRound(f * 2048)`` (round half to even) as int16.  Along x a tap
+    left of the image or on its last column is moved onto the border pixel with f = 0 (``clamp_taps``); along y the weights
+    stay and the two ROWS are clipped to the image instead."""
+    scale = 1.0 / (float(n_out) / float(n_in))
+    f = ((np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    if clamp_taps:
+        low, high = s < 0, s >= n_in - 1
+        f = np.where(low | high, np.float32(0), f).astype(np.float32)
+        s = np.where(low, 0, np.where(high, n_in - 1, s))
+    w0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+    w1 = np.rint(f * np.float32(2048)).astype(np.int64)
+    return s, w0, w1
+
+
+def resize_cv2_fixed(img: np.ndarray, size_wh: Tuple[int, int]) -> np.ndarray:
+    """``cv2.resize(img, size_wh)`` (INTER_LINEAR) for uint8 in integer arithmetic, as OpenCV's generic resize does it:
+    horizontal pass ``S = p[sx] * a0 + p[sx + 1] * a1`` (int32, weights scaled by 2^11), vertical pass
+    ``(((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2``.  Restated from memory of imgproc/resize.cpp (cv2 is
+    not in this image; parity unpinned); host, device (csrc/vq_frames.hip) and oracle agree bit for bit."""
     w, h = size_wh
     ih, iw = img.shape[:2]
-    if (ih, iw) == (h, w):
-        return img
+    sx, a0, a1 = _cv2_linear_taps(iw, w, True)
+    sy, b0, b1 = _cv2_linear_taps(ih, h, False)
+    x1 = np.minimum(sx + 1, iw - 1)
+    y0, y1 = np.clip(sy, 0, ih - 1), np.clip(sy + 1, 0, ih - 1)
+    a = img.astype(np.int64)
+    if a.ndim == 3:
+        a0, a1 = a0[:, None], a1[:, None]
+    rows = a[:, sx] * a0 + a[:, x1] * a1                           # [ih, w(, c)]: the horizontal pass of every source row
+    bshape = (-1, 1) + (1,) * (a.ndim - 2)
+    out = (((b0.reshape(bshape) * (rows[y0] >> 4)) >> 16) + ((b1.reshape(bshape) * (rows[y1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def resize_exact(img: np.ndarray, size_wh: Tuple[int, int]) -> np.ndarray:
+    """Bilinear resize on cv2.resize's sampling grid (half-pixel centres) with exact fp64 weights, rounded half to even --
+    the rule of rounds 1-2, kept as an option (``--exact_resize``): differs from the fixed-point rule by at most one grey
+    level on about one pixel in eight."""
+    w, h = size_wh
+    ih, iw = img.shape[:2]
     ys = np.clip((np.arange(h) + 0.5) * ih / h - 0.5, 0, ih - 1)
     xs = np.clip((np.arange(w) + 0.5) * iw / w - 0.5, 0, iw - 1)
     y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
@@ -150,9 +192,22 @@ def resize_bilinear(img: np.ndarray, size_wh: Tuple[int, int]) -> np.ndarray:
     return np.clip(np.rint(out), 0, 255).astype(np.uint8)
 
 
-def crop0(img: np.ndarray, frame_size=(340, 256), crop=224) -> np.ndarray:
+def resize_bilinear(img: np.ndarray, size_wh: Tuple[int, int], rule: str = "cv2") -> np.ndarray:
+    """The ``cv2.resize(frame, size_wh)`` of the reference's dependency (calcSig_wOF.py:94,111 through
+    predict_single_frame / predict_single_flow_stack; build_wof_clips.py:41): rule "cv2" = OpenCV's 11-bit fixed-point
+    INTER_LINEAR (the default: a drop-in follows the dependency), "exact" = exact fp64 weights.  An image that already has
+    the size is returned as it is (cv::resize copies it)."""
+    w, h = size_wh
+    if img.shape[:2] == (h, w):
+        return img
+    if rule not in RESIZE_RULES:
+        raise ValueError("resize rule must be 'cv2' or 'exact', not %r" % (rule,))
+    return resize_cv2_fixed(img, size_wh) if rule == "cv2" else resize_exact(img, size_wh)
+
+
+def crop0(img: np.ndarray, frame_size=(340, 256), crop=224, rule: str = "cv2") -> np.ndarray:
     """Resize to frame_size (w, h) and keep over-sample crop 0 = top-left, un-mirrored."""
-    return resize_bilinear(img, frame_size)[:crop, :crop]
+    return resize_bilinear(img, frame_size, rule)[:crop, :crop]
 
 
 def load_rgb_frames(clip_dir: str, ticks: List[int], rgb_prefix='img_', ext='.jpg') -> np.ndarray:
@@ -194,19 +249,19 @@ def load_flow_jpegs(clip_dir: str, ticks: List[int], frame_cnt: int, stk_depth=5
     return out
 
 
-def load_rgb_snippets(clip_dir: str, ticks: List[int], rgb_prefix='img_', ext='.jpg') -> np.ndarray:
+def load_rgb_snippets(clip_dir: str, ticks: List[int], rgb_prefix='img_', ext='.jpg', rule: str = "cv2") -> np.ndarray:
     """[T, 224, 224, 3] uint8 BGR (calcSig_wOF.py:88-96)."""
-    return np.stack([crop0(imread(os.path.join(clip_dir, '{}{:05d}{}'.format(rgb_prefix, t, ext)), True)) for t in ticks])
+    return np.stack([crop0(imread(os.path.join(clip_dir, '{}{:05d}{}'.format(rgb_prefix, t, ext)), True), rule=rule) for t in ticks])
 
 
 def load_flow_snippets(clip_dir: str, ticks: List[int], frame_cnt: int, stk_depth=5, flow_x_prefix='flow_x_',
-                       flow_y_prefix='flow_y_', ext='.jpg') -> np.ndarray:
+                       flow_y_prefix='flow_y_', ext='.jpg', rule: str = "cv2") -> np.ndarray:
     """[T, 224, 224, 10] uint8: x/y of 5 consecutive flow frames interleaved (calcSig_wOF.py:99-113)."""
     out = []
     for tick in ticks:
         stack = []
         for idx in flow_stack_indices(tick, frame_cnt, stk_depth):
-            stack.append(crop0(imread(os.path.join(clip_dir, '{}{:05d}{}'.format(flow_x_prefix, idx, ext)), False)))
-            stack.append(crop0(imread(os.path.join(clip_dir, '{}{:05d}{}'.format(flow_y_prefix, idx, ext)), False)))
+            stack.append(crop0(imread(os.path.join(clip_dir, '{}{:05d}{}'.format(flow_x_prefix, idx, ext)), False), rule=rule))
+            stack.append(crop0(imread(os.path.join(clip_dir, '{}{:05d}{}'.format(flow_y_prefix, idx, ext)), False), rule=rule))
         out.append(np.stack(stack, axis=-1))
     return np.stack(out)
