@@ -76,46 +76,9 @@ def host_cores():
     return max(1, n)
 
 
-def bench_tsn(args, rank, world, device, stream):
-    if args.profile_only:
-        os.environ["VQ_TSN_SPLIT"] = "1"             # read when the network handle is created
-    g = bn_inception.bn_inception(CH)
-    weights = tsn_net.synthetic_weights(g, seed=2)
-    n_crops = B_CLIPS * T_SEG
-    model = tsn_net.TsnNet(g, weights, max_crops=n_crops, device=device.index)
-    model.set_stream(stream.cuda_stream)
-    if args.tiles and os.path.exists(args.tiles):          # tiling table of an earlier run: skip the autotune launches
-        with open(args.tiles) as f:
-            model.set_layer_tiles(n_crops, np.array(json.load(f)["tiles"], dtype=np.int32))
-    gen = torch.Generator(device=device).manual_seed(1 + rank)
-    crops = torch.randint(0, 256, (n_crops, 224, 224, CH), dtype=torch.uint8, device=device, generator=gen)
-    feat_ptr, _ = model.feat_devptr()
-    feat = dev_tensor(feat_ptr, (B_CLIPS, model.feature_dim), "<f8", device)
-    import torch.distributed as dist
-
-    def step():
-        model.forward_device(crops.data_ptr(), n_crops, T_SEG, tsn_net.RGB_MEAN)
-        if world > 1:
-            all_gather_rows(feat, world * B_CLIPS)           # RCCL over xGMI: per-GPU feature blocks
-
-    with torch.cuda.stream(stream):
-        model.set_profile(1)                         # warm up in the mode of the timed region (tunes this batch size)
-        for _ in range(max(args.warmup, 1)):
-            step()
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        model.set_profile(min(cdiv(args.steps, PROFILE_EVERY), 1024), every=PROFILE_EVERY)   # start/stop events per launch, no host sync
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
+def tsn_roofline(model, n_crops, steps, every):
+    """Roofline object of a timed region from the per-launch begin/end timestamps the library kept (mean over the profiled
+    steps): executed and algorithmic MFMA FLOP/s over the convolution launches, by kernel family."""
     names, kinds, ms_layers, fl = model.layer_times()    # mean over the profiled steps of the timed region
     ms_layers = ms_layers.astype(np.float64)
     conv = np.array([k == "conv" for k in kinds])
@@ -165,13 +128,69 @@ def bench_tsn(args, rank, world, device, stream):
             # count); pool1 inside conv2/3x3_reduce's loader cannot be separated and stays in
             "pooling_share_of_conv_launches_ms": float(ms_layers[in_conv_launch & ~conv].sum()),
             "frac_without_pooling_share": executed / float(ms_layers[conv].sum()) / 1e9 / PEAK_FP32_MFMA_TFLOPS,
-            "flops_per_step": conv_flops, "executed_flops_per_step": executed, "profiled_steps": cdiv(args.steps, PROFILE_EVERY),
+            "flops_per_step": conv_flops, "executed_flops_per_step": executed, "profiled_steps": cdiv(steps, every),
             "families": fam,
             "note": "achieved/frac = MFMA FLOPs the matrix pipe EXECUTED (K / tile padding included; Winograd layers issue 16 of the 36 "
                     "direct-form multiplies) per second of convolution-kernel time; effective_* prices the same time against the "
                     "ALGORITHMIC direct-convolution FLOPs of SURVEY 8(d) (2 x MACs of Appendix A).  Kernel times: the launches' own "
                     "begin/end timestamps on every %d-th step of the timed region (a launch shared by sibling layers is split between "
-                    "them by matrix work)" % PROFILE_EVERY}
+                    "them by matrix work)" % every}
+    return roof
+
+
+def bench_tsn(args, rank, world, device, stream):
+    if args.profile_only:
+        os.environ["VQ_TSN_SPLIT"] = "1"             # read when the network handle is created
+    g = bn_inception.bn_inception(CH)
+    weights = tsn_net.synthetic_weights(g, seed=2)
+    n_crops = B_CLIPS * T_SEG
+    model = tsn_net.TsnNet(g, weights, max_crops=n_crops, device=device.index)
+    model.set_stream(stream.cuda_stream)
+    if args.tiles and os.path.exists(args.tiles):          # tiling table of an earlier run: skip the autotune launches
+        with open(args.tiles) as f:
+            model.set_layer_tiles(n_crops, np.array(json.load(f)["tiles"], dtype=np.int32))
+    gen = torch.Generator(device=device).manual_seed(1 + rank)
+    crops = torch.randint(0, 256, (n_crops, 224, 224, CH), dtype=torch.uint8, device=device, generator=gen)
+    feat_ptr, _ = model.feat_devptr()
+    feat = dev_tensor(feat_ptr, (B_CLIPS, model.feature_dim), "<f8", device)
+    import torch.distributed as dist
+
+    gather_events = []
+
+    def step(timed=False):
+        model.forward_device(crops.data_ptr(), n_crops, T_SEG, tsn_net.RGB_MEAN)
+        if world > 1:
+            if timed:                                        # the collective's own time: events on the stream it is ordered on
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            all_gather_rows(feat, world * B_CLIPS)           # RCCL over xGMI: per-GPU feature blocks
+            if timed:
+                e1.record(stream)
+                gather_events.append((e0, e1))
+
+    with torch.cuda.stream(stream):
+        model.set_profile(1)                         # warm up in the mode of the timed region (tunes this batch size)
+        for _ in range(max(args.warmup, 1)):
+            step()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        model.set_profile(min(cdiv(args.steps, PROFILE_EVERY), 1024), every=PROFILE_EVERY)   # start/stop events per launch, no host sync
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(timed=True)
+        torch.cuda.synchronize(device)
+        dt_rank = time.perf_counter() - t0                   # this rank's own K steps (before the closing barrier)
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+    roof = tsn_roofline(model, n_crops, args.steps, PROFILE_EVERY)
+    roof["rank_ms_per_step"] = dt_rank / args.steps * 1e3
+    if gather_events:
+        roof["all_gather_ms_per_step"] = float(np.mean([a.elapsed_time(b) for a, b in gather_events]))
     # Off-line PMC evidence for the same command, committed under profiles/ (NOT measured in this run): HBM bytes per conv
     # launch (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as the microarchitecture guide
     # prescribes for gfx950) and the SQ matrix-pipe utilisation per kernel family.
@@ -215,6 +234,99 @@ def bench_tsn(args, rank, world, device, stream):
         with open(args.tiles, "w") as f:
             json.dump({"n_crops": n_crops, "tiles": model.layer_tiles(n_crops).tolist()}, f)
     return dt, roof, model, crops, feats
+
+
+def bench_two_stream(args, device, stream, with_cpu):
+    """configs[2]: TSN two-stream, T = 7 segments, B = 64 clips: RGB crops [448,224,224,3] and 5-frame flow stacks
+    [448,224,224,10] (x/y interleaved, mean 128) resident in HBM, one forward per stream per step, both on this GPU one after
+    the other.  value = clips/s for the PAIR of streams; each stream carries its own roofline from the launches' own timestamps.
+    Algorithmic work: 7 x (4.063 + 4.614) = 60.74 GFLOP per clip, 3.887 TFLOP per step."""
+    B2, T2 = 64, 7
+    n_crops = B2 * T2
+    steps = max(4, args.steps // 5)
+    every = 2
+    out = {"metric": "clips/sec TSN two-stream feature-extract (RGB + 5-frame flow stack)", "unit": "clips/s", "steps": steps,
+           "config": {"workload": "configs[2]: TSN two-stream RGB + warped-optical-flow (5-frame stack = 10 channels), T=7 segments, "
+                                  "B=64 clips: 448 + 448 uint8 crops of 224x224 resident in HBM, random-init weights",
+                      "crops_per_step": 2 * n_crops},
+           "dtype": "f32", "streams": {}}
+    total_ms = 0.0
+    flops = 0.0
+    keep = {}
+    for name, ch, seed, mean in (("rgb", 3, 2, tsn_net.RGB_MEAN), ("warped_optical_flow", 10, 5, tsn_net.FLOW_MEAN)):
+        if args.profile_only:
+            os.environ["VQ_TSN_SPLIT"] = "1"
+        g = bn_inception.bn_inception(ch)
+        weights = tsn_net.synthetic_weights(g, seed=seed)
+        model = tsn_net.TsnNet(g, weights, max_crops=n_crops, device=device.index)
+        model.set_stream(stream.cuda_stream)
+        gen = torch.Generator(device=device).manual_seed(40 + ch)
+        crops = torch.randint(0, 256, (n_crops, 224, 224, ch), dtype=torch.uint8, device=device, generator=gen)
+        with torch.cuda.stream(stream):
+            model.set_profile(1)
+            for _ in range(2):
+                model.forward_device(crops.data_ptr(), n_crops, T2, mean)
+            torch.cuda.synchronize(device)
+            model.set_profile(min(cdiv(steps, every), 1024), every=every)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                model.forward_device(crops.data_ptr(), n_crops, T2, mean)
+            torch.cuda.synchronize(device)
+            ms = (time.perf_counter() - t0) / steps * 1e3
+        roof = tsn_roofline(model, n_crops, steps, every)
+        fl = model.flops_per_crop() * n_crops
+        feat_ptr, _ = model.feat_devptr()
+        keep[name] = (g, weights, crops[:T2].cpu().numpy(), dev_tensor(feat_ptr, (B2, model.feature_dim), "<f8", device)[:1].cpu().numpy(), mean)
+        model.set_profile(0)
+        prod_ms = float("nan")
+        if not args.profile_only:                       # production mode: no events, the batch split over two HIP streams
+            with torch.cuda.stream(stream):
+                for _ in range(2):
+                    model.forward_device(crops.data_ptr(), n_crops, T2, mean)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    model.forward_device(crops.data_ptr(), n_crops, T2, mean)
+                torch.cuda.synchronize(device)
+                prod_ms = (time.perf_counter() - t0) / steps * 1e3
+        out["streams"][name] = {"ms_per_step": ms, "clips_per_s": B2 / ms * 1e3, "algorithmic_gflop_per_clip": fl / B2 / 1e9,
+                                "whole_step_algorithmic_tflops": fl / ms / 1e9, "production_mode_ms_per_step": prod_ms, "roofline": roof}
+        total_ms += ms
+        flops += fl
+        model.close()
+        del crops
+    out["value"] = B2 / total_ms * 1e3
+    out["ms_per_step"] = total_ms
+    out["algorithmic_gflop_per_clip"] = flops / B2 / 1e9
+    prod = sum(v["production_mode_ms_per_step"] for v in out["streams"].values())
+    if prod == prod:
+        out["production_mode"] = {"value": B2 / prod * 1e3, "unit": "clips/s", "ms_per_step": prod}
+    # one roofline for the pair: the two streams' convolution launches together
+    ex = sum(v["roofline"]["executed_flops_per_step"] for v in out["streams"].values())
+    al = sum(v["roofline"]["flops_per_step"] for v in out["streams"].values())
+    cm = sum(v["roofline"]["conv_ms_per_step"] for v in out["streams"].values())
+    nl = sum(v["roofline"]["launches_per_step"] for v in out["streams"].values())
+    out["roofline"] = {"bound": "mfma", "achieved": ex / cm / 1e9, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                       "frac": ex / cm / 1e9 / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "effective_tflops": al / cm / 1e9,
+                       "effective_frac": al / cm / 1e9 / PEAK_FP32_MFMA_TFLOPS, "conv_ms_per_step": cm, "launches_per_step": nl,
+                       "avg_launch_ms": cm / nl, "kernel": "the convolution launches of both streams' forwards (per stream: streams.*.roofline)"}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import tsn_oracle as to
+        threads = host_cores()
+        t0 = time.perf_counter()
+        errs = {}
+        for name, (g, weights, x, got, mean) in keep.items():
+            ps, _ = to.features(g.layers, "data", weights, x, mean, T2, dtype=np.float32, threads=threads)
+            ref = ps.astype(np.float64).reshape(1, T2, -1).mean(axis=1)
+            errs[name] = float(np.abs(got - ref).max() / np.abs(ref).max())
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / dt, "unit": "clips/s", "cores": threads, "kind": "port",
+                               "sample": "clip 0 of the batch through both streams (7 + 7 crops), oracle/tsn_oracle.py fp32 torch-CPU, "
+                                         "%d threads, %.1f s" % (threads, dt)}
+        out["parity_vs_oracle_rel_err"] = errs
+    return out
 
 
 def cpu_baseline_tsn(crops_u8, weights_graph, seconds_target=12.0):
@@ -274,13 +386,18 @@ def bench_sim(args, rank, world, device, stream):
         if world > 1:
             dist.barrier()
         kern_ms = 0.0
+        sim_gather = []
         t0 = time.perf_counter()
         for _ in range(steps):
             call("vq_timer_start", tm, C.c_void_p(stream.cuda_stream))
             db.scan(weights=w)                               # one launch: dots, ensemble mean, weighted score
             call("vq_timer_stop", tm, C.c_void_p(stream.cuda_stream))
             if world > 1:
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record(stream)
                 all_scores = all_gather_rows(scores, SIM_N)      # score slices -> every rank (N x 8 B, RCCL)
+                g1.record(stream)
+                sim_gather.append((g0, g1))
             ms = C.c_float()
             call("vq_timer_elapsed_ms", tm, C.byref(ms))
             kern_ms += ms.value
@@ -289,10 +406,11 @@ def bench_sim(args, rank, world, device, stream):
             dist.barrier()
         dt = time.perf_counter() - t0
     kern_ms /= steps
+    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in sim_gather])) if sim_gather else None
     nbytes = rows * SIM_S * SIM_E * SIM_D * 4 + rows * 8
     roof = {"bound": "hbm", "kernel": "scan_kernel<float,2,5,4>", "achieved": nbytes / kern_ms / 1e6, "peak": PEAK_HBM_GBS,
             "unit": "GB/s", "frac": nbytes / kern_ms / 1e6 / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": kern_ms,
-            "bytes_per_launch": nbytes}
+            "bytes_per_launch": nbytes, "score_all_gather_ms_per_query": gather_ms}
     # HBM bytes per launch from the PMC counters (collected off-line by tools/pmc_sim.sh on the full 1M-row launch and
     # committed; FETCH_SIZE doubled as the microarchitecture guide prescribes for gfx950); scaled to this rank's rows
     tpath = os.path.join(ROOT, "profiles", "r01_scan_traffic.json")
@@ -489,6 +607,7 @@ def main():
     ap.add_argument("--skip-sim", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-flow", action="store_true")
+    ap.add_argument("--skip-two-stream", action="store_true")
     ap.add_argument("--profile-only", action="store_true",
                     help="for rocprofv3 comparisons: every forward of the process runs like the timed region (one stream, "
                          "VQ_TSN_SPLIT=1) and the un-profiled production-mode pass is skipped")
@@ -515,11 +634,28 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     stream = torch.cuda.Stream(device=device)
+    dist_info = None
+    if world > 1:
+        # the run must be what --gpus says it is: N ranks, one per GPU, over RCCL (backend "nccl" IS RCCL on ROCm)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        assert rehearse or dist.get_backend() == "nccl", dist.get_backend()
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:      # noqa: BLE001
+            ver = "unavailable (%s)" % type(e).__name__
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": ver,
+                     "devices_visible": torch.cuda.device_count(), "rank0_device": torch.cuda.get_device_name(device),
+                     "rehearsal_on_one_gpu": rehearse}
 
     dt, roof, model, crops, feats = bench_tsn(args, rank, world, device, stream)
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        per_rank = torch.zeros(world, dtype=torch.float64, device=device)
+        per_rank[rank] = roof["rank_ms_per_step"]
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+        roof["rank_ms_per_step"] = {"min": float(per_rank.min().item()), "max": float(per_rank.max().item()),
+                                    "all": [float(v) for v in per_rank.cpu().tolist()]}
     dt = float(tmax.item())
     value = world * B_CLIPS * args.steps / dt
     out = {"metric": "clips/sec TSN feature-extract", "value": value, "unit": "clips/s", "n_gpus": world,
@@ -528,7 +664,8 @@ def main():
            "config": {"workload": "configs[1]: TSN BN-Inception RGB stream, 224x224x3 uint8 crops resident in HBM, "
                                   "T=3 segments, B=32 clips per GPU (96 crops per step), random-init weights",
                       "global_batch": world * B_CLIPS, "crops_per_step_per_gpu": B_CLIPS * T_SEG,
-                      "parallelism": "dp%d" % world, "collective": "all_gather feature blocks (RCCL)" if world > 1 else None},
+                      "parallelism": "dp%d" % world, "collective": "all_gather feature blocks (RCCL)" if world > 1 else None,
+                      "distributed": dist_info},
            "roofline": roof}
     up = torch.tensor([roof.pop("unprofiled_ms_per_step")], dtype=torch.float64, device=device)
     if world > 1:
@@ -547,6 +684,8 @@ def main():
         out["parity_vs_oracle_rel_err"] = float(np.abs(got - ref).max() / np.abs(ref).max())
     model.close()
     del crops
+    if rank == 0 and world == 1 and not args.skip_two_stream:
+        out["two_stream"] = bench_two_stream(args, device, stream, not args.skip_cpu)
 
     if not args.skip_sim:
         sdt, ssteps, sroof, db, row0, rows = bench_sim(args, rank, world, device, stream)

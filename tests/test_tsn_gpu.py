@@ -297,7 +297,9 @@ def test_bn_inception_flow_features(tsn):
 
 def test_cfg2_shape_runs_and_is_deterministic(tsn):
     """BASELINE config[1]: B = 32 clips x T = 3 snippets, RGB.  Two runs must agree bit for bit (no atomics,
-    fixed reduction order), features finite and non-negative."""
+    fixed reduction order), features finite and non-negative; a sample of the 96 crops of THIS batch (first, last, a clip
+    boundary, the middle) against the fp64 CPU evaluation of the layer list at the stated whole-network tolerance, and the
+    consensus of every clip recomputed in fp64 from the per-snippet features, bit for bit."""
     bi, net = tsn
     g = bi.bn_inception(3)
     w = net.synthetic_weights(g, seed=2)
@@ -307,6 +309,10 @@ def test_cfg2_shape_runs_and_is_deterministic(tsn):
     f2, p2 = m.forward(crops, 3, net.RGB_MEAN)
     assert (f1 == f2).all() and (p1 == p2).all()
     assert f1.shape == (32, 1024) and np.isfinite(f1).all() and (f1 >= 0).all()
+    pick = np.array([0, 2, 3, 47, 50, 95])
+    ref = to.forward(g.layers, "data", w, to.preprocess(crops[pick], net.RGB_MEAN), keep=("global_pool",))["global_pool"].reshape(len(pick), -1)
+    assert np.abs(p1[pick] - ref).max() <= 2e-4 * np.abs(ref).max()
+    assert (f1 == to.consensus(p1, 3)).all()
     # same crops in a smaller batch give the same bits (tile choice may differ with M: k-order is fixed)
     m2 = net.TsnNet(g, w, max_crops=6)
     f3, p3 = m2.forward(crops[:6], 3, net.RGB_MEAN)
