@@ -349,6 +349,35 @@ def test_batched_scan_equals_single_scans_to_rounding(vqa, dtype, q, n):
     db.close()
 
 
+@pytest.mark.parametrize("n,s,e,d,q,masked", [(140_000, 2, 1, 256, 16, False), (70_000, 2, 3, 256, 5, False), (5_000, 1, 2, 512, 16, True),
+                                              (33, 2, 5, 1024, 16, False), (4_100, 3, 2, 768, 9, True)])
+def test_fused_batched_scan_has_the_bits_of_the_two_kernel_form(vqa, monkeypatch, n, s, e, d, q, masked):
+    """The single-launch batched scan (per-tile sums kept in registers across the slices, several rounds of tiles per
+    workgroup, the chunk ring refilled across slice changes) against the round-2 form (ten slice launches into a
+    [slice][query][clip] matrix + a finalising launch; VQ_BATCH_TWO_KERNEL=1): the same operations per (clip, query) in the
+    same order, so the same bits -- with and without a presence mask, 1 to 3 streams, ragged last tiles, a database large
+    enough for a second round (140 000 clips > 256 workgroups x 16 waves x 2 tiles x 16 clips), every D the kernel takes."""
+    db = vqa.FeatureDB.synthetic(n, s, e, d, seed=23, scales=(4.0, 1.0, 2.0)[:s])
+    if masked:
+        present = np.ones((n, s, e), dtype=np.uint8)
+        present[::7, 0, 0] = 0
+        present[3::11, s - 1, e - 1] = 0
+        present[n - 1, :, 0] = 0
+        present[..., 0] |= (present.sum(axis=2) == 0).astype(np.uint8)      # every (clip, stream) keeps at least one split
+        db.set_present(present)
+    rng = np.random.default_rng(n)
+    targets = rng.standard_normal((q, s, e, d)) / d
+    weights = 0.5 + rng.random((q, s))
+    monkeypatch.setenv("VQ_BATCH_TWO_KERNEL", "1")
+    want = db.scan_batch(targets, weights)
+    monkeypatch.setenv("VQ_BATCH_TWO_KERNEL", "0")
+    got = db.scan_batch(targets, weights)
+    assert got.shape == (q, n) and np.isfinite(got).all()
+    assert (got == want).all()
+    assert (db.scan_batch(targets, weights) == got).all()
+    db.close()
+
+
 def test_cfg4_full_size_scan_one_million_clips(vqa):
     """BASELINE configs[3] at FULL size on one GPU: 1 query x 1 000 000 clips x 2 streams x 5 splits x 1024 fp32
     (40.96 GB resident, generated on the device), the real ``scan_kernel<float,2,5,4>`` launch of the bench.

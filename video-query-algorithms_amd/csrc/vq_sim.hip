@@ -276,6 +276,33 @@ struct Chunk<double> {
     __device__ __forceinline__ double at(int m, int e) const { return (e & 1) ? v[m][e >> 1].y : v[m][e >> 1].x; }
 };
 
+// The same with P pieces of 16 elements per chunk (the fused kernel: a refill is then 64 P contiguous bytes of each clip).
+template <typename T, int P>
+struct ChunkP;
+template <int P>
+struct ChunkP<float, P> {
+    float4 v[P];
+    __device__ __forceinline__ void load(const float* p) {
+#pragma unroll
+        for (int m = 0; m < P; ++m) v[m] = *reinterpret_cast<const float4*>(p + 16 * m);
+    }
+    __device__ __forceinline__ double at(int m, int e) const {
+        return (double)(e == 0 ? v[m].x : e == 1 ? v[m].y : e == 2 ? v[m].z : v[m].w);
+    }
+};
+template <int P>
+struct ChunkP<double, P> {
+    double2 v[P][2];
+    __device__ __forceinline__ void load(const double* p) {
+#pragma unroll
+        for (int m = 0; m < P; ++m) {
+            v[m][0] = *reinterpret_cast<const double2*>(p + 16 * m);
+            v[m][1] = *reinterpret_cast<const double2*>(p + 16 * m + 2);
+        }
+    }
+    __device__ __forceinline__ double at(int m, int e) const { return (e & 1) ? v[m][e >> 1].y : v[m][e >> 1].x; }
+};
+
 // Where query slot q starts in LDS (in doubles): rows of D doubles plus a swizzle that makes the 32 lanes of a
 // ds_read_b64 group (16 queries x 2 k quarters, 4 doubles apart) hit 32 distinct 8-byte bank slots: D is a multiple
 // of 32, so slot = (q % 4) + 8 (q / 4) + 4 kk + const is a bijection onto 0..31.
@@ -358,6 +385,165 @@ __global__ void batch_finalize_kernel(const double* sims, const uint8_t* present
         ww[s] = w[q * S + s];
     }
     scores[i] = score_from_avg(av, ww, S);
+}
+
+// ---- the same pass as ONE launch: no dot matrix in memory ----------------------------------------------------------------
+// A workgroup (16 waves, one per CU) owns TW tiles of 16 clips per wave and "round" and walks the (stream, split) slices
+// itself: barrier, the slice's sixteen query rows into LDS (128 KB; from L2 after the first workgroup), barrier, then every
+// wave multiplies its tiles against them.  What a tile carries from slice to slice lives in registers: the running sum
+// over the splits of the stream being walked (ticket.py:155-160) and the running sum of the weighted squared misses over the
+// streams already closed (ticket.py:172-180) -- 16 VGPRs per tile -- so the [slice][query][clip] matrix of the two-kernel
+// form (2.6 GB written and read back per pass at cfg 4) and its ten launch ramps never exist.  The operations per (clip,
+// query) are those of batch_mfma_kernel + batch_finalize_kernel in the same order: same bits.
+// The feature stream never stops at a slice change: the ring of chunk buffers is refilled from the NEXT (slice, tile) of
+// the wave while the last chunks of the current one are multiplied, so the loads are in flight across the two barriers (a
+// plain __syncthreads() does not wait for vector memory) and HBM stays busy while the matrix pipe waits for the new rows.
+// Tiles are dealt so that a short last round spreads over ALL workgroups (tile = base + slot * gridDim + block).
+struct BatchFusedArgs {
+    const void* feats;
+    const double* t;          // [Q][NV][D]
+    const double* w;          // [Q][S]
+    const uint8_t* present;   // [n][S][E] or null
+    double* scores;           // [Q][n]
+    int64_t n;
+    int32_t Q, S, E, D;
+};
+
+template <typename T, int CH, int TW, bool PRES, int P>
+__global__ __launch_bounds__(1024) void batch_fused_kernel(BatchFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double tq[];      // 16 swizzled rows of D doubles (+ 32 of slack)
+    constexpr int D = CH * 256, CE = 16 * P, NCHUNK = D / CE;       // a chunk = P pieces of 16 elements
+    constexpr int NBUF = (sizeof(T) == 4 ? 16 : 8) / P;              // the ring holds 64 VGPRs of features per lane
+    static_assert(NCHUNK % NBUF == 0, "chunk ring must divide the vector");
+    const int lane = threadIdx.x & 63, col = lane & 15, kk = lane >> 4;
+    // everything that indexes tiles is wave-uniform: kept on the scalar unit (the register budget of 4 waves per SIMD is
+    // the ring of chunk buffers + the per-tile sums)
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int NV = a.S * a.E;
+    const int64_t ntiles = (a.n + 15) / 16;
+    const int64_t per_round = (int64_t)gridDim.x * 16 * TW;
+    const int rounds = (int)((ntiles + per_round - 1) / per_round);
+    const int64_t clip_elems = (int64_t)NV * D;
+    const T* feats = static_cast<const T*>(a.feats);
+    const double* tb = tq + query_row(col, D) + 4 * kk;               // this lane's query (B operand column), its k quarter
+    for (int i = threadIdx.x; i < kBatchSlots * D; i += blockDim.x) {  // slots beyond Q stay zero for the whole pass
+        const int q = i / D, k = i - q * D;
+        if (q >= a.Q) tq[query_row(q, D) + k] = 0.0;
+    }
+    // tile j of this wave in round r (scalar), and how many of its TW tiles exist (a prefix: the tiles grow with j)
+    auto tile_of = [&](int r, int j) -> int64_t { return (int64_t)r * per_round + (int64_t)(wv * TW + j) * gridDim.x + blockIdx.x; };
+    auto valid_in = [&](int r) -> int {
+        int nv = 0;
+        for (int j = 0; j < TW; ++j) nv += (r < rounds && tile_of(r, j) < ntiles) ? 1 : 0;
+        return nv;
+    };
+    // a tile's slice = a scalar base + this lane's 32-bit element offset (its clip row, its k quarter); rows past n re-read the
+    // last clip and are never stored
+    auto base_of = [&](int64_t tile, int v) -> const T* { return feats + tile * 16 * clip_elems + (int64_t)v * D; };
+    auto lane_off = [&](int64_t tile) -> uint32_t {
+        const int last = (int)min((int64_t)15, a.n - 1 - tile * 16);
+        return (uint32_t)(min(col, last) * (int)clip_elems + 4 * kk);
+    };
+    ChunkP<T, P> buf[NBUF];
+    if (valid_in(0) > 0) {
+        const T* x0 = base_of(tile_of(0, 0), 0) + lane_off(tile_of(0, 0));
+#pragma unroll
+        for (int bq = 0; bq < NBUF; ++bq) buf[bq].load(x0 + CE * bq);
+    }
+    for (int r = 0; r < rounds; ++r) {
+        const int nval = valid_in(r), nval_next = valid_in(r + 1);
+        doublex4 miss[TW];                                            // sum over closed streams of (w_s (1 - avg_s))^2
+#pragma unroll
+        for (int j = 0; j < TW; ++j) miss[j] = {0.0, 0.0, 0.0, 0.0};
+        double denom = 0.0;
+        for (int s = 0; s < a.S; ++s) {
+            doublex4 ssum[TW];
+            int cnt[TW][4];
+#pragma unroll
+            for (int j = 0; j < TW; ++j) {
+                ssum[j] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) cnt[j][rr] = 0;
+            }
+            for (int e = 0; e < a.E; ++e) {
+                const int v = s * a.E + e;
+                __syncthreads();                                      // every wave is done with the previous slice's rows
+                for (int i = threadIdx.x; i < a.Q * D; i += blockDim.x) {
+                    const int q = i / D, k = i - q * D;
+                    tq[query_row(q, D) + k] = a.t[((size_t)q * NV + v) * D + k];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < TW; ++j) {
+                    if (j >= nval) continue;                          // wave-uniform
+                    const int64_t tile = tile_of(r, j);
+                    const T* x = base_of(tile, v) + lane_off(tile);
+                    // the wave's next (tile, slice): next tile of this slice, first tile of the next slice, first of the next round
+                    // (after the wave's very last one the ring is refilled from the lines just read: the refill stays
+                    // unconditional -- a branch around it makes the compiler drain the whole ring at every loop head)
+                    int64_t tn = tile;
+                    int vn = v;
+                    if (j + 1 < nval) tn = tile_of(r, j + 1);
+                    else if (v + 1 < NV) { tn = tile_of(r, 0); vn = v + 1; }
+                    else if (nval_next > 0) { tn = tile_of(r + 1, 0); vn = 0; }
+                    const T* xn = base_of(tn, vn) + lane_off(tn);
+                    doublex4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+                    for (int ch0 = 0; ch0 < NCHUNK; ch0 += NBUF) {
+                        const T* src = ch0 + NBUF < NCHUNK ? x + CE * (ch0 + NBUF) : xn;
+#pragma unroll
+                        for (int bq = 0; bq < NBUF; ++bq) {
+                            int off = CE * (ch0 + bq);
+                            asm volatile("" : "+v"(off));             // keeps every LDS read next to its MFMA (see batch_mfma_kernel)
+                            const double* tbc = tb + off;
+#pragma unroll
+                            for (int m = 0; m < P; ++m)
+#pragma unroll
+                                for (int ee = 0; ee < 4; ++ee)
+                                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[bq].at(m, ee), tbc[16 * m + ee], acc, 0, 0, 0);
+                            buf[bq].load(src + CE * bq);
+                        }
+                    }
+                    // ticket.py:155-160: the mean runs over the splits PRESENT for the clip
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        bool here = true;
+                        if (PRES) {
+                            const int64_t cc = min(tile * 16 + kk + 4 * rr, a.n - 1);
+                            here = a.present[(cc * a.S + s) * a.E + e] != 0;
+                        }
+                        if (here) {
+                            ssum[j][rr] = ssum[j][rr] + acc[rr];
+                            if (PRES) ++cnt[j][rr];
+                        }
+                    }
+                }
+            }
+            // the stream closes: avg = sum / count, then the terms of ticket.py:172-180 in stream order
+            const double ws = col < a.Q ? a.w[col * a.S + s] : 0.0;
+            denom = denom + ws * ws;
+#pragma unroll
+            for (int j = 0; j < TW; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const double av = ssum[j][rr] / (double)(PRES ? cnt[j][rr] : a.E);
+                    const double term = ws * (1.0 - av);
+                    miss[j][rr] = miss[j][rr] + term * term;
+                }
+        }
+        if (col < a.Q) {
+#pragma unroll
+            for (int j = 0; j < TW; ++j) {
+                if (j >= nval) continue;
+                const int64_t tile = tile_of(r, j);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int64_t cc = tile * 16 + kk + 4 * rr;
+                    if (cc < a.n) a.scores[(int64_t)col * a.n + cc] = 1.0 - sqrt(miss[j][rr] / denom);
+                }
+            }
+        }
+    }
 }
 
 __global__ void rescore_kernel(const double* avg, const double* w, double* scores, int64_t n, int S) {
@@ -663,7 +849,8 @@ struct vq_db {
     int64_t last_n0 = 0, last_n1 = 0;
     uint64_t* tk_state = nullptr;    // [2]
     unsigned int* tk_hist = nullptr; // [256]
-    double* batch_buf = nullptr;     // batched scan: queries [Q][NV][D] | weights [Q][S] | sims [Q][N][NV] | scores [Q][N]
+    double* batch_buf = nullptr;     // batched scan: queries [Q][NV][D] | weights [Q][S] | (two-kernel form: sims [NV][Q][N]) | scores [Q][N]
+    double* batch_scores = nullptr;  // where the scores of the last batched scan start inside batch_buf
     int64_t batch_cap = 0;           // doubles
     int batch_q = 0;                 // queries of the last batched scan
     double* grid_buf = nullptr;      // scratch for grid / gathers
@@ -1046,7 +1233,11 @@ int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const d
     std::lock_guard<std::mutex> lk(db->mu);
     DeviceGuard g(db->device);
     const int Q = n_queries, NV = db->S * db->E;
-    const int64_t n_t = (int64_t)Q * NV * db->D, n_w = (int64_t)Q * db->S, n_s = (int64_t)Q * db->n * NV, n_sc = (int64_t)Q * db->n;
+    // VQ_BATCH_TWO_KERNEL=1 keeps the round-2 form (ten slice launches into a [slice][query][clip] matrix + a finalising
+    // launch) for A/B measurements; the product runs the single fused launch
+    const char* two_env = getenv("VQ_BATCH_TWO_KERNEL");
+    const bool two_kernel = two_env && *two_env == '1';
+    const int64_t n_t = (int64_t)Q * NV * db->D, n_w = (int64_t)Q * db->S, n_s = two_kernel ? (int64_t)Q * db->n * NV : 0, n_sc = (int64_t)Q * db->n;
     const int64_t need = n_t + n_w + n_s + n_sc;
     if (db->batch_cap < need) {
         if (db->batch_buf) VQ_HIP(hipFree(db->batch_buf));
@@ -1059,8 +1250,43 @@ int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const d
     double* d_w = d_t + n_t;
     double* d_sims = d_w + n_w;
     double* d_scores = d_sims + n_s;
+    db->batch_scores = d_scores;
     VQ_HIP(hipMemcpyAsync(d_t, t_host, (size_t)n_t * 8, hipMemcpyHostToDevice, db->stream));
     VQ_HIP(hipMemcpyAsync(d_w, w_host, (size_t)n_w * 8, hipMemcpyHostToDevice, db->stream));
+    const size_t lds = ((size_t)kBatchSlots * db->D + 32) * 8;   // sixteen swizzled query rows
+    const int ch = db->D / 256;
+    if (!two_kernel) {
+        BatchFusedArgs f;
+        f.feats = db->feats;
+        f.t = d_t;
+        f.w = d_w;
+        f.present = db->present;
+        f.scores = d_scores;
+        f.n = db->n;
+        f.Q = Q;
+        f.S = db->S;
+        f.E = db->E;
+        f.D = db->D;
+        constexpr int TW = 2;                                     // tiles of 16 clips per wave and round
+        // chunks of 8 pieces = 128 elements: a refill reads 512 contiguous bytes of each of the 16 clips (two ring buffers).  With 64-
+        // element chunks and four buffers the pass took 7.60 ms instead of 7.45 at cfg 4 (65 k slow streams of 256-byte reads)
+        const int64_t ntiles = (db->n + 15) / 16;
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((ntiles + 16 * TW - 1) / (16 * TW), (int64_t)db->cus));
+#define VQ_FUSED_LAUNCH(T, CH)                                                                                             \
+    {                                                                                                                      \
+        auto kern = db->present ? batch_fused_kernel<T, CH, TW, true, 8> : batch_fused_kernel<T, CH, TW, false, 8>;       \
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                   (kBatchSlots * CH * 256 + 32) * 8));                                                     \
+        kern<<<blocks, 1024, lds, db->stream>>>(f);                                                                        \
+    }
+        if (db->dtype == VQ_F32) {
+            if (ch == 4) VQ_FUSED_LAUNCH(float, 4) else if (ch == 3) VQ_FUSED_LAUNCH(float, 3) else if (ch == 2) VQ_FUSED_LAUNCH(float, 2) else VQ_FUSED_LAUNCH(float, 1)
+        } else {
+            if (ch == 4) VQ_FUSED_LAUNCH(double, 4) else if (ch == 3) VQ_FUSED_LAUNCH(double, 3) else if (ch == 2) VQ_FUSED_LAUNCH(double, 2) else VQ_FUSED_LAUNCH(double, 1)
+        }
+#undef VQ_FUSED_LAUNCH
+        VQ_CHECK_LAUNCH();
+    } else {
     BatchArgs a;
     a.feats = db->feats;
     a.t = d_t;
@@ -1069,7 +1295,6 @@ int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const d
     a.Q = Q;
     a.NV = NV;
     a.D = db->D;
-    const size_t lds = ((size_t)kBatchSlots * db->D + 32) * 8;   // sixteen swizzled query rows
     // one 16-wave workgroup per CU (the query block takes most of its LDS); a wave walks tiles of 16 clips
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(((db->n + 15) / 16 + 15) / 16, (int64_t)db->cus));
     for (int v = 0; v < NV; ++v) {
@@ -1085,7 +1310,6 @@ int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const d
         }                                                                                                                  \
         kern<<<blocks, 1024, lds, db->stream>>>(a);                                                                        \
     }
-        const int ch = db->D / 256;
         if (db->dtype == VQ_F32) {
             if (ch == 4) VQ_BATCH_LAUNCH(float, 4) else if (ch == 3) VQ_BATCH_LAUNCH(float, 3) else if (ch == 2) VQ_BATCH_LAUNCH(float, 2) else VQ_BATCH_LAUNCH(float, 1)
         } else {
@@ -1096,6 +1320,7 @@ int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const d
     }
     batch_finalize_kernel<<<cdiv(n_sc, 256), 256, 0, db->stream>>>(d_sims, db->present, d_w, d_scores, db->n, Q, db->S, db->E);
     VQ_CHECK_LAUNCH();
+    }
     db->batch_q = Q;
     if (scores_host) {
         VQ_HIP(hipMemcpyAsync(scores_host, d_scores, (size_t)n_sc * 8, hipMemcpyDeviceToHost, db->stream));
@@ -1109,7 +1334,8 @@ int vq_db_batch_scores_devptr(vq_db* db, void** dev_ptr, int32_t* n_queries) {
     std::lock_guard<std::mutex> lk(db->mu);
     if (db->batch_q == 0) return fail(VQ_E_STATE, "no batched scan has run");
     const int NV = db->S * db->E;
-    *dev_ptr = db->batch_buf + (int64_t)db->batch_q * NV * db->D + (int64_t)db->batch_q * db->S + (int64_t)db->batch_q * db->n * NV;
+    (void)NV;
+    *dev_ptr = db->batch_scores;
     if (n_queries) *n_queries = db->batch_q;
     return VQ_OK;
 }
