@@ -317,14 +317,17 @@ def bench_two_stream(args, device, stream, with_cpu):
         threads = host_cores()
         t0 = time.perf_counter()
         errs = {}
-        for name, (g, weights, x, got, mean) in keep.items():
-            ps, _ = to.features(g.layers, "data", weights, x, mean, T2, dtype=np.float32, threads=threads)
-            ref = ps.astype(np.float64).reshape(1, T2, -1).mean(axis=1)
-            errs[name] = float(np.abs(got - ref).max() / np.abs(ref).max())
+        reps = 0
+        while reps == 0 or time.perf_counter() - t0 < 8.0:       # a bounded sample: the same clip through both streams, repeatedly
+            for name, (g, weights, x, got, mean) in keep.items():
+                ps, _ = to.features(g.layers, "data", weights, x, mean, T2, dtype=np.float32, threads=threads)
+                ref = ps.astype(np.float64).reshape(1, T2, -1).mean(axis=1)
+                errs[name] = float(np.abs(got - ref).max() / np.abs(ref).max())
+            reps += 1
         dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": 1.0 / dt, "unit": "clips/s", "cores": threads, "kind": "port",
-                               "sample": "clip 0 of the batch through both streams (7 + 7 crops), oracle/tsn_oracle.py fp32 torch-CPU, "
-                                         "%d threads, %.1f s" % (threads, dt)}
+        out["cpu_baseline"] = {"value": reps / dt, "unit": "clips/s", "cores": threads, "kind": "port",
+                               "sample": "%d x clip 0 of the batch through both streams (7 + 7 crops each time), oracle/tsn_oracle.py fp32 "
+                                         "torch-CPU, %d threads, %.1f s" % (reps, threads, dt)}
         out["parity_vs_oracle_rel_err"] = errs
     return out
 
@@ -433,16 +436,28 @@ def bench_sim(args, rank, world, device, stream):
             torch.cuda.synchronize(device)
             tb0 = time.perf_counter()
             reps = max(3, steps // 4)
+            ev_ms = 0.0
             for _ in range(reps):
+                call("vq_timer_start", tm, C.c_void_p(stream.cuda_stream))
                 db.scan_batch(tb, wb, want=False)
+                call("vq_timer_stop", tm, C.c_void_p(stream.cuda_stream))
+                ms = C.c_float()
+                call("vq_timer_elapsed_ms", tm, C.byref(ms))
+                ev_ms += ms.value
             torch.cuda.synchronize(device)
             bdt = (time.perf_counter() - tb0) / reps
-        bbytes = rows * SIM_S * SIM_E * SIM_D * 4 + 2 * Q * rows * SIM_S * SIM_E * 8 + Q * rows * 8
+            ev_ms /= reps
+        # one launch reads the database once and writes Q score vectors: no intermediate matrix since round 3
+        bbytes = rows * SIM_S * SIM_E * SIM_D * 4 + Q * rows * 8
         batched = {"queries_per_pass": Q, "value": Q / bdt, "unit": "queries/s", "ms_per_pass": bdt * 1e3,
-                   "hbm_GBps": bbytes / bdt / 1e9, "hbm_frac": bbytes / bdt / 1e9 / PEAK_HBM_GBS,
-                   "mfma_f64_tflops": 2.0 * Q * rows * SIM_S * SIM_E * SIM_D / bdt / 1e12, "mfma_f64_peak_tflops": 78.6,
-                   "note": "vq_db_scan_batch: the database is read once for 16 queries (slice by slice, query vectors in LDS, dots on "
-                           "v_mfma_f64_16x16x4); scores within 1e-12 of 16 single scans; includes the 80 KB x 16 query upload per pass"}
+                   "kernel": "batch_fused_kernel<float,4,2,false,8> (one launch per pass)", "pass_ms_by_hip_events": ev_ms,
+                   "bytes_per_pass": bbytes, "hbm_GBps": bbytes / ev_ms / 1e6, "hbm_frac": bbytes / ev_ms / 1e6 / PEAK_HBM_GBS,
+                   "mfma_f64_tflops": 2.0 * Q * rows * SIM_S * SIM_E * SIM_D / ev_ms / 1e9, "mfma_f64_peak_tflops": 78.6,
+                   "note": "vq_db_scan_batch: the database is read ONCE for 16 queries by a single launch (a workgroup walks the (stream, "
+                           "split) slices itself: the slice's 16 query rows in LDS, dots on v_mfma_f64_16x16x4, per-tile sums in registers; "
+                           "no [slice][query][clip] matrix in memory); scores within 1e-12 of 16 single scans, bit-identical to the round-2 "
+                           "two-kernel form; value = wall clock over the passes incl. the 1.3 MB query upload of each; hbm_* from the HIP "
+                           "events around the pass"}
     roof["batched"] = batched
     return dt, steps, roof, db, row0, rows
 
