@@ -79,3 +79,38 @@ def test_homography_warp_and_consecutive_frames(flow_mod):
     with pytest.raises(Exception):
         m.flow(f0[None, :50], f1[None, :50])
     m.close()
+
+
+def test_blocked_iterations_have_the_bits_of_the_two_launch_form(flow_mod, monkeypatch):
+    """The blocked form of the inner loop (4 iterations per launch on tiles resident in LDS / registers with a 4-pixel halo, the
+    fields ping-ponging between two sets of planes, the stopping rule kept exact by replaying a block that ran past the stop)
+    against the round-2 form (a primal and a dual launch per iteration, VQ_FLOW_TWO_LAUNCH=1 when the handle is created).
+    With a fixed iteration count (epsilon = 0) the per-pixel operations are the same in the same order: the same bits --
+    iteration counts that are and are not multiples of the block (the tail block runs fewer), frames smaller than a tile and
+    larger than several, every level shape of the default pyramid.  With the convergence test active the two forms sum the
+    squared update in a different order (tiles vs strided pixels), so a pair may stop one iteration apart when its error
+    grazes the threshold: the tolerances of the oracle comparison above; identical frames stop after exactly one iteration
+    in both (the first block is replayed with one iteration)."""
+    rng = np.random.default_rng(12)
+    for (h, w, iters, warps, scales) in ((64, 80, 7, 2, 3), (100, 132, 12, 3, 2), (256, 340, 5, 1, 5), (48, 50, 9, 2, 2)):
+        pairs = [_shifted_pair(h, w, float(rng.uniform(-3, 3)), float(rng.uniform(-2, 2)), seed=100 + k, margin=16) for k in range(3)]
+        f0, f1 = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+        out = {}
+        for form in ("1", "0"):
+            monkeypatch.setenv("VQ_FLOW_TWO_LAUNCH", form)
+            m = flow_mod.Tvl1Flow(4, h, w, epsilon=0.0, iterations=iters, warps=warps, nscales=scales)
+            out[form] = m.flow(f0, f1, iterations=True)
+            m.close()
+        assert (out["0"]["iters"] == iters).all() and (out["1"]["iters"] == iters).all()
+        assert (out["0"]["u1"] == out["1"]["u1"]).all() and (out["0"]["u2"] == out["1"]["u2"]).all()
+    # default parameters (convergence test active): same fields to the oracle tolerance, iteration counts at most one apart
+    pairs = [_shifted_pair(256, 340, dx, dy, seed=20 + k, margin=40) for k, (dx, dy) in enumerate([(2.0, 1.0), (-4.5, 0.5)])]
+    f0, f1 = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+    out = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("VQ_FLOW_TWO_LAUNCH", form)
+        m = flow_mod.Tvl1Flow(2, 256, 340)
+        out[form] = m.flow(f0, f1, iterations=True)
+        m.close()
+    assert np.abs(out["0"]["iters"] - out["1"]["iters"]).max() <= 1
+    assert np.abs(out["0"]["u1"] - out["1"]["u1"]).max() <= 2e-2 and np.abs(out["0"]["u2"] - out["1"]["u2"]).max() <= 2e-2

@@ -83,10 +83,20 @@ __device__ __forceinline__ float sample_bilinear(const float* __restrict__ a, in
     return top * (1.0f - wy) + bot * wy;
 }
 
-struct alignas(128) PairState {   // one cache line per pair: the error sums of different pairs never contend for a line
-    double err;          // sum of squared primal updates of the iteration in flight
-    int stop_iter;       // iterations >= stop_iter of the current warp do not run (INT_MAX while the inner loop is live)
-    int iters;           // inner iterations run in the current warp
+constexpr int kBlkIters = 4;      // inner iterations per launch of the blocked form (= the halo of a tile)
+struct BlkSched {                 // what a pair does in one launch of the blocked form
+    int mode;                     // kBlkRun: a block of n iterations; kBlkReplay: the exact n iterations of a block that ran past the stop; kBlkDone
+    int src;                      // the set of planes the launch reads (it writes the other one)
+    int base;                     // inner iterations completed before this launch
+    int n;                        // iterations this launch runs
+};
+constexpr int kBlkRun = 0, kBlkReplay = 1, kBlkDone = 2;
+struct alignas(128) PairState {   // own cache lines per pair: the error sums of different pairs never contend for a line
+    double err[3][kBlkIters];     // sums of squared primal updates; slot L % 3 belongs to launch L (the two-launch form uses err[0][0])
+    BlkSched blk[3];              // slot L % 3: the schedule of launch L (written by its first thread, read by launch L + 1)
+    int stop_iter;                // two-launch form: iterations >= stop_iter of the current warp do not run
+    int iters;                    // inner iterations run in the current warp
+    int final_set;                // the set of planes that holds the pair's fields when the warp's loop is over
 };
 constexpr int kNoStop = 0x7FFFFFFF;
 
@@ -110,7 +120,11 @@ __global__ void tvl1_warp_kernel(const float* __restrict__ i0, const float* __re
     grad[i] = wx * wx + wy * wy;
     rho_c[i] = w0 - wx * a - wy * b - i0[i];
     if (x == 0 && y == 0) {
-        st[p].err = 0.0;
+        for (int q = 0; q < 3; ++q) {
+            for (int m = 0; m < kBlkIters; ++m) st[p].err[q][m] = 0.0;
+            st[p].blk[q] = BlkSched{kBlkRun, 0, 0, 0};
+        }
+        st[p].final_set = 0;
         st[p].stop_iter = kNoStop;
         st[p].iters = 0;
     }
@@ -180,7 +194,7 @@ __global__ __launch_bounds__(256) void tvl1_primal_kernel(IterArgs a) {
         a.u1[g] = n1;
         a.u2[g] = n2;
     }
-    block_add(&a.st[p].err, local);
+    block_add(&a.st[p].err[0][0], local);
 }
 
 // Dual step.  Its first thread also closes the iteration: the squared update of the primal step just finished (complete: it
@@ -205,8 +219,8 @@ __global__ __launch_bounds__(256) void tvl1_dual_kernel(IterArgs a, double eps2,
         a.p22[g] = (a.p22[g] + a.taut * u2y) / ng2;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const double mean = a.st[p].err / (double)hw;
-        a.st[p].err = 0.0;
+        const double mean = a.st[p].err[0][0] / (double)hw;
+        a.st[p].err[0][0] = 0.0;
         a.st[p].iters = a.k + 1;
         if (!(mean > eps2) || a.k + 1 >= max_iters) {
             a.st[p].stop_iter = a.k + 1;
@@ -275,7 +289,7 @@ __global__ __launch_bounds__(256) void tvl1_primal_kernel4(IterArgs a) {
         *reinterpret_cast<floatx4*>(a.u1 + g) = n1v;
         *reinterpret_cast<floatx4*>(a.u2 + g) = n2v;
     }
-    block_add(&a.st[p].err, local);
+    block_add(&a.st[p].err[0][0], local);
 }
 
 __global__ __launch_bounds__(256) void tvl1_dual_kernel4(IterArgs a, double eps2, int max_iters, int* n_active) {
@@ -315,13 +329,240 @@ __global__ __launch_bounds__(256) void tvl1_dual_kernel4(IterArgs a, double eps2
         *reinterpret_cast<floatx4*>(a.p22 + g) = q22;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const double mean = a.st[p].err / (double)hw;
-        a.st[p].err = 0.0;
+        const double mean = a.st[p].err[0][0] / (double)hw;
+        a.st[p].err[0][0] = 0.0;
         a.st[p].iters = a.k + 1;
         if (!(mean > eps2) || a.k + 1 >= max_iters) {
             a.st[p].stop_iter = a.k + 1;
             atomicSub(n_active, 1);
         }
+    }
+}
+
+
+
+// ---- the blocked form: kBlkIters inner iterations per launch, the fields of a tile resident in LDS ----------------------------
+// The two-launch form streams every plane through the caches twice per inner iteration (22 floats per pixel) and needs two
+// dependent launches for it; on the coarse levels a launch is a few microseconds of work.  Here a workgroup loads a tile of
+// E x E pixels -- T x T of its own plus a halo of K = kBlkIters on every side -- ONCE: u1, u2, p11..p22 into LDS, the four constant
+// planes into registers (a thread owns fixed cells), runs n <= K iterations on it (primal step in place, barrier, dual step in
+// place, barrier: the primal step reads the dual variables of the left / upper neighbour, the dual step the new primal values of
+// the right / lower one, so the region whose values are exact shrinks by one pixel per iteration and side and is the tile itself
+// after K) and writes its T x T pixels to the OTHER set of planes.  Per pixel the operations and their order are those of the
+// kernels above: same bits.  Traffic per pixel and iteration: (10 x (E/T)^2 + 6) / K floats (5 at E = 56) instead of 22.
+//
+// The stopping rule stays EXACT (iteration k + 1 runs iff the mean squared update of iteration k exceeds epsilon^2): a block runs
+// its iterations speculatively and records every iteration's sum; the next launch reads them.  If the rule stopped inside the
+// block -- at its iteration j, not the last -- the block's output is too far: the set it READ is still intact (it wrote the
+// other one), so the pair runs exactly j + 1 iterations from it again ("replay": once per pair and warp) and is done.  Every
+// workgroup of a pair derives the schedule from the same numbers of the previous launch (slots L % 3: launch L writes its own,
+// reads those of L - 1 and clears those of L + 1, which nobody touches meanwhile); one thread records it.
+struct BlockArgs {
+    const float *i1wx, *i1wy, *grad, *rho_c;
+    float* set[2][6];                 // u1, u2, p11, p12, p21, p22 of set 0 and set 1
+    PairState* st;
+    int* n_active;
+    int h, w, L, max_iters;
+    float l_t, theta, taut;
+    double eps2;
+};
+
+__device__ __forceinline__ void primal_pixel(float ux, float uy, float gx, float gy, float gr, float rc, float div1, float div2, float l_t,
+                                             float theta, float& n1, float& n2, float& err) {
+    const float rho = rc + (gx * ux + gy * uy);
+    float d1, d2;
+    if (rho < -l_t * gr) {
+        d1 = l_t * gx;
+        d2 = l_t * gy;
+    } else if (rho > l_t * gr) {
+        d1 = -l_t * gx;
+        d2 = -l_t * gy;
+    } else if (gr > kGradIsZero) {
+        const float fi = -rho / gr;
+        d1 = fi * gx;
+        d2 = fi * gy;
+    } else {
+        d1 = d2 = 0.0f;
+    }
+    n1 = (ux + d1) + theta * div1;
+    n2 = (uy + d2) + theta * div2;
+    err = (n1 - ux) * (n1 - ux) + (n2 - uy) * (n2 - uy);
+}
+
+__device__ __forceinline__ BlkSched next_schedule(const PairState& st, int L, int hw, double eps2, int max_iters) {
+    if (L == 0) return BlkSched{kBlkRun, 0, 0, min(kBlkIters, max_iters)};
+    const BlkSched prev = st.blk[(L - 1) % 3];
+    if (prev.mode == kBlkDone) return prev;
+    if (prev.mode == kBlkReplay) return BlkSched{kBlkDone, 1 - prev.src, prev.base + prev.n, 0};
+    int j = -1;
+    for (int m = prev.n - 1; m >= 0; --m)
+        if (!(st.err[(L - 1) % 3][m] / (double)hw > eps2)) j = m;                 // the FIRST iteration whose update was small enough
+    if (j < 0) {
+        const int base = prev.base + prev.n;
+        if (base >= max_iters) return BlkSched{kBlkDone, 1 - prev.src, base, 0};
+        return BlkSched{kBlkRun, 1 - prev.src, base, min(kBlkIters, max_iters - base)};
+    }
+    if (j == prev.n - 1) return BlkSched{kBlkDone, 1 - prev.src, prev.base + prev.n, 0};
+    return BlkSched{kBlkReplay, prev.src, prev.base, j + 1};
+}
+
+template <int E>
+__global__ __launch_bounds__(512) void tvl1_block_kernel(BlockArgs a) {
+    // 512 threads as 32 x 16: a thread owns the cells (tx + 32 i, ty + 16 j) of the E x E tile
+    constexpr int K = kBlkIters, T = E - 2 * K, NI = (E + 31) / 32, NJ = (E + 15) / 16, PITCH = E + 1;
+    extern __shared__ float lds[];                       // u1, u2, p11, p12, p21, p22: [E][PITCH] each
+    __shared__ double part[8];
+    constexpr int PLANE = E * PITCH;
+    float* __restrict__ U1 = lds;
+    float* __restrict__ U2 = lds + PLANE;
+    float* __restrict__ P11 = lds + 2 * PLANE;
+    float* __restrict__ P12 = lds + 3 * PLANE;
+    float* __restrict__ P21 = lds + 4 * PLANE;
+    float* __restrict__ P22 = lds + 5 * PLANE;
+    const int p = blockIdx.z;
+    PairState& st = a.st[p];
+    const int hw = a.h * a.w;
+    const BlkSched cur = next_schedule(st, a.L, hw, a.eps2, a.max_iters);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const bool scribe = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+    if (scribe) {
+        st.blk[a.L % 3] = cur;
+        for (int m = 0; m < K; ++m) st.err[(a.L + 1) % 3][m] = 0.0;
+        if (cur.mode == kBlkDone && (a.L == 0 || st.blk[(a.L - 1) % 3].mode != kBlkDone)) {      // the pair has just finished
+            st.final_set = cur.src;
+            st.iters = cur.base;
+            atomicSub(a.n_active, 1);
+        }
+    }
+    if (cur.mode == kBlkDone) return;
+    const float* const* src = a.set[cur.src];
+    float* const* dst = a.set[1 - cur.src];
+    const int xo = (int)blockIdx.x * T - K, yo = (int)blockIdx.y * T - K;
+    const int64_t base = (int64_t)p * hw;
+    // A thread's own cells live in registers (fields and constants); LDS carries what NEIGHBOURS read: p11 / p21 of the left cell
+    // and p12 / p22 of the upper one for the primal step, the new u1 / u2 of the right and lower cell for the dual step.
+    float cgx[NJ][NI], cgy[NJ][NI], cgr[NJ][NI], crc[NJ][NI];
+    float ru1[NJ][NI], ru2[NJ][NI], r11[NJ][NI], r12[NJ][NI], r21[NJ][NI], r22[NJ][NI];
+    bool live[NJ][NI];                                    // the cell exists in the tile and in the image
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int cx = tx + 32 * i, cy = ty + 16 * j, x = xo + cx, y = yo + cy;
+            cgx[j][i] = cgy[j][i] = cgr[j][i] = crc[j][i] = 0.f;
+            ru1[j][i] = ru2[j][i] = r11[j][i] = r12[j][i] = r21[j][i] = r22[j][i] = 0.f;
+            live[j][i] = cx < E && cy < E && x >= 0 && x < a.w && y >= 0 && y < a.h;
+            if (live[j][i]) {
+                const int64_t g = base + (int64_t)y * a.w + x;
+                ru1[j][i] = src[0][g];
+                ru2[j][i] = src[1][g];
+                r11[j][i] = src[2][g];
+                r12[j][i] = src[3][g];
+                r21[j][i] = src[4][g];
+                r22[j][i] = src[5][g];
+                cgx[j][i] = a.i1wx[g];
+                cgy[j][i] = a.i1wy[g];
+                cgr[j][i] = a.grad[g];
+                crc[j][i] = a.rho_c[g];
+            }
+            if (cx < E && cy < E) {
+                const int c = cy * PITCH + cx;
+                P11[c] = r11[j][i];
+                P12[c] = r12[j][i];
+                P21[c] = r21[j][i];
+                P22[c] = r22[j][i];
+            }
+        }
+    __syncthreads();
+    for (int m = 0; m < cur.n; ++m) {
+        double local = 0.0;
+        // primal step (a cell reads its own old u and p, the p11 / p21 of its left and the p12 / p22 of its upper neighbour)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int cx = tx + 32 * i, cy = ty + 16 * j, x = xo + cx, y = yo + cy;
+                if (live[j][i]) {
+                    const int c = cy * PITCH + cx;
+                    const float q11 = r11[j][i], q12 = r12[j][i], q21 = r21[j][i], q22 = r22[j][i];
+                    // divergence: backward differences, p[-1] = 0 at the image border (a tile-edge cell is outside the exact region)
+                    const float l11 = cx > 0 ? P11[c - 1] : 0.f, l21 = cx > 0 ? P21[c - 1] : 0.f;
+                    const float t12 = cy > 0 ? P12[c - PITCH] : 0.f, t22 = cy > 0 ? P22[c - PITCH] : 0.f;
+                    const float div1 = (x > 0 ? q11 - l11 : q11) + (y > 0 ? q12 - t12 : q12);
+                    const float div2 = (x > 0 ? q21 - l21 : q21) + (y > 0 ? q22 - t22 : q22);
+                    float n1, n2, err;
+                    primal_pixel(ru1[j][i], ru2[j][i], cgx[j][i], cgy[j][i], cgr[j][i], crc[j][i], div1, div2, a.l_t, a.theta, n1, n2, err);
+                    ru1[j][i] = n1;
+                    ru2[j][i] = n2;
+                    U1[c] = n1;
+                    U2[c] = n2;
+                    if (cx >= K && cx < E - K && cy >= K && cy < E - K) local += (double)err;
+                }
+            }
+        // the tile's squared update of this iteration: one atomic per workgroup
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
+        __syncthreads();                                 // also: every new primal value is in LDS, every old p has been read
+        if (threadIdx.x == 0) {
+            const double sum = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+            if (sum != 0.0) atomicAdd(&st.err[a.L % 3][m], sum);
+        }
+        // dual step (a cell reads its own p and new u, the new u of its right and lower neighbour)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int cx = tx + 32 * i, cy = ty + 16 * j, x = xo + cx, y = yo + cy;
+                if (live[j][i]) {
+                    const int c = cy * PITCH + cx;
+                    const bool has_right = x + 1 < a.w && cx + 1 < E, below = y + 1 < a.h && cy + 1 < E;
+                    const float c1 = ru1[j][i], c2 = ru2[j][i];
+                    const float u1x = has_right ? U1[c + 1] - c1 : 0.0f, u1y = below ? U1[c + PITCH] - c1 : 0.0f;
+                    const float u2x = has_right ? U2[c + 1] - c2 : 0.0f, u2y = below ? U2[c + PITCH] - c2 : 0.0f;
+                    const float ng1 = 1.0f + a.taut * sqrtf(u1x * u1x + u1y * u1y);
+                    const float ng2 = 1.0f + a.taut * sqrtf(u2x * u2x + u2y * u2y);
+                    r11[j][i] = (r11[j][i] + a.taut * u1x) / ng1;
+                    r12[j][i] = (r12[j][i] + a.taut * u1y) / ng1;
+                    r21[j][i] = (r21[j][i] + a.taut * u2x) / ng2;
+                    r22[j][i] = (r22[j][i] + a.taut * u2y) / ng2;
+                    P11[c] = r11[j][i];
+                    P12[c] = r12[j][i];
+                    P21[c] = r21[j][i];
+                    P22[c] = r22[j][i];
+                }
+            }
+        __syncthreads();                                 // every new p is in LDS, every new u has been read
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int cx = tx + 32 * i, cy = ty + 16 * j, x = xo + cx, y = yo + cy;
+            if (live[j][i] && cx >= K && cx < E - K && cy >= K && cy < E - K) {
+                const int64_t g = base + (int64_t)y * a.w + x;
+                dst[0][g] = ru1[j][i];
+                dst[1][g] = ru2[j][i];
+                dst[2][g] = r11[j][i];
+                dst[3][g] = r12[j][i];
+                dst[4][g] = r21[j][i];
+                dst[5][g] = r22[j][i];
+            }
+        }
+}
+
+// After the inner loop of a warp: a pair whose fields ended in set 1 gets them copied back to set 0.
+struct SettleArgs {
+    float* set0[6];
+    const float* set1[6];
+};
+__global__ void tvl1_settle_kernel(const PairState* __restrict__ st, SettleArgs a, int hw) {
+    const int p = blockIdx.y;
+    if (st[p].final_set == 0) return;
+    for (int q = 0; q < 6; ++q) {
+        const float* src = a.set1[q] + (int64_t)p * hw;
+        float* dst = a.set0[q] + (int64_t)p * hw;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) dst[i] = src[i];
     }
 }
 
@@ -584,6 +825,7 @@ struct vq_flow {
     size_t pyr_floats = 0;                 // floats of one pair's pyramid
     float *pyr0 = nullptr, *pyr1 = nullptr;      // [level][pair][h_l][w_l]
     float* plane[12] = {nullptr};          // i1x, i1y, i1wx, i1wy, grad, rho_c, u1, u2 / p11, p12, p21, p22 at the current level ...
+    float* alt[6] = {nullptr};             // second set of u1, u2, p11, p12, p21, p22 (the one-launch iteration ping-pongs between the sets)
     float* tmp[2] = {nullptr, nullptr};    // flow of the coarser level while it is resized
     uint8_t* frames_dev[2] = {nullptr, nullptr};
     uint8_t* img_dev[2] = {nullptr, nullptr};
@@ -596,12 +838,15 @@ struct vq_flow {
     unsigned* frame_max = nullptr;         // [max_pairs] bit pattern of the largest corner strength of a frame
     void* match_dev = nullptr;             // RANSAC scratch (matches, winners, masks), grown on demand
     size_t match_bytes = 0;
+    bool two_launch = false;               // VQ_FLOW_TWO_LAUNCH=1 at creation: the round-2 primal + dual launch pair per inner iteration (A/B tests)
 };
 
 static void flow_free(vq_flow* f) {
     for (float* p : f->plane)
         if (p) (void)hipFree(p);
     for (float* p : f->tmp)
+        if (p) (void)hipFree(p);
+    for (float* p : f->alt)
         if (p) (void)hipFree(p);
     if (f->pyr0) (void)hipFree(f->pyr0);
     if (f->pyr1) (void)hipFree(f->pyr1);
@@ -656,6 +901,12 @@ int vq_flow_create(int32_t max_pairs, int32_t h, int32_t w, const vq_tvl1_params
     f->h = h;
     f->w = w;
     f->prm = prm;
+    {
+        const char* e2 = getenv("VQ_FLOW_TWO_LAUNCH");
+        f->two_launch = e2 && *e2 == '1';
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tvl1_block_kernel<56>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   6 * 56 * 57 * (int)sizeof(float)));
+    }
     // level sizes, finest first: round(previous * scale_step), stop before 16 pixels (oracle.pyramid_sizes)
     size_t off = 0;
     int lh = h, lw = w;
@@ -682,6 +933,8 @@ int vq_flow_create(int32_t max_pairs, int32_t h, int32_t w, const vq_tvl1_params
     for (float*& p : f->plane)
         if ((e = hipMalloc((void**)&p, full * sizeof(float))) != hipSuccess) return bail("hipMalloc(plane)", e);
     for (float*& p : f->tmp)
+        if ((e = hipMalloc((void**)&p, full * sizeof(float))) != hipSuccess) return bail("hipMalloc(plane)", e);
+    for (float*& p : f->alt)
         if ((e = hipMalloc((void**)&p, full * sizeof(float))) != hipSuccess) return bail("hipMalloc(plane)", e);
     for (int k = 0; k < 2; ++k) {
         if ((e = hipMalloc((void**)&f->frames_dev[k], full)) != hipSuccess) return bail("hipMalloc(frames)", e);
@@ -811,13 +1064,56 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
         const bool vec = L.w % 4 == 0;
         const dim3 grid4((unsigned)cdiv((int64_t)L.h * L.w / 4, 256), (unsigned)n_pairs);
         const dim3 grid4p(std::min(grid4.x, 32u), (unsigned)n_pairs);      // primal: few blocks per pair = few atomics on its error sum
+        // the blocked form: tiles of T x T own pixels (+ a halo of kBlkIters) per 256-thread workgroup
+        constexpr int E = 56, T = E - 2 * kBlkIters;
+        const dim3 bgrid((unsigned)cdiv(L.w, T), (unsigned)cdiv(L.h, T), (unsigned)n_pairs);
+        const size_t blds = (size_t)6 * E * (E + 1) * sizeof(float);
+        BlockArgs ba;
+        ba.i1wx = i1wx;
+        ba.i1wy = i1wy;
+        ba.grad = grad;
+        ba.rho_c = rho_c;
+        ba.st = f->st;
+        ba.n_active = f->n_active;
+        ba.h = L.h;
+        ba.w = L.w;
+        ba.max_iters = P.iterations;
+        ba.l_t = a.l_t;
+        ba.theta = a.theta;
+        ba.taut = a.taut;
+        ba.eps2 = eps2;
+        float* set[2][6] = {{u1, u2, p11, p12, p21, p22}, {f->alt[0], f->alt[1], f->alt[2], f->alt[3], f->alt[4], f->alt[5]}};
+        SettleArgs sa;
+        for (int q = 0; q < 6; ++q) {
+            sa.set0[q] = ba.set[0][q] = set[0][q];
+            sa.set1[q] = ba.set[1][q] = set[1][q];
+        }
         for (int wp = 0; wp < P.warps; ++wp) {
             tvl1_warp_kernel<<<cdiv(tot, 256), 256, 0, st>>>(i0, i1, i1x, i1y, u1, u2, i1wx, i1wy, grad, rho_c, f->st, f->n_active, n_pairs, L.h, L.w);
             // Converged pairs switch themselves off on the device (their workgroups exit at once).  The host polls the number
             // of live pairs once per chunk of iterations, one chunk BEHIND what it has queued: the stream never runs dry while
             // the host waits, at the price of at most one chunk of empty launches after the last pair has stopped.
             int chunk_no = 0;
-            for (int it = 0; it < P.iterations; ++chunk_no) {
+            if (!f->two_launch) {
+                // blocks of kBlkIters iterations; a pair needs at most ceil(iterations / K) blocks, one replay and one closing launch
+                const int max_launches = cdiv(P.iterations, kBlkIters) + 2;
+                for (int l0 = 0; l0 < max_launches; ++chunk_no) {
+                    const int chunk = std::min(max_launches - l0, l0 < 4 ? 2 : 4);
+                    for (int k = 0; k < chunk; ++k) {
+                        ba.L = l0 + k;
+                        tvl1_block_kernel<E><<<bgrid, 512, blds, st>>>(ba);
+                    }
+                    VQ_CHECK_LAUNCH();
+                    l0 += chunk;
+                    VQ_HIP(hipMemcpyAsync(f->live_host + (chunk_no & 1), f->n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+                    VQ_HIP(hipEventRecord(f->poll_ev[chunk_no & 1], st));
+                    if (chunk_no > 0) {
+                        VQ_HIP(hipEventSynchronize(f->poll_ev[(chunk_no - 1) & 1]));
+                        if (f->live_host[(chunk_no - 1) & 1] == 0) break;
+                    }
+                }
+            }
+            for (int it = 0; f->two_launch && it < P.iterations; ++chunk_no) {
                 const int chunk = std::min(P.iterations - it, it < 16 ? 8 : 16);
                 for (int k = 0; k < chunk; ++k) {
                     a.k = it + k;
@@ -837,6 +1133,10 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
                     VQ_HIP(hipEventSynchronize(f->poll_ev[(chunk_no - 1) & 1]));
                     if (f->live_host[(chunk_no - 1) & 1] == 0) break;
                 }
+            }
+            if (!f->two_launch) {
+                tvl1_settle_kernel<<<dim3((unsigned)std::min(cdiv((int64_t)L.h * L.w, 256), 32), (unsigned)n_pairs), 256, 0, st>>>(f->st, sa, L.h * L.w);
+                VQ_CHECK_LAUNCH();
             }
             if (iters_host)
                 log_iters_kernel<<<cdiv(n_pairs, 256), 256, 0, st>>>(f->st, f->iters_log + ((size_t)(nl - 1 - s) * P.warps + wp) * n_pairs, n_pairs);
