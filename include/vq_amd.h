@@ -327,6 +327,9 @@ int vq_flow_levels(vq_flow* flow, int32_t* n_levels, int32_t* sizes_hw, int32_t 
 int vq_flow_tvl1(vq_flow* flow, const uint8_t* frames0, const uint8_t* frames1, int32_t frames_on_device, int32_t n_pairs,
                  const double* homographies_host, float* u1_host, float* u2_host, uint8_t* flow_x_host, uint8_t* flow_y_host,
                  int32_t* iters_host, void* hip_stream);
+/* Device time of the inner loops (the iteration kernels of every level and warp: HIP events around each loop, summed) and the
+ * number of iteration-kernel launches of the LAST vq_flow_tvl1 call on this handle -- what bench.py prices the kernel with. */
+int vq_flow_last_timing(vq_flow* flow, double* inner_loops_ms, int32_t* iteration_launches);
 
 /* Camera-motion estimation, the flow-match branch of extract_warp_gpu's "warp" step (improved dense trajectories, Wang &
  * Schmid 2013, as dense_flow applies it): Shi-Tomasi corners of the first frame (cv::goodFeaturesToTrack semantics: 3x3 block,

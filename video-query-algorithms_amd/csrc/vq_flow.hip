@@ -349,7 +349,12 @@ __global__ __launch_bounds__(256) void tvl1_dual_kernel4(IterArgs a, double eps2
 // place, barrier: the primal step reads the dual variables of the left / upper neighbour, the dual step the new primal values of
 // the right / lower one, so the region whose values are exact shrinks by one pixel per iteration and side and is the tile itself
 // after K) and writes its T x T pixels to the OTHER set of planes.  Per pixel the operations and their order are those of the
-// kernels above: same bits.  Traffic per pixel and iteration: (10 x (E/T)^2 + 6) / K floats (5 at E = 56) instead of 22.
+// kernels above: same bits.  Traffic per pixel and iteration: (10 x (E/T)^2 + 6) / K floats (4.8 at E = 64) instead of 22.  What the
+// kernel is bound by after that is arithmetic: five correctly rounded divisions and two square roots per pixel and iteration.
+// Shapes measured on 64 pairs of 340 x 256 (two-launch form: 39.2 ms per batch): E = 56 with 256 threads and every field in LDS
+// 41.6 ms; 512 threads 41.5; own cells in registers, LDS for the neighbours' values only 36.5; the same without branches around
+// dead cells and with the thresholding as selects 39.1 (the division then runs for every cell); forced to 128 VGPRs for two
+// workgroups per CU 49.0 (spills); E = 64 with 1024 threads (four cells per thread, no idle slots, 16 waves per CU) 29.9.
 //
 // The stopping rule stays EXACT (iteration k + 1 runs iff the mean squared update of iteration k exceeds epsilon^2): a block runs
 // its iterations speculatively and records every iteration's sum; the next launch reads them.  If the rule stopped inside the
@@ -406,12 +411,12 @@ __device__ __forceinline__ BlkSched next_schedule(const PairState& st, int L, in
     return BlkSched{kBlkReplay, prev.src, prev.base, j + 1};
 }
 
-template <int E>
-__global__ __launch_bounds__(512) void tvl1_block_kernel(BlockArgs a) {
-    // 512 threads as 32 x 16: a thread owns the cells (tx + 32 i, ty + 16 j) of the E x E tile
-    constexpr int K = kBlkIters, T = E - 2 * K, NI = (E + 31) / 32, NJ = (E + 15) / 16, PITCH = E + 1;
+template <int E, int NT>
+__global__ __launch_bounds__(NT) void tvl1_block_kernel(BlockArgs a) {
+    // NT threads as 32 x RY: a thread owns the cells (tx + 32 i, ty + RY j) of the E x E tile
+    constexpr int K = kBlkIters, T = E - 2 * K, RY = NT / 32, NI = (E + 31) / 32, NJ = (E + RY - 1) / RY, PITCH = E + 1;
     extern __shared__ float lds[];                       // u1, u2, p11, p12, p21, p22: [E][PITCH] each
-    __shared__ double part[8];
+    __shared__ double part[NT / 64];
     constexpr int PLANE = E * PITCH;
     float* __restrict__ U1 = lds;
     float* __restrict__ U2 = lds + PLANE;
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(512) void tvl1_block_kernel(BlockArgs a) {
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int cx = tx + 32 * i, cy = ty + 16 * j, x = xo + cx, y = yo + cy;
+            const int cx = tx + 32 * i, cy = ty + RY * j, x = xo + cx, y = yo + cy;
             cgx[j][i] = cgy[j][i] = cgr[j][i] = crc[j][i] = 0.f;
             ru1[j][i] = ru2[j][i] = r11[j][i] = r12[j][i] = r21[j][i] = r22[j][i] = 0.f;
             live[j][i] = cx < E && cy < E && x >= 0 && x < a.w && y >= 0 && y < a.h;
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(512) void tvl1_block_kernel(BlockArgs a) {
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int cx = tx + 32 * i, cy = ty + 16 * j, x = xo + cx, y = yo + cy;
+                const int cx = tx + 32 * i, cy = ty + RY * j, x = xo + cx, y = yo + cy;
                 if (live[j][i]) {
                     const int c = cy * PITCH + cx;
                     const float q11 = r11[j][i], q12 = r12[j][i], q21 = r21[j][i], q22 = r22[j][i];
@@ -505,7 +510,9 @@ __global__ __launch_bounds__(512) void tvl1_block_kernel(BlockArgs a) {
         if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
         __syncthreads();                                 // also: every new primal value is in LDS, every old p has been read
         if (threadIdx.x == 0) {
-            const double sum = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+            double sum = 0.0;
+#pragma unroll
+            for (int q = 0; q < NT / 64; ++q) sum += part[q];
             if (sum != 0.0) atomicAdd(&st.err[a.L % 3][m], sum);
         }
         // dual step (a cell reads its own p and new u, the new u of its right and lower neighbour)
@@ -513,7 +520,7 @@ __global__ __launch_bounds__(512) void tvl1_block_kernel(BlockArgs a) {
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int cx = tx + 32 * i, cy = ty + 16 * j, x = xo + cx, y = yo + cy;
+                const int cx = tx + 32 * i, cy = ty + RY * j, x = xo + cx, y = yo + cy;
                 if (live[j][i]) {
                     const int c = cy * PITCH + cx;
                     const bool has_right = x + 1 < a.w && cx + 1 < E, below = y + 1 < a.h && cy + 1 < E;
@@ -538,7 +545,7 @@ __global__ __launch_bounds__(512) void tvl1_block_kernel(BlockArgs a) {
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int cx = tx + 32 * i, cy = ty + 16 * j, x = xo + cx, y = yo + cy;
+            const int cx = tx + 32 * i, cy = ty + RY * j, x = xo + cx, y = yo + cy;
             if (live[j][i] && cx >= K && cx < E - K && cy >= K && cy < E - K) {
                 const int64_t g = base + (int64_t)y * a.w + x;
                 dst[0][g] = ru1[j][i];
@@ -838,6 +845,9 @@ struct vq_flow {
     unsigned* frame_max = nullptr;         // [max_pairs] bit pattern of the largest corner strength of a frame
     void* match_dev = nullptr;             // RANSAC scratch (matches, winners, masks), grown on demand
     size_t match_bytes = 0;
+    std::vector<hipEvent_t> loop_ev;       // a start / stop pair around the inner loop of every (level, warp) of a call
+    double last_inner_ms = 0.0;            // device time of those loops in the last vq_flow_tvl1 call (sum of the pairs)
+    int last_iter_launches = 0;            // iteration-kernel launches of the last call
     bool two_launch = false;               // VQ_FLOW_TWO_LAUNCH=1 at creation: the round-2 primal + dual launch pair per inner iteration (A/B tests)
 };
 
@@ -859,6 +869,8 @@ static void flow_free(vq_flow* f) {
     if (f->iters_log) (void)hipFree(f->iters_log);
     if (f->live_host) (void)hipHostFree(f->live_host);
     for (hipEvent_t e : f->poll_ev)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : f->loop_ev)
         if (e) (void)hipEventDestroy(e);
     if (f->hinv_dev) (void)hipFree(f->hinv_dev);
     if (f->frame_max) (void)hipFree(f->frame_max);
@@ -904,8 +916,8 @@ int vq_flow_create(int32_t max_pairs, int32_t h, int32_t w, const vq_tvl1_params
     {
         const char* e2 = getenv("VQ_FLOW_TWO_LAUNCH");
         f->two_launch = e2 && *e2 == '1';
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tvl1_block_kernel<56>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   6 * 56 * 57 * (int)sizeof(float)));
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tvl1_block_kernel<64, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   6 * 64 * 65 * (int)sizeof(float)));
     }
     // level sizes, finest first: round(previous * scale_step), stop before 16 pixels (oracle.pyramid_sizes)
     size_t off = 0;
@@ -947,6 +959,9 @@ int vq_flow_create(int32_t max_pairs, int32_t h, int32_t w, const vq_tvl1_params
     if ((e = hipHostMalloc((void**)&f->live_host, 2 * sizeof(int))) != hipSuccess) return bail("hipHostMalloc(poll)", e);
     for (hipEvent_t& ev : f->poll_ev)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    f->loop_ev.assign((size_t)2 * f->levels.size() * prm.warps, nullptr);
+    for (hipEvent_t& ev : f->loop_ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc((void**)&f->hinv_dev, (size_t)max_pairs * 9 * sizeof(double))) != hipSuccess) return bail("hipMalloc(homographies)", e);
     if ((e = hipMalloc((void**)&f->frame_max, (size_t)max_pairs * sizeof(unsigned))) != hipSuccess) return bail("hipMalloc(state)", e);
     *out = f;
@@ -1035,6 +1050,7 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
         VQ_HIP(hipMemsetAsync(u2, 0, (size_t)n_pairs * c.h * c.w * sizeof(float), st));
     }
     const double eps2 = (double)P.epsilon * (double)P.epsilon;      // oracle: float(float32(epsilon)) ** 2
+    int iter_launches = 0;
     for (int s = nl - 1; s >= 0; --s) {
         const Level& L = f->levels[s];
         const int64_t tot = (int64_t)n_pairs * L.h * L.w;
@@ -1065,7 +1081,7 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
         const dim3 grid4((unsigned)cdiv((int64_t)L.h * L.w / 4, 256), (unsigned)n_pairs);
         const dim3 grid4p(std::min(grid4.x, 32u), (unsigned)n_pairs);      // primal: few blocks per pair = few atomics on its error sum
         // the blocked form: tiles of T x T own pixels (+ a halo of kBlkIters) per 256-thread workgroup
-        constexpr int E = 56, T = E - 2 * kBlkIters;
+        constexpr int E = 64, NT = 1024, T = E - 2 * kBlkIters;
         const dim3 bgrid((unsigned)cdiv(L.w, T), (unsigned)cdiv(L.h, T), (unsigned)n_pairs);
         const size_t blds = (size_t)6 * E * (E + 1) * sizeof(float);
         BlockArgs ba;
@@ -1094,6 +1110,8 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
             // of live pairs once per chunk of iterations, one chunk BEHIND what it has queued: the stream never runs dry while
             // the host waits, at the price of at most one chunk of empty launches after the last pair has stopped.
             int chunk_no = 0;
+            const size_t ev_i = 2 * ((size_t)(nl - 1 - s) * P.warps + wp);
+            VQ_HIP(hipEventRecord(f->loop_ev[ev_i], st));
             if (!f->two_launch) {
                 // blocks of kBlkIters iterations; a pair needs at most ceil(iterations / K) blocks, one replay and one closing launch
                 const int max_launches = cdiv(P.iterations, kBlkIters) + 2;
@@ -1101,7 +1119,8 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
                     const int chunk = std::min(max_launches - l0, l0 < 4 ? 2 : 4);
                     for (int k = 0; k < chunk; ++k) {
                         ba.L = l0 + k;
-                        tvl1_block_kernel<E><<<bgrid, 512, blds, st>>>(ba);
+                        tvl1_block_kernel<E, NT><<<bgrid, NT, blds, st>>>(ba);
+                        ++iter_launches;
                     }
                     VQ_CHECK_LAUNCH();
                     l0 += chunk;
@@ -1124,6 +1143,7 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
                         tvl1_primal_kernel<<<grid, 256, 0, st>>>(a);
                         tvl1_dual_kernel<<<grid, 256, 0, st>>>(a, eps2, P.iterations, f->n_active);
                     }
+                    iter_launches += 2;
                 }
                 VQ_CHECK_LAUNCH();
                 it += chunk;
@@ -1134,6 +1154,7 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
                     if (f->live_host[(chunk_no - 1) & 1] == 0) break;
                 }
             }
+            VQ_HIP(hipEventRecord(f->loop_ev[ev_i + 1], st));
             if (!f->two_launch) {
                 tvl1_settle_kernel<<<dim3((unsigned)std::min(cdiv((int64_t)L.h * L.w, 256), 32), (unsigned)n_pairs), 256, 0, st>>>(f->st, sa, L.h * L.w);
                 VQ_CHECK_LAUNCH();
@@ -1164,6 +1185,21 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
         if (flow_y_host) VQ_HIP(hipMemcpyAsync(flow_y_host, f->img_dev[1], (size_t)full, hipMemcpyDeviceToHost, st));
     }
     VQ_HIP(hipStreamSynchronize(st));
+    f->last_iter_launches = iter_launches;
+    f->last_inner_ms = 0.0;
+    for (size_t q = 0; q + 1 < f->loop_ev.size(); q += 2) {
+        float ms = 0.f;
+        VQ_HIP(hipEventElapsedTime(&ms, f->loop_ev[q], f->loop_ev[q + 1]));
+        f->last_inner_ms += ms;
+    }
+    return VQ_OK;
+}
+
+int vq_flow_last_timing(vq_flow* f, double* inner_loops_ms, int32_t* iteration_launches) {
+    VQ_REQUIRE(f, "NULL argument");
+    std::lock_guard<std::mutex> lk(f->mu);
+    if (inner_loops_ms) *inner_loops_ms = f->last_inner_ms;
+    if (iteration_launches) *iteration_launches = f->last_iter_launches;
     return VQ_OK;
 }
 

@@ -67,6 +67,12 @@ class Tvl1Flow:
              hm.ctypes.data_as(C.c_void_p) if hm is not None else None, ptr("u1"), ptr("u2"), ptr("flow_x"), ptr("flow_y"), ptr("iters"), None)
         return out
 
+    def last_timing(self):
+        """(device ms of the inner loops, iteration-kernel launches) of the last ``flow`` call (HIP events inside the library)."""
+        ms, n = C.c_double(), C.c_int32()
+        call("vq_flow_last_timing", self._h, C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
     def consecutive(self, frames: np.ndarray):
         """Grey frames [n + 1, h, w] of a video -> (flow_x, flow_y) uint8 [n, h, w] between consecutive frames
         (``extract_warp_gpu -s 1``), in batches of ``max_pairs``."""
