@@ -143,10 +143,13 @@ def test_committed_libjpeg_fixtures(jpeg):
 
 
 @needs_pil
-def test_damaged_files_never_take_the_process_down(jpeg):
+@pytest.mark.parametrize("form", ["1", "0"])
+def test_damaged_files_never_take_the_process_down(jpeg, monkeypatch, form):
     """600 random mutations (overwritten bytes, truncation, a 4-byte splice) of four valid files: every one is either decoded
-    to SOMETHING of the right shape or refused with VqError; the handle keeps working."""
+    to SOMETHING of the right shape or refused with VqError; the handle keeps working.  Both entropy decoders: on host threads
+    (form 1) and on the device (form 0: a lane per stream must stay inside its stream, its ring and its block whatever the bits say)."""
     from video_query_algorithms_amd import VqError
+    monkeypatch.setenv("VQ_JPEG_HOST_HUFFMAN", form)
     rng = np.random.default_rng(0)
     dec = jpeg.JpegDecoder(2, 48, 64)
     seeds = [encode(picture(48, 64, 1), quality=90, subsampling=2), encode(picture(48, 64, 2), quality=70, subsampling=1, restart_marker_blocks=2),
@@ -170,3 +173,41 @@ def test_damaged_files_never_take_the_process_down(jpeg):
     assert decoded > 100 and refused > 100
     assert (dec.decode([seeds[0]])[0] == pil_bgr(seeds[0])).all()
     dec.close()
+
+
+@needs_pil
+def test_device_entropy_decoding_equals_the_host_decoder(jpeg, monkeypatch):
+    """Huffman decoding on the device (one lane per stream: a frame's scan, or one restart interval of it; streams grouped by
+    Huffman table set) against the host decoder of rounds 1-2 (VQ_JPEG_HOST_HUFFMAN=1 when the handle is created) and against
+    libjpeg-turbo: the same pixels, bit for bit, on a batch that mixes 4:2:0 / 4:2:2 / 4:4:4 / grey files, per-file optimised
+    tables (several table sets in one batch: several waves), restart intervals of 1, 2 and 5 MCU rows, odd sizes; more than 64
+    streams of one table set (more than one wave) and a batch of one."""
+    h, w = 72, 104
+    files = []
+    for k, (q, sub) in enumerate([(95, 2), (80, 1), (60, 0), (30, 2), (90, 2)]):
+        files.append(encode(picture(h, w, 10 * k + 3), quality=q, subsampling=sub))
+    files.append(encode(picture(h, w, 77)[:, :, 1], quality=88))
+    files.append(encode(picture(h, w, 5), quality=85, subsampling=2, optimize=True))
+    files.append(encode(picture(h, w, 6), quality=75, subsampling=0, optimize=True))
+    try:
+        for rows in (1, 2, 5):
+            files.append(encode(picture(h, w, 20 + rows), quality=85, subsampling=2, restart_marker_rows=rows))
+        files.append(encode(picture(h, w, 31), quality=85, subsampling=1, restart_marker_blocks=3))
+    except TypeError:
+        pass                                      # an older Pillow without restart-marker options
+    files += [encode(picture(h, w, 100 + k), quality=92, subsampling=2) for k in range(70)]      # > 64 streams of one set
+    out = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("VQ_JPEG_HOST_HUFFMAN", form)
+        dec = jpeg.JpegDecoder(len(files), h, w)
+        out[form] = dec.decode(files)
+        one = dec.decode(files[8:9])
+        assert (one[0] == out[form][8]).all()
+        dec.close()
+    assert (out["0"] == out["1"]).all()
+    for i in (0, 1, 2, 6, 7, len(files) - 1):
+        assert (out["0"][i] == pil_bgr(files[i])).all()
+    grey = jpeg.JpegDecoder(4, h, w)
+    g = grey.decode([files[5], files[0]], color=False)
+    assert (g[0] == np.asarray(Image.open(io.BytesIO(files[5])).convert("L"))).all()
+    grey.close()

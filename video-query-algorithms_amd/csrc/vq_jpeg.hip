@@ -7,9 +7,19 @@
 // The arithmetic is the one restated in oracle/jpeg_oracle.py, which is pinned bit for bit against libjpeg-turbo (through
 // Pillow): the same bits come out here.
 //
-// Split of the work: the entropy-coded segment is a serial bit stream -- marker parsing and Huffman decoding (ITU-T T.81
-// F.2.2) run on the host, one frame per host thread, into 16-bit coefficient blocks; everything that is data-parallel
-// runs on the GPU for the whole batch of frames at once:
+// Split of the work.  An entropy-coded segment is a serial bit stream, but a BATCH of frames is many independent streams (and a
+// file written with restart intervals is several): the host only parses the marker segments and strips the byte stuffing
+// (FF 00 -> FF, one pass per file on host threads, cut at the RSTn markers), the compressed bytes go to the device as they are
+// (a quarter of the size of the coefficients) and Huffman decoding (ITU-T T.81 F.2.2) runs there, one LANE per stream:
+//   jpeg_entropy_idct_kernel   a DECODER wave decodes 64 streams side by side (64-bit bit buffer per lane fed from an LDS ring of the
+//                         stream's words, an 11-bit look-up + loop-free canonical decoding of the files' Huffman tables in LDS --
+//                         streams are grouped by table set: all files of one writer share one --, DC prediction per lane), one block
+//                         per lane and round into an LDS image; a WRITER wave of the same workgroup turns the round's 64 blocks into
+//                         pixels (dequantisation + IDCT in registers) and keeps the rings filled.  Throughput comes from the number
+//                         of streams in flight (a symbol costs a lane ~600 cycles whatever the other lanes do): from LARGE batches.
+// The host decoder of rounds 1-2 (one frame per host thread into 16-bit coefficient blocks, then jpeg_idct_kernel) serves the small
+// batches (fewer than VQ_JPEG_DEVICE_MIN_STREAMS = 2 048 streams; VQ_JPEG_HOST_HUFFMAN=1 / 0 forces one or the other): same pixels,
+// same errors (tested).  Everything that is data-parallel follows on the GPU for the whole batch of frames at once:
 //   jpeg_idct_kernel      one thread per 8x8 block: dequantise, two-pass 13-bit fixed-point IDCT in registers, +128, clamp,
 //                         eight 8-byte row stores into the component plane
 //   jpeg_pixels_kernel    one thread per output pixel: h2v2 / h2v1 triangle-filter upsampling of the chroma planes with
@@ -43,7 +53,7 @@ struct Huff {
 
 bool build_huff(const uint8_t* counts, const uint8_t* symbols, int n_symbols, Huff& h) {
     int code = 0, k = 0;
-    memset(h.look_len, 0, sizeof h.look_len);
+    memset(&h, 0, sizeof h);             // every byte defined: identical tables of different files compare equal
     for (int ln = 1; ln <= 16; ++ln) {
         h.valptr[ln] = k;
         h.mincode[ln] = code;
@@ -295,6 +305,76 @@ int decode_scan(const uint8_t* d, size_t n, Frame& f, int16_t* coef, const size_
 
 // ---- device side ------------------------------------------------------------------------------------------------------
 
+// ---- entropy decoding on the device -----------------------------------------------------------------------------------
+
+constexpr int kFastBits = 11;
+struct DevHuff {               // one Huffman table as the decoder wants it
+    uint16_t fast[1 << kFastBits];   // the next 11 bits -> (code length << 8) | symbol, 0 = the code is longer
+    uint32_t lim[8];           // codes of 12..16 bits without a loop: lim[l - 12] = first left-aligned 16-bit pattern that is NOT a code of
+                               // <= l bits (non-decreasing); the length is 12 + the number of limits the next 16 bits reach
+    int32_t valptr[17];        // canonical decoding (T.81 F.2.2.3): index of the first symbol of every length ...
+    int32_t mincode[17];       // ... and its code
+    uint8_t vals[256];
+    uint8_t pad[8];
+};
+static_assert(sizeof(DevHuff) == 4096 + 32 + 68 + 68 + 256 + 8 && sizeof(DevHuff) % 16 == 0, "DevHuff layout");
+struct DevTableSet {           // the tables a frame's components use: DC, AC of component 0, 1, 2
+    DevHuff t[6];
+};
+struct SegDesc {               // one stream: a frame's scan, or one restart interval of it
+    uint32_t word_off, n_words;          // its unstuffed bytes inside the batch's stream buffer (32-bit words, zero padded)
+    int32_t frame;                       // -1: padding of a wave
+    int32_t mcu0, mcu1;                  // MCUs [mcu0, mcu1) of the frame
+    int32_t set;                         // its table set (the same for all 64 streams of a wave)
+};
+struct EntFrame {              // what the decoder needs to place a frame's blocks
+    int32_t nc, mx;                      // components, MCUs per row
+    int32_t h[3], v[3], bw[3];           // blocks per MCU in x / y, blocks per plane row
+    uint32_t coef_off[3];                // first block of each component in the coefficient buffer
+};
+
+struct DevBits {
+    const uint32_t* w;
+    uint32_t p, end;
+    uint64_t acc;
+    int bits;
+    __device__ __forceinline__ void refill() {            // >= 33 bits afterwards; behind the stream: zeros, as the host reader
+        if (bits <= 32) {
+            const uint32_t x = p < end ? __builtin_bswap32(w[p]) : 0u;
+            ++p;
+            acc = (acc << 32) | x;
+            bits += 32;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(int k) const { return (uint32_t)(acc >> (bits - k)) & ((1u << k) - 1u); }
+    __device__ __forceinline__ uint32_t get(int k) {
+        const uint32_t v = peek(k);
+        bits -= k;
+        return v;
+    }
+};
+
+// 64 lanes decode side by side: whatever ONE lane needs, the wave executes.  So the common case is one look-up (11 bits cover all
+// but a fraction of a percent of the symbols of a typical table) and the long codes take a loop-free path.  Needs >= 16 bits.
+__device__ __forceinline__ int dev_symbol(DevBits& br, const DevHuff& h) {
+    const uint32_t look = br.peek(16);
+    const uint32_t e = h.fast[look >> (16 - kFastBits)];
+    if (e) {
+        br.bits -= (int)(e >> 8);
+        return (int)(e & 255u);
+    }
+    int l = kFastBits + 1;
+#pragma unroll
+    for (int i = 0; i < 16 - kFastBits; ++i) l += look >= h.lim[i] ? 1 : 0;
+    if (l > 16) return -1;
+    br.bits -= l;
+    const int idx = h.valptr[l] + (int)(look >> (16 - l)) - h.mincode[l];
+    return idx >= 0 && idx < 256 ? h.vals[idx] : -1;
+}
+
+__device__ __forceinline__ int dev_extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+
+
 struct PlaneDesc {             // one component of one frame
     unsigned coef_off;         // first block (in blocks) inside the batch's coefficient buffer
     unsigned plane_off;        // first byte inside the batch's plane buffer
@@ -387,6 +467,245 @@ __global__ __launch_bounds__(128) void jpeg_idct_kernel(const int16_t* __restric
     }
 }
 
+// Entropy decoding + IDCT of the batch: a workgroup = a DECODER wave (one stream per lane) and a WRITER wave.  Per round every
+// decoder lane decodes ONE block of its stream into its slot of an LDS image (natural order, 16-bit); behind the round's barrier the
+// writer wave takes the 64 blocks over -- dequantisation, the two IDCT passes in registers, eight 8-byte row stores into the
+// component plane, the slot cleared for its next use -- while the decoder wave is already in the next block (two images).  The
+// split is what makes the decoder fast: a wave's vector-memory operations complete in order, so a lane that stored coefficients
+// itself waited for its own scattered stores at every refill of its bit buffer (measured: 1 900 cycles per symbol); now the
+// decoder wave only LOADS (the next word of every stream is requested one refill ahead) and the stores are another wave's.
+// status[s]: 0 ok, 1 corrupt DC, 2 corrupt AC, 3 run past the block.
+struct BlockOut {              // where a decoded block goes (written by the decoder lane, read by the writer lane)
+    uint32_t plane_off;        // byte offset of its first pixel in the batch's plane buffer; 0xFFFFFFFF = no block this round
+    uint32_t stride;           // bytes per plane row
+    uint32_t qt;               // its quantisation table
+};
+// kUnzig[n] = position in zigzag order of the coefficient with natural index n (the inverse of kZigzag)
+constexpr int kUnzig[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30, 41, 43, 9,  11, 18, 24, 31, 40, 44, 53,
+                            10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+constexpr int kBlkPitch = 66;  // 16-bit slots per lane in the LDS image: 33 dwords, so that lanes land in different banks
+constexpr int kRing = 128;     // words of every stream kept in LDS ahead of its decoder lane (a block needs 8 on average, 54 at most)
+constexpr int kRingPitch = kRing + 1;
+
+__global__ __launch_bounds__(128) void jpeg_entropy_idct_kernel(const SegDesc* __restrict__ segs, const EntFrame* __restrict__ frames,
+                                                               const FrameDesc* __restrict__ fdesc, const DevTableSet* __restrict__ sets,
+                                                               const uint32_t* __restrict__ words, const uint16_t* __restrict__ qts,
+                                                               uint8_t* __restrict__ planes, int* __restrict__ status, long long* stamps) {
+    __shared__ DevTableSet ts;
+    __shared__ int16_t img[2][64 * kBlkPitch];
+    long long t_work = 0, t_wait = 0, t_a = 0, t_b = 0;
+    __shared__ BlockOut outd[2][64];
+    __shared__ uint32_t ring[64 * kRingPitch];             // ring[lane][word index % kRing]: the stream's next words, filled by the writer wave
+    __shared__ uint32_t ring_hi[64], ring_lo[64];          // words [0, ring_hi) are in the ring (written by the writer); the decoder is at ring_lo
+    __shared__ int rounds_s;
+    const int lane = threadIdx.x & 63;
+    const bool decoder = threadIdx.x < 64;
+    const int si = blockIdx.x * 64 + lane;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(sets + segs[blockIdx.x * 64].set);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&ts);
+        for (int i = threadIdx.x; i < (int)(sizeof(DevTableSet) / 4); i += 128) dst[i] = src[i];
+        for (int i = threadIdx.x; i < 2 * 64 * kBlkPitch / 2; i += 128) reinterpret_cast<uint32_t*>(&img[0][0])[i] = 0u;
+        if (threadIdx.x == 0) rounds_s = 0;
+    }
+    const SegDesc sg = segs[si];
+    const uint32_t* w = words + sg.word_off;
+    // The writer wave keeps every stream's ring topped up: the decoder lanes then read their bit stream from LDS only.  (A wave's
+    // vector-memory operations complete in order and are counted per WAVE: with 64 lanes refilling from global memory at their own
+    // pace, every symbol of every lane waited for some other lane's load -- 1 250 cycles of waiting per symbol, measured.)
+    uint32_t hi = 0;                                        // writer lane: words of its stream already in the ring
+    auto top_up = [&](uint32_t lo) {                        // keep [lo, lo + kRing) resident: up to 16 words per call, all loads in flight together
+        const uint32_t room = lo + kRing - hi, left = sg.n_words - hi;
+        const uint32_t n = min(min(room, left), 16u);
+        uint32_t v[16];
+#pragma unroll
+        for (uint32_t q = 0; q < 16; ++q) v[q] = q < n ? w[hi + q] : 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < 16; ++q)
+            if (q < n) ring[lane * kRingPitch + ((hi + q) & (kRing - 1))] = v[q];
+        hi += n;
+    };
+    if (!decoder && sg.frame >= 0) {
+        for (int q = 0; q < kRing / 16; ++q) top_up(0);
+        ring_hi[lane] = hi;
+    }
+    if (decoder) ring_lo[lane] = 0;
+    __syncthreads();
+    // per-component facts in scalar registers, picked by comparisons: an array indexed by the running component would live in scratch
+    // memory, i.e. behind the vector-memory counter of the decoder wave
+    int nc = 0, mxw = 1, blocks_per_mcu = 0;
+    int ch0 = 1, ch1 = 1, ch2 = 1, cv0 = 1, cv1 = 1, cv2 = 1;
+    uint32_t po0 = 0, po1 = 0, po2 = 0, ps0 = 0, ps1 = 0, ps2 = 0, pq0 = 0, pq1 = 0, pq2 = 0;
+    if (sg.frame >= 0) {
+        const EntFrame fr = frames[sg.frame];
+        const FrameDesc fd = fdesc[sg.frame];
+        nc = fr.nc;
+        mxw = fr.mx;
+        ch0 = fr.h[0], cv0 = fr.v[0], po0 = fd.pl[0].plane_off, ps0 = (uint32_t)fd.pl[0].bw * 8u, pq0 = (uint32_t)fd.pl[0].qt;
+        if (nc > 1) {
+            ch1 = fr.h[1], cv1 = fr.v[1], po1 = fd.pl[1].plane_off, ps1 = (uint32_t)fd.pl[1].bw * 8u, pq1 = (uint32_t)fd.pl[1].qt;
+            ch2 = fr.h[2], cv2 = fr.v[2], po2 = fd.pl[2].plane_off, ps2 = (uint32_t)fd.pl[2].bw * 8u, pq2 = (uint32_t)fd.pl[2].qt;
+        }
+        blocks_per_mcu = ch0 * cv0 + (nc > 1 ? ch1 * cv1 + ch2 * cv2 : 0);
+    }
+#define VQ_SEL3(c, a0, a1, a2) ((c) == 0 ? (a0) : (c) == 1 ? (a1) : (a2))
+    if (decoder) atomicMax(&rounds_s, sg.frame >= 0 ? (sg.mcu1 - sg.mcu0) * blocks_per_mcu : 0);
+    __syncthreads();
+    const int rounds = rounds_s;
+    // decoder state
+    DevBits br{w, 0u, sg.n_words, 0ull, 0};
+    uint32_t avail = decoder && sg.frame >= 0 ? ring_hi[lane] : 0u;      // words of the stream in the ring, as of the last barrier
+    int pred0 = 0, pred1 = 0, pred2 = 0;
+    int err = 0, mcu = sg.mcu0, ci = 0, by = 0, bx = 0;
+    bool more = decoder && sg.frame >= 0 && mcu < sg.mcu1;
+    // Two words of the stream sit in registers: `nextw` (the word that goes into the bit buffer next) and `cand` (the one behind it,
+    // read from the ring when its predecessor moved up): a ring read is then consumed one refill after it was issued and its LDS
+    // latency is off the symbol-to-symbol chain, on which only the look-up of the symbol's code remains.  The ring is never dry: the
+    // writer fills it up at every round (>= 74 words ahead at every barrier) and a block consumes at most 54.
+    auto ring_word = [&](uint32_t p) -> uint32_t {          // behind the stream: zeros, as the host reader behind a marker
+        const uint32_t v = ring[lane * kRingPitch + (p & (kRing - 1))];
+        return p < br.end ? v : 0u;
+    };
+    uint32_t nextw = 0u, cand = 0u;
+    if (decoder && sg.frame >= 0) {
+        nextw = ring_word(0);
+        cand = ring_word(1);
+    }
+    auto refill = [&]() {                                   // >= 33 bits afterwards
+        if (br.bits <= 32) {
+            br.acc = (br.acc << 32) | __builtin_bswap32(nextw);
+            br.bits += 32;
+            ++br.p;
+            if (br.p + 1 >= avail && br.p + 1 < br.end) err = 4;    // cannot happen (see above); never use what is not there
+            nextw = cand;
+            cand = ring_word(br.p + 1);
+        }
+    };
+    for (int t = 0; t <= rounds; ++t) {
+        if (stamps) t_a = (long long)__builtin_readcyclecounter();
+        if (decoder) {
+            BlockOut bo{0xFFFFFFFFu, 0u, 0u};
+            if (more && t < rounds) {
+                int16_t* blk = &img[t & 1][lane * kBlkPitch];
+                const DevHuff &hd = ts.t[2 * ci], &ha = ts.t[2 * ci + 1];
+                refill();
+                int s = dev_symbol(br, hd);
+                if (s < 0 || s > 11) {
+                    err = 1;
+                } else {
+                    const int diff = s ? dev_extend((int)br.get(s), s) : 0;
+                    pred0 += ci == 0 ? diff : 0;
+                    pred1 += ci == 1 ? diff : 0;
+                    pred2 += ci == 2 ? diff : 0;
+                    blk[0] = (int16_t)VQ_SEL3(ci, pred0, pred1, pred2);
+                    for (int k = 1; k < 64;) {
+                        refill();
+                        const int rs = dev_symbol(br, ha);
+                        if (rs < 0) {
+                            err = 2;
+                            break;
+                        }
+                        const int r = rs >> 4;
+                        s = rs & 15;
+                        if (s == 0) {
+                            if (r == 15) {
+                                k += 16;
+                                continue;
+                            }
+                            break;
+                        }
+                        k += r;
+                        if (k > 63) {
+                            err = 3;
+                            break;
+                        }
+                        blk[k] = (int16_t)dev_extend((int)br.get(s), s);      // in ZIGZAG order: the writer undoes it with constant indices
+                        ++k;
+                    }
+                }
+                if (!err) {
+                    const int hh = VQ_SEL3(ci, ch0, ch1, ch2), vv = VQ_SEL3(ci, cv0, cv1, cv2);
+                    const int my_ = mcu / mxw, mx_ = mcu - my_ * mxw;
+                    const int row = my_ * vv + by, col = mx_ * hh + bx;
+                    bo.stride = VQ_SEL3(ci, ps0, ps1, ps2);
+                    bo.plane_off = VQ_SEL3(ci, po0, po1, po2) + (uint32_t)row * 8u * bo.stride + (uint32_t)col * 8u;
+                    bo.qt = VQ_SEL3(ci, pq0, pq1, pq2);
+                    if (++bx == hh) {
+                        bx = 0;
+                        if (++by == vv) {
+                            by = 0;
+                            if (++ci == nc) {
+                                ci = 0;
+                                ++mcu;
+                            }
+                        }
+                    }
+                    more = mcu < sg.mcu1;
+                } else {
+                    more = false;                         // (its half-written slot is cleared by the writer like any other)
+                }
+            }
+            outd[t & 1][lane] = bo;
+            ring_lo[lane] = min(br.p, br.end);            // words below this are consumed: the writer may overwrite their ring slots
+        } else {
+            if (t > 0) {
+                const int b = (t - 1) & 1;
+                const BlockOut bo = outd[b][lane];
+                int16_t* c = &img[b][lane * kBlkPitch];
+                if (bo.plane_off != 0xFFFFFFFFu) {
+                    const uint16_t* q = qts + (size_t)bo.qt * 64;
+                    int ws[64];
+#pragma unroll
+                    for (int col = 0; col < 8; ++col) {       // pass 1: columns
+                        int v[8], o[8];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = (int)c[kUnzig[r * 8 + col]] * (int)q[r * 8 + col];
+                        idct8(v, CONST_BITS - PASS1_BITS, o);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) ws[r * 8 + col] = o[r];
+                    }
+                    uint8_t* dst = planes + bo.plane_off;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {             // pass 2: rows, +128, clamp, one 8-byte store
+                        int o[8];
+                        idct8(ws + r * 8, CONST_BITS + PASS1_BITS + 3, o);
+                        unsigned lo = 0, hi8 = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            lo |= (unsigned)min(max(o[k] + 128, 0), 255) << (8 * k);
+                            hi8 |= (unsigned)min(max(o[4 + k] + 128, 0), 255) << (8 * k);
+                        }
+                        *reinterpret_cast<uint2*>(dst + (size_t)r * bo.stride) = make_uint2(lo, hi8);
+                    }
+                }
+                uint32_t* z = reinterpret_cast<uint32_t*>(c);   // the slot starts its next round from zero
+#pragma unroll
+                for (int i = 0; i < 32; ++i) z[i] = 0u;
+            }
+            // the decoder's position as of the LAST barrier: everything below it may be overwritten.  (During this round it reads
+            // on from there, at most up to ring_hi as of the last barrier -- words the top-up does not touch.)
+            if (sg.frame >= 0 && t > 0) {
+                const uint32_t lo = ring_lo[lane];
+                for (int q = 0; q < kRing / 16 && hi < sg.n_words && hi < lo + kRing; ++q) top_up(lo);
+                ring_hi[lane] = hi;
+            }
+        }
+        if (stamps) t_b = (long long)__builtin_readcyclecounter();
+        __syncthreads();
+        if (stamps) {
+            t_work += t_b - t_a;
+            t_wait += (long long)__builtin_readcyclecounter() - t_b;
+        }
+        if (decoder && sg.frame >= 0) avail = ring_hi[lane];
+    }
+    if (stamps && lane == 0) {                              // [workgroup][decoder | writer][work, wait at the barrier] in cycles
+        stamps[(blockIdx.x * 2 + (decoder ? 0 : 1)) * 2 + 0] = t_work;
+        stamps[(blockIdx.x * 2 + (decoder ? 0 : 1)) * 2 + 1] = t_wait;
+    }
+    if (decoder) status[si] = err;
+#undef VQ_SEL3
+}
+
 __device__ __forceinline__ int chroma_at(const uint8_t* __restrict__ p, const PlaneDesc& pd, int mode, int x, int y) {
     const int stride = pd.bw * 8;
     if (mode == 0) return p[(size_t)y * stride + x];
@@ -437,6 +756,72 @@ __global__ void jpeg_pixels_kernel(const FrameDesc* __restrict__ frames, const u
     o[2] = (uint8_t)r;
 }
 
+// One pass over a file's scan: byte stuffing removed (FF 00 -> FF), cut at the RSTn markers, every piece zero-padded to whole
+// 32-bit words + two words (the decoder reads zeros behind a stream, like the host reader behind a marker).  dst has room for
+// n - scan + 16 * (max_segs + 1) bytes.  Returns the number of pieces found (<= max_segs are recorded).
+int unstuff_scan(const uint8_t* d, size_t n, size_t scan, uint8_t* dst, int max_segs, uint32_t* seg_off_bytes, uint32_t* seg_len_bytes) {
+    size_t p = scan, o = 0;
+    int segs = 0;
+    size_t start = 0;
+    auto close = [&]() {
+        if (segs < max_segs) {
+            seg_off_bytes[segs] = (uint32_t)start;
+            seg_len_bytes[segs] = (uint32_t)(o - start);
+        }
+        ++segs;
+        const size_t padded = ((o + 3) & ~(size_t)3) + 8;
+        memset(dst + o, 0, padded - o);
+        o = padded;
+        start = o;
+    };
+    while (p < n) {
+        const uint8_t* q = (const uint8_t*)memchr(d + p, 0xFF, n - p);
+        const size_t run = q ? (size_t)(q - (d + p)) : n - p;
+        memcpy(dst + o, d + p, run);
+        o += run;
+        p += run;
+        if (!q) break;
+        const uint8_t nx = p + 1 < n ? d[p + 1] : 0xD9;
+        if (nx == 0) {
+            dst[o++] = 0xFF;
+            p += 2;
+        } else if (nx >= 0xD0 && nx <= 0xD7) {
+            if (segs + 1 >= max_segs) break;  // more restart markers than the frame has intervals: the rest is not decoded
+            close();
+            p += 2;
+        } else if (nx == 0xFF) {              // fill byte before a marker
+            ++p;
+        } else {
+            break;                            // EOI or any other marker: the entropy-coded data ends here
+        }
+    }
+    close();
+    return segs;
+}
+
+void fill_dev_huff(const Huff& h, DevHuff& d) {
+    memset(&d, 0, sizeof d);
+    // every code of <= kFastBits bits fills its span of the look-up (codes are left-aligned in the index)
+    for (int ln = 1; ln <= kFastBits; ++ln) {
+        if (h.maxcode[ln] < 0) continue;
+        for (int code = h.mincode[ln]; code <= h.maxcode[ln]; ++code) {
+            const int sym = h.vals[h.valptr[ln] + code - h.mincode[ln]];
+            const int first = code << (kFastBits - ln), span = 1 << (kFastBits - ln);
+            for (int q = 0; q < span && first + q < (1 << kFastBits); ++q) d.fast[first + q] = (uint16_t)((ln << 8) | sym);
+        }
+    }
+    uint32_t run = 0;
+    for (int ln = 1; ln <= 16; ++ln) {
+        if (h.maxcode[ln] >= 0) run = std::max(run, (uint32_t)(h.maxcode[ln] + 1) << (16 - ln));
+        if (ln > kFastBits) d.lim[ln - kFastBits - 1] = run;
+    }
+    for (int i = 0; i < 17; ++i) {
+        d.valptr[i] = h.valptr[i];
+        d.mincode[i] = h.mincode[i];
+    }
+    memcpy(d.vals, h.vals, 256);
+}
+
 }  // namespace
 
 struct vq_jpeg {
@@ -451,6 +836,17 @@ struct vq_jpeg {
     uint16_t* qt_dev = nullptr;
     FrameDesc* desc_dev = nullptr;
     uint8_t* out_dev = nullptr;        // [max_frames][max_h][max_w][3]
+    // device entropy decoding: the batch's unstuffed streams and their descriptors (grown on demand)
+    uint32_t* stream_host = nullptr;   // pinned
+    uint32_t* stream_dev = nullptr;
+    size_t stream_words = 0;
+    void* ent_dev = nullptr;           // SegDesc[] | EntFrame[] | DevTableSet[] | status int[]
+    size_t ent_bytes = 0;
+    int* status_host = nullptr;        // pinned
+    size_t status_cap = 0;
+    int host_huffman = -1;             // VQ_JPEG_HOST_HUFFMAN at creation: 1 = always the host decoder of rounds 1-2, 0 = always the device
+                                       // decoder, unset = by batch size
+    long long dev_min_streams = 2048;  // VQ_JPEG_DEVICE_MIN_STREAMS: batches with at least this many streams decode on the device
 };
 
 static void jpeg_free(vq_jpeg* j) {
@@ -462,6 +858,10 @@ static void jpeg_free(vq_jpeg* j) {
     if (j->qt_dev) (void)hipFree(j->qt_dev);
     if (j->desc_dev) (void)hipFree(j->desc_dev);
     if (j->out_dev) (void)hipFree(j->out_dev);
+    if (j->stream_host) (void)hipHostFree(j->stream_host);
+    if (j->stream_dev) (void)hipFree(j->stream_dev);
+    if (j->ent_dev) (void)hipFree(j->ent_dev);
+    if (j->status_host) (void)hipHostFree(j->status_host);
 }
 
 extern "C" {
@@ -486,6 +886,12 @@ int vq_jpeg_create(int32_t max_frames, int32_t max_h, int32_t max_w, int32_t dev
     VQ_REQUIRE(device >= 0 && device < ndev, "device %d out of range (%d visible)", device, ndev);
     DeviceGuard g(device);
     auto* j = new vq_jpeg;
+    {
+        const char* hh = getenv("VQ_JPEG_HOST_HUFFMAN");
+        if (hh && (*hh == '0' || *hh == '1')) j->host_huffman = *hh - '0';
+        const char* dm = getenv("VQ_JPEG_DEVICE_MIN_STREAMS");
+        if (dm && atoll(dm) > 0) j->dev_min_streams = atoll(dm);
+    }
     j->device = device;
     j->max_frames = max_frames;
     j->max_h = max_h;
@@ -570,10 +976,24 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
         for (int t = 0; t < 4; ++t)
             if (f.qt_present[t]) memcpy(&qts[((size_t)i * 4 + t) * 64], f.qt[t], 64 * sizeof(uint16_t));
     }
-    // ---- entropy decoding: one frame per host thread
     const int workers = std::max(1, std::min<int>({n, 16, (int)std::thread::hardware_concurrency()}));
     std::vector<int> status((size_t)n, VQ_OK);
     std::vector<std::string> message((size_t)n);
+    int n_seg_padded = 0;
+    // Where the entropy decoding runs: a 66 KB stream costs a device lane ~35 ms whatever the batch (600 cycles per symbol, 64 streams
+    // per wave, as many waves as there are streams / 64), a host thread ~0.5 ms: 16 host threads decode 31 k frames/s at any batch
+    // size, the device 7 k at 256 frames, 22 k at 1 024, 53 k at 4 096 -- and small files (the grey flow frames, of which the command
+    // line hands over 8 000 per batch of 32 clips) cost a lane proportionally less.
+    long long total_streams = 0;
+    for (int i = 0; i < n; ++i) {
+        const Frame& f = fr[i];
+        const bool single = f.nc == 1;
+        const int nm = (single ? cdiv(w, 8) : cdiv(w, 8 * f.hmax)) * (single ? cdiv(h, 8) : cdiv(h, 8 * f.vmax));
+        total_streams += f.ri ? cdiv(nm, f.ri) : 1;
+    }
+    const bool use_host = j->host_huffman == 1 || (j->host_huffman < 0 && total_streams < j->dev_min_streams);
+    if (use_host) {
+    // ---- entropy decoding on the host: one frame per host thread
     auto work = [&](int first) {
         for (int i = first; i < n; i += workers) {
             // the frame's blocks start from zero (only non-zero coefficients are written): cleared here, by the frame's own thread
@@ -589,12 +1009,155 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
     for (std::thread& th : pool) th.join();
     for (int i = 0; i < n; ++i)
         if (status[i] != VQ_OK) return fail(status[i], "file %d: %s", i, message[i].c_str());
-    // ---- device: IDCT per block, then pixels
     VQ_HIP(hipMemcpyAsync(j->coef_dev, j->coef_host, blocks * 64 * sizeof(int16_t), hipMemcpyHostToDevice, st));
-    VQ_HIP(hipMemcpyAsync(j->block_plane_dev, j->block_plane_host, blocks * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    } else {
+    // ---- entropy decoding on the device: the host strips the byte stuffing and cuts the scans at the restart markers
+    std::vector<int> n_mcu((size_t)n), want_segs((size_t)n);
+    std::vector<size_t> region((size_t)n + 1, 0);                   // byte offset of every frame's region in the stream buffer
+    for (int i = 0; i < n; ++i) {
+        const Frame& f = fr[i];
+        const bool single = f.nc == 1;
+        n_mcu[i] = (single ? cdiv(w, 8) : cdiv(w, 8 * f.hmax)) * (single ? cdiv(h, 8) : cdiv(h, 8 * f.vmax));
+        want_segs[i] = f.ri ? cdiv(n_mcu[i], f.ri) : 1;
+        region[i + 1] = region[i] + (((size_t)sizes[i] - f.scan + 16 * ((size_t)want_segs[i] + 2)) + 3) / 4 * 4;
+    }
+    const size_t need_words = region[n] / 4 + 4;
+    if (j->stream_words < need_words) {
+        if (j->stream_host) (void)hipHostFree(j->stream_host);
+        if (j->stream_dev) (void)hipFree(j->stream_dev);
+        j->stream_host = nullptr;
+        j->stream_dev = nullptr;
+        j->stream_words = 0;
+        const size_t cap = need_words + need_words / 4;
+        VQ_HIP(hipHostMalloc((void**)&j->stream_host, cap * 4));
+        VQ_HIP(hipMalloc((void**)&j->stream_dev, cap * 4));
+        j->stream_words = cap;
+    }
+    // table sets: the (DC, AC) tables of a frame's components; files of one writer share one set
+    std::vector<DevTableSet> sets;
+    std::vector<int> set_of((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        DevTableSet ts;
+        memset(&ts, 0, sizeof ts);
+        for (int c = 0; c < fr[i].nc; ++c) {
+            fill_dev_huff(fr[i].dc[fr[i].comp[c].td], ts.t[2 * c]);
+            fill_dev_huff(fr[i].ac[fr[i].comp[c].ta], ts.t[2 * c + 1]);
+        }
+        int found = -1;
+        for (size_t q = 0; q < sets.size() && found < 0; ++q)
+            if (!memcmp(&sets[q], &ts, sizeof ts)) found = (int)q;
+        if (found < 0) {
+            sets.push_back(ts);
+            found = (int)sets.size() - 1;
+        }
+        set_of[i] = found;
+    }
+    std::vector<std::vector<uint32_t>> seg_off((size_t)n), seg_len((size_t)n);
+    auto work = [&](int first) {
+        for (int i = first; i < n; i += workers) {
+            seg_off[i].assign((size_t)want_segs[i], 0);
+            seg_len[i].assign((size_t)want_segs[i], 0);
+            const int got = unstuff_scan(files[i], (size_t)sizes[i], fr[i].scan, reinterpret_cast<uint8_t*>(j->stream_host) + region[i], want_segs[i],
+                                         seg_off[i].data(), seg_len[i].data());
+            if (got < want_segs[i]) {
+                status[i] = VQ_E_INVALID;
+                message[i] = "JPEG: restart marker missing";
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int k = 1; k < workers; ++k) pool.emplace_back(work, k);
+    work(0);
+    for (std::thread& th : pool) th.join();
+    for (int i = 0; i < n; ++i)
+        if (status[i] != VQ_OK) return fail(status[i], "file %d: %s", i, message[i].c_str());
+    // streams grouped by table set, every group padded to whole waves
+    std::vector<SegDesc> segs;
+    std::vector<int> seg_frame;
+    for (size_t q = 0; q < sets.size(); ++q) {
+        for (int i = 0; i < n; ++i) {
+            if (set_of[i] != (int)q) continue;
+            for (int k = 0; k < want_segs[i]; ++k) {
+                SegDesc sd;
+                sd.word_off = (uint32_t)((region[i] + seg_off[i][k]) / 4);
+                sd.n_words = (seg_len[i][k] + 3) / 4;
+                sd.frame = i;
+                sd.mcu0 = fr[i].ri ? k * fr[i].ri : 0;
+                sd.mcu1 = fr[i].ri ? std::min(n_mcu[i], (k + 1) * fr[i].ri) : n_mcu[i];
+                sd.set = (int)q;
+                segs.push_back(sd);
+            }
+        }
+        while (segs.size() % 64) segs.push_back(SegDesc{0, 0, -1, 0, 0, (int)q});
+    }
+    n_seg_padded = (int)segs.size();
+    std::vector<EntFrame> ef((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const Frame& f = fr[i];
+        const bool single = f.nc == 1;
+        memset(&ef[i], 0, sizeof(EntFrame));
+        ef[i].nc = f.nc;
+        ef[i].mx = single ? cdiv(w, 8) : cdiv(w, 8 * f.hmax);
+        for (int c = 0; c < f.nc; ++c) {
+            ef[i].h[c] = single ? 1 : f.comp[c].h;
+            ef[i].v[c] = single ? 1 : f.comp[c].v;
+            ef[i].bw[c] = f.comp[c].bw;
+            ef[i].coef_off[c] = (uint32_t)comp_off[(size_t)i * 3 + c];
+        }
+    }
+    const size_t b_seg = segs.size() * sizeof(SegDesc), b_fr = (ef.size() * sizeof(EntFrame) + 15) / 16 * 16, b_set = sets.size() * sizeof(DevTableSet),
+                 b_stat = segs.size() * sizeof(int);
+    const size_t o_fr = (b_seg + 15) / 16 * 16, o_set = o_fr + b_fr, o_stat = o_set + b_set, ent_need = o_stat + b_stat;
+    if (j->ent_bytes < ent_need) {
+        if (j->ent_dev) (void)hipFree(j->ent_dev);
+        j->ent_dev = nullptr;
+        j->ent_bytes = 0;
+        VQ_HIP(hipMalloc(&j->ent_dev, ent_need * 2));
+        j->ent_bytes = ent_need * 2;
+    }
+    if (j->status_cap < segs.size()) {
+        if (j->status_host) (void)hipHostFree(j->status_host);
+        j->status_host = nullptr;
+        j->status_cap = 0;
+        VQ_HIP(hipHostMalloc((void**)&j->status_host, segs.size() * 2 * sizeof(int)));
+        j->status_cap = segs.size() * 2;
+    }
+    uint8_t* eb = static_cast<uint8_t*>(j->ent_dev);
+    VQ_HIP(hipMemcpyAsync(j->stream_dev, j->stream_host, region[n], hipMemcpyHostToDevice, st));
+    VQ_HIP(hipMemcpyAsync(eb, segs.data(), b_seg, hipMemcpyHostToDevice, st));
+    VQ_HIP(hipMemcpyAsync(eb + o_fr, ef.data(), ef.size() * sizeof(EntFrame), hipMemcpyHostToDevice, st));
+    VQ_HIP(hipMemcpyAsync(eb + o_set, sets.data(), b_set, hipMemcpyHostToDevice, st));
     VQ_HIP(hipMemcpyAsync(j->qt_dev, qts.data(), qts.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
     VQ_HIP(hipMemcpyAsync(j->desc_dev, desc.data(), desc.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
-    jpeg_idct_kernel<<<cdiv((long long)blocks, 128), 128, 0, st>>>(j->coef_dev, j->qt_dev, j->desc_dev, j->block_plane_dev, j->planes_dev, (unsigned)blocks);
+    long long* stamps_dev = nullptr;                      // VQ_JPEG_STAMPS=1: where the two waves of a workgroup spend their cycles (stderr)
+    if (getenv("VQ_JPEG_STAMPS")) VQ_HIP(hipMalloc((void**)&stamps_dev, (size_t)n_seg_padded / 64 * 4 * sizeof(long long)));
+    jpeg_entropy_idct_kernel<<<n_seg_padded / 64, 128, 0, st>>>(reinterpret_cast<const SegDesc*>(eb), reinterpret_cast<const EntFrame*>(eb + o_fr),
+                                                                j->desc_dev, reinterpret_cast<const DevTableSet*>(eb + o_set), j->stream_dev, j->qt_dev,
+                                                                j->planes_dev, reinterpret_cast<int*>(eb + o_stat), stamps_dev);
+    VQ_CHECK_LAUNCH();
+    if (stamps_dev) {
+        std::vector<long long> sh((size_t)n_seg_padded / 64 * 4);
+        VQ_HIP(hipMemcpyAsync(sh.data(), stamps_dev, sh.size() * 8, hipMemcpyDeviceToHost, st));
+        VQ_HIP(hipStreamSynchronize(st));
+        for (size_t g2 = 0; g2 < sh.size() / 4 && g2 < 4; ++g2)
+            fprintf(stderr, "jpeg stamps wg %zu: decoder work %lld wait %lld | writer work %lld wait %lld cycles\n", g2, sh[4 * g2], sh[4 * g2 + 1],
+                    sh[4 * g2 + 2], sh[4 * g2 + 3]);
+        (void)hipFree(stamps_dev);
+    }
+    VQ_HIP(hipMemcpyAsync(j->status_host, eb + o_stat, b_stat, hipMemcpyDeviceToHost, st));
+    VQ_HIP(hipStreamSynchronize(st));            // segs / ef / sets leave scope; the statuses are wanted before the pixels are handed out
+    static const char* const what[8] = {"", "JPEG: corrupt entropy-coded data (DC)", "JPEG: corrupt entropy-coded data (AC)",
+                                        "JPEG: corrupt entropy-coded data (run past the block)", "JPEG: internal error (stream ring ran dry)", "", "", ""};
+    for (size_t q = 0; q < segs.size(); ++q)
+        if (segs[q].frame >= 0 && j->status_host[q] != 0) return fail(VQ_E_INVALID, "file %d: %s", segs[q].frame, what[j->status_host[q] & 7]);
+    }
+    // ---- device: (host-decoded coefficients: IDCT per block,) then pixels
+    if (use_host) {
+        VQ_HIP(hipMemcpyAsync(j->block_plane_dev, j->block_plane_host, blocks * sizeof(unsigned), hipMemcpyHostToDevice, st));
+        VQ_HIP(hipMemcpyAsync(j->qt_dev, qts.data(), qts.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+        VQ_HIP(hipMemcpyAsync(j->desc_dev, desc.data(), desc.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+        jpeg_idct_kernel<<<cdiv((long long)blocks, 128), 128, 0, st>>>(j->coef_dev, j->qt_dev, j->desc_dev, j->block_plane_dev, j->planes_dev, (unsigned)blocks);
+    }
     const int ch = color ? 3 : 1;
     const int64_t px = (int64_t)n * h * w;
     jpeg_pixels_kernel<<<cdiv(px, 256), 256, 0, st>>>(j->desc_dev, j->planes_dev, j->out_dev, n, h, w, ch);
