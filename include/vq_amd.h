@@ -186,6 +186,11 @@ int vq_jpeg_create(int32_t max_frames, int32_t max_h, int32_t max_w, int32_t dev
 int vq_jpeg_destroy(vq_jpeg* jpeg);
 int vq_jpeg_decode(vq_jpeg* jpeg, const uint8_t* const* files, const int64_t* sizes, int32_t n, int32_t color, int32_t h, int32_t w,
                    uint8_t* out_host, uint8_t** out_dev, void* hip_stream);
+/* The same on file paths: the library's worker threads read the files (no interpreter in the loop); vq_jpeg_info_file reads
+ * a file's frame header. */
+int vq_jpeg_decode_files(vq_jpeg* jpeg, const char* const* paths, int32_t n, int32_t color, int32_t h, int32_t w, uint8_t* out_host,
+                         uint8_t** out_dev, void* hip_stream);
+int vq_jpeg_info_file(const char* path, int32_t* h, int32_t* w, int32_t* components);
 
 enum {
     VQ_OP_CONV = 1,

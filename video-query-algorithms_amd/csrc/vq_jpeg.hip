@@ -835,7 +835,9 @@ struct vq_jpeg {
     unsigned* block_plane_dev = nullptr;
     uint16_t* qt_dev = nullptr;
     FrameDesc* desc_dev = nullptr;
-    uint8_t* out_dev = nullptr;        // [max_frames][max_h][max_w][3]
+    uint8_t* out_dev = nullptr;        // [frames of the call][h][w][3]
+    size_t cap_coef_host = 0, cap_bmap_host = 0;
+    size_t cap_coef = 0, cap_planes = 0, cap_bmap = 0, cap_qt = 0, cap_desc = 0, cap_out = 0;   // bytes; every buffer grows on demand
     // device entropy decoding: the batch's unstuffed streams and their descriptors (grown on demand)
     uint32_t* stream_host = nullptr;   // pinned
     uint32_t* stream_dev = nullptr;
@@ -863,6 +865,31 @@ static void jpeg_free(vq_jpeg* j) {
     if (j->ent_dev) (void)hipFree(j->ent_dev);
     if (j->status_host) (void)hipHostFree(j->status_host);
 }
+
+namespace {
+template <typename T>
+int grow_dev(T** p, size_t* cap, size_t need) {
+    if (*cap >= need) return VQ_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = need + need / 4;
+    VQ_HIP(hipMalloc((void**)p, want));
+    *cap = want;
+    return VQ_OK;
+}
+template <typename T>
+int grow_host(T** p, size_t* cap, size_t need) {
+    if (*cap >= need) return VQ_OK;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = need + need / 4;
+    VQ_HIP(hipHostMalloc((void**)p, want));
+    *cap = want;
+    return VQ_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -897,22 +924,7 @@ int vq_jpeg_create(int32_t max_frames, int32_t max_h, int32_t max_w, int32_t dev
     j->max_h = max_h;
     j->max_w = max_w;
     j->max_blocks = (size_t)3 * cdiv(max_w, 16) * 2 * cdiv(max_h, 16) * 2;
-    const size_t blocks = j->max_blocks * max_frames;
-    VQ_REQUIRE(blocks < 0x7FFFFFFFull && blocks * 64 < 0xFFFFFFFFull, "batch too large for one JPEG workspace (blocks are numbered with 32 bits)");
-    auto bail = [&](const char* what, hipError_t e) {
-        jpeg_free(j);
-        delete j;
-        return fail(e == hipErrorOutOfMemory ? VQ_E_NOMEM : VQ_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
-    };
-    hipError_t e;
-    if ((e = hipHostMalloc((void**)&j->coef_host, blocks * 64 * sizeof(int16_t))) != hipSuccess) return bail("hipHostMalloc(coefficients)", e);
-    if ((e = hipHostMalloc((void**)&j->block_plane_host, blocks * sizeof(unsigned))) != hipSuccess) return bail("hipHostMalloc(block map)", e);
-    if ((e = hipMalloc((void**)&j->coef_dev, blocks * 64 * sizeof(int16_t))) != hipSuccess) return bail("hipMalloc(coefficients)", e);
-    if ((e = hipMalloc((void**)&j->planes_dev, blocks * 64)) != hipSuccess) return bail("hipMalloc(planes)", e);
-    if ((e = hipMalloc((void**)&j->block_plane_dev, blocks * sizeof(unsigned))) != hipSuccess) return bail("hipMalloc(block map)", e);
-    if ((e = hipMalloc((void**)&j->qt_dev, (size_t)max_frames * 4 * 64 * sizeof(uint16_t))) != hipSuccess) return bail("hipMalloc(tables)", e);
-    if ((e = hipMalloc((void**)&j->desc_dev, (size_t)max_frames * sizeof(FrameDesc))) != hipSuccess) return bail("hipMalloc(descriptors)", e);
-    if ((e = hipMalloc((void**)&j->out_dev, (size_t)max_frames * max_h * max_w * 3)) != hipSuccess) return bail("hipMalloc(frames)", e);
+    // nothing is allocated here: the buffers of the path a call takes (host or device entropy decoding) grow to what the call needs
     *out = j;
     return VQ_OK;
 }
@@ -968,11 +980,9 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
             pd.dh = cdiv((long long)h * cp.v, f.vmax);
             pd.qt = i * 4 + cp.tq;
             comp_off[(size_t)i * 3 + c] = blocks;
-            for (size_t b = 0; b < (size_t)cp.bw * cp.bh; ++b) j->block_plane_host[blocks + b] = ((unsigned)i << 2) | (unsigned)c;
             blocks += (size_t)cp.bw * cp.bh;
             plane_bytes += (size_t)cp.bw * cp.bh * 64;
         }
-        VQ_REQUIRE(blocks <= j->max_blocks * (size_t)j->max_frames, "JPEG workspace too small");
         for (int t = 0; t < 4; ++t)
             if (f.qt_present[t]) memcpy(&qts[((size_t)i * 4 + t) * 64], f.qt[t], 64 * sizeof(uint16_t));
     }
@@ -992,8 +1002,31 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
         total_streams += f.ri ? cdiv(nm, f.ri) : 1;
     }
     const bool use_host = j->host_huffman == 1 || (j->host_huffman < 0 && total_streams < j->dev_min_streams);
+    VQ_REQUIRE(plane_bytes < 0xFFFFFFFFull, "batch too large for one call (planes are addressed with 32 bits)");
+    {
+        int rc;
+        if ((rc = grow_dev(&j->planes_dev, &j->cap_planes, plane_bytes)) != VQ_OK) return rc;
+        if ((rc = grow_dev(&j->qt_dev, &j->cap_qt, qts.size() * sizeof(uint16_t))) != VQ_OK) return rc;
+        if ((rc = grow_dev(&j->desc_dev, &j->cap_desc, desc.size() * sizeof(FrameDesc))) != VQ_OK) return rc;
+        if ((rc = grow_dev(&j->out_dev, &j->cap_out, (size_t)n * h * w * 3)) != VQ_OK) return rc;
+    }
     if (use_host) {
     // ---- entropy decoding on the host: one frame per host thread
+    {
+        int rc;
+        size_t cap_h = j->cap_coef_host, cap_bh = j->cap_bmap_host;
+        if ((rc = grow_host(&j->coef_host, &cap_h, blocks * 64 * sizeof(int16_t))) != VQ_OK) return rc;
+        if ((rc = grow_host(&j->block_plane_host, &cap_bh, blocks * sizeof(unsigned))) != VQ_OK) return rc;
+        j->cap_coef_host = cap_h;
+        j->cap_bmap_host = cap_bh;
+        if ((rc = grow_dev(&j->coef_dev, &j->cap_coef, blocks * 64 * sizeof(int16_t))) != VQ_OK) return rc;
+        if ((rc = grow_dev(&j->block_plane_dev, &j->cap_bmap, blocks * sizeof(unsigned))) != VQ_OK) return rc;
+        for (int i = 0; i < n; ++i)
+            for (int c = 0; c < fr[i].nc; ++c) {
+                const size_t b0 = comp_off[(size_t)i * 3 + c], nb = (size_t)fr[i].comp[c].bw * fr[i].comp[c].bh;
+                for (size_t b = 0; b < nb; ++b) j->block_plane_host[b0 + b] = ((unsigned)i << 2) | (unsigned)c;
+            }
+    }
     auto work = [&](int first) {
         for (int i = first; i < n; i += workers) {
             // the frame's blocks start from zero (only non-zero coefficients are written): cleared here, by the frame's own thread
@@ -1165,6 +1198,78 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
     if (out_host) VQ_HIP(hipMemcpyAsync(out_host, j->out_dev, (size_t)px * ch, hipMemcpyDeviceToHost, st));
     if (out_dev) *out_dev = j->out_dev;
     VQ_HIP(hipStreamSynchronize(st));      // qts / desc leave scope; the pinned buffers are reused by the next call
+    return VQ_OK;
+}
+
+// The same on file PATHS: the files are read by the library's worker threads (70 000 open / read / close calls per 256 clips at the
+// reference's defaults are a second of interpreter time when Python threads make them; here they overlap freely).
+int vq_jpeg_decode_files(vq_jpeg* j, const char* const* paths, int32_t n, int32_t color, int32_t h, int32_t w, uint8_t* out_host, uint8_t** out_dev,
+                         void* hip_stream) {
+    VQ_REQUIRE(j && paths && n > 0, "bad argument");
+    std::vector<std::vector<uint8_t>> data((size_t)n);
+    std::vector<int> bad((size_t)n, 0);
+    const int workers = std::max(1, std::min<int>({n, 16, (int)std::thread::hardware_concurrency()}));
+    auto work = [&](int first) {
+        for (int i = first; i < n; i += workers) {
+            FILE* f = paths[i] ? fopen(paths[i], "rb") : nullptr;
+            if (!f) {
+                bad[i] = 1;
+                continue;
+            }
+            if (fseek(f, 0, SEEK_END) == 0) {
+                const long sz = ftell(f);
+                if (sz > 0 && fseek(f, 0, SEEK_SET) == 0) {
+                    data[i].resize((size_t)sz);
+                    if (fread(data[i].data(), 1, (size_t)sz, f) != (size_t)sz) bad[i] = 1;
+                } else {
+                    bad[i] = 1;
+                }
+            } else {
+                bad[i] = 1;
+            }
+            fclose(f);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int k = 1; k < workers; ++k) pool.emplace_back(work, k);
+    work(0);
+    for (std::thread& th : pool) th.join();
+    std::vector<const uint8_t*> ptrs((size_t)n);
+    std::vector<int64_t> sizes((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (bad[i]) return fail(VQ_E_INVALID, "cannot read file %d: %s", i, paths[i] ? paths[i] : "(null)");
+        ptrs[i] = data[i].data();
+        sizes[i] = (int64_t)data[i].size();
+    }
+    return vq_jpeg_decode(j, ptrs.data(), sizes.data(), n, color, h, w, out_host, out_dev, hip_stream);
+}
+
+int vq_jpeg_info_file(const char* path, int32_t* h, int32_t* w, int32_t* components) {
+    VQ_REQUIRE(path, "NULL argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(VQ_E_INVALID, "cannot read %s", path);
+    std::vector<uint8_t> head(65536);
+    const size_t got = fread(head.data(), 1, head.size(), f);
+    fclose(f);
+    if (got == 0) return fail(VQ_E_INVALID, "%s is empty", path);
+    Frame fr;
+    // the frame header of a file with large APPn segments may lie beyond the first 64 KB: then the whole file is read
+    int rc = parse_headers(head.data(), got, fr);
+    if (rc != VQ_OK && fr.H == 0) {
+        f = fopen(path, "rb");
+        if (!f) return fail(VQ_E_INVALID, "cannot read %s", path);
+        std::vector<uint8_t> all;
+        uint8_t buf[65536];
+        size_t k;
+        while ((k = fread(buf, 1, sizeof buf, f)) > 0) all.insert(all.end(), buf, buf + k);
+        fclose(f);
+        fr = Frame();
+        rc = parse_headers(all.data(), all.size(), fr);
+        if (rc != VQ_OK && fr.H == 0) return rc;
+    }
+    if (h) *h = fr.H;
+    if (w) *w = fr.W;
+    if (components) *components = fr.nc;
     return VQ_OK;
 }
 

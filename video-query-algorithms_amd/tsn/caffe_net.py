@@ -145,7 +145,8 @@ class CaffeNet:
         out = torch.empty((n, crop, crop, ch), dtype=torch.uint8, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         h, w, _ = jpeg.info(files[0])
-        cap = 256
+        # files per decoder call (its buffers grow to what a call needs; a call addresses its component planes with 32 bits)
+        cap = max(1, min(8192, int(3.0e9 // (2 * (h + 16) * (w + 16)))))
         dec = getattr(self, "_jpeg", None)
         if dec is None or dec.max_h < h or dec.max_w < w:
             if dec is not None:
@@ -158,13 +159,18 @@ class CaffeNet:
                      C.c_void_p(out[i:i + m].data_ptr()), 3, 0, self._model.device, C.c_void_p(stream))
                 torch.cuda.current_stream(dev).synchronize()          # the decoder's buffer is reused by its next call
         else:
-            for k in range(ch):                                       # plane k of every snippet: contiguous grey frames
-                plane_files = files[k::ch]
-                for i in range(0, n, cap):
-                    ptr, (m, _, _) = dec.decode_to_device(plane_files[i:i + cap], color=False)
-                    call("vq_resize_crop", C.c_void_p(ptr), 1, m, h, w, 1, frame_size[0], frame_size[1], crop, frames.RESIZE_RULES[self._resize_rule],
-                         C.c_void_p(out[i:i + m].data_ptr()), ch, k, self._model.device, C.c_void_p(stream))
-                    torch.cuda.current_stream(dev).synchronize()
+            # the grey frames of `per` snippets in ONE decoder call, plane-major (all x0 frames, then all y0 frames, ...): a batch of
+            # 32 clips x 25 snippets is 8 000 small files -- the size at which the entropy decoding runs on the device -- and every
+            # plane's frames are contiguous for the resize that interleaves them into the 10-channel crops
+            per = max(1, cap // ch)
+            for i in range(0, n, per):
+                m = min(per, n - i)
+                group = [files[(i + q) * ch + k] for k in range(ch) for q in range(m)]
+                ptr, _ = dec.decode_to_device(group, color=False)
+                for k in range(ch):
+                    call("vq_resize_crop", C.c_void_p(ptr + k * m * h * w), 1, m, h, w, 1, frame_size[0], frame_size[1], crop,
+                         frames.RESIZE_RULES[self._resize_rule], C.c_void_p(out[i:i + m].data_ptr()), ch, k, self._model.device, C.c_void_p(stream))
+                torch.cuda.current_stream(dev).synchronize()
         return out
 
     def extract_clips_from_jpegs(self, files, T: int, frame_size=(340, 256), on_device: bool = False):

@@ -233,19 +233,19 @@ def _read_file(path: str) -> bytes:
         return f.read()
 
 
-def load_rgb_jpegs(clip_dir: str, ticks: List[int], rgb_prefix='img_', ext='.jpg') -> List[bytes]:
-    """The JPEG FILES of the snippets, undecoded (the library decodes them: tsn/jpeg.py)."""
-    return [_read_file(os.path.join(clip_dir, '{}{:05d}{}'.format(rgb_prefix, t, ext))) for t in ticks]
+def load_rgb_jpegs(clip_dir: str, ticks: List[int], rgb_prefix='img_', ext='.jpg') -> List[str]:
+    """The JPEG files of the snippets as PATHS: the library reads and decodes them (tsn/jpeg.py)."""
+    return [os.path.join(clip_dir, '{}{:05d}{}'.format(rgb_prefix, t, ext)) for t in ticks]
 
 
 def load_flow_jpegs(clip_dir: str, ticks: List[int], frame_cnt: int, stk_depth=5, flow_x_prefix='flow_x_', flow_y_prefix='flow_y_',
-                    ext='.jpg') -> List[bytes]:
-    """The x / y flow JPEG files of every snippet in stack order (x0, y0, x1, y1, ...), undecoded."""
+                    ext='.jpg') -> List[str]:
+    """The x / y flow JPEG files of every snippet in stack order (x0, y0, x1, y1, ...) as PATHS."""
     out = []
     for tick in ticks:
         for idx in flow_stack_indices(tick, frame_cnt, stk_depth):
-            out.append(_read_file(os.path.join(clip_dir, '{}{:05d}{}'.format(flow_x_prefix, idx, ext))))
-            out.append(_read_file(os.path.join(clip_dir, '{}{:05d}{}'.format(flow_y_prefix, idx, ext))))
+            out.append(os.path.join(clip_dir, '{}{:05d}{}'.format(flow_x_prefix, idx, ext)))
+            out.append(os.path.join(clip_dir, '{}{:05d}{}'.format(flow_y_prefix, idx, ext)))
     return out
 
 

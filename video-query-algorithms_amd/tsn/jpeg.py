@@ -8,6 +8,7 @@ libjpeg(-turbo) produces (oracle/jpeg_oracle.py, pinned bit for bit against Pill
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Sequence, Tuple, Union
 
 import numpy as np
@@ -16,10 +17,13 @@ from .. import _lib
 from .._lib import call
 
 
-def info(data: bytes) -> Tuple[int, int, int]:
-    """(height, width, components) of a JPEG file's frame header."""
+def info(data: Union[bytes, str]) -> Tuple[int, int, int]:
+    """(height, width, components) of a JPEG file's frame header (file contents, or a path)."""
     h, w, c = C.c_int32(), C.c_int32(), C.c_int32()
-    call("vq_jpeg_info", data, len(data), C.byref(h), C.byref(w), C.byref(c))
+    if isinstance(data, str):
+        call("vq_jpeg_info_file", os.fsencode(data), C.byref(h), C.byref(w), C.byref(c))
+    else:
+        call("vq_jpeg_info", data, len(data), C.byref(h), C.byref(w), C.byref(c))
     return h.value, w.value, c.value
 
 
@@ -30,6 +34,15 @@ class JpegDecoder:
         call("vq_jpeg_create", self.max_frames, self.max_h, self.max_w, self.device, C.byref(self._h))
 
     def _submit(self, files: Sequence[Union[bytes, str]], color: bool, out_host, want_dev: bool):
+        if len(files) and all(isinstance(f, str) for f in files):      # paths only: the library's threads read the files
+            n = len(files)
+            h, w, _ = info(files[0])
+            paths = (C.c_char_p * n)(*[os.fsencode(f) for f in files])
+            dev = C.c_void_p()
+            host = np.empty((n, h, w, 3) if color else (n, h, w), dtype=np.uint8) if out_host else None
+            call("vq_jpeg_decode_files", self._h, paths, n, int(bool(color)), h, w, host.ctypes.data_as(C.c_void_p) if host is not None else None,
+                 C.byref(dev) if want_dev else None, None)
+            return host, dev.value, (n, h, w)
         blobs: List[bytes] = []
         for f in files:
             if isinstance(f, (bytes, bytearray, memoryview)):
