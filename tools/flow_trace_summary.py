@@ -9,7 +9,7 @@ batches = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 d = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
-    name = r["Kernel_Name"].split("(")[0].split("::")[-1]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     if "tvl1_block" in name or "tvl1_primal" in name or "tvl1_dual" in name:
         name += " grid %sx%sx%s" % (r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])
     d[name][0] += 1

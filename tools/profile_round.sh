@@ -5,8 +5,9 @@
 #   <tag>_bench_kernel_stats.csv     rocprofv3's per-kernel summary of that run
 #   <tag>_rocprof_summary.txt        the summary by kernel family next to bench.py's HIP-event averages
 #   <tag>_mfma_util.json, <tag>_tsn_traffic.json   separate --pmc passes (tools/pmc_mfma.sh, tools/pmc_tsn.sh)
+#   <tag>_flow_kernel_stats.csv, <tag>_flow_trace_summary.txt, <tag>_flow_summary.json   TV-L1: kernel trace + FETCH / WRITE passes (tools/pmc_flow.sh)
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
@@ -21,4 +22,5 @@ python3 tools/summarize_rocprof.py "$STATS" gpurun_out/${TAG}_bench_under_rocpro
 cat gpurun_out/${TAG}_rocprof_summary.txt
 bash tools/pmc_mfma.sh > gpurun_out/${TAG}_pmc_mfma.log 2>&1 && cp gpurun_out/mfma_util.json gpurun_out/${TAG}_mfma_util.json
 bash tools/pmc_tsn.sh > gpurun_out/${TAG}_pmc_tsn.log 2>&1 && cp gpurun_out/tsn_traffic.json gpurun_out/${TAG}_tsn_traffic.json
-tail -n 2 gpurun_out/${TAG}_pmc_mfma.log gpurun_out/${TAG}_pmc_tsn.log
+bash tools/pmc_flow.sh ${TAG} > gpurun_out/${TAG}_pmc_flow.log 2>&1 || true
+tail -n 2 gpurun_out/${TAG}_pmc_mfma.log gpurun_out/${TAG}_pmc_tsn.log gpurun_out/${TAG}_pmc_flow.log
