@@ -739,6 +739,10 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-flow", action="store_true")
     ap.add_argument("--skip-two-stream", action="store_true")
+    ap.add_argument("--profile-two-stream", action="store_true",
+                    help="with --profile-only: keep the configs[2] section in the process (for a rocprofv3 summary of the 448-crop launches); "
+                         "by default --profile-only runs configs[1] (and the scan) only, so that the profiler's per-kernel averages are those "
+                         "of the timed region")
     ap.add_argument("--profile-only", action="store_true",
                     help="for rocprofv3 comparisons: every forward of the process runs like the timed region (one stream, "
                          "VQ_TSN_SPLIT=1) and the un-profiled production-mode pass is skipped")
@@ -815,7 +819,7 @@ def main():
         out["parity_vs_oracle_rel_err"] = float(np.abs(got - ref).max() / np.abs(ref).max())
     model.close()
     del crops
-    if rank == 0 and world == 1 and not args.skip_two_stream:
+    if rank == 0 and world == 1 and not args.skip_two_stream and (not args.profile_only or args.profile_two_stream):
         out["two_stream"] = bench_two_stream(args, device, stream, not args.skip_cpu)
 
     if not args.skip_sim:

@@ -8,7 +8,7 @@ fam = {}
 for r in csv.DictReader(open(stats)):
     name = r["Name"]
     key = ("conv direct (conv_igemm*)" if "conv_igemm" in name else "conv winograd (wino_f2x2_3x3, incl. the pooling that rides along)" if "wino_f2x2" in name
-           else "scan_kernel" if "scan_kernel" in name
+           else "scan_kernel" if "scan_kernel" in name else "batch_fused_kernel (16-query pass)" if "batch_fused" in name
            else "pool/gavgpool/preprocess/consensus" if any(k in name for k in ("pool_kernel", "gavgpool", "preprocess", "consensus"))
            else "other")
     f = fam.setdefault(key, [0, 0.0])
@@ -31,3 +31,8 @@ if "scan_kernel" in fam:
     c, t = fam["scan_kernel"]
     print("scan: rocprof avg launch %.4f ms over %d launches; bench.py HIP-event avg launch %.4f ms"
           % (t / c / 1e6, c, b["similarity"]["roofline"]["avg_launch_ms"]))
+bk = [k for k in fam if k.startswith("batch_fused")]
+if bk and b.get("similarity", {}).get("batched"):
+    c, t = fam[bk[0]]
+    print("batched scan: rocprof avg launch %.4f ms over %d launches; bench.py HIP events around a pass (upload + launch) %.4f ms"
+          % (t / c / 1e6, c, b["similarity"]["batched"]["pass_ms_by_hip_events"]))
