@@ -75,7 +75,8 @@ def winograd_filters(W: np.ndarray) -> np.ndarray:
     """[Cout][Cin][3][3] (fp64, BN folded) -> device layout [Cin/8][16][Cout][8] fp32 (csrc/vq_wino.hip): transformed
     in fp64 and rounded once."""
     cout, cin = W.shape[:2]
-    U = np.einsum("ia,ocab,jb->ocij", _WINO_G, W.astype(np.float64), _WINO_G)          # [o][c][i][j]
+    U = np.matmul(np.matmul(_WINO_G, W.astype(np.float64)), _WINO_G.T)                  # G g G^T per (o, c): [o][c][i][j] (G's entries are
+                                                                                         # 0, 1/2, 1: every product is exact in fp64)
     U = U.reshape(cout, cin // 8, 8, 16).transpose(1, 3, 0, 2)                           # [c/8][xi][o][c%8]
     return np.ascontiguousarray(U, dtype=np.float32)
 
