@@ -498,5 +498,27 @@ def test_comm_group_of_the_c_abi_single_rank(vqa):
     assert torch.equal(allb, block) and torch.equal(q.cpu(), torch.arange(2 * 3 * 1024, dtype=torch.float64))
     with pytest.raises(vqa.VqError):
         call("vq_allgather_scores", comm, db._h, 100, C.c_void_p(out.data_ptr()), C.c_void_p(stream))   # slice too small
+    # The stream contract (vq_amd.h): the scan is only ENQUEUED on the database handle's stream; the gather may run on any other
+    # stream and still sees the scores of the scan just enqueued (an event orders the copy behind it) -- here the scan of a new
+    # query on the handle's own non-blocking stream, the gather at once on another one, no synchronisation in between.
+    s_scan, s_gather = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    db.set_stream(s_scan.cuda_stream)
+    for row in (77, 1234, 5):
+        db.set_query_from_row(row, want=False)
+        db.scan(weights=[1.0, 1.5])
+        out.fill_(-1.0)
+        torch.cuda.synchronize()
+        db.set_query_from_row(row, want=False)
+        db.scan(weights=[0.5, 2.5])                      # enqueued ...
+        call("vq_allgather_scores", comm, db._h, 3072, C.c_void_p(out.data_ptr()), C.c_void_p(s_gather.cuda_stream))   # ... and gathered at once
+        s_gather.synchronize()
+        got = out.cpu().numpy()
+        assert (got[:3000] == db.scores()).all() and got[row] == 1.0
+    # a handle that holds no scores (a new query, no scan yet) is refused, not gathered stale
+    db.set_query_from_row(9, want=False)
+    with pytest.raises(vqa.VqError) as ei:
+        call("vq_allgather_scores", comm, db._h, 3072, C.c_void_p(out.data_ptr()), C.c_void_p(stream))
+    assert ei.value.code == -4                           # VQ_E_STATE
+    db.set_stream(None)
     call("vq_comm_destroy", comm)
     db.close()
