@@ -335,6 +335,14 @@ int vq_flow_tvl1(vq_flow* flow, const uint8_t* frames0, const uint8_t* frames1, 
 /* Device time of the inner loops (the iteration kernels of every level and warp: HIP events around each loop, summed) and the
  * number of iteration-kernel launches of the LAST vq_flow_tvl1 call on this handle -- what bench.py prices the kernel with. */
 int vq_flow_last_timing(vq_flow* flow, double* inner_loops_ms, int32_t* iteration_launches);
+/* The warped flow of extract_warp_gpu's flow-match branch in one call (build_wof_clips.py:70-73): first-pass flow, corners of the
+ * first frame (1000 / 0.001 / 3, selection on host threads), the corners moved by the flow, RANSAC homography (threshold 1 px,
+ * `hypotheses` samples from `seed`, refit on the inliers; identity unless > 50 matches and > 25 inliers), second frame warped back,
+ * flow again.  The frames go up once and the first-pass fields stay on the device.  Outputs as vq_flow_tvl1 (any may be NULL), plus
+ * the homographies frames0 -> frames1 [n][9], the match and inlier counts [n]. */
+int vq_flow_warped(vq_flow* flow, const uint8_t* frames0, const uint8_t* frames1, int32_t n_pairs, uint32_t seed, int32_t hypotheses,
+                   float* u1_host, float* u2_host, uint8_t* flow_x_host, uint8_t* flow_y_host, double* h_host, int32_t* matches_host,
+                   int32_t* inliers_host, void* hip_stream);
 
 /* Camera-motion estimation, the flow-match branch of extract_warp_gpu's "warp" step (improved dense trajectories, Wang &
  * Schmid 2013, as dense_flow applies it): Shi-Tomasi corners of the first frame (cv::goodFeaturesToTrack semantics: 3x3 block,

@@ -122,3 +122,23 @@ def test_warped_consecutive_frames_of_a_panning_clip(flow_mod):
     assert abs(np.median(px[inner]) - tv.flow_to_image(np.float32([2.0]))[0]) <= 1 and abs(np.median(py[inner]) - tv.flow_to_image(np.float32([-1.0]))[0]) <= 1
     assert abs(int(np.median(fx[inner])) - 128) <= 1 and abs(int(np.median(fy[inner])) - 128) <= 1
     m.close()
+
+
+def test_one_call_warped_flow_equals_the_steps(flow_mod):
+    """vq_flow_warped (frames uploaded once, first-pass fields kept on the device, corners moved by a kernel) against the same
+    sequence made of the public calls (Tvl1Flow.warped_steps: flow -> good_features -> numpy gather -> ransac_homography -> flow):
+    identical corner / inlier counts, homographies equal to rounding (the inverse handed to the second pass is computed by cofactors
+    here and by LAPACK there), flow images equal up to one grey level on a handful of pixels, fields to 1e-3 px."""
+    pairs = [analytic_pair(96, 128, np.array([[1.002, 0.004, 2.5], [-0.003, 0.999, -1.5], [0, 0, 1.0]]), seed=7 + k) for k in range(3)]
+    f0, f1 = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+    m = flow_mod.Tvl1Flow(4, 96, 128)
+    a = m.warped(f0, f1, seed=3, images=True, fields=True)
+    b = m.warped_steps(f0, f1, seed=3, images=True, fields=True)
+    assert (a["matches"] == b["matches"]).all() and (a["inliers"] == b["inliers"]).all() and a["matches"].min() > 50
+    assert np.abs(a["H"] - b["H"]).max() <= 1e-9 * np.abs(b["H"]).max()
+    assert np.abs(a["u1"] - b["u1"]).max() <= 1e-3 and np.abs(a["u2"] - b["u2"]).max() <= 1e-3
+    d = np.abs(a["flow_x"].astype(int) - b["flow_x"].astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 0.001
+    only = m.warped(f0[:1], f1[:1], seed=3, images=True, fields=False)            # a pair's result does not depend on its batch
+    assert (only["flow_x"][0] == a["flow_x"][0]).all() and "u1" not in only
+    m.close()

@@ -91,6 +91,7 @@ SIGNATURES = {
     "vq_flow_levels": [_P, _pI32, _pI32, _I32],
     "vq_flow_tvl1": [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _P, _P],
     "vq_flow_last_timing": [_P, _pF64, _pI32],
+    "vq_flow_warped": [_P, _P, _P, _I32, C.c_uint32, _I32, _P, _P, _P, _P, _P, _P, _P, _P],
     "vq_jpeg_info": [_P, _I64, _pI32, _pI32, _pI32],
     "vq_jpeg_create": [_I32, _I32, _I32, _I32, _PP], "vq_jpeg_destroy": [_P],
     "vq_jpeg_decode": [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P],

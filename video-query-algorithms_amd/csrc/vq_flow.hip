@@ -573,6 +573,23 @@ __global__ void tvl1_settle_kernel(const PairState* __restrict__ st, SettleArgs 
     }
 }
 
+// Where the first-pass flow moves the corners: moved = (xi + u1[yi][xi], yi + u2[yi][xi]) with (xi, yi) the corner rounded to a pixel.
+__global__ void move_corners_kernel(const float* __restrict__ corners, const int* __restrict__ counts, const float* __restrict__ u1,
+                                    const float* __restrict__ u2, float* __restrict__ moved, int n, int max_corners, int h, int w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * max_corners) return;
+    const int p = i / max_corners, k = i - p * max_corners;
+    float mx = 0.f, my = 0.f;
+    if (k < counts[p]) {
+        const int xi = min(max((int)rintf(corners[2 * i]), 0), w - 1), yi = min(max((int)rintf(corners[2 * i + 1]), 0), h - 1);
+        const int64_t g = ((int64_t)p * h + yi) * w + xi;
+        mx = (float)xi + u1[g];
+        my = (float)yi + u2[g];
+    }
+    moved[2 * i] = mx;
+    moved[2 * i + 1] = my;
+}
+
 __global__ void flow_to_image_kernel(const float* __restrict__ flow, uint8_t* __restrict__ img, int64_t total, float bound) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -825,7 +842,7 @@ __global__ void ransac_homography_kernel(const float* __restrict__ src, const fl
 }  // namespace
 
 struct vq_flow {
-    std::mutex mu;
+    std::recursive_mutex mu;               // recursive: vq_flow_warped holds it across the calls it is composed of
     int device = 0, max_pairs = 0, h = 0, w = 0;
     vq_tvl1_params prm;
     std::vector<Level> levels;
@@ -845,6 +862,10 @@ struct vq_flow {
     unsigned* frame_max = nullptr;         // [max_pairs] bit pattern of the largest corner strength of a frame
     void* match_dev = nullptr;             // RANSAC scratch (matches, winners, masks), grown on demand
     size_t match_bytes = 0;
+    float* peaks_host = nullptr;           // pinned: the corner-peak maps of a batch on their way to the host's selection
+    size_t peaks_host_floats = 0;
+    void* warp_dev = nullptr;              // vq_flow_warped: corners, moved corners, counts
+    size_t warp_bytes = 0;
     std::vector<hipEvent_t> loop_ev;       // a start / stop pair around the inner loop of every (level, warp) of a call
     double last_inner_ms = 0.0;            // device time of those loops in the last vq_flow_tvl1 call (sum of the pairs)
     int last_iter_launches = 0;            // iteration-kernel launches of the last call
@@ -875,6 +896,8 @@ static void flow_free(vq_flow* f) {
     if (f->hinv_dev) (void)hipFree(f->hinv_dev);
     if (f->frame_max) (void)hipFree(f->frame_max);
     if (f->match_dev) (void)hipFree(f->match_dev);
+    if (f->warp_dev) (void)hipFree(f->warp_dev);
+    if (f->peaks_host) (void)hipHostFree(f->peaks_host);
 }
 
 extern "C" {
@@ -994,7 +1017,7 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
                  int32_t* iters_host, void* hip_stream) {
     VQ_REQUIRE(f && frames0 && frames1, "NULL argument");
     VQ_REQUIRE(n_pairs > 0 && n_pairs <= f->max_pairs, "n_pairs %d outside (0,%d]", n_pairs, f->max_pairs);
-    std::lock_guard<std::mutex> lk(f->mu);
+    std::lock_guard<std::recursive_mutex> lk(f->mu);
     DeviceGuard g(f->device);
     hipStream_t st = (hipStream_t)hip_stream;
     const vq_tvl1_params& P = f->prm;
@@ -1197,7 +1220,7 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
 
 int vq_flow_last_timing(vq_flow* f, double* inner_loops_ms, int32_t* iteration_launches) {
     VQ_REQUIRE(f, "NULL argument");
-    std::lock_guard<std::mutex> lk(f->mu);
+    std::lock_guard<std::recursive_mutex> lk(f->mu);
     if (inner_loops_ms) *inner_loops_ms = f->last_inner_ms;
     if (iteration_launches) *iteration_launches = f->last_iter_launches;
     return VQ_OK;
@@ -1345,7 +1368,7 @@ int vq_flow_good_features(vq_flow* f, const uint8_t* frames, int32_t frames_on_d
     VQ_REQUIRE(f && frames && corners_host && counts_host, "NULL argument");
     VQ_REQUIRE(n > 0 && n <= f->max_pairs, "n %d outside (0,%d]", n, f->max_pairs);
     VQ_REQUIRE(max_corners > 0 && quality > 0.f && quality < 1.f && min_distance >= 0.f, "corner parameters out of range");
-    std::lock_guard<std::mutex> lk(f->mu);
+    std::lock_guard<std::recursive_mutex> lk(f->mu);
     DeviceGuard g(f->device);
     hipStream_t st = (hipStream_t)hip_stream;
     const int h = f->h, w = f->w;
@@ -1360,9 +1383,16 @@ int vq_flow_good_features(vq_flow* f, const uint8_t* frames, int32_t frames_on_d
     corner_strength_kernel<<<dim3((unsigned)cdiv((int64_t)h * w, 256), (unsigned)n), 256, 0, st>>>(d, strength, f->frame_max, n, h, w);
     corner_peaks_kernel<<<cdiv(full, 256), 256, 0, st>>>(strength, peaks, n, h, w);
     VQ_CHECK_LAUNCH();
-    std::vector<float> host((size_t)full);
+    if (f->peaks_host_floats < (size_t)f->max_pairs * h * w) {          // pinned, once: 22 MB per batch of 64 frames come back through it
+        if (f->peaks_host) (void)hipHostFree(f->peaks_host);
+        f->peaks_host = nullptr;
+        f->peaks_host_floats = 0;
+        VQ_HIP(hipHostMalloc((void**)&f->peaks_host, (size_t)f->max_pairs * h * w * sizeof(float)));
+        f->peaks_host_floats = (size_t)f->max_pairs * h * w;
+    }
+    float* host_peaks = f->peaks_host;
     std::vector<unsigned> top((size_t)n);
-    VQ_HIP(hipMemcpyAsync(host.data(), peaks, (size_t)full * sizeof(float), hipMemcpyDeviceToHost, st));
+    VQ_HIP(hipMemcpyAsync(host_peaks, peaks, (size_t)full * sizeof(float), hipMemcpyDeviceToHost, st));
     VQ_HIP(hipMemcpyAsync(top.data(), f->frame_max, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     VQ_HIP(hipStreamSynchronize(st));
     // the selection is per frame and sequential inside a frame: frames are spread over host threads
@@ -1371,7 +1401,7 @@ int vq_flow_good_features(vq_flow* f, const uint8_t* frames, int32_t frames_on_d
         for (int p = first; p < n; p += workers) {
             float t;
             memcpy(&t, &top[p], sizeof t);
-            counts_host[p] = select_corners(host.data() + (size_t)p * h * w, h, w, t, max_corners, quality, min_distance,
+            counts_host[p] = select_corners(host_peaks + (size_t)p * h * w, h, w, t, max_corners, quality, min_distance,
                                             corners_host + (size_t)p * max_corners * 2);
         }
     };
@@ -1389,7 +1419,7 @@ int vq_flow_ransac_homography(vq_flow* f, const float* src_host, const float* ds
     VQ_REQUIRE(n > 0 && max_points >= 4 && max_points <= 8192 && hypotheses > 0 && hypotheses <= (1 << 20) && threshold > 0.f,
                "RANSAC parameters out of range (at most 8192 matches per pair)");
     for (int p = 0; p < n; ++p) VQ_REQUIRE(counts_host[p] >= 0 && counts_host[p] <= max_points, "pair %d: %d matches of at most %d", p, counts_host[p], max_points);
-    std::lock_guard<std::mutex> lk(f->mu);
+    std::lock_guard<std::recursive_mutex> lk(f->mu);
     DeviceGuard g(f->device);
     hipStream_t st = (hipStream_t)hip_stream;
     const size_t pts_b = (size_t)n * max_points * 2 * sizeof(float);
@@ -1439,6 +1469,74 @@ int vq_flow_ransac_homography(vq_flow* f, const float* src_host, const float* ds
     if (winner_host) memcpy(winner_host, win.data(), (size_t)n * sizeof(int));
     if (mask_host) memcpy(mask_host, mask.data(), mask.size());
     return VQ_OK;
+}
+
+// The warped flow of extract_warp_gpu (flow-match branch) in one call, the frames uploaded once and the first-pass fields never leaving the
+// device: TV-L1 -> Shi-Tomasi corners of the first frame (selection on host threads) -> the corners moved by the flow (device) -> RANSAC
+// homography (device kernel + host refit) with dense_flow's guards (> 50 matches, > 25 inliers, else identity) -> the second frame warped
+// back by it -> TV-L1 again.  tsn/flow.py:Tvl1Flow.warped_steps is the same sequence call by call (tests compare the two).
+int vq_flow_warped(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int32_t n_pairs, uint32_t seed, int32_t hypotheses, float* u1_host,
+                   float* u2_host, uint8_t* flow_x_host, uint8_t* flow_y_host, double* h_host, int32_t* matches_host, int32_t* inliers_host,
+                   void* hip_stream) {
+    VQ_REQUIRE(f && frames0 && frames1, "NULL argument");
+    VQ_REQUIRE(n_pairs > 0 && n_pairs <= f->max_pairs, "n_pairs %d outside (0,%d]", n_pairs, f->max_pairs);
+    std::lock_guard<std::recursive_mutex> lk(f->mu);
+    DeviceGuard g(f->device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    constexpr int kMaxCorners = 1000, kMinMatches = 50, kMinInliers = 25;
+    int rc = vq_flow_tvl1(f, frames0, frames1, 0, n_pairs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, hip_stream);
+    if (rc != VQ_OK) return rc;
+    const int n = n_pairs, h = f->h, w = f->w;
+    std::vector<float> corners((size_t)n * kMaxCorners * 2), moved((size_t)n * kMaxCorners * 2);
+    std::vector<int32_t> counts((size_t)n), inl((size_t)n);
+    rc = vq_flow_good_features(f, f->frames_dev[0], 1, n, kMaxCorners, 0.001f, 3.0f, corners.data(), counts.data(), hip_stream);
+    if (rc != VQ_OK) return rc;
+    const size_t cb = corners.size() * sizeof(float);
+    const size_t need = 2 * cb + (size_t)n * sizeof(int);
+    if (need > f->warp_bytes) {
+        if (f->warp_dev) (void)hipFree(f->warp_dev);
+        f->warp_dev = nullptr;
+        f->warp_bytes = 0;
+        VQ_HIP(hipMalloc(&f->warp_dev, need));
+        f->warp_bytes = need;
+    }
+    float* c_dev = (float*)f->warp_dev;
+    float* m_dev = (float*)((char*)f->warp_dev + cb);
+    int* n_dev = (int*)((char*)f->warp_dev + 2 * cb);
+    VQ_HIP(hipMemcpyAsync(c_dev, corners.data(), cb, hipMemcpyHostToDevice, st));
+    VQ_HIP(hipMemcpyAsync(n_dev, counts.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+    move_corners_kernel<<<cdiv((int64_t)n * kMaxCorners, 256), 256, 0, st>>>(c_dev, n_dev, f->plane[6], f->plane[7], m_dev, n, kMaxCorners, h, w);
+    VQ_CHECK_LAUNCH();
+    VQ_HIP(hipMemcpyAsync(moved.data(), m_dev, cb, hipMemcpyDeviceToHost, st));
+    VQ_HIP(hipStreamSynchronize(st));
+    std::vector<double> H((size_t)n * 9), Hinv((size_t)n * 9);
+    rc = vq_flow_ransac_homography(f, corners.data(), moved.data(), counts.data(), n, kMaxCorners, 1.0f, hypotheses, seed, 1, H.data(), inl.data(), nullptr,
+                                   nullptr, hip_stream);
+    if (rc != VQ_OK) return rc;
+    for (int p = 0; p < n; ++p) {
+        double* m = H.data() + (size_t)p * 9;
+        double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+        if (counts[p] <= kMinMatches || inl[p] <= kMinInliers || !(std::fabs(det) > 1e-300)) {
+            const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            memcpy(m, eye, sizeof eye);
+            det = 1.0;
+        }
+        // vq_flow_tvl1(homographies = G) shows the second frame as out(x) = frame1(G^-1 x); the compensated frame is frame1(H x): G = H^-1
+        double* o = Hinv.data() + (size_t)p * 9;
+        o[0] = (m[4] * m[8] - m[5] * m[7]) / det;
+        o[1] = (m[2] * m[7] - m[1] * m[8]) / det;
+        o[2] = (m[1] * m[5] - m[2] * m[4]) / det;
+        o[3] = (m[5] * m[6] - m[3] * m[8]) / det;
+        o[4] = (m[0] * m[8] - m[2] * m[6]) / det;
+        o[5] = (m[2] * m[3] - m[0] * m[5]) / det;
+        o[6] = (m[3] * m[7] - m[4] * m[6]) / det;
+        o[7] = (m[1] * m[6] - m[0] * m[7]) / det;
+        o[8] = (m[0] * m[4] - m[1] * m[3]) / det;
+    }
+    if (h_host) memcpy(h_host, H.data(), H.size() * sizeof(double));
+    if (matches_host) memcpy(matches_host, counts.data(), (size_t)n * sizeof(int32_t));
+    if (inliers_host) memcpy(inliers_host, inl.data(), (size_t)n * sizeof(int32_t));
+    return vq_flow_tvl1(f, f->frames_dev[0], f->frames_dev[1], 1, n, Hinv.data(), u1_host, u2_host, flow_x_host, flow_y_host, nullptr, hip_stream);
 }
 
 }  // extern "C"

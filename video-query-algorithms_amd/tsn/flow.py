@@ -133,7 +133,30 @@ class Tvl1Flow:
 
     def warped(self, frames0: np.ndarray, frames1: np.ndarray, seed: int = 0, images: bool = True, fields: bool = False):
         """The warped flow of extract_warp_gpu (flow-match branch): first-pass flow -> camera homography -> frames1 warped
-        back by it -> flow again.  Returns flow()'s dict plus ``H`` (frames0 -> frames1), ``matches`` and ``inliers``."""
+        back by it -> flow again, in ONE library call (``vq_flow_warped``: the frames go up once, the first-pass fields never
+        leave the device).  Returns flow()'s dict plus ``H`` (frames0 -> frames1), ``matches`` and ``inliers``."""
+        f0 = np.ascontiguousarray(frames0, dtype=np.uint8)
+        f1 = np.ascontiguousarray(frames1, dtype=np.uint8)
+        if f0.shape != f1.shape or f0.ndim != 3 or f0.shape[1:] != (self.h, self.w):
+            raise ValueError("frames must both be [n, %d, %d] uint8" % (self.h, self.w))
+        n = f0.shape[0]
+        out = {"H": np.zeros((n, 3, 3)), "matches": np.zeros(n, np.int32), "inliers": np.zeros(n, np.int32)}
+        if fields:
+            out["u1"] = np.empty((n, self.h, self.w), dtype=np.float32)
+            out["u2"] = np.empty((n, self.h, self.w), dtype=np.float32)
+        if images:
+            out["flow_x"] = np.empty((n, self.h, self.w), dtype=np.uint8)
+            out["flow_y"] = np.empty((n, self.h, self.w), dtype=np.uint8)
+
+        def ptr(key):
+            return out[key].ctypes.data_as(C.c_void_p) if key in out else None
+        call("vq_flow_warped", self._h, f0.ctypes.data_as(C.c_void_p), f1.ctypes.data_as(C.c_void_p), n, int(seed) & 0xFFFFFFFF, 512, ptr("u1"), ptr("u2"),
+             ptr("flow_x"), ptr("flow_y"), ptr("H"), ptr("matches"), ptr("inliers"), None)
+        return out
+
+    def warped_steps(self, frames0: np.ndarray, frames1: np.ndarray, seed: int = 0, images: bool = True, fields: bool = False):
+        """The same sequence call by call through the public pieces (flow, good_features, ransac_homography, flow): what
+        ``warped`` is tested against."""
         first = self.flow(frames0, frames1, images=False, fields=True)
         H, matches, inliers = self.camera_motion(frames0, first["u1"], first["u2"], seed=seed)
         # flow(homographies=G) shows the second frame as out(x) = frame1(G^-1 x); the compensated frame is frame1(H x)
