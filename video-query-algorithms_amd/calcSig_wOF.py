@@ -164,6 +164,7 @@ def main(argv=None, net_factory=None, program=None):
     device_jpeg = args.device_jpeg and args.frame_ext.lower() in ('.jpg', '.jpeg') and not args.host_resize
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=max(1, args.num_worker))
+    prep_pool = ThreadPoolExecutor(max_workers=1)        # --device_jpeg: the stage in front of the network (see the batch loop)
     for video_path in sorted(glob.glob(frame_path + '*/')):                            # calcSig_wOF.py:193-195
         f_info = frames.parse_directory(video_path, args.rgb_prefix, args.flow_x_prefix, args.flow_y_prefix)
         clip_list = sorted(list(f_info[0]), key=lambda clip: int(clip[-4:]))           # calcSig_wOF.py:199-200
@@ -191,21 +192,30 @@ def main(argv=None, net_factory=None, program=None):
             # calcSig_wOF.py:204-210); the batch after the one on the GPU is decoded meanwhile
             batches = [clip_list[b0:min(b0 + args.batch_clips, first + count)] for b0 in range(first, first + count, args.batch_clips)]
             pending = [pool.submit(load_clip, vid) for vid in batches[0]] if batches else []
+            on_gpu = world > 1                           # blocks that will be all-gathered never visit the host
+            staged = None                                # --device_jpeg: the crops of the batch in front of the network, being made by prep_pool
             for bi, vids in enumerate(batches):
                 crops = [f.result() for f in pending]
                 pending = [pool.submit(load_clip, vid) for vid in batches[bi + 1]] if bi + 1 < len(batches) else []
                 for vid in vids:
                     print('video {} for {} modality done'.format(vid, s['modality']))
-                if crops:
-                    on_gpu = world > 1                   # blocks that will be all-gathered never visit the host
-                    if device_jpeg:                      # lists of undecoded files: decoded, resized and cropped on the GPU
-                        mine.append(net.extract_clips_from_jpegs([f for c in crops for f in c], T, on_device=on_gpu))
-                    elif args.host_resize:
-                        mine.append(net.extract_clips(np.concatenate(crops, axis=0), T, on_device=on_gpu))
-                    elif len({c.shape[1:] for c in crops}) == 1:
-                        mine.append(net.extract_clips_from_frames(np.concatenate(crops, axis=0), T, on_device=on_gpu))   # resize + crop on the GPU
-                    else:                                        # clips of different frame sizes in one batch
-                        mine += [net.extract_clips_from_frames(c, T, on_device=on_gpu) for c in crops]
+                if not crops:
+                    continue
+                if device_jpeg:
+                    # Two stages: a thread reads, decodes, resizes and crops batch b + 1 on the GPU (lists of undecoded files in, device crops
+                    # out; the library's calls release the interpreter) while this one runs batch b through the network
+                    nxt = prep_pool.submit(net.crops_from_jpegs, [f for c in crops for f in c])
+                    if staged is not None:
+                        mine.append(net.extract_clips_from_crops(staged.result(), T, on_device=on_gpu))
+                    staged = nxt
+                elif args.host_resize:
+                    mine.append(net.extract_clips(np.concatenate(crops, axis=0), T, on_device=on_gpu))
+                elif len({c.shape[1:] for c in crops}) == 1:
+                    mine.append(net.extract_clips_from_frames(np.concatenate(crops, axis=0), T, on_device=on_gpu))   # resize + crop on the GPU
+                else:                                        # clips of different frame sizes in one batch
+                    mine += [net.extract_clips_from_frames(c, T, on_device=on_gpu) for c in crops]
+            if staged is not None:
+                mine.append(net.extract_clips_from_crops(staged.result(), T, on_device=on_gpu))
             local_feat = _stack_rows(mine, net.feature_dim)
             if world > 1:
                 import torch
@@ -222,6 +232,7 @@ def main(argv=None, net_factory=None, program=None):
             write_features(args.outFeatures_dir, video, video_path, args.modelname, args.featureBlob, clip_list, features,
                            {'rgb': args.net_weights_rgb, 'warped_optical_flow': args.net_weights_flow}, args.number_format)
     pool.shutdown()
+    prep_pool.shutdown()
     for n in nets.values():
         n.close()
     return 0

@@ -143,7 +143,11 @@ class CaffeNet:
         n = len(files) // per_snip
         dev = torch.device("cuda", self._model.device)
         out = torch.empty((n, crop, crop, ch), dtype=torch.uint8, device=dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        # a stream of its own (non-blocking): this method may run in a thread of its own for the NEXT batch while the network works on the
+        # current one on the default stream -- decoding a batch of flow files keeps a few CUs busy for tens of milliseconds
+        if getattr(self, "_ingest_stream", None) is None:
+            self._ingest_stream = torch.cuda.Stream(device=dev)
+        stream = self._ingest_stream.cuda_stream
         h, w, _ = jpeg.info(files[0])
         # files per decoder call (its buffers grow to what a call needs; a call addresses its component planes with 32 bits)
         cap = max(1, min(8192, int(3.0e9 // (2 * (h + 16) * (w + 16)))))
@@ -154,10 +158,10 @@ class CaffeNet:
             dec = self._jpeg = jpeg.JpegDecoder(cap, h, w, self._model.device)
         if ch == 3:
             for i in range(0, n, cap):
-                ptr, (m, _, _) = dec.decode_to_device(files[i:i + cap], color=True)
+                ptr, (m, _, _) = dec.decode_to_device(files[i:i + cap], color=True, stream=stream)
                 call("vq_resize_crop", C.c_void_p(ptr), 1, m, h, w, 3, frame_size[0], frame_size[1], crop, frames.RESIZE_RULES[self._resize_rule],
                      C.c_void_p(out[i:i + m].data_ptr()), 3, 0, self._model.device, C.c_void_p(stream))
-                torch.cuda.current_stream(dev).synchronize()          # the decoder's buffer is reused by its next call
+                self._ingest_stream.synchronize()                     # the decoder's buffer is reused by its next call
         else:
             # the grey frames of `per` snippets in ONE decoder call, plane-major (all x0 frames, then all y0 frames, ...): a batch of
             # 32 clips x 25 snippets is 8 000 small files -- the size at which the entropy decoding runs on the device -- and every
@@ -166,11 +170,11 @@ class CaffeNet:
             for i in range(0, n, per):
                 m = min(per, n - i)
                 group = [files[(i + q) * ch + k] for k in range(ch) for q in range(m)]
-                ptr, _ = dec.decode_to_device(group, color=False)
+                ptr, _ = dec.decode_to_device(group, color=False, stream=stream)
                 for k in range(ch):
                     call("vq_resize_crop", C.c_void_p(ptr + k * m * h * w), 1, m, h, w, 1, frame_size[0], frame_size[1], crop,
                          frames.RESIZE_RULES[self._resize_rule], C.c_void_p(out[i:i + m].data_ptr()), ch, k, self._model.device, C.c_void_p(stream))
-                torch.cuda.current_stream(dev).synchronize()
+                self._ingest_stream.synchronize()
         return out
 
     def extract_clips_from_jpegs(self, files, T: int, frame_size=(340, 256), on_device: bool = False):
@@ -192,6 +196,18 @@ class CaffeNet:
             else:
                 out.append(self._model.read_features(np.empty((nb // T, self._model.feature_dim), dtype=np.float64)))
         return torch.cat(out, dim=0) if on_device else np.concatenate(out, axis=0)
+
+    def extract_clips_from_crops(self, crops, T: int, on_device: bool = False):
+        """Device crops (torch uint8 [B*T, crop, crop, C], e.g. from ``crops_from_jpegs`` run by another thread for the NEXT batch while
+        this one is in the network) -> consensus features [B, D]."""
+        import torch
+        nb = crops.shape[0]
+        if nb > self._model.max_crops or nb % T:
+            raise ValueError("%d crops: at most max_crops (%d), a multiple of T (%d)" % (nb, self._model.max_crops, T))
+        self._model.forward_device(crops.data_ptr(), nb, T, self._mean)
+        if on_device:
+            return self._model.features_tensor(nb // T).clone()
+        return self._model.read_features(np.empty((nb // T, self._model.feature_dim), dtype=np.float64))
 
     def extract_clips_from_frames(self, frames_: np.ndarray, T: int, frame_size=(340, 256), on_device: bool = False):
         """Decoded frames of B*T snippets -> consensus features [B, D]: resize + crop 0 on the device, then the

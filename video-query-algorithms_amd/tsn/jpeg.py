@@ -33,7 +33,7 @@ class JpegDecoder:
         self._h = C.c_void_p()
         call("vq_jpeg_create", self.max_frames, self.max_h, self.max_w, self.device, C.byref(self._h))
 
-    def _submit(self, files: Sequence[Union[bytes, str]], color: bool, out_host, want_dev: bool):
+    def _submit(self, files: Sequence[Union[bytes, str]], color: bool, out_host, want_dev: bool, stream: int = 0):
         if len(files) and all(isinstance(f, str) for f in files):      # paths only: the library's threads read the files
             n = len(files)
             h, w, _ = info(files[0])
@@ -41,7 +41,7 @@ class JpegDecoder:
             dev = C.c_void_p()
             host = np.empty((n, h, w, 3) if color else (n, h, w), dtype=np.uint8) if out_host else None
             call("vq_jpeg_decode_files", self._h, paths, n, int(bool(color)), h, w, host.ctypes.data_as(C.c_void_p) if host is not None else None,
-                 C.byref(dev) if want_dev else None, None)
+                 C.byref(dev) if want_dev else None, C.c_void_p(stream) if stream else None)
             return host, dev.value, (n, h, w)
         blobs: List[bytes] = []
         for f in files:
@@ -61,17 +61,18 @@ class JpegDecoder:
         if out_host:
             host = np.empty((n, h, w, 3) if color else (n, h, w), dtype=np.uint8)
         call("vq_jpeg_decode", self._h, ptrs, sizes, n, int(bool(color)), h, w, host.ctypes.data_as(C.c_void_p) if host is not None else None,
-             C.byref(dev) if want_dev else None, None)
+             C.byref(dev) if want_dev else None, C.c_void_p(stream) if stream else None)
         return host, dev.value, (n, h, w)
 
     def decode(self, files: Sequence[Union[bytes, str]], color: bool = True) -> np.ndarray:
         """File contents or paths -> uint8 [n, h, w, 3] (B, G, R: cv2 order) or [n, h, w] (grey: the Y plane)."""
         return self._submit(files, color, True, False)[0]
 
-    def decode_to_device(self, files: Sequence[Union[bytes, str]], color: bool = True):
+    def decode_to_device(self, files: Sequence[Union[bytes, str]], color: bool = True, stream: int = 0):
         """-> (device pointer of [n, h, w, 3 | 1] uint8, (n, h, w)); the memory belongs to the decoder and is valid until
-        its next call -- feed it to ``vq_resize_crop(frames_on_device=1)``."""
-        _, dev, shape = self._submit(files, color, False, True)
+        its next call -- feed it to ``vq_resize_crop(frames_on_device=1)``.  ``stream``: the HIP stream the copies and kernels run
+        on (the call returns when they are done)."""
+        _, dev, shape = self._submit(files, color, False, True, stream)
         return dev, shape
 
     def close(self):
