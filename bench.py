@@ -730,6 +730,53 @@ def bench_e2e_cli(device_index):
                     "through the two networks (which also loads / folds / uploads the weights), CSV writing"}
 
 
+def bench_e2e_wof(device_index):
+    """The drop-in build_wof_clips.py command line end to end on ONE GPU: a "video" (a directory of its 257 frames of 340 x 256, the form
+    the command line takes where cv2.VideoCapture is missing) -> grey conversion -> warped TV-L1 flow in windows of 64 pairs -> 768
+    img_ / flow_x_ / flow_y_ JPEG files (encoded by --num_worker host threads) -> clip directories.  Needs Pillow; absent -> skipped."""
+    try:
+        import io
+        from PIL import Image
+    except ImportError:
+        return None
+    import contextlib
+    import shutil
+    import tempfile
+    from video_query_algorithms_amd import build_wof_clips
+    n_frames, h, w = 257, 256, 340
+    rng = np.random.default_rng(33)
+    tex = rng.random((h + 128, w + 128))
+    for _ in range(6):
+        tex = (tex + np.roll(tex, 1, 0) + np.roll(tex, -1, 0) + np.roll(tex, 1, 1) + np.roll(tex, -1, 1)) / 5.0
+    tex = (tex - tex.min()) / (tex.max() - tex.min()) * 255.0
+    root = tempfile.mkdtemp(prefix="vq_wof_")
+    try:
+        src = os.path.join(root, "src", "pan")
+        os.makedirs(src)
+        for t in range(n_frames):                            # a slow pan over a smooth texture
+            x0, y0 = 32 + (t * 3) // 8, 32 + t // 8
+            g = np.clip(tex[y0:y0 + h, x0:x0 + w] + rng.normal(0, 1.0, (h, w)), 0, 255).astype(np.uint8)
+            Image.fromarray(np.repeat(g[:, :, None], 3, 2)).save(os.path.join(src, "frame_%05d.jpg" % t), "JPEG", quality=95, subsampling=2)
+        times = []
+        for rep in range(2):
+            out = os.path.join(root, "out%d" % rep)
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                rc = build_wof_clips.main([os.path.join(root, "src"), out, "--fps", "15", "--clip_time", "10", "--max_pairs", "64", "--num_worker", "16",
+                                           "--starting_gpu", str(device_index)])
+            times.append(time.perf_counter() - t0)
+            assert rc == 0
+        clips = sorted(os.listdir(os.path.join(root, "out1", "pan")))
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    return {"metric": "frames/sec end to end through the drop-in build_wof_clips.py (frames -> warped TV-L1 flow -> img / flow_x / flow_y JPEG files -> clips)",
+            "value": (n_frames - 1) / times[1], "unit": "frames/s", "frames": n_frames - 1, "seconds": times[1], "first_run_seconds": times[0],
+            "clip_directories": clips,
+            "config": {"workload": "one 257-frame video of 340x256 given as a directory of frames, --max_pairs 64 --num_worker 16, one GPU"},
+            "note": "whole process time of main(): reading and decoding the frames (host image library), grey conversion, 256 warped flows on the "
+                    "GPU, 768 JPEG encodings on 16 host threads, the clip regrouping"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -849,6 +896,9 @@ def main():
         e2e = bench_e2e_cli(local_rank)
         if e2e:
             out["e2e_cli"] = e2e
+        wof = bench_e2e_wof(local_rank)
+        if wof:
+            out["e2e_wof_cli"] = wof
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -93,12 +93,14 @@ def read_video(path: str) -> np.ndarray:
     return np.stack(list(iter_video(path)))
 
 
-def process_video(vid_path: str, out_path: str, flow_for, new_size=(0, 0), seed: int = 0, max_pairs: int = 64) -> int:
+def process_video(vid_path: str, out_path: str, flow_for, new_size=(0, 0), seed: int = 0, max_pairs: int = 64, writers=None) -> int:
     """Steps (1) and (2) for one video: ``img_NNNNN`` for frames 1.. (resized to ``new_size`` when given, as the reference's
     dump_frames does, build_wof_clips.py:40-42), ``flow_x/y_NNNNN`` for the warped flow (k-1 -> k) of the frames AS DECODED
     (the reference hands the video file itself to extract_warp_gpu, :70-73: the flow never sees --new_width / --new_height).
     The video streams through in windows of ``max_pairs`` frame pairs.  ``flow_for(h, w)`` gives the flow workspace for a
-    frame size.  Returns the number of frames written."""
+    frame size.  ``writers``: a thread pool that encodes and writes the image files (three JPEG encodings per frame are more host
+    time than the flow is GPU time; --num_worker threads, the reference's "CPU workers", share them) -- all files of the video are
+    on disk when the call returns.  Returns the number of frames written."""
     vid_name = os.path.basename(os.path.normpath(vid_path)).split('.')[0]
     out_full_path = os.path.join(out_path, vid_name)
     os.makedirs(out_full_path, exist_ok=True)
@@ -107,6 +109,17 @@ def process_video(vid_path: str, out_path: str, flow_for, new_size=(0, 0), seed:
     window, greys = [], []                  # frames k0 .. of the current window; greys[0] is the last frame of the one before
     done = 0                                # frame pairs written so far
 
+    jobs = []
+
+    def put(path, img):
+        if writers is None:
+            write(path, img)
+        else:
+            jobs.append(writers.submit(write, path, img))
+
+    def write_rgb(path, frame):
+        write(path, frame if new_size == (0, 0) else frames_mod.resize_bilinear(frame, new_size))
+
     def flush():
         nonlocal done
         if len(greys) < 2:
@@ -114,9 +127,12 @@ def process_video(vid_path: str, out_path: str, flow_for, new_size=(0, 0), seed:
         fx, fy = flow.warped_consecutive(np.stack(greys), seed=seed + done)
         for j, frame in enumerate(window):
             k = done + j + 1
-            write('{}/img_{:05d}'.format(out_full_path, k), frame if new_size == (0, 0) else frames_mod.resize_bilinear(frame, new_size))
-            write('{}/flow_x_{:05d}'.format(out_full_path, k), fx[j])
-            write('{}/flow_y_{:05d}'.format(out_full_path, k), fy[j])
+            if writers is None:
+                write_rgb('{}/img_{:05d}'.format(out_full_path, k), frame)
+            else:
+                jobs.append(writers.submit(write_rgb, '{}/img_{:05d}'.format(out_full_path, k), frame))
+            put('{}/flow_x_{:05d}'.format(out_full_path, k), fx[j])
+            put('{}/flow_y_{:05d}'.format(out_full_path, k), fy[j])
         done += len(window)
 
     for i, frame in enumerate(iter_video(vid_path)):
@@ -132,6 +148,8 @@ def process_video(vid_path: str, out_path: str, flow_for, new_size=(0, 0), seed:
             flush()
             window, greys = [], [g]
     flush()
+    for j in jobs:
+        j.result()                                                              # an encoder's exception is the command's
     return done
 
 
@@ -164,7 +182,7 @@ def main(argv=None, program=None) -> int:
     parser.add_argument("out_dir")
     parser.add_argument("--fps", type=int, default=15, help="frames per second, default = 15")
     parser.add_argument("--clip_time", type=int, default=10, help="clip time in seconds, default = 10")
-    parser.add_argument("--num_worker", type=int, default=16, help="CPU workers, default=16")
+    parser.add_argument("--num_worker", type=int, default=16, help="CPU workers, default=16 (here: the threads that encode and write the image files)")
     parser.add_argument("--df_path", type=str, default='./lib/dense_flow/', help='accepted for compatibility; no external toolbox is used')
     parser.add_argument("--out_format", type=str, default='dir', choices=['dir', 'zip'], help='format of output, default=dir')
     parser.add_argument("--ext", type=str, default='mp4', choices=['avi', 'mp4'], help='video file extensions, default = mp4')
@@ -199,13 +217,17 @@ def main(argv=None, program=None) -> int:
             flows[(h, w)] = Tvl1Flow(args.max_pairs, h, w, device=device)
         return flows[(h, w)]
 
+    from concurrent.futures import ThreadPoolExecutor
+    writers = ThreadPoolExecutor(max_workers=max(1, args.num_worker // world)) if args.num_worker > 1 else None
     mine = [(vid_id, vid_path) for vid_id, vid_path in enumerate(vid_list) if vid_id % world == rank]
     for vid_id, vid_path in mine:                                               # the seed is the video's GLOBAL index: the
-        n = process_video(vid_path, args.out_dir, flow_for, new_size, seed=vid_id, max_pairs=args.max_pairs)   # files do not depend on --num_gpu
+        n = process_video(vid_path, args.out_dir, flow_for, new_size, seed=vid_id, max_pairs=args.max_pairs, writers=writers)   # files do not depend on --num_gpu
         print('warp + rgb for {} {} done ({} frames)'.format(vid_id, os.path.basename(os.path.normpath(vid_path)), n))
         sys.stdout.flush()
     for _, vid_path in mine:                                                    # build_wof_clips.py:188-191
         create_clip(vid_path, args.out_dir, frames_per_clip=args.clip_time * args.fps, frames_per_second=args.fps)
+    if writers is not None:
+        writers.shutdown()
     for f in flows.values():
         f.close()
     return 0
