@@ -416,12 +416,15 @@ def bench_sim(args, rank, world, device, stream):
             "bytes_per_launch": nbytes, "score_all_gather_ms_per_query": gather_ms}
     # HBM bytes per launch from the PMC counters (collected off-line by tools/pmc_sim.sh on the full 1M-row launch and
     # committed; FETCH_SIZE doubled as the microarchitecture guide prescribes for gfx950); scaled to this rank's rows
-    tpath = os.path.join(ROOT, "profiles", "r01_scan_traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            tj = json.load(f)
-        roof["traffic"] = tj["hbm_bytes_per_launch"] * rows / SIM_N
-        roof["traffic_source"] = "profiles/r01_scan_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+    scan_traffic = None
+    for name in ("r03_scan_traffic.json", "r01_scan_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                scan_traffic = json.load(f)
+            roof["traffic"] = scan_traffic["hbm_bytes_per_launch"] * rows / SIM_N
+            roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch; committed, not collected in this run)" % name
+            break
     # batched form (N = 1 only, reported beside the single-query metric): 16 queries per pass over the database on the
     # fp64 matrix cores -- the pass stays HBM-bound, so its roofline is the same byte count over its own duration
     batched = None
@@ -452,6 +455,7 @@ def bench_sim(args, rank, world, device, stream):
         batched = {"queries_per_pass": Q, "value": Q / bdt, "unit": "queries/s", "ms_per_pass": bdt * 1e3,
                    "kernel": "batch_fused_kernel<float,4,2,false,8> (one launch per pass)", "pass_ms_by_hip_events": ev_ms,
                    "bytes_per_pass": bbytes, "hbm_GBps": bbytes / ev_ms / 1e6, "hbm_frac": bbytes / ev_ms / 1e6 / PEAK_HBM_GBS,
+                   "traffic": (scan_traffic or {}).get("batch_fused_kernel", {}).get("hbm_bytes_per_launch"),
                    "mfma_f64_tflops": 2.0 * Q * rows * SIM_S * SIM_E * SIM_D / ev_ms / 1e9, "mfma_f64_peak_tflops": 78.6,
                    "note": "vq_db_scan_batch: the database is read ONCE for 16 queries by a single launch (a workgroup walks the (stream, "
                            "split) slices itself: the slice's 16 query rows in LDS, dots on v_mfma_f64_16x16x4, per-tile sums in registers; "

@@ -23,4 +23,5 @@ cat gpurun_out/${TAG}_rocprof_summary.txt
 bash tools/pmc_mfma.sh > gpurun_out/${TAG}_pmc_mfma.log 2>&1 && cp gpurun_out/mfma_util.json gpurun_out/${TAG}_mfma_util.json
 bash tools/pmc_tsn.sh > gpurun_out/${TAG}_pmc_tsn.log 2>&1 && cp gpurun_out/tsn_traffic.json gpurun_out/${TAG}_tsn_traffic.json
 bash tools/pmc_flow.sh ${TAG} > gpurun_out/${TAG}_pmc_flow.log 2>&1 || true
-tail -n 2 gpurun_out/${TAG}_pmc_mfma.log gpurun_out/${TAG}_pmc_tsn.log gpurun_out/${TAG}_pmc_flow.log
+bash tools/pmc_sim.sh ${TAG} > gpurun_out/${TAG}_pmc_sim.log 2>&1 || true
+tail -n 2 gpurun_out/${TAG}_pmc_mfma.log gpurun_out/${TAG}_pmc_tsn.log gpurun_out/${TAG}_pmc_flow.log gpurun_out/${TAG}_pmc_sim.log
