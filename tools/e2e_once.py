@@ -1,0 +1,10 @@
+"""bench.py's end-to-end command-line object on its own (no profiler): value, seconds, steady state."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+
+r = bench.bench_e2e_cli(0)
+print(json.dumps({k: r[k] for k in ("value", "seconds", "first_run_seconds", "steady_state")}))

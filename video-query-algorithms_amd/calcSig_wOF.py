@@ -165,15 +165,21 @@ def main(argv=None, net_factory=None, program=None):
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=max(1, args.num_worker))
     prep_pool = ThreadPoolExecutor(max_workers=1)        # --device_jpeg: the stage in front of the network (see the batch loop)
+    build_pool = ThreadPoolExecutor(max_workers=len(streamCNN))
+    net_jobs = {}                                        # both extractors are built side by side when the first video turns up: the flow
+                                                         # net's weights are folded and uploaded while the RGB stream is already running
     for video_path in sorted(glob.glob(frame_path + '*/')):                            # calcSig_wOF.py:193-195
         f_info = frames.parse_directory(video_path, args.rgb_prefix, args.flow_x_prefix, args.flow_y_prefix)
         clip_list = sorted(list(f_info[0]), key=lambda clip: int(clip[-4:]))           # calcSig_wOF.py:199-200
         first, count = shard_range(len(clip_list), world, rank)
         features = {}
+        if not net_jobs:
+            for s in streamCNN:
+                net_jobs[s['modality']] = build_pool.submit(net_factory, s['net_proto'], s['net_weights'], device, max_crops=args.batch_clips * T,
+                                                            feature_blob=args.featureBlob, resize_rule=rule)
         for s in streamCNN:
             if s['modality'] not in nets:
-                nets[s['modality']] = net_factory(s['net_proto'], s['net_weights'], device, max_crops=args.batch_clips * T,
-                                                  feature_blob=args.featureBlob, resize_rule=rule)
+                nets[s['modality']] = net_jobs[s['modality']].result()
             net = nets[s['modality']]
             mine = []
 
@@ -233,6 +239,7 @@ def main(argv=None, net_factory=None, program=None):
                            {'rgb': args.net_weights_rgb, 'warped_optical_flow': args.net_weights_flow}, args.number_format)
     pool.shutdown()
     prep_pool.shutdown()
+    build_pool.shutdown()
     for n in nets.values():
         n.close()
     return 0
