@@ -866,6 +866,9 @@ struct vq_flow {
     size_t peaks_host_floats = 0;
     void* warp_dev = nullptr;              // vq_flow_warped: corners, moved corners, counts
     size_t warp_bytes = 0;
+    float* corner_plane[2] = {nullptr, nullptr};   // corner strength / peak maps: their own memory, so that the corner search of a
+    hipStream_t side_stream = nullptr;             // batch can run (on this stream) beside its first flow pass
+    hipEvent_t side_ev = nullptr;
     std::vector<hipEvent_t> loop_ev;       // a start / stop pair around the inner loop of every (level, warp) of a call
     double last_inner_ms = 0.0;            // device time of those loops in the last vq_flow_tvl1 call (sum of the pairs)
     int last_iter_launches = 0;            // iteration-kernel launches of the last call
@@ -898,6 +901,10 @@ static void flow_free(vq_flow* f) {
     if (f->match_dev) (void)hipFree(f->match_dev);
     if (f->warp_dev) (void)hipFree(f->warp_dev);
     if (f->peaks_host) (void)hipHostFree(f->peaks_host);
+    for (float* p : f->corner_plane)
+        if (p) (void)hipFree(p);
+    if (f->side_stream) (void)hipStreamDestroy(f->side_stream);
+    if (f->side_ev) (void)hipEventDestroy(f->side_ev);
 }
 
 extern "C" {
@@ -1361,24 +1368,15 @@ bool refit_homography(const float* src, const float* dst, const uint8_t* mask, i
 
 }  // namespace
 
-extern "C" {
-
-int vq_flow_good_features(vq_flow* f, const uint8_t* frames, int32_t frames_on_device, int32_t n, int32_t max_corners, float quality,
-                          float min_distance, float* corners_host, int32_t* counts_host, void* hip_stream) {
-    VQ_REQUIRE(f && frames && corners_host && counts_host, "NULL argument");
-    VQ_REQUIRE(n > 0 && n <= f->max_pairs, "n %d outside (0,%d]", n, f->max_pairs);
-    VQ_REQUIRE(max_corners > 0 && quality > 0.f && quality < 1.f && min_distance >= 0.f, "corner parameters out of range");
-    std::lock_guard<std::recursive_mutex> lk(f->mu);
-    DeviceGuard g(f->device);
-    hipStream_t st = (hipStream_t)hip_stream;
+// The corner search of n frames already in device memory, on `st`; the caller holds the handle's lock (or is the helper thread
+// vq_flow_warped starts while it holds it).  Touches only the corner planes, frame_max and the pinned peak buffer.
+static int good_features_core(vq_flow* f, const uint8_t* d, int n, int max_corners, float quality, float min_distance, float* corners_host,
+                              int32_t* counts_host, hipStream_t st) {
     const int h = f->h, w = f->w;
     const int64_t full = (int64_t)n * h * w;
-    const uint8_t* d = frames;
-    if (!frames_on_device) {
-        VQ_HIP(hipMemcpyAsync(f->frames_dev[0], frames, (size_t)full, hipMemcpyHostToDevice, st));
-        d = f->frames_dev[0];
-    }
-    float *strength = f->plane[0], *peaks = f->plane[1];
+    for (float*& p : f->corner_plane)
+        if (!p) VQ_HIP(hipMalloc((void**)&p, (size_t)f->max_pairs * h * w * sizeof(float)));
+    float *strength = f->corner_plane[0], *peaks = f->corner_plane[1];
     VQ_HIP(hipMemsetAsync(f->frame_max, 0, (size_t)n * sizeof(unsigned), st));
     corner_strength_kernel<<<dim3((unsigned)cdiv((int64_t)h * w, 256), (unsigned)n), 256, 0, st>>>(d, strength, f->frame_max, n, h, w);
     corner_peaks_kernel<<<cdiv(full, 256), 256, 0, st>>>(strength, peaks, n, h, w);
@@ -1410,6 +1408,24 @@ int vq_flow_good_features(vq_flow* f, const uint8_t* frames, int32_t frames_on_d
     work(0);
     for (std::thread& th : pool) th.join();
     return VQ_OK;
+}
+
+extern "C" {
+
+int vq_flow_good_features(vq_flow* f, const uint8_t* frames, int32_t frames_on_device, int32_t n, int32_t max_corners, float quality,
+                          float min_distance, float* corners_host, int32_t* counts_host, void* hip_stream) {
+    VQ_REQUIRE(f && frames && corners_host && counts_host, "NULL argument");
+    VQ_REQUIRE(n > 0 && n <= f->max_pairs, "n %d outside (0,%d]", n, f->max_pairs);
+    VQ_REQUIRE(max_corners > 0 && quality > 0.f && quality < 1.f && min_distance >= 0.f, "corner parameters out of range");
+    std::lock_guard<std::recursive_mutex> lk(f->mu);
+    DeviceGuard g(f->device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const uint8_t* d = frames;
+    if (!frames_on_device) {
+        VQ_HIP(hipMemcpyAsync(f->frames_dev[0], frames, (size_t)n * f->h * f->w, hipMemcpyHostToDevice, st));
+        d = f->frames_dev[0];
+    }
+    return good_features_core(f, d, n, max_corners, quality, min_distance, corners_host, counts_host, st);
 }
 
 int vq_flow_ransac_homography(vq_flow* f, const float* src_host, const float* dst_host, const int32_t* counts_host, int32_t n,
@@ -1484,13 +1500,29 @@ int vq_flow_warped(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, i
     DeviceGuard g(f->device);
     hipStream_t st = (hipStream_t)hip_stream;
     constexpr int kMaxCorners = 1000, kMinMatches = 50, kMinInliers = 25;
-    int rc = vq_flow_tvl1(f, frames0, frames1, 0, n_pairs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, hip_stream);
-    if (rc != VQ_OK) return rc;
     const int n = n_pairs, h = f->h, w = f->w;
     std::vector<float> corners((size_t)n * kMaxCorners * 2), moved((size_t)n * kMaxCorners * 2);
     std::vector<int32_t> counts((size_t)n), inl((size_t)n);
-    rc = vq_flow_good_features(f, f->frames_dev[0], 1, n, kMaxCorners, 0.001f, 3.0f, corners.data(), counts.data(), hip_stream);
+    // The corners depend on the first frames alone: their search (two small kernels, 22 MB of peak maps to the host, the selection on
+    // host threads) runs on a stream and a thread of its own beside the first flow pass instead of between the two passes.
+    if (!f->side_stream) VQ_HIP(hipStreamCreateWithFlags(&f->side_stream, hipStreamNonBlocking));
+    if (!f->side_ev) VQ_HIP(hipEventCreateWithFlags(&f->side_ev, hipEventDisableTiming));
+    const size_t full = (size_t)n * h * w;
+    VQ_HIP(hipMemcpyAsync(f->frames_dev[0], frames0, full, hipMemcpyHostToDevice, st));
+    VQ_HIP(hipEventRecord(f->side_ev, st));
+    VQ_HIP(hipMemcpyAsync(f->frames_dev[1], frames1, full, hipMemcpyHostToDevice, st));
+    VQ_HIP(hipStreamWaitEvent(f->side_stream, f->side_ev, 0));
+    int rc_corners = VQ_OK;
+    std::string err_corners;
+    std::thread side([&] {
+        DeviceGuard gs(f->device);
+        rc_corners = good_features_core(f, f->frames_dev[0], n, kMaxCorners, 0.001f, 3.0f, corners.data(), counts.data(), f->side_stream);
+        if (rc_corners != VQ_OK) err_corners = last_error_ref();        // the message lives in the helper thread's slot
+    });
+    int rc = vq_flow_tvl1(f, f->frames_dev[0], f->frames_dev[1], 1, n_pairs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, hip_stream);
+    side.join();
     if (rc != VQ_OK) return rc;
+    if (rc_corners != VQ_OK) return fail(rc_corners, "%s", err_corners.c_str());
     const size_t cb = corners.size() * sizeof(float);
     const size_t need = 2 * cb + (size_t)n * sizeof(int);
     if (need > f->warp_bytes) {
