@@ -164,7 +164,7 @@ def main(argv=None, net_factory=None, program=None):
     device_jpeg = args.device_jpeg and args.frame_ext.lower() in ('.jpg', '.jpeg') and not args.host_resize
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=max(1, args.num_worker))
-    prep_pool = ThreadPoolExecutor(max_workers=1)        # --device_jpeg: the stage in front of the network (see the batch loop)
+    prep_pool = ThreadPoolExecutor(max_workers=2)        # --device_jpeg: the stages in front of the network (see the batch loop)
     build_pool = ThreadPoolExecutor(max_workers=len(streamCNN))
     net_jobs = {}                                        # both extractors are built side by side when the first video turns up: the flow
                                                          # net's weights are folded and uploaded while the RGB stream is already running
@@ -199,7 +199,7 @@ def main(argv=None, net_factory=None, program=None):
             batches = [clip_list[b0:min(b0 + args.batch_clips, first + count)] for b0 in range(first, first + count, args.batch_clips)]
             pending = [pool.submit(load_clip, vid) for vid in batches[0]] if batches else []
             on_gpu = world > 1                           # blocks that will be all-gathered never visit the host
-            staged = None                                # --device_jpeg: the crops of the batch in front of the network, being made by prep_pool
+            staged = []                                  # --device_jpeg: the crops of the batches in front of the network, being made by prep_pool
             for bi, vids in enumerate(batches):
                 crops = [f.result() for f in pending]
                 pending = [pool.submit(load_clip, vid) for vid in batches[bi + 1]] if bi + 1 < len(batches) else []
@@ -208,20 +208,21 @@ def main(argv=None, net_factory=None, program=None):
                 if not crops:
                     continue
                 if device_jpeg:
-                    # Two stages: a thread reads, decodes, resizes and crops batch b + 1 on the GPU (lists of undecoded files in, device crops
-                    # out; the library's calls release the interpreter) while this one runs batch b through the network
-                    nxt = prep_pool.submit(net.crops_from_jpegs, [f for c in crops for f in c])
-                    if staged is not None:
-                        mine.append(net.extract_clips_from_crops(staged.result(), T, on_device=on_gpu))
-                    staged = nxt
+                    # Three stages: two threads read, decode, resize and crop batches b + 1 and b + 2 on the GPU (lists of undecoded files in,
+                    # device crops out; the library's calls release the interpreter; each thread has a decoder and a stream of its own, so
+                    # one batch's host half -- reading the files, stripping the byte stuffing -- overlaps the other's device half) while
+                    # this one runs batch b through the network
+                    staged.append(prep_pool.submit(net.crops_from_jpegs, [f for c in crops for f in c], lane=bi % 2))
+                    if len(staged) > 2:
+                        mine.append(net.extract_clips_from_crops(staged.pop(0).result(), T, on_device=on_gpu))
                 elif args.host_resize:
                     mine.append(net.extract_clips(np.concatenate(crops, axis=0), T, on_device=on_gpu))
                 elif len({c.shape[1:] for c in crops}) == 1:
                     mine.append(net.extract_clips_from_frames(np.concatenate(crops, axis=0), T, on_device=on_gpu))   # resize + crop on the GPU
                 else:                                        # clips of different frame sizes in one batch
                     mine += [net.extract_clips_from_frames(c, T, on_device=on_gpu) for c in crops]
-            if staged is not None:
-                mine.append(net.extract_clips_from_crops(staged.result(), T, on_device=on_gpu))
+            for job in staged:
+                mine.append(net.extract_clips_from_crops(job.result(), T, on_device=on_gpu))
             local_feat = _stack_rows(mine, net.feature_dim)
             if world > 1:
                 import torch

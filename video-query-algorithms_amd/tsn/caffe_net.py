@@ -127,15 +127,15 @@ class CaffeNet:
                      crop, frames.RESIZE_RULES[self._resize_rule], C.c_void_p(out.data_ptr()), self._channels, k, self._model.device, C.c_void_p(stream))
         return out
 
-    def crops_from_jpegs(self, files, frame_size=(340, 256), crop=224):
+    def crops_from_jpegs(self, files, frame_size=(340, 256), crop=224, lane=0):
         """JPEG file contents -> device crops (torch uint8 [n, crop, crop, C]) without the frames ever visiting the host:
         entropy decoding on the library's host threads, IDCT / upsampling / colour on the device (tsn/jpeg.py), resize +
         crop 0 straight from the decoder's device buffer.  RGB net: n files; flow net: n * C files in stack order per
-        snippet (x0, y0, x1, y1, ...).  The pixels are libjpeg's (what cv2.imread returns), bit for bit."""
-        import ctypes as C
+        snippet (x0, y0, x1, y1, ...).  The pixels are libjpeg's (what cv2.imread returns), bit for bit.  ``lane``: calls of
+        different lanes own different decoders and streams and may run at the same time in different threads (the command line
+        keeps two batches in preparation: one's host half -- reading, unstuffing -- overlaps the other's device half)."""
+        import threading
         import torch
-        from .._lib import call
-        from . import jpeg
         ch = self._channels
         per_snip = 1 if ch == 3 else ch
         if len(files) % per_snip:
@@ -143,25 +143,36 @@ class CaffeNet:
         n = len(files) // per_snip
         dev = torch.device("cuda", self._model.device)
         out = torch.empty((n, crop, crop, ch), dtype=torch.uint8, device=dev)
-        # a stream of its own (non-blocking): this method may run in a thread of its own for the NEXT batch while the network works on the
+        lanes = self.__dict__.setdefault("_ingest_lanes", {})
+        st = lanes.setdefault(lane, {"stream": None, "jpeg": None, "lock": threading.Lock()})
+        with st["lock"]:                                 # a lane's decoder buffer and stream serve one call at a time
+            return self._crops_from_jpegs_on(st, files, n, ch, frame_size, crop, out, dev)
+
+    def _crops_from_jpegs_on(self, st, files, n, ch, frame_size, crop, out, dev):
+        import ctypes as C
+        import torch
+        from .._lib import call
+        from . import jpeg
+        # a stream of its own (non-blocking): the call may run in a thread of its own for a LATER batch while the network works on the
         # current one on the default stream -- decoding a batch of flow files keeps a few CUs busy for tens of milliseconds
-        if getattr(self, "_ingest_stream", None) is None:
-            self._ingest_stream = torch.cuda.Stream(device=dev)
-        stream = self._ingest_stream.cuda_stream
+        if st["stream"] is None:
+            st["stream"] = torch.cuda.Stream(device=dev)
+        ingest = st["stream"]
+        stream = ingest.cuda_stream
         h, w, _ = jpeg.info(files[0])
         # files per decoder call (its buffers grow to what a call needs; a call addresses its component planes with 32 bits)
         cap = max(1, min(8192, int(3.0e9 // (2 * (h + 16) * (w + 16)))))
-        dec = getattr(self, "_jpeg", None)
+        dec = st["jpeg"]
         if dec is None or dec.max_h < h or dec.max_w < w:
             if dec is not None:
                 dec.close()
-            dec = self._jpeg = jpeg.JpegDecoder(cap, h, w, self._model.device)
+            dec = st["jpeg"] = jpeg.JpegDecoder(cap, h, w, self._model.device)
         if ch == 3:
             for i in range(0, n, cap):
                 ptr, (m, _, _) = dec.decode_to_device(files[i:i + cap], color=True, stream=stream)
                 call("vq_resize_crop", C.c_void_p(ptr), 1, m, h, w, 3, frame_size[0], frame_size[1], crop, frames.RESIZE_RULES[self._resize_rule],
                      C.c_void_p(out[i:i + m].data_ptr()), 3, 0, self._model.device, C.c_void_p(stream))
-                self._ingest_stream.synchronize()                     # the decoder's buffer is reused by its next call
+                ingest.synchronize()                                  # the decoder's buffer is reused by its next call
         else:
             # the grey frames of `per` snippets in ONE decoder call, plane-major (all x0 frames, then all y0 frames, ...): a batch of
             # 32 clips x 25 snippets is 8 000 small files -- the size at which the entropy decoding runs on the device -- and every
@@ -174,7 +185,7 @@ class CaffeNet:
                 for k in range(ch):
                     call("vq_resize_crop", C.c_void_p(ptr + k * m * h * w), 1, m, h, w, 1, frame_size[0], frame_size[1], crop,
                          frames.RESIZE_RULES[self._resize_rule], C.c_void_p(out[i:i + m].data_ptr()), ch, k, self._model.device, C.c_void_p(stream))
-                self._ingest_stream.synchronize()
+                ingest.synchronize()
         return out
 
     def extract_clips_from_jpegs(self, files, T: int, frame_size=(340, 256), on_device: bool = False):
@@ -234,7 +245,8 @@ class CaffeNet:
         return self._model.feature_dim
 
     def close(self):
-        if getattr(self, "_jpeg", None) is not None:
-            self._jpeg.close()
-            self._jpeg = None
+        for st in self.__dict__.get("_ingest_lanes", {}).values():
+            if st["jpeg"] is not None:
+                st["jpeg"].close()
+                st["jpeg"] = None
         self._model.close()
