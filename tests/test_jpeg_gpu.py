@@ -211,3 +211,31 @@ def test_device_entropy_decoding_equals_the_host_decoder(jpeg, monkeypatch):
     g = grey.decode([files[5], files[0]], color=False)
     assert (g[0] == np.asarray(Image.open(io.BytesIO(files[5])).convert("L"))).all()
     grey.close()
+
+
+@needs_pil
+def test_two_batches_in_preparation_at_once_give_the_crops_of_one_at_a_time(jpeg):
+    """The command line keeps two batches in preparation (CaffeNet.crops_from_jpegs on lanes 0 and 1 from two threads, a decoder and a
+    stream per lane): RGB and flow crops equal the ones the same calls give one after the other, and a second call on a busy lane waits."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from video_query_algorithms_amd.tsn import bn_inception
+    from video_query_algorithms_amd.tsn.caffe_net import CaffeNet
+    rng = np.random.default_rng(11)
+    base = picture(256, 340, 9).astype(np.int16)
+
+    def rgb_file():
+        return encode(np.clip(base + rng.integers(-25, 25, base.shape), 0, 255).astype(np.uint8), quality=95, subsampling=2)
+
+    def grey_file():
+        return encode(np.clip(base[:, :, 1] + rng.integers(-25, 25, base.shape[:2]), 0, 255).astype(np.uint8), quality=95)
+    for ch, make, per in ((3, rgb_file, 1), (10, grey_file, 10)):
+        net = CaffeNet(bn_inception.bn_inception(ch), "synthetic:3", 0, max_crops=6)
+        batches = [[make() for _ in range(6 * per)] for _ in range(4)]
+        one_by_one = [net.crops_from_jpegs(b).cpu().numpy() for b in batches]
+        with ThreadPoolExecutor(max_workers=3) as pool:
+            jobs = [pool.submit(net.crops_from_jpegs, b, lane=k % 2) for k, b in enumerate(batches)]       # three threads, two lanes
+            together = [j.result().cpu().numpy() for j in jobs]
+        for a, b in zip(one_by_one, together):
+            assert a.shape == (6, 224, 224, ch) and (a == b).all()
+        net.close()
