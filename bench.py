@@ -744,11 +744,12 @@ def bench_e2e_cli(device_index):
             "unit": "clips/s", "clips": n_clips, "seconds": times[1], "first_run_seconds": times[0], "csv_rows": rows,
             "steady_state": {"value": steady, "unit": "clips/s",
                              "note": "(256 - 32 clips) / (time of the 256-clip run - time of a 32-clip run): what a long job sees once the two "
-                                     "network handles exist (building them -- weights folded, Winograd filter transforms in fp64 on the host, "
-                                     "upload -- is %.2f s of every run)" % max(times[2] - 32 / max(steady, 1e-9), 0.0)},
+                                     "network handles exist (building them -- packed weights read from the cache, upload, buffers -- is %.2f s of every "
+                                     "run; the first run on a machine also reads, folds and transforms the weights)" % max(times[2] - 32 / max(steady, 1e-9), 0.0)},
             "files_read_per_clip": 25 + 250, "mean_file_kb": {"rgb": sum(map(len, rgb_blobs)) / 8 / 1024, "flow": sum(map(len, grey_blobs)) / 8 / 1024},
             "config": {"workload": "calcSig_wOF.py --device_jpeg --num_worker 16, 256 clips x 30 frames of 340x256, T=25 (the reference's default), "
-                                   "both streams, one GPU, network handles rebuilt per run"},
+                                   "both streams, one GPU, network handles rebuilt per run (packed weights from the cache next to the library, as on every "
+                                   "run after a machine's first)"},
             "note": "whole process time of main(): directory parsing, reading 70 400 files (8 batches of 32 clips per stream), JPEG decoding, resize + crop, 800 + 800 crops "
                     "through the two networks (which also loads / folds / uploads the weights), CSV writing"}
 

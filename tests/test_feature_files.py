@@ -366,3 +366,50 @@ def test_clip_plan_follows_create_clip():
     assert frames.clip_plan(480) == ([(1, 1, 150), (2, 151, 300), (3, 301, 450), (4, 451, 480)], 0)
     assert frames.clip_plan(100) == ([(1, 1, 100)], 0) and frames.clip_plan(20) == ([], 20)
     assert frames.clip_plan(310, frames_per_clip=100, frames_per_second=5) == ([(1, 1, 100), (2, 101, 200), (3, 201, 300), (4, 301, 310)], 0)
+
+
+def test_packed_weight_cache_skips_the_loader_and_returns_the_same_blob(tmp_path, monkeypatch):
+    """TsnNet(cache_key=...): the second handle of the same network takes its packed device blob (BN folded, GEMM / Winograd layouts,
+    biases) and its layer table from the cache and never asks for the weights; another key, other packing options or VQ_WEIGHT_CACHE=0
+    pack afresh.  The library call is stubbed (no GPU here): what would have been uploaded is what is compared."""
+    import ctypes as C
+
+    from video_query_algorithms_amd.tsn import bn_inception
+    from video_query_algorithms_amd.tsn import net as tnet
+    g = bn_inception.bn_inception(3)
+    seen, loads = {}, []
+
+    def fake_call(name, *a):
+        if name != "vq_tsn_create":
+            raise tnet._lib.VqError(tnet._lib.VQ_E_INVALID if hasattr(tnet._lib, "VQ_E_INVALID") else -1, "stubbed library: " + name)
+        seen["blob"] = np.ctypeslib.as_array(C.cast(a[6], C.POINTER(C.c_float)), shape=(a[7],)).copy()
+        seen["layers"], seen["segments"] = bytes(a[2]), bytes(a[4])
+
+    def loader(seed):
+        def load():
+            loads.append(seed)
+            return tnet.synthetic_weights(g, seed)
+        return load
+    monkeypatch.setattr(tnet, "call", fake_call)
+    monkeypatch.setenv("VQ_WEIGHT_CACHE", str(tmp_path / "wc"))
+    monkeypatch.setenv("VQ_TUNE_CACHE", "0")
+    tnet.TsnNet(g, loader(2), cache_key="synthetic:2")
+    first = dict(seen)
+    tnet.TsnNet(g, loader(2), cache_key="synthetic:2")
+    assert loads == [2] and (seen["blob"] == first["blob"]).all() and seen["layers"] == first["layers"] and seen["segments"] == first["segments"]
+    direct = tnet.TsnNet(g, tnet.synthetic_weights(g, 2))                        # no key: packed from the weights, same result
+    assert (seen["blob"] == first["blob"]).all() and seen["layers"] == first["layers"]
+    assert direct.conv_kp == tnet.TsnNet(g, loader(2), cache_key="synthetic:2").conv_kp and loads == [2]
+    tnet.TsnNet(g, loader(3), cache_key="synthetic:3")                           # other weights: other entry
+    assert loads == [2, 3] and not (seen["blob"] == first["blob"]).all()
+    tnet.TsnNet(g, loader(2), cache_key="synthetic:2", winograd=False)           # other packing options: other entry
+    assert loads == [2, 3, 2] and seen["blob"].size != first["blob"].size
+    monkeypatch.setenv("VQ_WEIGHT_CACHE", "0")
+    tnet.TsnNet(g, loader(2), cache_key="synthetic:2")
+    assert loads == [2, 3, 2, 2] and (seen["blob"] == first["blob"]).all()
+    # a damaged entry is ignored, not trusted
+    monkeypatch.setenv("VQ_WEIGHT_CACHE", str(tmp_path / "wc"))
+    for f in (tmp_path / "wc").glob("*.npy"):
+        f.write_bytes(f.read_bytes()[:1000])
+    tnet.TsnNet(g, loader(2), cache_key="synthetic:2")
+    assert loads[-1] == 2 and len(loads) == 5 and (seen["blob"] == first["blob"]).all()

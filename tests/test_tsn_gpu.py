@@ -710,3 +710,30 @@ def test_tiling_tables_survive_the_process(tsn, monkeypatch, tmp_path):
     m = net.TsnNet(g, w, max_crops=6)
     assert m.tuned_sizes() == []
     m.close()
+
+
+def test_features_from_cached_packed_weights_equal_features_from_the_weights(tmp_path, monkeypatch):
+    """CaffeNet on a weights FILE: the first handle packs and stores, the second takes the packed blob from the cache (its loader is never
+    called), a third with the cache switched off packs again -- the same features, bit for bit."""
+    from video_query_algorithms_amd.tsn import bn_inception, caffe_net
+    from video_query_algorithms_amd.tsn.net import synthetic_weights
+    g = bn_inception.bn_inception(3)
+    path = str(tmp_path / "w.npz")
+    caffe_net.save_weights(path, synthetic_weights(g, 4))
+    crops = np.random.default_rng(3).integers(0, 256, (6, 224, 224, 3), dtype=np.uint8)
+    monkeypatch.setenv("VQ_WEIGHT_CACHE", str(tmp_path / "wc"))
+    loads = []
+    real = caffe_net.load_weights
+    monkeypatch.setattr(caffe_net, "load_weights", lambda graph, spec: (loads.append(spec), real(graph, spec))[1])
+    feats = []
+    for _ in range(2):
+        net = caffe_net.CaffeNet(g, path, 0, max_crops=6)
+        feats.append(net.extract_clips(crops, 3))
+        net.close()
+    assert loads == [path]
+    monkeypatch.setenv("VQ_WEIGHT_CACHE", "0")
+    net = caffe_net.CaffeNet(g, path, 0, max_crops=6)
+    feats.append(net.extract_clips(crops, 3))
+    net.close()
+    assert loads == [path, path]
+    assert (feats[0] == feats[1]).all() and (feats[0] == feats[2]).all() and np.isfinite(feats[0]).all()

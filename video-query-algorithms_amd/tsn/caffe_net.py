@@ -36,6 +36,18 @@ def load_weights(graph, spec: str):
     raise ValueError("weights file %r: expected .caffemodel, .npz or synthetic:<seed>" % spec)
 
 
+def weights_digest(spec: str) -> str:
+    """Names the CONTENT of a weights specification: ``synthetic:<seed>`` as it is, a file by the SHA-1 of its bytes."""
+    if spec.startswith("synthetic:"):
+        return spec
+    import hashlib
+    h = hashlib.sha1()
+    with open(spec, "rb") as f:
+        for piece in iter(lambda: f.read(1 << 22), b""):
+            h.update(piece)
+    return "file:" + h.hexdigest()
+
+
 def save_weights(path: str, weights):
     np.savez(path, **{"%s/%s" % (layer, f): a for layer, d in weights.items() for f, a in d.items()})
 
@@ -58,11 +70,16 @@ class CaffeNet:
             raise ValueError("resize_rule must be 'cv2' or 'exact'")
         self._resize_rule = resize_rule
         self._graph = bn_inception.load_prototxt(net_proto) if isinstance(net_proto, str) else net_proto
-        self._weights = load_weights(self._graph, net_weights) if isinstance(net_weights, str) else net_weights
         self._blob = feature_blob
         self._channels = self._graph.input_shape[0]
         self._mean = RGB_MEAN if self._channels == 3 else tuple([128.0] * self._channels)
-        self._model = TsnNet(self._graph, self._weights, max_crops=max_crops, device=device_id, feature_blob=feature_blob)
+        if isinstance(net_weights, str):
+            # read (and fold, and lay out) only if the packed form of exactly these weights is not in the cache next to the library
+            graph = self._graph
+            self._model = TsnNet(graph, lambda: load_weights(graph, net_weights), max_crops=max_crops, device=device_id, feature_blob=feature_blob,
+                                 cache_key=weights_digest(net_weights))
+        else:
+            self._model = TsnNet(self._graph, net_weights, max_crops=max_crops, device=device_id, feature_blob=feature_blob)
         self._net = _NetView()
 
     # -- the reference's per-snippet interface ------------------------------------------------------------

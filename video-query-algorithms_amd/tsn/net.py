@@ -109,10 +109,52 @@ def s2d_stem_weights(W: np.ndarray) -> np.ndarray:
     return out
 
 
+def _load_packed(path: str, n_ops: int):
+    """(blob, layers, segments, conv_kp) of a packed network from the weight cache, or None."""
+    try:
+        with open(path + ".json") as f:
+            meta = json.load(f)
+        if meta["n_ops"] != n_ops:
+            return None
+        blob = np.load(path + ".npy", mmap_mode="r", allow_pickle=False)
+        if blob.dtype != np.float32 or blob.ndim != 1 or blob.size != meta["blob_floats"]:
+            return None
+        layers = (LayerDesc * n_ops).from_buffer_copy(bytes.fromhex(meta["layers"]))
+        n_seg = meta["n_segments"]
+        segs = list((ConvSegment * n_seg).from_buffer_copy(bytes.fromhex(meta["segments"]))) if n_seg else []
+        return np.ascontiguousarray(blob), layers, segs, {int(k): v for k, v in meta["conv_kp"].items()}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def _store_packed(path: str, blob, layers, seg_list, conv_kp) -> None:
+    """Best effort, atomic per file (several ranks of a fan-out may store the same network at once); the .json goes last and is
+    what a reader looks for first."""
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        with open(tmp + ".npy", "wb") as f:
+            np.save(f, blob, allow_pickle=False)
+        os.replace(tmp + ".npy", path + ".npy")
+        segs = (ConvSegment * max(len(seg_list), 1))(*seg_list)
+        meta = {"n_ops": len(layers), "blob_floats": int(blob.size), "layers": bytes(layers).hex(), "n_segments": len(seg_list),
+                "segments": bytes(segs).hex() if seg_list else "", "conv_kp": {str(k): int(v) for k, v in conv_kp.items()}}
+        with open(tmp + ".json", "w") as f:
+            json.dump(meta, f)
+        os.replace(tmp + ".json", path + ".json")
+    except OSError:
+        pass
+
+
 class TsnNet:
-    def __init__(self, graph: Graph, weights: Dict[str, Dict[str, np.ndarray]], max_crops: int = 96, device: int = 0,
+    def __init__(self, graph: Graph, weights, max_crops: int = 96, device: int = 0,
                  feature_blob: str = "global_pool", bn_eps: float = 1e-5, fuse: bool = True,
-                 winograd: bool | None = None, stem_s2d: bool | None = None):
+                 winograd: bool | None = None, stem_s2d: bool | None = None, cache_key: str | None = None):
+        """``weights``: {layer: {field: array}}, or a function without arguments that returns it (called only when the packed form
+        is not in the cache).  ``cache_key``: names the weights' CONTENT (a digest of the file they come from, "synthetic:<seed>");
+        with it the packed device blob -- BN folded, GEMM / Winograd layouts, biases -- is kept next to the library
+        (``VQ_WEIGHT_CACHE=<dir>`` moves it, ``=0`` disables) under a digest of (key, layer plan, packing options, library ABI), and
+        a later handle of the same network skips reading, folding and transforming the weights (0.3-0.5 s of every command-line run)."""
         self.graph = graph
         self.plan: Plan = graph.plan(feature_blob, fuse=fuse)
         self.in_channels = graph.input_shape[0]
@@ -147,84 +189,97 @@ class TsnNet:
         else:
             tensors[0] = TensorDesc(self.in_h, self.in_w, cin_pad)
         self.conv_kp = {}                                  # op index -> packed K of the direct kernel (bench accounting)
-        layers = (LayerDesc * len(plan.ops))()
-        seg_list = []
-        chunks = []
-        off = 0
+        cache_file = None
+        where = os.environ.get("VQ_WEIGHT_CACHE", os.path.join(os.path.dirname(_lib.LIB_PATH), ".weight_cache"))
+        if cache_key is not None and where != "0":
+            opts = [_lib.ABI_VERSION, BK, cache_key, repr(plan.ops), repr(plan.tensors), bool(self.winograd), bool(self.stem_s2d), float(bn_eps), cin_pad]
+            cache_file = os.path.join(where, hashlib.sha1(json.dumps(opts).encode()).hexdigest()[:24])
+        cached = _load_packed(cache_file, len(plan.ops)) if cache_file else None
+        if cached is not None:
+            blob, layers, seg_list, self.conv_kp = cached
+        else:
+            if callable(weights):
+                weights = weights()
+            layers = (LayerDesc * len(plan.ops))()
+            seg_list = []
+            chunks = []
+            off = 0
 
-        def packed_conv(name, bn, cin, cout, k, cin_dev, with_bias=True):
-            W, b = fold_bn(weights[name], weights[bn] if bn else None, bn_eps)
-            if W.shape != (cout, cin, k, k):
-                raise ValueError("weights of %s have shape %s, expected %s" % (name, W.shape, (cout, cin, k, k)))
-            ohwi = np.zeros((cout, k, k, cin_dev), dtype=np.float32)
-            ohwi[..., :cin] = W.transpose(0, 2, 3, 1)                      # [Cout][kh][kw][Cin]
-            kdim = k * k * cin_dev
-            kp = (kdim + BK - 1) // BK * BK
-            packed = np.zeros((cout, kp), dtype=np.float32)
-            packed[:, :kdim] = ohwi.reshape(cout, kdim)
-            return packed, (b if with_bias else np.zeros_like(b))
+            def packed_conv(name, bn, cin, cout, k, cin_dev, with_bias=True):
+                W, b = fold_bn(weights[name], weights[bn] if bn else None, bn_eps)
+                if W.shape != (cout, cin, k, k):
+                    raise ValueError("weights of %s have shape %s, expected %s" % (name, W.shape, (cout, cin, k, k)))
+                ohwi = np.zeros((cout, k, k, cin_dev), dtype=np.float32)
+                ohwi[..., :cin] = W.transpose(0, 2, 3, 1)                      # [Cout][kh][kw][Cin]
+                kdim = k * k * cin_dev
+                kp = (kdim + BK - 1) // BK * BK
+                packed = np.zeros((cout, kp), dtype=np.float32)
+                packed[:, :kdim] = ohwi.reshape(cout, kdim)
+                return packed, (b if with_bias else np.zeros_like(b))
 
-        for i, op in enumerate(plan.ops):
-            d = LayerDesc(op=_OPS[op.kind], src=op.src, dst=op.dst, src_coff=op.src_coff, dst_coff=op.dst_coff,
-                          cin=op.cin, cout=op.cout, k=op.k, stride=op.stride, pad=op.pad, relu=int(op.relu),
-                          ceil_mode=1, has_bias=0, seg_first=0, seg_count=0, w_off=0, b_off=0,
-                          pre_pool_k=op.pre_pool[0] if op.pre_pool else 0, pre_pool_stride=op.pre_pool[1] if op.pre_pool else 0)
-            if op.kind == "conv":
-                cin_dev = cin_pad if op.src == 0 else op.cin
-                if op.segments:                                            # sibling 1x1 convolutions: one GEMM
-                    parts = [packed_conv(sg.name, sg.bn, op.cin, sg.cout, 1, cin_dev, sg.bias) for sg in op.segments]
-                    packed = np.concatenate([q[0] for q in parts], axis=0)
-                    b = np.concatenate([q[1] for q in parts])
-                    d.seg_first, d.seg_count = len(seg_list), len(op.segments)
-                    for sg in op.segments:
-                        seg_list.append(ConvSegment(sg.cout, sg.dst, sg.dst_coff, int(sg.relu)))
-                elif (self.winograd and op.k == 3 and op.stride == 1 and op.pad == 1
-                      and op.cin % 8 == 0 and op.cout % 32 == 0):
-                    W64, b = fold_bn(weights[op.name], weights[op.bn] if op.bn else None, bn_eps, keep64=True)
-                    if W64.shape != (op.cout, op.cin, 3, 3):
-                        raise ValueError("weights of %s have shape %s" % (op.name, W64.shape))
-                    packed = winograd_filters(W64)
-                    if not op.bias:
-                        b = np.zeros_like(b)
-                    d.op = _lib.VQ_OP_CONV_WINOGRAD
-                elif self.stem_s2d and op.src == 0:
-                    W, b = fold_bn(weights[op.name], weights[op.bn] if op.bn else None, bn_eps)
-                    if W.shape != (op.cout, op.cin, op.k, op.k):
-                        raise ValueError("weights of %s have shape %s" % (op.name, W.shape))
-                    w2 = s2d_stem_weights(W)
-                    cin_dev = in_slot_c
-                    kdim = w2.shape[1] * w2.shape[2] * cin_dev
-                    packed = np.zeros((op.cout, _round_up(kdim, BK)), dtype=np.float32)
-                    packed[:, :kdim] = w2.reshape(op.cout, kdim)
-                    if not op.bias:
-                        b = np.zeros_like(b)
-                    d.k, d.stride, d.pad = w2.shape[1], 1, 0
-                else:
-                    packed, b = packed_conv(op.name, op.bn, op.cin, op.cout, op.k, cin_dev, op.bias)
-                if d.op == _lib.VQ_OP_CONV:
-                    self.conv_kp[i] = packed.shape[1]
-                d.cin = cin_dev
-                d.w_off = off
-                chunks.append(packed.reshape(-1))
-                off += packed.size
-                d.b_off = off
-                bias = np.zeros(pad4(op.cout), dtype=np.float32)
-                bias[:op.cout] = b
-                chunks.append(bias)
-                off += bias.size
-            elif op.kind == "avgpool" and op.bias_from is not None:       # finishes a commuted projection
-                _, b = fold_bn(weights[op.bias_from[0]], weights[op.bias_from[1]] if op.bias_from[1] else None, bn_eps)
-                d.has_bias = 1
-                d.b_off = off
-                bias = np.zeros(pad4(op.cout), dtype=np.float32)
-                bias[:op.cout] = b
-                chunks.append(bias)
-                off += bias.size
-            elif op.src == 0:
-                d.cin = d.cout = cin_pad
-            layers[i] = d
+            for i, op in enumerate(plan.ops):
+                d = LayerDesc(op=_OPS[op.kind], src=op.src, dst=op.dst, src_coff=op.src_coff, dst_coff=op.dst_coff,
+                              cin=op.cin, cout=op.cout, k=op.k, stride=op.stride, pad=op.pad, relu=int(op.relu),
+                              ceil_mode=1, has_bias=0, seg_first=0, seg_count=0, w_off=0, b_off=0,
+                              pre_pool_k=op.pre_pool[0] if op.pre_pool else 0, pre_pool_stride=op.pre_pool[1] if op.pre_pool else 0)
+                if op.kind == "conv":
+                    cin_dev = cin_pad if op.src == 0 else op.cin
+                    if op.segments:                                            # sibling 1x1 convolutions: one GEMM
+                        parts = [packed_conv(sg.name, sg.bn, op.cin, sg.cout, 1, cin_dev, sg.bias) for sg in op.segments]
+                        packed = np.concatenate([q[0] for q in parts], axis=0)
+                        b = np.concatenate([q[1] for q in parts])
+                        d.seg_first, d.seg_count = len(seg_list), len(op.segments)
+                        for sg in op.segments:
+                            seg_list.append(ConvSegment(sg.cout, sg.dst, sg.dst_coff, int(sg.relu)))
+                    elif (self.winograd and op.k == 3 and op.stride == 1 and op.pad == 1
+                          and op.cin % 8 == 0 and op.cout % 32 == 0):
+                        W64, b = fold_bn(weights[op.name], weights[op.bn] if op.bn else None, bn_eps, keep64=True)
+                        if W64.shape != (op.cout, op.cin, 3, 3):
+                            raise ValueError("weights of %s have shape %s" % (op.name, W64.shape))
+                        packed = winograd_filters(W64)
+                        if not op.bias:
+                            b = np.zeros_like(b)
+                        d.op = _lib.VQ_OP_CONV_WINOGRAD
+                    elif self.stem_s2d and op.src == 0:
+                        W, b = fold_bn(weights[op.name], weights[op.bn] if op.bn else None, bn_eps)
+                        if W.shape != (op.cout, op.cin, op.k, op.k):
+                            raise ValueError("weights of %s have shape %s" % (op.name, W.shape))
+                        w2 = s2d_stem_weights(W)
+                        cin_dev = in_slot_c
+                        kdim = w2.shape[1] * w2.shape[2] * cin_dev
+                        packed = np.zeros((op.cout, _round_up(kdim, BK)), dtype=np.float32)
+                        packed[:, :kdim] = w2.reshape(op.cout, kdim)
+                        if not op.bias:
+                            b = np.zeros_like(b)
+                        d.k, d.stride, d.pad = w2.shape[1], 1, 0
+                    else:
+                        packed, b = packed_conv(op.name, op.bn, op.cin, op.cout, op.k, cin_dev, op.bias)
+                    if d.op == _lib.VQ_OP_CONV:
+                        self.conv_kp[i] = packed.shape[1]
+                    d.cin = cin_dev
+                    d.w_off = off
+                    chunks.append(packed.reshape(-1))
+                    off += packed.size
+                    d.b_off = off
+                    bias = np.zeros(pad4(op.cout), dtype=np.float32)
+                    bias[:op.cout] = b
+                    chunks.append(bias)
+                    off += bias.size
+                elif op.kind == "avgpool" and op.bias_from is not None:       # finishes a commuted projection
+                    _, b = fold_bn(weights[op.bias_from[0]], weights[op.bias_from[1]] if op.bias_from[1] else None, bn_eps)
+                    d.has_bias = 1
+                    d.b_off = off
+                    bias = np.zeros(pad4(op.cout), dtype=np.float32)
+                    bias[:op.cout] = b
+                    chunks.append(bias)
+                    off += bias.size
+                elif op.src == 0:
+                    d.cin = d.cout = cin_pad
+                layers[i] = d
+            blob = np.ascontiguousarray(np.concatenate(chunks))
+            if cache_file:
+                _store_packed(cache_file, blob, layers, seg_list, self.conv_kp)
         segs = (ConvSegment * max(len(seg_list), 1))(*seg_list)
-        blob = np.ascontiguousarray(np.concatenate(chunks))
         self._h = C.c_void_p()
         inp = InputDesc(self.in_h, self.in_w, self.in_channels, stem[0].pad if self.stem_s2d else -1, stem[0].k if self.stem_s2d else 0)
         call("vq_tsn_create", tensors, len(plan.tensors), layers, len(plan.ops), segs, len(seg_list),
