@@ -30,6 +30,7 @@
 // reference's pipeline writes them.
 #include <algorithm>
 #include <cstring>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -849,6 +850,7 @@ struct vq_jpeg {
     int host_huffman = -1;             // VQ_JPEG_HOST_HUFFMAN at creation: 1 = always the host decoder of rounds 1-2, 0 = always the device
                                        // decoder, unset = by batch size
     long long dev_min_streams = 2048;  // VQ_JPEG_DEVICE_MIN_STREAMS: batches with at least this many streams decode on the device
+    std::vector<Frame> frames;         // the parsed headers of a call (12 KB each: kept, so that a call does not clear 100 MB first)
 };
 
 static void jpeg_free(vq_jpeg* j) {
@@ -948,18 +950,55 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
     std::lock_guard<std::mutex> lk(j->mu);
     DeviceGuard g(j->device);
     hipStream_t st = (hipStream_t)hip_stream;
-    // ---- headers (serial, cheap): sizes, layouts, where everything goes
-    std::vector<Frame> fr((size_t)n);
+    // VQ_JPEG_HOST_STAMPS=1: wall time of the call's host phases on stderr
+    const bool host_stamps = getenv("VQ_JPEG_HOST_STAMPS") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!host_stamps) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "jpeg host phase %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
+    // ---- headers: parsed by the worker threads (2.6 us per file: 21 ms for the 8 000 flow files of a command-line batch when one thread
+    //      did it), then sizes, layouts and where everything goes (serial, cheap)
+    if (j->frames.size() < (size_t)n) j->frames.resize((size_t)n);
+    Frame* fr = j->frames.data();
+    const int workers = std::max(1, std::min<int>({n, 16, (int)std::thread::hardware_concurrency()}));
+    std::vector<int> status((size_t)n, VQ_OK);
+    std::vector<std::string> message((size_t)n);
+    {
+        auto parse = [&](int first) {
+            for (int i = first; i < n; i += workers) {
+                fr[i] = Frame();
+                if (!files[i] || sizes[i] <= 0) {
+                    status[i] = VQ_E_INVALID;
+                    message[i] = "file is empty";
+                    continue;
+                }
+                status[i] = parse_headers(files[i], (size_t)sizes[i], fr[i]);
+                if (status[i] != VQ_OK) {
+                    message[i] = last_error_ref();                        // thread-local message of this worker
+                } else if (fr[i].H != h || fr[i].W != w) {
+                    status[i] = VQ_E_INVALID;
+                    char buf[96];
+                    snprintf(buf, sizeof buf, "is %dx%d, the call decodes %dx%d frames", fr[i].W, fr[i].H, w, h);
+                    message[i] = buf;
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int k = 1; k < workers; ++k) pool.emplace_back(parse, k);
+        parse(0);
+        for (std::thread& th : pool) th.join();
+        for (int i = 0; i < n; ++i)
+            if (status[i] != VQ_OK) return fail(status[i], "file %d: %s", i, message[i].c_str());
+    }
     std::vector<FrameDesc> desc((size_t)n);
     std::vector<uint16_t> qts((size_t)n * 4 * 64, 0);
     std::vector<size_t> comp_off((size_t)n * 3, 0);
     size_t blocks = 0, plane_bytes = 0;
     for (int i = 0; i < n; ++i) {
-        VQ_REQUIRE(files[i] && sizes[i] > 0, "file %d is empty", i);
         Frame& f = fr[i];
-        const int rc = parse_headers(files[i], (size_t)sizes[i], f);
-        if (rc != VQ_OK) return rc;
-        VQ_REQUIRE(f.H == h && f.W == w, "file %d is %dx%d, the call decodes %dx%d frames", i, f.W, f.H, w, h);
         FrameDesc& fd = desc[i];
         memset(&fd, 0, sizeof fd);
         fd.nc = f.nc;
@@ -986,9 +1025,7 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
         for (int t = 0; t < 4; ++t)
             if (f.qt_present[t]) memcpy(&qts[((size_t)i * 4 + t) * 64], f.qt[t], 64 * sizeof(uint16_t));
     }
-    const int workers = std::max(1, std::min<int>({n, 16, (int)std::thread::hardware_concurrency()}));
-    std::vector<int> status((size_t)n, VQ_OK);
-    std::vector<std::string> message((size_t)n);
+    lap("headers");
     int n_seg_padded = 0;
     // Where the entropy decoding runs: a 66 KB stream costs a device lane ~35 ms whatever the batch (600 cycles per symbol, 64 streams
     // per wave, as many waves as there are streams / 64), a host thread ~0.5 ms: 16 host threads decode 31 k frames/s at any batch
@@ -1066,25 +1103,40 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
         VQ_HIP(hipMalloc((void**)&j->stream_dev, cap * 4));
         j->stream_words = cap;
     }
-    // table sets: the (DC, AC) tables of a frame's components; files of one writer share one set
+    // table sets: the (DC, AC) tables of a frame's components; files of one writer share one set -- found by comparing the parsed
+    // tables themselves (build_huff defines every byte), so that the device form is built once per set, not once per file
     std::vector<DevTableSet> sets;
+    std::vector<int> set_rep;                                        // a frame that uses the set
     std::vector<int> set_of((size_t)n);
+    auto same_tables = [&](const Frame& x, const Frame& y) {
+        if (x.nc != y.nc) return false;
+        for (int c = 0; c < x.nc; ++c)
+            if (memcmp(&x.dc[x.comp[c].td], &y.dc[y.comp[c].td], sizeof(Huff)) || memcmp(&x.ac[x.comp[c].ta], &y.ac[y.comp[c].ta], sizeof(Huff)))
+                return false;
+        return true;
+    };
     for (int i = 0; i < n; ++i) {
-        DevTableSet ts;
-        memset(&ts, 0, sizeof ts);
-        for (int c = 0; c < fr[i].nc; ++c) {
-            fill_dev_huff(fr[i].dc[fr[i].comp[c].td], ts.t[2 * c]);
-            fill_dev_huff(fr[i].ac[fr[i].comp[c].ta], ts.t[2 * c + 1]);
-        }
         int found = -1;
         for (size_t q = 0; q < sets.size() && found < 0; ++q)
-            if (!memcmp(&sets[q], &ts, sizeof ts)) found = (int)q;
+            if (same_tables(fr[i], fr[set_rep[q]])) found = (int)q;
         if (found < 0) {
-            sets.push_back(ts);
-            found = (int)sets.size() - 1;
+            DevTableSet ts;
+            memset(&ts, 0, sizeof ts);
+            for (int c = 0; c < fr[i].nc; ++c) {
+                fill_dev_huff(fr[i].dc[fr[i].comp[c].td], ts.t[2 * c]);
+                fill_dev_huff(fr[i].ac[fr[i].comp[c].ta], ts.t[2 * c + 1]);
+            }
+            for (size_t q = 0; q < sets.size() && found < 0; ++q)    // different source tables, same device form
+                if (!memcmp(&sets[q], &ts, sizeof ts)) found = (int)q;
+            if (found < 0) {
+                sets.push_back(ts);
+                set_rep.push_back(i);
+                found = (int)sets.size() - 1;
+            }
         }
         set_of[i] = found;
     }
+    lap("table sets");
     std::vector<std::vector<uint32_t>> seg_off((size_t)n), seg_len((size_t)n);
     auto work = [&](int first) {
         for (int i = first; i < n; i += workers) {
@@ -1104,6 +1156,7 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
     for (std::thread& th : pool) th.join();
     for (int i = 0; i < n; ++i)
         if (status[i] != VQ_OK) return fail(status[i], "file %d: %s", i, message[i].c_str());
+    lap("unstuffing (threads)");
     // streams grouped by table set, every group padded to whole waves
     std::vector<SegDesc> segs;
     std::vector<int> seg_frame;
@@ -1162,6 +1215,7 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
     VQ_HIP(hipMemcpyAsync(eb + o_set, sets.data(), b_set, hipMemcpyHostToDevice, st));
     VQ_HIP(hipMemcpyAsync(j->qt_dev, qts.data(), qts.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
     VQ_HIP(hipMemcpyAsync(j->desc_dev, desc.data(), desc.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+    lap("stream lists, copies queued");
     long long* stamps_dev = nullptr;                      // VQ_JPEG_STAMPS=1: where the two waves of a workgroup spend their cycles (stderr)
     if (getenv("VQ_JPEG_STAMPS")) VQ_HIP(hipMalloc((void**)&stamps_dev, (size_t)n_seg_padded / 64 * 4 * sizeof(long long)));
     jpeg_entropy_idct_kernel<<<n_seg_padded / 64, 128, 0, st>>>(reinterpret_cast<const SegDesc*>(eb), reinterpret_cast<const EntFrame*>(eb + o_fr),
@@ -1179,6 +1233,7 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
     }
     VQ_HIP(hipMemcpyAsync(j->status_host, eb + o_stat, b_stat, hipMemcpyDeviceToHost, st));
     VQ_HIP(hipStreamSynchronize(st));            // segs / ef / sets leave scope; the statuses are wanted before the pixels are handed out
+    lap("copies + entropy kernel");
     static const char* const what[8] = {"", "JPEG: corrupt entropy-coded data (DC)", "JPEG: corrupt entropy-coded data (AC)",
                                         "JPEG: corrupt entropy-coded data (run past the block)", "JPEG: internal error (stream ring ran dry)", "", "", ""};
     for (size_t q = 0; q < segs.size(); ++q)
@@ -1198,6 +1253,7 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
     if (out_host) VQ_HIP(hipMemcpyAsync(out_host, j->out_dev, (size_t)px * ch, hipMemcpyDeviceToHost, st));
     if (out_dev) *out_dev = j->out_dev;
     VQ_HIP(hipStreamSynchronize(st));      // qts / desc leave scope; the pinned buffers are reused by the next call
+    lap("pixels kernel");
     return VQ_OK;
 }
 
