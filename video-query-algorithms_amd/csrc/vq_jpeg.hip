@@ -29,6 +29,7 @@
 // Progressive, arithmetic-coded, 12-bit, multi-scan and CMYK files are refused (VQ_E_UNSUPPORTED) -- nothing in the
 // reference's pipeline writes them.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <chrono>
 #include <thread>
@@ -102,6 +103,22 @@ struct BitReader {
     int bits = 0;
     bool hit_marker = false;
     void fill() {                       // keep at least 25 bits; behind a marker the stream continues with zeros
+        if (!hit_marker && p + 8 <= n) {
+            // fast path: as many whole bytes as fit, in one go, unless one of them is 0xFF (stuffing or a marker: the byte loop below)
+            const int take = (64 - bits) >> 3;
+            uint64_t wd;
+            memcpy(&wd, d + p, 8);                                    // little-endian: the first stream byte is the lowest
+            const uint64_t x = ~wd;                                    // a zero byte of x = a 0xFF byte of the stream
+            uint64_t ff = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+            if (take < 8) ff &= (1ull << (8 * take)) - 1;
+            if (!ff && take > 0) {
+                const uint64_t be = __builtin_bswap64(wd);
+                acc = take == 8 ? be : (acc << (8 * take)) | (be >> (64 - 8 * take));
+                bits += 8 * take;
+                p += (size_t)take;
+                return;
+            }
+        }
         while (bits <= 56) {
             uint32_t b = 0;
             if (!hit_marker && p < n) {
@@ -1064,6 +1081,13 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
                 for (size_t b = 0; b < nb; ++b) j->block_plane_host[b0 + b] = ((unsigned)i << 2) | (unsigned)c;
             }
     }
+    // The coefficients travel in kCopyGroups pieces (frames [g n / G, (g + 1) n / G)): a piece is queued as soon as its frames are decoded
+    // -- the workers walk the frames in index order, so the pieces finish roughly in order -- and the copies (4 ms for the 800 RGB
+    // frames of a command-line batch) overlap the decoding of the later pieces instead of following it.
+    constexpr int kCopyGroups = 4;
+    std::atomic<int> group_done[kCopyGroups];
+    for (auto& g2 : group_done) g2.store(0);
+    auto group_of = [&](int i) { return (int)((long long)i * kCopyGroups / n); };
     auto work = [&](int first) {
         for (int i = first; i < n; i += workers) {
             // the frame's blocks start from zero (only non-zero coefficients are written): cleared here, by the frame's own thread
@@ -1071,15 +1095,32 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
             memset(j->coef_host + b0 * 64, 0, (b1 - b0) * 64 * sizeof(int16_t));
             status[i] = decode_scan(files[i], (size_t)sizes[i], fr[i], j->coef_host, &comp_off[(size_t)i * 3]);
             if (status[i] != VQ_OK) message[i] = last_error_ref();       // thread-local message of this worker
+            group_done[group_of(i)].fetch_add(1, std::memory_order_release);
         }
     };
     std::vector<std::thread> pool;
-    for (int k = 1; k < workers; ++k) pool.emplace_back(work, k);
-    work(0);
+    for (int k = 0; k < workers; ++k) pool.emplace_back(work, k);
+    hipError_t copy_err = hipSuccess;
+    for (int g2 = 0; g2 < kCopyGroups; ++g2) {
+        int i0 = 0, i1 = 0;                                           // the group's frames
+        while (i0 < n && group_of(i0) < g2) ++i0;
+        i1 = i0;
+        while (i1 < n && group_of(i1) == g2) ++i1;
+        if (i1 == i0) continue;
+        while (group_done[g2].load(std::memory_order_acquire) < i1 - i0) std::this_thread::yield();
+        const size_t b0 = comp_off[(size_t)i0 * 3], b1 = i1 < n ? comp_off[(size_t)i1 * 3] : blocks;
+        if (copy_err == hipSuccess)
+            copy_err = hipMemcpyAsync(j->coef_dev + b0 * 64, j->coef_host + b0 * 64, (b1 - b0) * 64 * sizeof(int16_t), hipMemcpyHostToDevice, st);
+    }
     for (std::thread& th : pool) th.join();
+    VQ_HIP(copy_err);
     for (int i = 0; i < n; ++i)
         if (status[i] != VQ_OK) return fail(status[i], "file %d: %s", i, message[i].c_str());
-    VQ_HIP(hipMemcpyAsync(j->coef_dev, j->coef_host, blocks * 64 * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    lap("entropy decoding (threads) + copies queued");
+    if (host_stamps) {
+        VQ_HIP(hipStreamSynchronize(st));
+        lap("coefficients on the device");
+    }
     } else {
     // ---- entropy decoding on the device: the host strips the byte stuffing and cuts the scans at the restart markers
     std::vector<int> n_mcu((size_t)n), want_segs((size_t)n);
