@@ -88,6 +88,66 @@ def iter_video(path: str):
         yield frame
 
 
+def iter_video_ahead(path: str, readers: int = 4, ahead: int = 32):
+    """``(frame, grey)`` of a video in order, decoded (and converted to grey) up to ``ahead`` frames in front of the consumer: a
+    directory of frames by ``readers`` threads, a video file by one (cv2.VideoCapture is sequential).  The consumer's GPU calls and
+    the decoding of the next window's frames then overlap instead of taking turns; memory stays bounded by ``ahead`` frames."""
+    import collections
+    from concurrent.futures import ThreadPoolExecutor
+
+    def prepared(frame):
+        return frame, bgr_to_grey(frame)
+    if os.path.isdir(path):
+        names = sorted(n for n in os.listdir(path) if os.path.splitext(n)[1].lower() in (".jpg", ".jpeg", ".ppm", ".pnm", ".npy", ".png"))
+        if not names:
+            raise IOError("no frames in " + path)
+        with ThreadPoolExecutor(max_workers=max(1, readers)) as pool:
+            pending = collections.deque()
+            todo = iter(names)
+            for n in todo:
+                pending.append(pool.submit(lambda n=n: prepared(frames_mod.imread(os.path.join(path, n), True))))
+                if len(pending) >= ahead:
+                    break
+            while pending:
+                item = pending.popleft().result()
+                n = next(todo, None)
+                if n is not None:
+                    pending.append(pool.submit(lambda n=n: prepared(frames_mod.imread(os.path.join(path, n), True))))
+                yield item
+        return
+    import queue
+    import threading
+    q = queue.Queue(maxsize=max(2, ahead))
+    stop = threading.Event()
+
+    def pump():
+        try:
+            for frame in iter_video(path):
+                if stop.is_set():
+                    return
+                q.put(prepared(frame))
+            q.put(None)
+        except BaseException as e:      # noqa: BLE001 -- handed to the consumer
+            q.put(e)
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    try:
+        while True:
+            item = q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+    finally:
+        stop.set()
+        while th.is_alive():            # unblock a producer waiting on a full queue
+            try:
+                q.get_nowait()
+            except queue.Empty:
+                th.join(0.01)
+
+
 def read_video(path: str) -> np.ndarray:
     """All frames of a (short) video as BGR uint8 [n, h, w, 3]."""
     return np.stack(list(iter_video(path)))
@@ -135,8 +195,7 @@ def process_video(vid_path: str, out_path: str, flow_for, new_size=(0, 0), seed:
             put('{}/flow_y_{:05d}'.format(out_full_path, k), fy[j])
         done += len(window)
 
-    for i, frame in enumerate(iter_video(vid_path)):
-        g = bgr_to_grey(frame)
+    for i, (frame, g) in enumerate(iter_video_ahead(vid_path)):
         if flow is None:
             flow = flow_for(g.shape[0], g.shape[1])
         elif g.shape != (flow.h, flow.w):
