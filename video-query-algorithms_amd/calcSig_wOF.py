@@ -165,6 +165,8 @@ def main(argv=None, net_factory=None, program=None):
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=max(1, args.num_worker))
     prep_pool = ThreadPoolExecutor(max_workers=2)        # --device_jpeg: the stages in front of the network (see the batch loop)
+    io_pool = ThreadPoolExecutor(max_workers=len(streamCNN))             # feature files are formatted and written here
+    csv_jobs = []
     build_pool = ThreadPoolExecutor(max_workers=len(streamCNN))
     net_jobs = {}                                        # both extractors are built side by side when the first video turns up: the flow
                                                          # net's weights are folded and uploaded while the RGB stream is already running
@@ -232,17 +234,23 @@ def main(argv=None, net_factory=None, program=None):
                     local_feat = local_feat.to(backend_device)
                 local_feat = all_gather_rows(local_feat, len(clip_list)).cpu().numpy()
             features[s['mode']] = local_feat
-        numFeatures = features['rgb'].shape[1] if len(clip_list) else args.featureBlob_size
-        assert numFeatures == args.featureBlob_size                                      # calcSig_wOF.py:219-220
-        if rank == 0 and clip_list:
-            video = video_path.split('/')[-2]
-            write_features(args.outFeatures_dir, video, video_path, args.modelname, args.featureBlob, clip_list, features,
-                           {'rgb': args.net_weights_rgb, 'warped_optical_flow': args.net_weights_flow}, args.number_format)
+            numFeatures = local_feat.shape[1] if len(clip_list) else args.featureBlob_size
+            assert numFeatures == args.featureBlob_size                                  # calcSig_wOF.py:219-220
+            if rank == 0 and clip_list:
+                # a stream's file is formatted and written (half a million float reprs per 256 clips) by a thread of its own while the
+                # next stream -- or the next video -- is on the GPU; the same two files as writing both at the end (:116-134)
+                video = video_path.split('/')[-2]
+                csv_jobs.append(io_pool.submit(write_features, args.outFeatures_dir, video, video_path, args.modelname, args.featureBlob, clip_list,
+                                               {s['mode']: local_feat}, {'rgb': args.net_weights_rgb, 'warped_optical_flow': args.net_weights_flow},
+                                               args.number_format))
     pool.shutdown()
     prep_pool.shutdown()
     build_pool.shutdown()
-    for n in nets.values():
+    for n in nets.values():                                              # releasing the device buffers overlaps the last file's formatting
         n.close()
+    for job in csv_jobs:
+        job.result()                                                     # a writer's exception is the command's
+    io_pool.shutdown()
     return 0
 
 

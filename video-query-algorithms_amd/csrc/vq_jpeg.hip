@@ -1064,6 +1064,7 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
         if ((rc = grow_dev(&j->desc_dev, &j->cap_desc, desc.size() * sizeof(FrameDesc))) != VQ_OK) return rc;
         if ((rc = grow_dev(&j->out_dev, &j->cap_out, (size_t)n * h * w * 3)) != VQ_OK) return rc;
     }
+    lap("device buffers");
     if (use_host) {
     // ---- entropy decoding on the host: one frame per host thread
     {
@@ -1081,6 +1082,7 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
                 for (size_t b = 0; b < nb; ++b) j->block_plane_host[b0 + b] = ((unsigned)i << 2) | (unsigned)c;
             }
     }
+    lap("host buffers, block map");
     // The coefficients travel in kCopyGroups pieces (frames [g n / G, (g + 1) n / G)): a piece is queued as soon as its frames are decoded
     // -- the workers walk the frames in index order, so the pieces finish roughly in order -- and the copies (4 ms for the 800 RGB
     // frames of a command-line batch) overlap the decoding of the later pieces instead of following it.

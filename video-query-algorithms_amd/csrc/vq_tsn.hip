@@ -746,6 +746,8 @@ struct vq_tsn {
                                           // a layer that reads what no earlier layer of THIS forward wrote then yields NaN features)
     int forced_tile = -1;                 // VQ_TSN_TILE = "BMxBN[xBK[xP]]" (read at creation): every direct conv uses this tiling
     std::vector<float*> slots;            // device activations, max_crops each
+    std::vector<size_t> slot_bytes;
+    size_t blob_bytes = 0;
     float* zeros = nullptr;               // 256 bytes of zeros (load target of masked lanes)
     ConvSeg* seg_table = nullptr;         // destination tables of all conv layers, back to back
     std::vector<int> seg_table_off;       // per layer: first entry
@@ -781,6 +783,60 @@ struct vq_tsn {
     std::vector<hipEvent_t> join_ev;              // per extra stream
 };
 
+// Activation slots, weights and split-K scratch of a closed extractor are kept (up to VQ_DEVICE_POOL_GB, default 40; 0 = off) for the
+// next one of the same shape in the process: on some hosts a hipMalloc of tens of GB right behind the hipFree of as much waits ~1 s for
+// the driver to reclaim the memory (seen as 1.2 s extractor builds in back-to-back command-line runs of one process).  A block is only
+// reused at its exact size on its device; whatever a forward reads it has written before.
+struct DevicePool {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, void*> blocks;
+    size_t held = 0, cap = 0;
+    DevicePool() {
+        const char* e = getenv("VQ_DEVICE_POOL_GB");
+        cap = (size_t)((e ? atof(e) : 40.0) * 1073741824.0);
+    }
+};
+static DevicePool& device_pool() {
+    static DevicePool p;
+    return p;
+}
+static hipError_t pool_alloc(int device, size_t bytes, void** out) {
+    DevicePool& dp = device_pool();
+    {
+        std::lock_guard<std::mutex> lk(dp.mu);
+        auto it = dp.blocks.find({device, bytes});
+        if (it != dp.blocks.end()) {
+            *out = it->second;
+            dp.blocks.erase(it);
+            dp.held -= bytes;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) {                       // give the pooled blocks back and try once more
+        std::lock_guard<std::mutex> lk(dp.mu);
+        for (auto& kv : dp.blocks) (void)hipFree(kv.second);
+        dp.blocks.clear();
+        dp.held = 0;
+        (void)hipGetLastError();
+        e = hipMalloc(out, bytes);
+    }
+    return e;
+}
+static void pool_free(int device, void* p, size_t bytes) {
+    if (!p) return;
+    DevicePool& dp = device_pool();
+    {
+        std::lock_guard<std::mutex> lk(dp.mu);
+        if (bytes >= (1u << 20) && dp.held + bytes <= dp.cap) {
+            dp.blocks.insert({{device, bytes}, p});
+            dp.held += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
 static void tsn_free(vq_tsn* net) {
     for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
     net->events.clear();
@@ -789,12 +845,11 @@ static void tsn_free(vq_tsn* net) {
     if (net->fork_ev) (void)hipEventDestroy(net->fork_ev);
     for (hipStream_t st : net->split_streams)
         if (st) (void)hipStreamDestroy(st);
-    for (float* p : net->slots)
-        if (p) (void)hipFree(p);
-    if (net->blob) (void)hipFree(net->blob);
+    for (size_t i = 0; i < net->slots.size(); ++i) pool_free(net->device, net->slots[i], i < net->slot_bytes.size() ? net->slot_bytes[i] : 0);
+    pool_free(net->device, net->blob, net->blob_bytes);
     if (net->zeros) (void)hipFree(net->zeros);
     if (net->seg_table) (void)hipFree(net->seg_table);
-    if (net->split_scratch) (void)hipFree(net->split_scratch);
+    pool_free(net->device, net->split_scratch, net->split_slice_floats * 4 * sizeof(float));
     if (net->zero_bias) (void)hipFree(net->zero_bias);
     if (net->crops_dev) (void)hipFree(net->crops_dev);
     if (net->mean_dev) (void)hipFree(net->mean_dev);
@@ -1446,12 +1501,15 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
         delete net;
         return fail(e == hipErrorOutOfMemory ? VQ_E_NOMEM : VQ_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
     };
+    net->slot_bytes.assign(n_tensors, 0);
     for (int i = 0; i < n_tensors; ++i) {
         const size_t bytes = (size_t)max_crops * tensors[i].h * tensors[i].w * tensors[i].c * sizeof(float);
-        hipError_t e = hipMalloc((void**)&net->slots[i], bytes);
+        hipError_t e = pool_alloc(device, bytes, (void**)&net->slots[i]);
         if (e != hipSuccess) return bail("hipMalloc(activation slot)", e);
+        net->slot_bytes[i] = bytes;
     }
-    hipError_t e = hipMalloc((void**)&net->blob, (size_t)blob_floats * sizeof(float));
+    net->blob_bytes = (size_t)blob_floats * sizeof(float);
+    hipError_t e = pool_alloc(device, net->blob_bytes, (void**)&net->blob);
     if (e != hipSuccess) return bail("hipMalloc(weights)", e);
     e = hipMemcpy(net->blob, blob_host, (size_t)blob_floats * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) return bail("hipMemcpy(weights)", e);
@@ -1480,7 +1538,7 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
         if (scratch > 0) {
             net->split_crop_floats = scratch + (size_t)max_cout;
             net->split_slice_floats = (size_t)max_crops * net->split_crop_floats;
-            e = hipMalloc((void**)&net->split_scratch, net->split_slice_floats * 4 * sizeof(float));      // up to 4 slices
+            e = pool_alloc(device, net->split_slice_floats * 4 * sizeof(float), (void**)&net->split_scratch);      // up to 4 slices
             if (e != hipSuccess) return bail("hipMalloc(split-K scratch)", e);
             e = hipMalloc((void**)&net->zero_bias, (size_t)max_cout * sizeof(float));
             if (e != hipSuccess) return bail("hipMalloc(zero bias)", e);
