@@ -69,4 +69,8 @@ int bootstrap_from_device_rows(const void* base_dev, int dtype, const std::vecto
 // own stream): an event recorded on the handle's stream, waited for by `st`.  VQ_E_STATE without a scan.  Takes the handle's lock.
 int db_copy_scores_ordered(vq_db* db, double* dst_dev, int64_t* n_out, hipStream_t st);
 
+// csrc/vq_tsn.hip: closed extractors leave their big device blocks in a process-wide pool for the next extractor of the same shape
+// (VQ_DEVICE_POOL_GB); this gives them back to the driver -- called by the other modules when an allocation of theirs runs out of memory.
+void device_pool_trim();
+
 }  // namespace vq

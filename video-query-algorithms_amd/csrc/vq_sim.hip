@@ -971,6 +971,11 @@ int vq_db_create(int64_t n, int32_t S, int32_t E, int32_t D, int32_t dtype, int3
 #define A_(ptr, bytes)                                    \
     do {                                                  \
         hipError_t e_ = hipMalloc((void**)&(ptr), bytes); \
+        if (e_ == hipErrorOutOfMemory) {                  \
+            (void)hipGetLastError();                      \
+            device_pool_trim();    /* blocks closed extractors left for reuse (vq_tsn.hip) */ \
+            e_ = hipMalloc((void**)&(ptr), bytes);        \
+        }                                                 \
         if (e_ != hipSuccess) {                           \
             db_free(db);                                  \
             delete db;                                    \

@@ -800,6 +800,13 @@ static DevicePool& device_pool() {
     static DevicePool p;
     return p;
 }
+void vq::device_pool_trim() {
+    DevicePool& dp = device_pool();
+    std::lock_guard<std::mutex> lk(dp.mu);
+    for (auto& kv : dp.blocks) (void)hipFree(kv.second);
+    dp.blocks.clear();
+    dp.held = 0;
+}
 static hipError_t pool_alloc(int device, size_t bytes, void** out) {
     DevicePool& dp = device_pool();
     {
@@ -814,11 +821,8 @@ static hipError_t pool_alloc(int device, size_t bytes, void** out) {
     }
     hipError_t e = hipMalloc(out, bytes);
     if (e == hipErrorOutOfMemory) {                       // give the pooled blocks back and try once more
-        std::lock_guard<std::mutex> lk(dp.mu);
-        for (auto& kv : dp.blocks) (void)hipFree(kv.second);
-        dp.blocks.clear();
-        dp.held = 0;
         (void)hipGetLastError();
+        vq::device_pool_trim();
         e = hipMalloc(out, bytes);
     }
     return e;
