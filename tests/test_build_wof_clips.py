@@ -129,3 +129,38 @@ def test_num_gpu_fans_out_one_process_per_gpu_and_the_files_do_not_change(tmp_pa
         devs = {line.split()[0] for line in open(str(tmp_path / ("dev3.%d" % rank))).read().split("\n") if line}
         assert devs == {str(2 + rank)}
     assert r.stdout.count("number of videos found") == 1
+
+
+def test_frames_read_ahead_arrive_in_order_with_their_grey_and_stop_cleanly(tmp_path):
+    """iter_video_ahead: the reader threads run in front of the consumer; what arrives is iter_video's sequence with bgr_to_grey of every
+    frame; a consumer that stops early leaves no thread waiting; a frame that cannot be read raises at its place in the sequence."""
+    import threading
+
+    import video_query_algorithms_amd  # noqa: F401
+    from video_query_algorithms_amd import build_wof_clips as bw
+    rng = np.random.default_rng(5)
+    d = tmp_path / "vid"
+    d.mkdir()
+    frames = [rng.integers(0, 256, (24, 32, 3), dtype=np.uint8) for _ in range(41)]
+    for i, f in enumerate(frames):
+        np.save(str(d / ("frame_%05d.npy" % i)), f)
+    got = list(bw.iter_video_ahead(str(d), readers=3, ahead=7))
+    assert len(got) == 41
+    for (f, g), want in zip(got, frames):
+        assert (f == want).all() and (g == bw.bgr_to_grey(want)).all()
+    before = threading.active_count()
+    it = bw.iter_video_ahead(str(d), readers=3, ahead=7)
+    for k, _ in enumerate(it):
+        if k == 4:
+            break
+    it.close()
+    assert threading.active_count() <= before                               # the pool's threads are gone with the generator
+    (d / "frame_00020.npy").write_bytes(b"not an array")
+    it = bw.iter_video_ahead(str(d), readers=3, ahead=7)
+    seen = 0
+    with pytest.raises(Exception):
+        for _ in it:
+            seen += 1
+    assert seen == 20
+    with pytest.raises(IOError):
+        list(bw.iter_video_ahead(str(tmp_path)))                            # a directory without frames
