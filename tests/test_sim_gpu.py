@@ -378,6 +378,76 @@ def test_fused_batched_scan_has_the_bits_of_the_two_kernel_form(vqa, monkeypatch
     db.close()
 
 
+@pytest.mark.parametrize("n,s,e,d,q,masked", [(70_003, 2, 3, 256, 16, False), (5_001, 1, 2, 512, 7, True), (33, 2, 5, 1024, 16, False),
+                                              (140_007, 2, 1, 1024, 16, True), (4_100, 3, 2, 768, 9, False)])
+def test_batched_scan_on_the_tiled_mirror_has_the_bits_of_the_scan_on_the_rows(vqa, monkeypatch, n, s, e, d, q, masked):
+    """From its second pass on, the 16-query pass of an fp32 database reads a tile-interleaved copy ([tile][slice][k / 4][clip][4],
+    built on the device behind the first pass).  Same operands per MFMA in the same order: the scores of the first pass (rows), of the
+    pass that builds the copy and of the passes on it are identical, and identical to a handle that never builds one
+    (VQ_BATCH_MIRROR=0) -- ragged last tiles, presence masks, every D.  A write through vq_db_upload invalidates the copy: the
+    next passes follow the new rows."""
+    rng = np.random.default_rng(n + d)
+    targets = rng.standard_normal((q, s, e, d)) / d
+    weights = 0.5 + rng.random((q, s))
+    present = None
+    if masked:
+        present = np.ones((n, s, e), dtype=np.uint8)
+        present[::5, 0, 0] = 0
+        present[n - 1, :, e - 1] = 0
+        present[..., 0] |= (present.sum(axis=2) == 0).astype(np.uint8)
+    monkeypatch.setenv("VQ_BATCH_MIRROR", "0")
+    plain = vqa.FeatureDB.synthetic(n, s, e, d, seed=29, scales=(4.0, 1.0, 2.0)[:s])
+    plain.set_present(present)
+    want = plain.scan_batch(targets, weights)
+    monkeypatch.delenv("VQ_BATCH_MIRROR")
+    db = vqa.FeatureDB.synthetic(n, s, e, d, seed=29, scales=(4.0, 1.0, 2.0)[:s])
+    db.set_present(present)
+    for _ in range(4):                                            # rows, build + mirror, mirror, mirror
+        assert (db.scan_batch(targets, weights) == want).all()
+    # new rows in the middle and at the ragged end: both handles see them
+    rows = (rng.random((40, s, e, d)) * 3).astype(np.float32)
+    for handle in (plain, db):
+        handle.upload(max(0, n // 2 - 10), rows[:25])
+        handle.upload(max(0, n - 15), rows[25:25 + min(15, n)])
+    monkeypatch.setenv("VQ_BATCH_MIRROR", "0")
+    want2 = plain.scan_batch(targets, weights)
+    monkeypatch.delenv("VQ_BATCH_MIRROR")
+    assert not (want2 == want).all()
+    for _ in range(3):
+        assert (db.scan_batch(targets, weights) == want2).all()
+    plain.close()
+    db.close()
+
+
+def test_a_database_whose_memory_others_can_write_is_never_mirrored(vqa):
+    """Once the raw device pointer of the features has been handed out (or the memory is the caller's own: adopt_device), writes cannot
+    be seen, so the 16-query pass must keep reading the rows themselves: values written through the pointer show up in every pass."""
+    import torch
+    n, s, e, d = 2_000, 2, 2, 256
+    db = vqa.FeatureDB.synthetic(n, s, e, d, seed=31, scales=(2.0, 1.0))
+    rng = np.random.default_rng(8)
+    targets = rng.standard_normal((4, s, e, d)) / d
+    weights = 0.5 + rng.random((4, s))
+    first = db.scan_batch(targets, weights)
+    assert (db.scan_batch(targets, weights) == first).all()       # a mirror exists by now
+    ptr = db.feats_devptr()                                       # ... and must be dropped here
+    # write through the raw pointer with a plain device copy
+    new = (rng.random((n, s, e, d)) * 2).astype(np.float32)
+    src = torch.from_numpy(new).cuda()
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(C.c_void_p(ptr), C.c_void_p(src.data_ptr()), C.c_size_t(new.nbytes), 3) == 0     # hipMemcpyDeviceToDevice
+    torch.cuda.synchronize()
+    fresh = vqa.FeatureDB(n, s, e, d)
+    fresh.upload(0, new)
+    want = fresh.scan_batch(targets, weights)
+    assert not (want == first).all()
+    for _ in range(3):
+        assert (db.scan_batch(targets, weights) == want).all()
+    fresh.close()
+    db.close()
+
+
 def test_cfg4_full_size_scan_one_million_clips(vqa):
     """BASELINE configs[3] at FULL size on one GPU: 1 query x 1 000 000 clips x 2 streams x 5 splits x 1024 fp32
     (40.96 GB resident, generated on the device), the real ``scan_kernel<float,2,5,4>`` launch of the bench.

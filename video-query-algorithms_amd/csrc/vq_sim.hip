@@ -297,6 +297,10 @@ struct ChunkP<float, P> {
 #pragma unroll                                                  // hint of the one-query scan the 16-query pass took 8.3 ms instead of 7.5)
         for (int m = 0; m < P; ++m) v[m] = *reinterpret_cast<const float4*>(p + 16 * m);
     }
+    __device__ __forceinline__ void load_tiled(const float* p) {   // the tiled mirror: a piece is 1 KB of contiguous memory for the wave,
+#pragma unroll                                                     // pieces 256 floats apart; whole lines, read once: non-temporal
+        for (int m = 0; m < P; ++m) v[m] = stream_load4(p + 256 * m);
+    }
     __device__ __forceinline__ double at(int m, int e) const {
         return (double)(e == 0 ? v[m].x : e == 1 ? v[m].y : e == 2 ? v[m].z : v[m].w);
     }
@@ -311,6 +315,7 @@ struct ChunkP<double, P> {
             v[m][1] = *reinterpret_cast<const double2*>(p + 16 * m + 2);
         }
     }
+    __device__ __forceinline__ void load_tiled(const double* p) { load(p); }   // never used: the mirror is fp32 only
     __device__ __forceinline__ double at(int m, int e) const { return (e & 1) ? v[m][e >> 1].y : v[m][e >> 1].x; }
 };
 
@@ -398,6 +403,28 @@ __global__ void batch_finalize_kernel(const double* sims, const uint8_t* present
     scores[i] = score_from_avg(av, ww, S);
 }
 
+// The 16-query pass's view of an fp32 database: [tile of 16 clips][slice][k / 4][clip][4] -- every load instruction of a wave then
+// takes 1 KB of contiguous memory (whole 128-byte lines: the non-temporal hint pays), where the row-major layout gives it 64 bytes of
+// each of 16 clips 40 KB apart.  One workgroup per (tile, slice): the 16 rows come in whole (a wave reads 1 KB of one clip per
+// instruction), turn in LDS and go out in the tiled order.  Rows past n repeat the last clip (the pass never stores them).
+__global__ __launch_bounds__(256) void mirror_build_kernel(const float* feats, float* mirror, int64_t n, int NV, int D) {
+    extern __shared__ __attribute__((aligned(16))) float tile_lds[];          // [16][D + 4]
+    const int64_t tile = blockIdx.x / NV;
+    const int v = (int)(blockIdx.x - tile * NV);
+    const int d4 = D / 4, row = D + 4;
+    for (int i = threadIdx.x; i < 16 * d4; i += 256) {
+        const int c = i / d4, g = i - c * d4;
+        const int64_t clip = min(tile * 16 + c, n - 1);
+        *reinterpret_cast<float4*>(tile_lds + c * row + 4 * g) = stream_load4(feats + (clip * NV + v) * (int64_t)D + 4 * g);
+    }
+    __syncthreads();
+    float* out = mirror + (tile * NV + v) * 16 * (int64_t)D;
+    for (int j = threadIdx.x; j < 16 * d4; j += 256) {
+        const int g = j >> 4, c = j & 15;
+        *reinterpret_cast<float4*>(out + 4 * (int64_t)j) = *reinterpret_cast<const float4*>(tile_lds + c * row + 4 * g);
+    }
+}
+
 // ---- the same pass as ONE launch: no dot matrix in memory ----------------------------------------------------------------
 // A workgroup (16 waves, one per CU) owns TW tiles of 16 clips per wave and "round" and walks the (stream, split) slices
 // itself: barrier, the slice's sixteen query rows into LDS (128 KB; from L2 after the first workgroup), barrier, then every
@@ -420,7 +447,7 @@ struct BatchFusedArgs {
     int32_t Q, S, E, D;
 };
 
-template <typename T, int CH, int TW, bool PRES, int P>
+template <typename T, int CH, int TW, bool PRES, int P, bool TILED = false>
 __global__ __launch_bounds__(1024) void batch_fused_kernel(BatchFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) double tq[];      // 16 swizzled rows of D doubles (+ 32 of slack)
     constexpr int D = CH * 256, CE = 16 * P, NCHUNK = D / CE;       // a chunk = P pieces of 16 elements
@@ -450,8 +477,15 @@ __global__ __launch_bounds__(1024) void batch_fused_kernel(BatchFusedArgs a) {
     };
     // a tile's slice = a scalar base + this lane's 32-bit element offset (its clip row, its k quarter); rows past n re-read the
     // last clip and are never stored
-    auto base_of = [&](int64_t tile, int v) -> const T* { return feats + tile * 16 * clip_elems + (int64_t)v * D; };
+    // TILED: a.feats is the tile-interleaved mirror [tile][slice][k / 4][16 clips][4] (mirror_build_kernel): element (clip, k) of a
+    // (tile, slice) block sits at (k / 4) * 64 + clip * 4 + k % 4, so the lane that owns (clip col, k quarter kk) reads piece m of chunk c
+    // at ((c P + m) * 4 + kk) * 64 + col * 4 -- the same k = 16 (c P + m) + 4 kk + e as in the row-major form: same operands, same bits.
+    constexpr int CSTEP = TILED ? 256 * P : CE;
+    auto base_of = [&](int64_t tile, int v) -> const T* {
+        return TILED ? feats + (tile * NV + v) * 16 * D : feats + tile * 16 * clip_elems + (int64_t)v * D;
+    };
     auto lane_off = [&](int64_t tile) -> uint32_t {
+        if (TILED) return (uint32_t)(kk * 64 + col * 4);
         const int last = (int)min((int64_t)15, a.n - 1 - tile * 16);
         return (uint32_t)(min(col, last) * (int)clip_elems + 4 * kk);
     };
@@ -459,7 +493,10 @@ __global__ __launch_bounds__(1024) void batch_fused_kernel(BatchFusedArgs a) {
     if (valid_in(0) > 0) {
         const T* x0 = base_of(tile_of(0, 0), 0) + lane_off(tile_of(0, 0));
 #pragma unroll
-        for (int bq = 0; bq < NBUF; ++bq) buf[bq].load(x0 + CE * bq);
+        for (int bq = 0; bq < NBUF; ++bq) {
+            if (TILED) buf[bq].load_tiled(x0 + CSTEP * bq);
+            else buf[bq].load(x0 + CSTEP * bq);
+        }
     }
     for (int r = 0; r < rounds; ++r) {
         const int nval = valid_in(r), nval_next = valid_in(r + 1);
@@ -501,7 +538,7 @@ __global__ __launch_bounds__(1024) void batch_fused_kernel(BatchFusedArgs a) {
                     doublex4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
                     for (int ch0 = 0; ch0 < NCHUNK; ch0 += NBUF) {
-                        const T* src = ch0 + NBUF < NCHUNK ? x + CE * (ch0 + NBUF) : xn;
+                        const T* src = ch0 + NBUF < NCHUNK ? x + CSTEP * (ch0 + NBUF) : xn;
 #pragma unroll
                         for (int bq = 0; bq < NBUF; ++bq) {
                             int off = CE * (ch0 + bq);
@@ -512,7 +549,8 @@ __global__ __launch_bounds__(1024) void batch_fused_kernel(BatchFusedArgs a) {
 #pragma unroll
                                 for (int ee = 0; ee < 4; ++ee)
                                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[bq].at(m, ee), tbc[16 * m + ee], acc, 0, 0, 0);
-                            buf[bq].load(src + CE * bq);
+                            if (TILED) buf[bq].load_tiled(src + CSTEP * bq);
+                            else buf[bq].load(src + CSTEP * bq);
                         }
                     }
                     // ticket.py:155-160: the mean runs over the splits PRESENT for the clip
@@ -841,6 +879,12 @@ struct vq_db {
     int cus = 256;
     void* feats = nullptr;
     bool owns_feats = true;
+    // the tile-interleaved copy the 16-query pass reads (fp32 databases whose memory nobody else can write: see vq_db_scan_batch)
+    float* mirror = nullptr;
+    size_t mirror_bytes = 0;
+    bool mirror_valid = false;
+    bool feats_exposed = false;      // adopted memory, or the raw pointer was handed out: writes can no longer be seen
+    int batch_passes_since_write = 0;
     uint8_t* present = nullptr;
     double* t = nullptr;        // [S*E*D]
     bool have_query = false, have_avg = false, have_scores = false, have_sims = false;
@@ -871,6 +915,7 @@ struct vq_db {
 
 static int db_free(vq_db* db) {
     if (db->owns_feats && db->feats) (void)hipFree(db->feats);
+    if (db->mirror) (void)hipFree(db->mirror);
     void* ptrs[] = {db->present, db->t,       db->w,        db->sims,  db->avg,      db->ne,      db->scores, db->blk_cnt,
                     db->blk_max, db->blk_arg, db->sel_result, db->rows0, db->rows1, db->tk_state, db->tk_hist, db->grid_buf, db->batch_buf};
     for (void* p : ptrs)
@@ -1040,6 +1085,8 @@ int vq_db_upload(vq_db* db, int64_t row0, int64_t nrows, const void* feats_host)
                           db->stream));
     VQ_HIP(hipStreamSynchronize(db->stream));
     db->have_avg = db->have_scores = db->have_sims = false;
+    db->mirror_valid = false;
+    db->batch_passes_since_write = 0;
     return VQ_OK;
 }
 
@@ -1052,6 +1099,8 @@ int vq_db_adopt_device(vq_db* db, void* feats_dev) {
     db->feats = feats_dev;
     db->owns_feats = false;
     db->have_avg = db->have_scores = db->have_sims = false;
+    db->feats_exposed = true;                 // the caller owns the memory and may rewrite it at any time: no mirror
+    db->mirror_valid = false;
     return VQ_OK;
 }
 
@@ -1094,13 +1143,18 @@ int vq_db_generate(vq_db* db, uint64_t seed, int64_t global_row0, const float* s
                                                                            db->E * db->D, db->S, scales_dev);
     VQ_CHECK_LAUNCH();
     VQ_HIP(hipStreamSynchronize(db->stream));
+    db->mirror_valid = false;
+    db->batch_passes_since_write = 0;
     db->have_avg = db->have_scores = db->have_sims = false;
     return VQ_OK;
 }
 
 int vq_db_feats_devptr(vq_db* db, void** p) {
     VQ_REQUIRE(db && p, "NULL argument");
+    std::lock_guard<std::mutex> lk(db->mu);
     *p = db->feats;
+    db->feats_exposed = true;                 // writes through the raw pointer cannot be seen: the 16-query pass stays on the rows themselves
+    db->mirror_valid = false;
     return VQ_OK;
 }
 
@@ -1272,8 +1326,44 @@ int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const d
     const size_t lds = ((size_t)kBatchSlots * db->D + 32) * 8;   // sixteen swizzled query rows
     const int ch = db->D / 256;
     if (!two_kernel) {
+        // The tiled mirror: fp32 databases that own their memory and never handed its address out (every write then goes through
+        // vq_db_upload / vq_db_generate, which invalidate it).  Built behind the first pass since the last write -- one more sweep
+        // of the database, read and written -- and used from the second on: 6.8 ms per pass instead of 7.3 at cfg 4.  Needs as much
+        // memory again; without it (or with VQ_BATCH_MIRROR=0) the pass reads the rows themselves.  Same operands per MFMA: same bits.
+        const char* mir_env = getenv("VQ_BATCH_MIRROR");
+        bool tiled = false;
+        if (db->dtype == VQ_F32 && db->owns_feats && !db->feats_exposed && !(mir_env && *mir_env == '0')) {
+            if (db->mirror_valid) {
+                tiled = true;
+            } else if (db->batch_passes_since_write >= 1 || (mir_env && *mir_env == '2')) {      // 2: build before the first pass (tests)
+                const size_t want = (size_t)((db->n + 15) / 16) * 16 * NV * db->D * sizeof(float);
+                if (db->mirror && db->mirror_bytes < want) {
+                    VQ_HIP(hipFree(db->mirror));
+                    db->mirror = nullptr;
+                    db->mirror_bytes = 0;
+                }
+                if (!db->mirror && hipMalloc((void**)&db->mirror, want) == hipSuccess) db->mirror_bytes = want;
+                if (db->mirror) {
+                    const int64_t wgs = (db->n + 15) / 16 * NV;
+                    VQ_REQUIRE(wgs < (1ll << 31), "database too large for one mirror launch");
+                    static bool mirror_attr = false;
+                    if (!mirror_attr) {
+                        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mirror_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   16 * (1024 + 4) * (int)sizeof(float)));
+                        mirror_attr = true;
+                    }
+                    mirror_build_kernel<<<(unsigned)wgs, 256, 16 * (db->D + 4) * sizeof(float), db->stream>>>((const float*)db->feats, db->mirror, db->n, NV,
+                                                                                                             db->D);
+                    VQ_CHECK_LAUNCH();
+                    db->mirror_valid = tiled = true;
+                } else {
+                    (void)hipGetLastError();                   // no room for a second copy: stay on the rows
+                }
+            }
+        }
+        ++db->batch_passes_since_write;
         BatchFusedArgs f;
-        f.feats = db->feats;
+        f.feats = tiled ? (const void*)db->mirror : db->feats;
         f.t = d_t;
         f.w = d_w;
         f.present = db->present;
@@ -1291,6 +1381,7 @@ int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const d
 #define VQ_FUSED_LAUNCH(T, CH)                                                                                             \
     {                                                                                                                      \
         auto kern = db->present ? batch_fused_kernel<T, CH, TW, true, 8> : batch_fused_kernel<T, CH, TW, false, 8>;       \
+        if (tiled) kern = db->present ? batch_fused_kernel<T, CH, TW, true, 8, true> : batch_fused_kernel<T, CH, TW, false, 8, true>; \
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,        \
                                    (kBatchSlots * CH * 256 + 32) * 8));                                                     \
         kern<<<blocks, 1024, lds, db->stream>>>(f);                                                                        \
