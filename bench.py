@@ -435,8 +435,15 @@ def bench_sim(args, rank, world, device, stream):
         db.set_query(t.cpu().numpy())                       # leave the single-query state as the checks below expect it
         db.scan(weights=w)
         with torch.cuda.stream(stream):
-            db.scan_batch(tb, wb, want=False)
-            torch.cuda.synchronize(device)
+            # the first pass since the database was written reads the rows themselves; the second builds the tile-interleaved mirror (one more
+            # sweep: database read and written once) and runs on it, like every later one -- both are reported, neither is in the timed region
+            setup_ms = []
+            for _ in range(2):
+                torch.cuda.synchronize(device)
+                t_s = time.perf_counter()
+                db.scan_batch(tb, wb, want=False)
+                torch.cuda.synchronize(device)
+                setup_ms.append((time.perf_counter() - t_s) * 1e3)
             tb0 = time.perf_counter()
             reps = max(3, steps // 4)
             ev_ms = 0.0
@@ -453,13 +460,16 @@ def bench_sim(args, rank, world, device, stream):
         # one launch reads the database once and writes Q score vectors: no intermediate matrix since round 3
         bbytes = rows * SIM_S * SIM_E * SIM_D * 4 + Q * rows * 8
         batched = {"queries_per_pass": Q, "value": Q / bdt, "unit": "queries/s", "ms_per_pass": bdt * 1e3,
-                   "kernel": "batch_fused_kernel<float,4,2,false,8> (one launch per pass)", "pass_ms_by_hip_events": ev_ms,
+                   "kernel": "batch_fused_kernel<float,4,2,false,8,tiled> (one launch per pass, on the tile-interleaved mirror of the database)",
+                   "pass_ms_by_hip_events": ev_ms, "first_pass_on_the_rows_ms": setup_ms[0], "pass_that_builds_the_mirror_ms": setup_ms[1],
                    "bytes_per_pass": bbytes, "hbm_GBps": bbytes / ev_ms / 1e6, "hbm_frac": bbytes / ev_ms / 1e6 / PEAK_HBM_GBS,
                    "traffic": (scan_traffic or {}).get("batch_fused_kernel", {}).get("hbm_bytes_per_launch"),
                    "mfma_f64_tflops": 2.0 * Q * rows * SIM_S * SIM_E * SIM_D / ev_ms / 1e9, "mfma_f64_peak_tflops": 78.6,
                    "note": "vq_db_scan_batch: the database is read ONCE for 16 queries by a single launch (a workgroup walks the (stream, "
                            "split) slices itself: the slice's 16 query rows in LDS, dots on v_mfma_f64_16x16x4, per-tile sums in registers; "
-                           "no [slice][query][clip] matrix in memory); scores within 1e-12 of 16 single scans, bit-identical to the round-2 "
+                           "no [slice][query][clip] matrix in memory; from the second pass since the last write the features come from a tile-interleaved "
+                           "copy of the database -- [tile of 16 clips][slice][k / 4][clip][4], as much memory again -- so that a wave's load "
+                           "instruction takes 1 KB of contiguous memory with the non-temporal hint); scores within 1e-12 of 16 single scans, bit-identical to the round-2 "
                            "two-kernel form; value = wall clock over the passes incl. the 1.3 MB query upload of each; hbm_* from the HIP "
                            "events around the pass"}
     roof["batched"] = batched

@@ -18,7 +18,7 @@ db.scores()
 rng = np.random.default_rng(0)
 t = rng.standard_normal((16, 2, 5, 1024)) / 1024
 w = 0.5 + rng.random((16, 2))
-for _ in range(3):
+for _ in range(5):                      # the first on the rows, the second builds the tiled mirror, the others run on it
     db.scan_batch(t, w, want=False)
 db.scan_batch(t[:1], w[:1])
 PY
@@ -40,6 +40,13 @@ for name, key, algo in (("scan_kernel", "scan_kernel", 1_000_000 * 2 * 5 * 1024 
     w, _ = per_launch("gpurun_out/pmc_sim_write/*/*counter_collection.csv", "WRITE_SIZE", key, True)
     out[name] = {"launches": n, "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w, "hbm_bytes_per_launch": (2 * f + w) * 1024,
                  "algorithmic_bytes_per_launch": algo, "ratio": (2 * f + w) * 1024 / algo}
+try:
+    f, n = per_launch("gpurun_out/pmc_sim_fetch/*/*counter_collection.csv", "FETCH_SIZE", "mirror_build_kernel", False)
+    w, _ = per_launch("gpurun_out/pmc_sim_write/*/*counter_collection.csv", "WRITE_SIZE", "mirror_build_kernel", False)
+    out["mirror_build_kernel"] = {"launches": n, "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w, "hbm_bytes_per_launch": (2 * f + w) * 1024,
+                                  "note": "once per database state: the rows read, the tile-interleaved copy written"}
+except (IndexError, ZeroDivisionError):
+    pass
 out["hbm_bytes_per_launch"] = out["scan_kernel"]["hbm_bytes_per_launch"]
 json.dump(out, open("gpurun_out/%s_scan_traffic.json" % tag, "w"), indent=1)
 print(json.dumps(out))
