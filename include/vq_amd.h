@@ -113,7 +113,12 @@ int vq_db_scan(vq_db* db, const double* w_host, int32_t keep_sims);
  * read once (slice by slice, the slice's query vectors in LDS) and the pass is HBM-bound: 16 queries cost what one does.
  * t_host [n_queries][S][E][D] fp64, w_host [n_queries][S] fp64, scores_host [n_queries][N] fp64 (may be NULL: use
  * vq_db_batch_scores_devptr).  Does not touch the state of the single-query path (query, avg, scores).
- * Needs D in {256, 512, 768, 1024}. */
+ * Needs D in {256, 512, 768, 1024}.
+ * Memory: from its second pass since the last write an fp32 database that owns its memory is read through a tile-interleaved
+ * copy of itself (as many bytes again, allocated on demand, built on the device; same scores bit for bit, 8 % less time
+ * per pass).  vq_db_upload / vq_db_generate drop the copy; a database on adopted memory, or whose address
+ * vq_db_feats_devptr has handed out, never gets one (writes could not be seen); no room, or VQ_BATCH_MIRROR=0: the pass
+ * reads the rows. */
 int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const double* w_host, double* scores_host);
 int vq_db_batch_scores_devptr(vq_db* db, void** dev_ptr /* double [n_queries][N] */, int32_t* n_queries);
 int vq_db_rescore(vq_db* db, const double* w_host);
