@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQ_ABI_VERSION 5
+#define VQ_ABI_VERSION 6
 
 enum {
     VQ_OK = 0,
@@ -37,6 +37,7 @@ enum {
 };
 
 enum { VQ_F32 = 0, VQ_F64 = 1 };
+enum { VQ_LAYOUT_ROWS = 0, VQ_LAYOUT_TILED = 1 };
 
 const char* vq_last_error(void);
 int vq_abi_version(void);
@@ -67,6 +68,16 @@ int vq_db_upload(vq_db* db, int64_t row0, int64_t nrows, const void* feats_host)
 /* Use caller-owned device memory ([N][S][E][D], e.g. the output of an RCCL all-gather of
  * per-GPU feature blocks) instead of the handle's own allocation.  The memory must outlive db. */
 int vq_db_adopt_device(vq_db* db, void* feats_dev);
+/* How the handle's own block is laid out.  VQ_LAYOUT_ROWS: [N][S][E][D] (the default; what vq_db_upload, vq_db_adopt_device and
+ * vq_db_feats_devptr speak).  VQ_LAYOUT_TILED: [tile of 16 clips][S*E][D/4][clip][4] -- the order the 16-query pass wants, in which
+ * every load instruction of a wave (one-query scan AND 16-query pass) takes 1 KB of contiguous memory.  The conversion is IN PLACE
+ * (a tile's rows and its tiled form cover the same bytes; no second copy of the database, 256 MB of scratch while it runs) and
+ * costs one sweep of the block: call it once after loading, off the query path.  Tiled needs fp32, D = 1024, S <= 2, E <= 5
+ * (VQ_E_UNSUPPORTED otherwise) and a block that is the library's alone (VQ_E_STATE after vq_db_adopt_device / vq_db_feats_devptr).
+ * Every other entry point works on either layout; results of the two layouts agree to rounding (<= 1e-12: the k order of a
+ * dot differs), each is bit-reproducible in itself.  vq_db_upload into a tiled database deals the rows into their tiles. */
+int vq_db_set_layout(vq_db* db, int32_t layout);
+int vq_db_layout(vq_db* db, int32_t* layout);
 /* Optional [N][S][E] presence mask (1 = this clip has this split); NULL restores "dense".
  * Mirrors clips that lack a split in ticket.py:146-160 (n_e = number of splits present). */
 int vq_db_set_present(vq_db* db, const uint8_t* present_host);
@@ -114,20 +125,24 @@ int vq_db_scan(vq_db* db, const double* w_host, int32_t keep_sims);
  * t_host [n_queries][S][E][D] fp64, w_host [n_queries][S] fp64, scores_host [n_queries][N] fp64 (may be NULL: use
  * vq_db_batch_scores_devptr).  Does not touch the state of the single-query path (query, avg, scores).
  * Needs D in {256, 512, 768, 1024}.
- * Memory: from its second pass since the last write an fp32 database that owns its memory is read through a tile-interleaved
- * copy of itself (as many bytes again, allocated on demand, built on the device; same scores bit for bit, 8 % less time
- * per pass).  vq_db_upload / vq_db_generate drop the copy; a database on adopted memory, or whose address
- * vq_db_feats_devptr has handed out, never gets one (writes could not be seen); no room, or VQ_BATCH_MIRROR=0: the pass
- * reads the rows. */
+ * On a row-major database a load instruction of the pass takes 64 bytes of each of 16 clips; on a TILED one
+ * (vq_db_set_layout) whole 128-byte lines: 8 % less time per pass, same scores bit for bit. */
 int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const double* w_host, double* scores_host);
 int vq_db_batch_scores_devptr(vq_db* db, void** dev_ptr /* double [n_queries][N] */, int32_t* n_queries);
 int vq_db_rescore(vq_db* db, const double* w_host);
 /* Copy results to the host.  Any pointer may be NULL.  avg [N][S], n_e [N][S], sims [N][S][E]. */
 int vq_db_read_similarities(vq_db* db, double* avg_host, int32_t* n_e_host, double* sims_host);
 int vq_db_read_scores(vq_db* db, double* scores_host);
+/* out[l] = score of row rows[l] (a sharded selection asks each rank for the score of its own best near miss). */
+int vq_db_read_scores_at(vq_db* db, const int64_t* rows_host, int32_t L, double* out_host);
 /* Device addresses of the result arrays (for an RCCL all-gather of score slices). */
 int vq_db_scores_devptr(vq_db* db, void** dev_ptr);
 int vq_db_avg_devptr(vq_db* db, void** dev_ptr);
+int vq_db_ne_devptr(vq_db* db, void** dev_ptr /* int32 [N][S] */);
+/* Rows of the resident block back to the host: out [L][S][E][D] in the database's dtype.  The sharded B seam uses it to
+ * send the handful of user-validated clips of a round (src/models/target_clip.py:114-135) to the rank that solves the
+ * bootstrapping problems; features never travel otherwise. */
+int vq_db_read_rows(vq_db* db, const int64_t* rows_host, int32_t L, void* out_host);
 /* Replace the cached avg[N][S]/n_e (e.g. after gathering slices from other ranks). */
 int vq_db_write_avg(vq_db* db, const double* avg_host, const int32_t* n_e_host);
 

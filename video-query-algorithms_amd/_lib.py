@@ -12,8 +12,9 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvqamd.so")
 
-ABI_VERSION = 5                 # include/vq_amd.h: VQ_ABI_VERSION
+ABI_VERSION = 6                 # include/vq_amd.h: VQ_ABI_VERSION
 VQ_F32, VQ_F64 = 0, 1
+VQ_LAYOUT_ROWS, VQ_LAYOUT_TILED = 0, 1
 VQ_OP_CONV, VQ_OP_MAXPOOL, VQ_OP_AVGPOOL, VQ_OP_GLOBAL_AVGPOOL, VQ_OP_CONV_WINOGRAD = 1, 2, 3, 4, 5
 
 _ERR_NAMES = {-1: "VQ_E_INVALID", -2: "VQ_E_HIP", -3: "VQ_E_NOMEM", -4: "VQ_E_STATE", -5: "VQ_E_UNSUPPORTED"}
@@ -64,6 +65,7 @@ SIGNATURES = {
     "vq_db_create": [_I64, _I32, _I32, _I32, _I32, _I32, _PP],
     "vq_db_destroy": [_P], "vq_db_set_stream": [_P, _P],
     "vq_db_shape": [_P, _pI64, _pI32, _pI32, _pI32, _pI32],
+    "vq_db_set_layout": [_P, _I32], "vq_db_layout": [_P, _pI32],
     "vq_db_upload": [_P, _I64, _I64, _P], "vq_db_adopt_device": [_P, _P], "vq_db_set_present": [_P, _P],
     "vq_db_generate": [_P, _U64, _I64, _pF32], "vq_db_feats_devptr": [_P, _PP],
     "vq_db_set_query": [_P, _P], "vq_db_set_query_from_row": [_P, _I64, _P],
@@ -72,7 +74,7 @@ SIGNATURES = {
     "vq_db_scan": [_P, _P, _I32], "vq_db_rescore": [_P, _P],
     "vq_db_scan_batch": [_P, _I32, _P, _P, _P], "vq_db_batch_scores_devptr": [_P, _PP, _pI32],
     "vq_db_read_similarities": [_P, _P, _P, _P], "vq_db_read_scores": [_P, _P],
-    "vq_db_scores_devptr": [_P, _PP], "vq_db_avg_devptr": [_P, _PP], "vq_db_write_avg": [_P, _P, _P],
+    "vq_db_scores_devptr": [_P, _PP], "vq_db_avg_devptr": [_P, _PP], "vq_db_ne_devptr": [_P, _PP], "vq_db_read_rows": [_P, _P, _I32, _P], "vq_db_read_scores_at": [_P, _P, _I32, _P], "vq_db_write_avg": [_P, _P, _P],
     "vq_db_scores_grid": [_P, _P, _I32, _P, _I32, _P],
     "vq_db_select": [_P, _F64, _F64, _pI64, _pI64, _pI64], "vq_db_select_fetch": [_P, _P, _I64, _P, _I64],
     "vq_db_select_rows": [_P, _F64, _F64, _P, _I64, _P, _I64, _pI64, _pI64, _pI64],

@@ -57,6 +57,32 @@ struct DeviceGuard {
     }
 };
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the (kernel, DEVICE) pair, and one process may hold handles on several
+// GPUs (vq_db_create / vq_tsn_create take a device): remember per device where it has been raised.  Use inside a function that
+// returns int, with the handle's device current.
+struct PerDeviceOnce {
+    std::mutex mu;
+    unsigned long long done = 0;          // bit d: set on device d
+    bool need(int device) {
+        std::lock_guard<std::mutex> lk(mu);
+        return device < 0 || device >= 64 || !((done >> device) & 1ull);
+    }
+    void mark(int device) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (device >= 0 && device < 64) done |= 1ull << device;
+    }
+};
+#define VQ_DYN_LDS(kern, bytes)                                                                                                  \
+    do {                                                                                                                         \
+        static ::vq::PerDeviceOnce once_;                                                                                        \
+        int dev_ = -1;                                                                                                           \
+        (void)hipGetDevice(&dev_);                                                                                               \
+        if (once_.need(dev_)) {                                                                                                  \
+            VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+            once_.mark(dev_);                                                                                                    \
+        }                                                                                                                        \
+    } while (0)
+
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // csrc/vq_boot.hip: closed-form target bootstrapping on rows that already live on the device.  row_off [P][stride]

@@ -1459,11 +1459,7 @@ int vq_flow_ransac_homography(vq_flow* f, const float* src_host, const float* ds
     VQ_HIP(hipMemcpyAsync(dst_dev, dst_host, pts_b, hipMemcpyHostToDevice, st));
     VQ_HIP(hipMemcpyAsync(cnt_dev, counts_host, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
     const size_t lds = (size_t)max_points * 4 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_homography_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16));
-        attr_set = true;
-    }
+    VQ_DYN_LDS(ransac_homography_kernel, 8192 * 16);
     ransac_homography_kernel<<<n, 256, lds, st>>>(src_dev, dst_dev, cnt_dev, max_points, hypotheses, seed, (double)threshold * (double)threshold,
                                                   h_dev, best_dev, win_dev, mask_dev);
     VQ_CHECK_LAUNCH();

@@ -232,6 +232,99 @@ __global__ __launch_bounds__(256) void scan_generic_kernel(ScanArgs a) {
     }
 }
 
+// The one-query scan over a TILED database (vq_db_set_layout): [tile of 16 clips][slice][k / 4][clip][4], fp32.  A wave owns a tile:
+// lane l = (clip l % 16, k quarter l / 16), and because piece g = 4 i + l / 16 of the slice sits at g * 64 + (l % 16) * 4 floats, load i
+// of a lane is at i * 256 + l * 4 -- a wave instruction still takes 1 KB of contiguous memory and a whole tile (all its slices) is ONE
+// contiguous run of NV * 64 KB.  A lane multiplies 256 of its clip's 1024 elements per slice (k = 16 i + 4 (l / 16) + 0..3; the
+// matching query values are four 32-byte groups per instruction in LDS: broadcast, conflict-free) and the clip's dot is the sum
+// over its four lanes: two butterfly steps per 16 clips and slice where the row-major kernel pays six per clip.  G loads of 1 KB
+// per wave are in flight behind the G being multiplied.  Same bookkeeping per clip as scan_kernel (ensemble mean over the splits
+// present, weighted score); the k order of a dot differs, so the two layouts agree to rounding (<= 1e-12, tested), not bit for bit.
+template <int S, int E, int CH, int G>
+__global__ __launch_bounds__(256) void scan_tiled_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double t_lds[];    // [NV][D], natural order
+    constexpr int NV = S * E;
+    constexpr int D = CH * 256;
+    constexpr int LOADS = D / 16;                                     // 1 KB loads of a wave per slice
+    constexpr int GROUPS = LOADS / G;
+    static_assert(LOADS % G == 0, "group size must divide the slice");
+    for (int i = threadIdx.x; i < NV * D; i += blockDim.x) t_lds[i] = a.t[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, col = lane & 15, kk = lane >> 4;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t ntiles = (a.n + 15) / 16;
+    constexpr int64_t tile_elems = (int64_t)NV * 16 * D;
+    const float* feats = static_cast<const float*>(a.feats) + lane * 4;
+    double w[S];
+    if (a.w) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) w[s] = a.w[s];
+    }
+    float4 cur[G], nxt[G];
+    int64_t tile = wave;
+    if (tile < ntiles) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) cur[j] = stream_load4(feats + tile * tile_elems + j * 256);
+    }
+    while (tile < ntiles) {
+        const int64_t tn = tile + nwaves;
+        const float* x = feats + tile * tile_elems;
+        // after the wave's last tile the ring is refilled from the tile just read: the refill stays unconditional
+        const float* xn = tn < ntiles ? feats + tn * tile_elems : x;
+        const int64_t c = tile * 16 + col;
+        const bool mine = kk == 0 && c < a.n;
+        const int64_t cc = min(c, a.n - 1);                            // the clip whose presence bits this lane follows
+        double acc = 0.0, av[S];
+        int cnt = 0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const double* tq = t_lds + v * D + 4 * kk;
+            double p = 0.0;
+#pragma unroll 1
+            for (int g = 0; g < GROUPS; ++g) {
+                const float* src = (v + 1 < NV || g + 1 < GROUPS) ? x + ((int64_t)v * GROUPS + g + 1) * (G * 256) : xn;
+#pragma unroll
+                for (int j = 0; j < G; ++j) nxt[j] = stream_load4(src + j * 256);
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const double2 ta = *reinterpret_cast<const double2*>(tq + 16 * (g * G + j));
+                    const double2 tb = *reinterpret_cast<const double2*>(tq + 16 * (g * G + j) + 2);
+                    p = fma((double)cur[j].x, ta.x, p);
+                    p = fma((double)cur[j].y, ta.y, p);
+                    p = fma((double)cur[j].z, tb.x, p);
+                    p = fma((double)cur[j].w, tb.y, p);
+                }
+#pragma unroll
+                for (int j = 0; j < G; ++j) cur[j] = nxt[j];
+            }
+            p += __shfl_xor(p, 16, 64);
+            p += __shfl_xor(p, 32, 64);
+            const int s = v / E, e = v % E;
+            const int64_t idx = (cc * S + s) * E + e;
+            const bool here = a.present ? a.present[idx] != 0 : true;
+            if (here) {
+                acc = acc + p;
+                ++cnt;
+            }
+            if (a.sims && mine) a.sims[idx] = p;
+            if (e == E - 1) {
+                const double m = acc / (double)cnt;
+                if (mine) {
+                    a.avg[c * S + s] = m;
+                    a.ne[c * S + s] = cnt;
+                }
+                av[s] = m;
+                acc = 0.0;
+                cnt = 0;
+            }
+        }
+        if (a.w && mine) a.scores[c] = score_from_avg(av, w, S);
+        tile = tn;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // batched scan: Q queries per pass over the database, on the fp64 matrix cores
 // ------------------------------------------------------------------------------------------------
@@ -256,6 +349,10 @@ struct BatchArgs {
     int32_t Q, NV, D, v;
 };
 constexpr int kBatchSlots = 16;
+#ifndef VQ_TILED_GROUP
+#define VQ_TILED_GROUP 4
+#endif
+constexpr int kTiledGroup = VQ_TILED_GROUP;     // 1 KB loads a wave of scan_tiled_kernel keeps in flight behind the ones it multiplies
 
 typedef double doublex4 __attribute__((ext_vector_type(4)));
 
@@ -423,6 +520,36 @@ __global__ __launch_bounds__(256) void mirror_build_kernel(const float* feats, f
         const int g = j >> 4, c = j & 15;
         *reinterpret_cast<float4*>(out + 4 * (int64_t)j) = *reinterpret_cast<const float4*>(tile_lds + c * row + 4 * g);
     }
+}
+
+// the inverse of mirror_build_kernel: one workgroup per (tile, slice) of a tiled block -> the 16 row segments (rows past n: none)
+__global__ __launch_bounds__(256) void untile_kernel(const float* tiled, float* rows, int64_t n, int NV, int D) {
+    extern __shared__ __attribute__((aligned(16))) float tile_lds[];          // [16][D + 4]
+    const int64_t tile = blockIdx.x / NV;
+    const int v = (int)(blockIdx.x - tile * NV);
+    const int d4 = D / 4, row = D + 4;
+    const float* in = tiled + (tile * NV + v) * 16 * (int64_t)D;
+    for (int j = threadIdx.x; j < 16 * d4; j += 256) {
+        const int g = j >> 4, c = j & 15;
+        *reinterpret_cast<float4*>(tile_lds + c * row + 4 * g) = *reinterpret_cast<const float4*>(in + 4 * (int64_t)j);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * d4; i += 256) {
+        const int c = i / d4, g = i - c * d4;
+        const int64_t clip = tile * 16 + c;
+        if (clip < n) *reinterpret_cast<float4*>(rows + (clip * NV + v) * (int64_t)D + 4 * g) = *reinterpret_cast<const float4*>(tile_lds + c * row + 4 * g);
+    }
+}
+
+// vq_db_upload into a tiled database: staged row-major rows -> their places in the tiles (16 bytes per thread)
+__global__ void scatter_rows_tiled_kernel(const float4* staged, float4* tiled, int64_t row0, int64_t nrows, int NV, int d4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per_row = (int64_t)NV * d4;
+    if (i >= nrows * per_row) return;
+    const int64_t r = i / per_row, rem = i - r * per_row;
+    const int v = (int)(rem / d4), g = (int)(rem - (int64_t)v * d4);
+    const int64_t clip = row0 + r, tile = clip >> 4;
+    tiled[((tile * NV + v) * d4 + g) * 16 + (clip & 15)] = staged[i];
 }
 
 // ---- the same pass as ONE launch: no dot matrix in memory ----------------------------------------------------------------
@@ -618,18 +745,25 @@ __global__ void grid_kernel(const double* avg, const double* w_grid, const int64
 }
 
 // target_clip.py:311-313: t = r / (r . r), one block per (s,e) vector of row `row`, fp64 throughout.
+// element k of vector (row, v): row-major, or inside the tiled layout [tile][v][k / 4][row % 16][4]
+__device__ __forceinline__ int64_t feat_index(bool tiled, int64_t row, int v, int k, int NV, int D) {
+    return tiled ? (((row >> 4) * NV + v) * (int64_t)(D / 4) + (k >> 2)) * 64 + (row & 15) * 4 + (k & 3) : (row * NV + v) * (int64_t)D + k;
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void scale_query_kernel(const T* feats, int64_t row, int NV, int D, double* t) {
+__global__ __launch_bounds__(256) void scale_query_kernel(const T* feats, int64_t row, int NV, int D, double* t, bool tiled) {
     __shared__ double part[4];
     const int v = blockIdx.x;
-    const T* r = feats + (row * NV + v) * (int64_t)D;
     double p = 0.0;
-    for (int k = threadIdx.x; k < D; k += blockDim.x) p = fma((double)r[k], (double)r[k], p);
+    for (int k = threadIdx.x; k < D; k += blockDim.x) {
+        const double x = (double)feats[feat_index(tiled, row, v, k, NV, D)];
+        p = fma(x, x, p);
+    }
     p = wave_sum(p);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = p;
     __syncthreads();
     const double rr = ((part[0] + part[1]) + part[2]) + part[3];
-    for (int k = threadIdx.x; k < D; k += blockDim.x) t[(int64_t)v * D + k] = (double)r[k] / rr;
+    for (int k = threadIdx.x; k < D; k += blockDim.x) t[(int64_t)v * D + k] = (double)feats[feat_index(tiled, row, v, k, NV, D)] / rr;
 }
 
 // counter-based synthetic rows (shared with oracle/sim_oracle.py::synth_features)
@@ -862,6 +996,21 @@ __global__ void topk_pick_kernel(int pass, uint64_t* state, unsigned int* hist) 
     for (int i = 0; i < 256; ++i) hist[i] = 0;
 }
 
+// rows of the database -> a dense [cnt][row_elems] block (vq_db_read_rows: the few validated clips a sharded round sends to the
+// rank that solves the bootstrapping problems).  16 bytes per thread.
+__global__ void gather_rows_kernel(const uint4* feats, const int64_t* rows, int64_t cnt, int64_t row_vec16, uint4* out, int tiled_nv, int tiled_d4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt * row_vec16) return;
+    const int64_t r = i / row_vec16, k = i - r * row_vec16;
+    if (tiled_nv) {                                   // fp32, tiled: piece g of (clip, v) is one 16-byte unit of the tile
+        const int v = (int)(k / tiled_d4), g = (int)(k - (int64_t)v * tiled_d4);
+        const int64_t clip = rows[r];
+        out[i] = feats[(((clip >> 4) * tiled_nv + v) * tiled_d4 + g) * 16 + (clip & 15)];
+    } else {
+        out[i] = feats[rows[r] * row_vec16 + k];
+    }
+}
+
 __global__ void gather_scores_kernel(const double* scores, const int64_t* rows, int64_t cnt, double* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cnt) out[i] = scores[rows[i]];
@@ -879,12 +1028,10 @@ struct vq_db {
     int cus = 256;
     void* feats = nullptr;
     bool owns_feats = true;
-    // the tile-interleaved copy the 16-query pass reads (fp32 databases whose memory nobody else can write: see vq_db_scan_batch)
-    float* mirror = nullptr;
-    size_t mirror_bytes = 0;
-    bool mirror_valid = false;
-    bool feats_exposed = false;      // adopted memory, or the raw pointer was handed out: writes can no longer be seen
-    int batch_passes_since_write = 0;
+    // VQ_LAYOUT_ROWS: [N][S][E][D].  VQ_LAYOUT_TILED (fp32, own memory): [tile of 16 clips][S*E][D/4][clip][4] in the SAME block (a
+    // tile's 16 rows and its tiled form cover the same bytes; the block is allocated for whole tiles) -- vq_db_set_layout
+    int layout = VQ_LAYOUT_ROWS;
+    bool feats_exposed = false;      // adopted memory, or the raw pointer was handed out: the library no longer controls the layout
     uint8_t* present = nullptr;
     double* t = nullptr;        // [S*E*D]
     bool have_query = false, have_avg = false, have_scores = false, have_sims = false;
@@ -915,12 +1062,67 @@ struct vq_db {
 
 static int db_free(vq_db* db) {
     if (db->owns_feats && db->feats) (void)hipFree(db->feats);
-    if (db->mirror) (void)hipFree(db->mirror);
     void* ptrs[] = {db->present, db->t,       db->w,        db->sims,  db->avg,      db->ne,      db->scores, db->blk_cnt,
                     db->blk_max, db->blk_arg, db->sel_result, db->rows0, db->rows1, db->tk_state, db->tk_hist, db->grid_buf, db->batch_buf};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     return VQ_OK;
+}
+
+static int ensure_grid_buf(vq_db* db, int64_t bytes);
+
+// rows (by number) -> a dense row-major [L][S][E][D] block in the handle's scratch, whatever the layout; caller holds the lock
+static int gather_rows_device(vq_db* db, const int64_t* rows_host, int L, const void** dense) {
+    const int64_t row_bytes = (int64_t)db->S * db->E * db->D * (int64_t)db->elem();      // D % 4 == 0: whole 16-byte pieces
+    const int64_t rb = ((int64_t)L * 8 + 15) / 16 * 16;
+    const int rc = ensure_grid_buf(db, rb + (int64_t)L * row_bytes);
+    if (rc != VQ_OK) return rc;
+    char* base = (char*)db->grid_buf;
+    VQ_HIP(hipMemcpyAsync(base, rows_host, (size_t)L * 8, hipMemcpyHostToDevice, db->stream));
+    const int64_t vec = row_bytes / 16;
+    const bool tiled = db->layout == VQ_LAYOUT_TILED;
+    gather_rows_kernel<<<cdiv((int64_t)L * vec, 256), 256, 0, db->stream>>>((const uint4*)db->feats, (const int64_t*)base, L, vec, (uint4*)(base + rb),
+                                                                            tiled ? db->S * db->E : 0, db->D / 4);
+    VQ_CHECK_LAUNCH();
+    *dense = base + rb;
+    return VQ_OK;
+}
+
+// In place: a tile's 16 rows and its tiled form occupy the same bytes, so the block is converted a bounded run of tiles at a time
+// through a scratch block (rows -> scratch in the new order -> back).  One sweep of reads and writes each way; caller holds the lock.
+static int convert_layout(vq_db* db, int to) {
+    const int NV = db->S * db->E;
+    const int64_t ntiles = (db->n + 15) / 16, tile_bytes = (int64_t)16 * NV * db->D * 4;
+    const int64_t per = std::max<int64_t>(1, std::min<int64_t>(ntiles, (int64_t)(256u << 20) / tile_bytes));
+    float* scratch = nullptr;
+    hipError_t e = hipMalloc((void**)&scratch, (size_t)(per * tile_bytes));
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        device_pool_trim();
+        e = hipMalloc((void**)&scratch, (size_t)(per * tile_bytes));
+    }
+    if (e != hipSuccess) return fail(VQ_E_NOMEM, "no room for the %lld MB conversion block: %s", (long long)(per * tile_bytes >> 20), hipGetErrorString(e));
+    const size_t lds = 16 * (size_t)(db->D + 4) * sizeof(float);
+    int rc = VQ_OK;
+    for (int64_t t0 = 0; t0 < ntiles && rc == VQ_OK; t0 += per) {
+        const int64_t k = std::min(per, ntiles - t0);
+        float* block = (float*)db->feats + t0 * 16 * NV * db->D;
+        const int64_t rows_here = std::min<int64_t>(db->n - t0 * 16, k * 16);
+        if (to == VQ_LAYOUT_TILED)
+            mirror_build_kernel<<<(unsigned)(k * NV), 256, lds, db->stream>>>(block, scratch, rows_here, NV, db->D);
+        else
+            untile_kernel<<<(unsigned)(k * NV), 256, lds, db->stream>>>(block, scratch, rows_here, NV, db->D);
+        e = hipGetLastError();
+        // tiled -> rows leaves the rows past n of the last tile unwritten in the scratch block: copy whole rows only
+        const size_t bytes = to == VQ_LAYOUT_TILED ? (size_t)(k * tile_bytes) : (size_t)rows_here * NV * db->D * 4;
+        if (e == hipSuccess) e = hipMemcpyAsync(block, scratch, bytes, hipMemcpyDeviceToDevice, db->stream);
+        if (e != hipSuccess) rc = fail(VQ_E_HIP, "layout conversion failed: %s", hipGetErrorString(e));
+    }
+    e = hipStreamSynchronize(db->stream);
+    if (rc == VQ_OK && e != hipSuccess) rc = fail(VQ_E_HIP, "layout conversion failed: %s", hipGetErrorString(e));
+    (void)hipFree(scratch);
+    if (rc == VQ_OK) db->layout = to;
+    return rc;
 }
 
 namespace vq {
@@ -1012,7 +1214,7 @@ int vq_db_create(int64_t n, int32_t S, int32_t E, int32_t D, int32_t dtype, int3
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) db->cus = prop.multiProcessorCount;
     db->nblk = cdiv(n, SEL_CHUNK);
-    const size_t fbytes = (size_t)n * S * E * D * db->elem();
+    const size_t fbytes = (size_t)((n + 15) / 16 * 16) * S * E * D * db->elem();      // whole tiles of 16 clips (vq_db_set_layout)
 #define A_(ptr, bytes)                                    \
     do {                                                  \
         hipError_t e_ = hipMalloc((void**)&(ptr), bytes); \
@@ -1028,6 +1230,7 @@ int vq_db_create(int64_t n, int32_t S, int32_t E, int32_t D, int32_t dtype, int3
         }                                                 \
     } while (0)
     A_(db->feats, fbytes);
+    if (n % 16) (void)hipMemset((char*)db->feats + (size_t)n * S * E * D * db->elem(), 0, fbytes - (size_t)n * S * E * D * db->elem());
     A_(db->t, (size_t)S * E * D * 8);
     A_(db->w, 8 * 8);
     A_(db->avg, (size_t)n * S * 8);
@@ -1081,12 +1284,32 @@ int vq_db_upload(vq_db* db, int64_t row0, int64_t nrows, const void* feats_host)
     std::lock_guard<std::mutex> lk(db->mu);
     DeviceGuard g(db->device);
     const size_t row_bytes = (size_t)db->S * db->E * db->D * db->elem();
-    VQ_HIP(hipMemcpyAsync((char*)db->feats + row0 * row_bytes, feats_host, nrows * row_bytes, hipMemcpyHostToDevice,
-                          db->stream));
-    VQ_HIP(hipStreamSynchronize(db->stream));
+    if (db->layout == VQ_LAYOUT_TILED) {
+        // rows land in a staging block and are dealt into their tiles by a kernel, a bounded chunk at a time
+        const int64_t chunk = std::max<int64_t>(1, (int64_t)(64u << 20) / (int64_t)row_bytes);
+        void* stage = nullptr;
+        VQ_HIP(hipMalloc(&stage, (size_t)std::min<int64_t>(chunk, std::max<int64_t>(nrows, 1)) * row_bytes));
+        const int NV = db->S * db->E, d4 = db->D / 4;
+        for (int64_t r = 0; r < nrows; r += chunk) {
+            const int64_t k = std::min(chunk, nrows - r);
+            hipError_t e = hipMemcpyAsync(stage, (const char*)feats_host + r * row_bytes, k * row_bytes, hipMemcpyHostToDevice, db->stream);
+            if (e == hipSuccess) {
+                scatter_rows_tiled_kernel<<<cdiv(k * NV * d4, 256), 256, 0, db->stream>>>((const float4*)stage, (float4*)db->feats, row0 + r, k, NV, d4);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(db->stream);
+            if (e != hipSuccess) {
+                (void)hipFree(stage);
+                return fail(VQ_E_HIP, "upload into the tiled layout failed: %s", hipGetErrorString(e));
+            }
+        }
+        VQ_HIP(hipFree(stage));
+    } else {
+        VQ_HIP(hipMemcpyAsync((char*)db->feats + row0 * row_bytes, feats_host, nrows * row_bytes, hipMemcpyHostToDevice,
+                              db->stream));
+        VQ_HIP(hipStreamSynchronize(db->stream));
+    }
     db->have_avg = db->have_scores = db->have_sims = false;
-    db->mirror_valid = false;
-    db->batch_passes_since_write = 0;
     return VQ_OK;
 }
 
@@ -1099,8 +1322,8 @@ int vq_db_adopt_device(vq_db* db, void* feats_dev) {
     db->feats = feats_dev;
     db->owns_feats = false;
     db->have_avg = db->have_scores = db->have_sims = false;
-    db->feats_exposed = true;                 // the caller owns the memory and may rewrite it at any time: no mirror
-    db->mirror_valid = false;
+    db->feats_exposed = true;                 // the caller owns the memory (row-major, possibly not whole tiles): never re-tiled
+    db->layout = VQ_LAYOUT_ROWS;
     return VQ_OK;
 }
 
@@ -1143,18 +1366,20 @@ int vq_db_generate(vq_db* db, uint64_t seed, int64_t global_row0, const float* s
                                                                            db->E * db->D, db->S, scales_dev);
     VQ_CHECK_LAUNCH();
     VQ_HIP(hipStreamSynchronize(db->stream));
-    db->mirror_valid = false;
-    db->batch_passes_since_write = 0;
     db->have_avg = db->have_scores = db->have_sims = false;
+    if (db->layout == VQ_LAYOUT_TILED) {          // the generator writes rows; a tiled database gets its layout back
+        db->layout = VQ_LAYOUT_ROWS;
+        return convert_layout(db, VQ_LAYOUT_TILED);
+    }
     return VQ_OK;
 }
 
 int vq_db_feats_devptr(vq_db* db, void** p) {
     VQ_REQUIRE(db && p, "NULL argument");
     std::lock_guard<std::mutex> lk(db->mu);
+    if (db->layout != VQ_LAYOUT_ROWS) return fail(VQ_E_STATE, "the database is tiled: its block is not [N][S][E][D] (vq_db_set_layout(VQ_LAYOUT_ROWS) first)");
     *p = db->feats;
-    db->feats_exposed = true;                 // writes through the raw pointer cannot be seen: the 16-query pass stays on the rows themselves
-    db->mirror_valid = false;
+    db->feats_exposed = true;                 // whoever holds the raw pointer assumes row-major memory: the layout is frozen
     return VQ_OK;
 }
 
@@ -1181,15 +1406,18 @@ int vq_db_bootstrap_target(vq_db* db, const int64_t* valid_rows, int32_t n_valid
     std::lock_guard<std::mutex> lk(db->mu);
     DeviceGuard g(db->device);
     const int P = db->S * db->E, stride = n_valid + n_invalid;
+    // the validated rows are gathered into a dense [stride][P][D] block first (whatever the layout; tens of rows of 40 KB)
+    std::vector<int64_t> rows((size_t)stride);
+    for (int k = 0; k < stride; ++k) rows[k] = k < n_valid ? valid_rows[k] : invalid_rows[k - n_valid];
+    const void* dense = nullptr;
+    int rc = gather_rows_device(db, rows.data(), stride, &dense);
+    if (rc != VQ_OK) return rc;
     std::vector<int64_t> off((size_t)P * stride);
     std::vector<int32_t> nv(P, n_valid), ni(P, n_invalid);
     for (int p = 0; p < P; ++p)
-        for (int k = 0; k < stride; ++k) {
-            const int64_t row = k < n_valid ? valid_rows[k] : invalid_rows[k - n_valid];
-            off[(size_t)p * stride + k] = (row * P + p) * db->D;      // [N][S][E][D], p = s * E + e
-        }
-    const int rc = bootstrap_from_device_rows(db->feats, db->dtype, off, stride, nv.data(), ni.data(), P, db->D, mu, db->stream, targets_host,
-                                              set_query ? db->t : nullptr);
+        for (int k = 0; k < stride; ++k) off[(size_t)p * stride + k] = ((int64_t)k * P + p) * db->D;      // p = s * E + e
+    rc = bootstrap_from_device_rows(dense, db->dtype, off, stride, nv.data(), ni.data(), P, db->D, mu, db->stream, targets_host,
+                                    set_query ? db->t : nullptr);
     if (rc != VQ_OK) return rc;
     if (set_query) {
         db->have_query = true;
@@ -1205,9 +1433,9 @@ int vq_db_set_query_from_row(vq_db* db, int64_t row, double* t_out_host) {
     DeviceGuard g(db->device);
     const int NV = db->S * db->E;
     if (db->dtype == VQ_F32)
-        scale_query_kernel<float><<<NV, 256, 0, db->stream>>>((const float*)db->feats, row, NV, db->D, db->t);
+        scale_query_kernel<float><<<NV, 256, 0, db->stream>>>((const float*)db->feats, row, NV, db->D, db->t, db->layout == VQ_LAYOUT_TILED);
     else
-        scale_query_kernel<double><<<NV, 256, 0, db->stream>>>((const double*)db->feats, row, NV, db->D, db->t);
+        scale_query_kernel<double><<<NV, 256, 0, db->stream>>>((const double*)db->feats, row, NV, db->D, db->t, false);
     VQ_CHECK_LAUNCH();
     if (t_out_host) {
         VQ_HIP(hipMemcpyAsync(t_out_host, db->t, (size_t)NV * db->D * 8, hipMemcpyDeviceToHost, db->stream));
@@ -1223,16 +1451,31 @@ int vq_db_set_query_from_row(vq_db* db, int64_t row, double* t_out_host) {
 template <typename T, int S, int E, int CH>
 static int launch_scan_t(vq_db* db, const ScanArgs& a) {
     const size_t lds = (size_t)S * E * CH * 256 * 8;
-    auto kern = scan_kernel<T, S, E, CH>;
-    VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
+    if (db->layout == VQ_LAYOUT_TILED) {
+        if constexpr (sizeof(T) == 4) {
+            auto kern = scan_tiled_kernel<S, E, CH, kTiledGroup>;
+            VQ_DYN_LDS(kern, lds);
+            const int64_t want = ((a.n + 15) / 16 + 3) / 4;   // 4 waves (tiles in flight) per block
+            const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)db->cus * per_cu));
+            kern<<<grid, 256, lds, db->stream>>>(a);
+            VQ_CHECK_LAUNCH();
+            return VQ_OK;
+        }
+        return fail(VQ_E_STATE, "internal: a tiled database is fp32");
+    }
+    auto kern = scan_kernel<T, S, E, CH>;
+    VQ_DYN_LDS(kern, lds);
     const int64_t want = (a.n + 3) / 4;   // 4 waves (clips in flight) per block
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)db->cus * per_cu));
     kern<<<grid, 256, lds, db->stream>>>(a);
     VQ_CHECK_LAUNCH();
     return VQ_OK;
 }
+
+// shapes the fast one-query kernels (and with them the tiled layout) exist for
+static bool fast_scan_shape(const vq_db* db) { return db->D == 1024 && db->S >= 1 && db->S <= 2 && db->E >= 1 && db->E <= 5; }
 
 template <typename T>
 static int launch_scan(vq_db* db, const ScanArgs& a) {
@@ -1243,6 +1486,7 @@ static int launch_scan(vq_db* db, const ScanArgs& a) {
         C_(2, 1) C_(2, 2) C_(2, 3) C_(2, 4) C_(2, 5)
 #undef C_
     }
+    if (db->layout != VQ_LAYOUT_ROWS) return fail(VQ_E_STATE, "internal: tiled layout on a shape without a tiled scan kernel");
     const int64_t want = (a.n + 3) / 4;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)db->cus * 8));
     scan_generic_kernel<T><<<grid, 256, 0, db->stream>>>(a);
@@ -1306,7 +1550,7 @@ int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const d
     // VQ_BATCH_TWO_KERNEL=1 keeps the round-2 form (ten slice launches into a [slice][query][clip] matrix + a finalising
     // launch) for A/B measurements; the product runs the single fused launch
     const char* two_env = getenv("VQ_BATCH_TWO_KERNEL");
-    const bool two_kernel = two_env && *two_env == '1';
+    const bool two_kernel = two_env && *two_env == '1' && db->layout == VQ_LAYOUT_ROWS;
     const int64_t n_t = (int64_t)Q * NV * db->D, n_w = (int64_t)Q * db->S, n_s = two_kernel ? (int64_t)Q * db->n * NV : 0, n_sc = (int64_t)Q * db->n;
     const int64_t need = n_t + n_w + n_s + n_sc;
     if (db->batch_cap < need) {
@@ -1326,44 +1570,9 @@ int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const d
     const size_t lds = ((size_t)kBatchSlots * db->D + 32) * 8;   // sixteen swizzled query rows
     const int ch = db->D / 256;
     if (!two_kernel) {
-        // The tiled mirror: fp32 databases that own their memory and never handed its address out (every write then goes through
-        // vq_db_upload / vq_db_generate, which invalidate it).  Built behind the first pass since the last write -- one more sweep
-        // of the database, read and written -- and used from the second on: 6.8 ms per pass instead of 7.3 at cfg 4.  Needs as much
-        // memory again; without it (or with VQ_BATCH_MIRROR=0) the pass reads the rows themselves.  Same operands per MFMA: same bits.
-        const char* mir_env = getenv("VQ_BATCH_MIRROR");
-        bool tiled = false;
-        if (db->dtype == VQ_F32 && db->owns_feats && !db->feats_exposed && !(mir_env && *mir_env == '0')) {
-            if (db->mirror_valid) {
-                tiled = true;
-            } else if (db->batch_passes_since_write >= 1 || (mir_env && *mir_env == '2')) {      // 2: build before the first pass (tests)
-                const size_t want = (size_t)((db->n + 15) / 16) * 16 * NV * db->D * sizeof(float);
-                if (db->mirror && db->mirror_bytes < want) {
-                    VQ_HIP(hipFree(db->mirror));
-                    db->mirror = nullptr;
-                    db->mirror_bytes = 0;
-                }
-                if (!db->mirror && hipMalloc((void**)&db->mirror, want) == hipSuccess) db->mirror_bytes = want;
-                if (db->mirror) {
-                    const int64_t wgs = (db->n + 15) / 16 * NV;
-                    VQ_REQUIRE(wgs < (1ll << 31), "database too large for one mirror launch");
-                    static bool mirror_attr = false;
-                    if (!mirror_attr) {
-                        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mirror_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   16 * (1024 + 4) * (int)sizeof(float)));
-                        mirror_attr = true;
-                    }
-                    mirror_build_kernel<<<(unsigned)wgs, 256, 16 * (db->D + 4) * sizeof(float), db->stream>>>((const float*)db->feats, db->mirror, db->n, NV,
-                                                                                                             db->D);
-                    VQ_CHECK_LAUNCH();
-                    db->mirror_valid = tiled = true;
-                } else {
-                    (void)hipGetLastError();                   // no room for a second copy: stay on the rows
-                }
-            }
-        }
-        ++db->batch_passes_since_write;
+        const bool tiled = db->layout == VQ_LAYOUT_TILED;      // whole 128-byte lines per load instruction, non-temporal: 0.75 of the HBM peak against 0.71
         BatchFusedArgs f;
-        f.feats = tiled ? (const void*)db->mirror : db->feats;
+        f.feats = db->feats;
         f.t = d_t;
         f.w = d_w;
         f.present = db->present;
@@ -1382,8 +1591,7 @@ int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const d
     {                                                                                                                      \
         auto kern = db->present ? batch_fused_kernel<T, CH, TW, true, 8> : batch_fused_kernel<T, CH, TW, false, 8>;       \
         if (tiled) kern = db->present ? batch_fused_kernel<T, CH, TW, true, 8, true> : batch_fused_kernel<T, CH, TW, false, 8, true>; \
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,        \
-                                   (kBatchSlots * CH * 256 + 32) * 8));                                                     \
+        VQ_DYN_LDS(kern, (kBatchSlots * CH * 256 + 32) * 8);                                                                \
         kern<<<blocks, 1024, lds, db->stream>>>(f);                                                                        \
     }
         if (db->dtype == VQ_F32) {
@@ -1409,12 +1617,7 @@ int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const d
 #define VQ_BATCH_LAUNCH(T, CH)                                                                                             \
     {                                                                                                                      \
         auto kern = batch_mfma_kernel<T, CH>;                                                                              \
-        static bool attr = false;                                                                                          \
-        if (!attr) {                                                                                                       \
-            VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                       (kBatchSlots * CH * 256 + 32) * 8));                                                 \
-            attr = true;                                                                                                   \
-        }                                                                                                                  \
+        VQ_DYN_LDS(kern, (kBatchSlots * CH * 256 + 32) * 8);                                                                \
         kern<<<blocks, 1024, lds, db->stream>>>(a);                                                                        \
     }
         if (db->dtype == VQ_F32) {
@@ -1493,6 +1696,71 @@ int vq_db_avg_devptr(vq_db* db, void** p) {
     *p = db->avg;
     return VQ_OK;
 }
+int vq_db_ne_devptr(vq_db* db, void** p) {
+    VQ_REQUIRE(db && p, "NULL argument");
+    *p = db->ne;
+    return VQ_OK;
+}
+
+int vq_db_read_scores_at(vq_db* db, const int64_t* rows_host, int32_t L, double* out_host) {
+    VQ_REQUIRE(db && out_host, "NULL argument");
+    VQ_REQUIRE(L >= 0 && (L == 0 || rows_host), "bad rows");
+    for (int l = 0; l < L; ++l)
+        VQ_REQUIRE(rows_host[l] >= 0 && rows_host[l] < db->n, "rows[%d] = %lld outside [0,%lld)", l, (long long)rows_host[l], (long long)db->n);
+    if (L == 0) return VQ_OK;
+    std::lock_guard<std::mutex> lk(db->mu);
+    if (!db->have_scores) return fail(VQ_E_STATE, "no scores computed (scan with weights, or rescore)");
+    DeviceGuard g(db->device);
+    int rc = ensure_grid_buf(db, (int64_t)L * 16);
+    if (rc != VQ_OK) return rc;
+    int64_t* rdev = (int64_t*)db->grid_buf;
+    double* vdev = (double*)((char*)db->grid_buf + (int64_t)L * 8);
+    VQ_HIP(hipMemcpyAsync(rdev, rows_host, (size_t)L * 8, hipMemcpyHostToDevice, db->stream));
+    gather_scores_kernel<<<cdiv(L, 256), 256, 0, db->stream>>>(db->scores, rdev, L, vdev);
+    VQ_CHECK_LAUNCH();
+    VQ_HIP(hipMemcpyAsync(out_host, vdev, (size_t)L * 8, hipMemcpyDeviceToHost, db->stream));
+    VQ_HIP(hipStreamSynchronize(db->stream));
+    return VQ_OK;
+}
+
+int vq_db_read_rows(vq_db* db, const int64_t* rows_host, int32_t L, void* out_host) {
+    VQ_REQUIRE(db && out_host, "NULL argument");
+    VQ_REQUIRE(L >= 0 && (L == 0 || rows_host), "bad rows");
+    for (int l = 0; l < L; ++l)
+        VQ_REQUIRE(rows_host[l] >= 0 && rows_host[l] < db->n, "rows[%d] = %lld outside [0,%lld)", l, (long long)rows_host[l], (long long)db->n);
+    if (L == 0) return VQ_OK;
+    std::lock_guard<std::mutex> lk(db->mu);
+    DeviceGuard g(db->device);
+    const void* dense = nullptr;
+    const int rc = gather_rows_device(db, rows_host, L, &dense);
+    if (rc != VQ_OK) return rc;
+    VQ_HIP(hipMemcpyAsync(out_host, dense, (size_t)L * db->S * db->E * db->D * db->elem(), hipMemcpyDeviceToHost, db->stream));
+    VQ_HIP(hipStreamSynchronize(db->stream));
+    return VQ_OK;
+}
+
+int vq_db_layout(vq_db* db, int32_t* layout) {
+    VQ_REQUIRE(db && layout, "NULL argument");
+    std::lock_guard<std::mutex> lk(db->mu);
+    *layout = db->layout;
+    return VQ_OK;
+}
+
+int vq_db_set_layout(vq_db* db, int32_t layout) {
+    VQ_REQUIRE(db, "db is NULL");
+    VQ_REQUIRE(layout == VQ_LAYOUT_ROWS || layout == VQ_LAYOUT_TILED, "layout must be VQ_LAYOUT_ROWS or VQ_LAYOUT_TILED");
+    std::lock_guard<std::mutex> lk(db->mu);
+    if (layout == db->layout) return VQ_OK;
+    if (layout == VQ_LAYOUT_TILED) {
+        if (db->dtype != VQ_F32 || !fast_scan_shape(db))
+            return fail(VQ_E_UNSUPPORTED, "the tiled layout exists for fp32 databases with D = 1024, S <= 2, E <= 5 (got dtype %d, D %d, S %d, E %d)", db->dtype,
+                        db->D, db->S, db->E);
+        if (!db->owns_feats || db->feats_exposed)
+            return fail(VQ_E_STATE, "the feature block is not the library's alone (adopted, or its address was handed out): it stays row-major");
+    }
+    DeviceGuard g(db->device);
+    return convert_layout(db, layout);
+}
 
 int vq_db_write_avg(vq_db* db, const double* avg_host, const int32_t* ne_host) {
     VQ_REQUIRE(db && avg_host, "NULL argument");
@@ -1506,6 +1774,7 @@ int vq_db_write_avg(vq_db* db, const double* avg_host, const int32_t* ne_host) {
     return VQ_OK;
 }
 
+}  // extern "C"
 static int ensure_grid_buf(vq_db* db, int64_t bytes) {
     if (db->grid_cap >= bytes) return VQ_OK;
     if (db->grid_buf) VQ_HIP(hipFree(db->grid_buf));
@@ -1515,6 +1784,7 @@ static int ensure_grid_buf(vq_db* db, int64_t bytes) {
     db->grid_cap = bytes;
     return VQ_OK;
 }
+extern "C" {
 
 int vq_db_scores_grid(vq_db* db, const double* w_grid_host, int32_t G, const int64_t* rows_host, int32_t L,
                       double* out_host) {

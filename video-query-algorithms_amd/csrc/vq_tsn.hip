@@ -866,11 +866,7 @@ static int launch_conv_t(vq_tsn* net, ConvArgs& a) {
     a.tiles_n = cdiv(a.Cout, BN);
     auto kern = conv_igemm_kernel<BM, BN, WM, WN, BK, SMALL>;
     const size_t lds = sizeof(ConvSmem<BM, BN, BK>);
-    static bool attr_set = false;     // per instantiation
-    if (!attr_set) {
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    VQ_DYN_LDS(kern, lds);            // per instantiation and device
     VQ_LAUNCH(kern, a.tiles_m * a.tiles_n * a.ksplit, 256, lds, net->ls, net->ev_start, net->ev_stop, a);
     VQ_CHECK_LAUNCH();
     return VQ_OK;
@@ -894,11 +890,7 @@ static int launch_conv_pipe_t(vq_tsn* net, ConvArgs& a) {
     a.tiles_n = cdiv(a.Cout, BN);
     auto kern = conv_igemm_pipe_kernel<BM, BN, WM, WN, BK, SMALL>;
     const size_t lds = sizeof(ConvSmem<BM, BN, BK>);
-    static bool attr_set = false;
-    if (!attr_set) {
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    VQ_DYN_LDS(kern, lds);            // per instantiation and device
     VQ_LAUNCH(kern, a.tiles_m * a.tiles_n * a.ksplit, 256, lds, net->ls, net->ev_start, net->ev_stop, a);
     VQ_CHECK_LAUNCH();
     return VQ_OK;
@@ -924,11 +916,7 @@ static int launch_conv_pool_t(vq_tsn* net, ConvArgs& a) {
     a.tiles_n = cdiv(a.Cout, BN);
     auto kern = conv_igemm_kernel<BM, BN, WM, WN, BK, false, true>;
     const size_t lds = sizeof(ConvSmem<BM, BN, BK>);
-    static bool attr_set = false;
-    if (!attr_set) {
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    VQ_DYN_LDS(kern, lds);            // per instantiation and device
     VQ_LAUNCH(kern, a.tiles_m * a.tiles_n, 256, lds, net->ls, net->ev_start, net->ev_stop, a);
     VQ_CHECK_LAUNCH();
     return VQ_OK;

@@ -39,12 +39,27 @@ def worker_devices(gpu_list: Optional[Sequence[int]], num_worker: int, visible: 
 
 
 def visible_gpus() -> int:
-    """Number of GPUs of the node WITHOUT initialising one (``torch.cuda.device_count()`` reads the topology only)."""
+    """Number of GPUs of the node, counted WITHOUT any HIP call (``torch.cuda.device_count()`` falls through to
+    ``hipGetDeviceCount`` when amdsmi is not usable, and a parent that has initialised a GPU must not start GPU children):
+    the KFD topology lists one node per agent, GPUs are the nodes with SIMDs; a ``*_VISIBLE_DEVICES`` list narrows it."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n = 0
+    root = "/sys/class/kfd/kfd/topology/nodes"
     try:
-        import torch
-        return int(torch.cuda.device_count())
-    except Exception:
+        for node in os.listdir(root):
+            try:
+                with open(os.path.join(root, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
         return 0
+    return n
 
 
 def is_child() -> bool:
@@ -57,36 +72,89 @@ def free_port() -> int:
         return sk.getsockname()[1]
 
 
-def run_children(program: str, argv: Sequence[str], child_envs: Sequence[Dict[str, str]], poll_s: float = 0.05) -> int:
-    """Start ``python program argv`` once per entry of ``child_envs`` (its variables on top of this process's), wait
-    for all.  The first child to fail ends the others (a rank that dies would leave its peers waiting in a collective) and
-    its exit code is returned; 0 when every child returned 0."""
+def start_children(program: str, argv: Sequence[str], child_envs: Sequence[Dict[str, str]]) -> List[subprocess.Popen]:
+    """Start ``python program argv`` once per entry of ``child_envs`` (its variables on top of this process's)."""
     cmd = [sys.executable, os.path.abspath(program)] + list(argv)
-    procs = []
-    for extra in child_envs:
-        env = dict(os.environ)
-        env.update(extra)
-        env[CHILD_ENV] = "1"
-        procs.append(subprocess.Popen(cmd, env=env))
+    procs: List[subprocess.Popen] = []
+    try:
+        for extra in child_envs:
+            env = dict(os.environ)
+            env.update(extra)
+            env[CHILD_ENV] = "1"
+            procs.append(subprocess.Popen(cmd, env=env))
+    except BaseException:
+        stop_children(procs)
+        raise
+    return procs
+
+
+def stop_children(procs: Sequence[subprocess.Popen], grace_s: float = 10.0):
+    """Terminate what is still running, kill what ignores it (a rank blocked in a collective does)."""
+    live = [p for p in procs if p.poll() is None]
+    for p in live:
+        p.terminate()
+    deadline = time.monotonic() + grace_s
+    for p in live:
+        try:
+            p.wait(timeout=max(0.0, deadline - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+
+
+def wait_children(procs: Sequence[subprocess.Popen], timeout_s: float = 60.0) -> int:
+    """Wait for children that were told to finish; whoever is still there after ``timeout_s`` is stopped.  First non-zero code."""
+    rc = 0
+    deadline = time.monotonic() + timeout_s
+    for p in procs:
+        try:
+            r = p.wait(timeout=max(0.0, deadline - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            stop_children([p])
+            r = p.returncode
+        if r and rc == 0:
+            rc = r if r > 0 else 128 - r
+    return rc
+
+
+def run_children(program: str, argv: Sequence[str], child_envs: Sequence[Dict[str, str]], poll_s: float = 0.05) -> int:
+    """Start ``python program argv`` once per entry of ``child_envs``, wait for all.  The first child to fail ends the others (a
+    rank that dies would leave its peers waiting in a collective) and its exit code is returned; 0 when every child returned 0.
+    Whatever ends the parent early -- an exception, Ctrl-C, SIGTERM -- ends the children too: they hold GPUs."""
+    import signal
+    procs = start_children(program, argv, child_envs)
+
+    def on_term(signum, _frame):
+        raise KeyboardInterrupt("signal %d" % signum)
+    previous = None
+    try:
+        previous = signal.signal(signal.SIGTERM, on_term)
+    except ValueError:                                   # not the main thread: no handler, the finally below still runs
+        pass
     rc = 0
     live = list(procs)
     kill_at = None
-    while live:
-        for p in list(live):
-            r = p.poll()
-            if r is None:
-                continue
-            live.remove(p)
-            if r != 0 and rc == 0:
-                rc = r if r > 0 else 128 - r            # a signal's negative code becomes the shell's 128 + signal
-                for q in live:
-                    q.terminate()
-                kill_at = time.monotonic() + 10.0        # a terminated child that ignores SIGTERM
-        if live:
-            if kill_at is not None and time.monotonic() > kill_at:
-                for q in live:
-                    q.kill()
-            time.sleep(poll_s)
+    try:
+        while live:
+            for p in list(live):
+                r = p.poll()
+                if r is None:
+                    continue
+                live.remove(p)
+                if r != 0 and rc == 0:
+                    rc = r if r > 0 else 128 - r            # a signal's negative code becomes the shell's 128 + signal
+                    for q in live:
+                        q.terminate()
+                    kill_at = time.monotonic() + 10.0        # a terminated child that ignores SIGTERM
+            if live:
+                if kill_at is not None and time.monotonic() > kill_at:
+                    for q in live:
+                        q.kill()
+                time.sleep(poll_s)
+    finally:
+        stop_children(procs)
+        if previous is not None:
+            signal.signal(signal.SIGTERM, previous)
     return rc
 
 

@@ -152,6 +152,17 @@ class FeatureDB:
             raise ValueError("rows must be [n,%d,%d,%d]" % (self.S, self.E, self.D))
         call("vq_db_upload", self._h, int(row0), a.shape[0], _np_ptr(a))
 
+    def set_layout(self, layout: str):
+        """"rows" ([N][S][E][D]) or "tiled" ([tile of 16 clips][S*E][D/4][clip][4]: the order in which every load of the scans
+        takes whole lines; fp32, D = 1024, S <= 2, E <= 5).  In place, one sweep of the block: call once after loading."""
+        call("vq_db_set_layout", self._h, {"rows": _lib.VQ_LAYOUT_ROWS, "tiled": _lib.VQ_LAYOUT_TILED}[layout])
+
+    @property
+    def layout(self) -> str:
+        v = C.c_int32()
+        call("vq_db_layout", self._h, C.byref(v))
+        return "tiled" if v.value == _lib.VQ_LAYOUT_TILED else "rows"
+
     def adopt_device(self, dev_ptr: int, keepalive=None):
         """Use caller-owned device memory (e.g. a torch tensor holding all-gathered blocks)."""
         call("vq_db_adopt_device", self._h, C.c_void_p(dev_ptr))
@@ -208,6 +219,33 @@ class FeatureDB:
         p = C.c_void_p()
         call("vq_db_avg_devptr", self._h, C.byref(p))
         return p.value
+
+    def device_tensor(self, kind: str):
+        """Zero-copy torch view of a result array in the library's device memory -- "avg" [N,S] f64, "ne" [N,S] i32, "scores"
+        [N] f64 -- for collectives that take device tensors (RCCL all-gather of score slices).  The caller orders its use
+        behind the scan (same stream as ``set_stream``)."""
+        import torch
+        name, shape, typestr = {"avg": ("vq_db_avg_devptr", (self.n, self.S), "<f8"), "ne": ("vq_db_ne_devptr", (self.n, self.S), "<i4"),
+                                "scores": ("vq_db_scores_devptr", (self.n,), "<f8")}[kind]
+        p = C.c_void_p()
+        call(name, self._h, C.byref(p))
+
+        class _View:
+            __cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(p.value), False), "version": 2}
+        return torch.as_tensor(_View(), device=torch.device("cuda", self.device))
+
+    def read_rows(self, rows: Sequence[int]) -> np.ndarray:
+        """Feature rows [L,S,E,D] back on the host (database dtype)."""
+        r = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1)
+        out = np.empty((r.size, self.S, self.E, self.D), dtype=self.dtype)
+        call("vq_db_read_rows", self._h, _np_ptr(r) if r.size else None, int(r.size), _np_ptr(out))
+        return out
+
+    def scores_at(self, rows: Sequence[int]) -> np.ndarray:
+        r = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1)
+        out = np.empty(r.size, dtype=np.float64)
+        call("vq_db_read_scores_at", self._h, _np_ptr(r) if r.size else None, int(r.size), _np_ptr(out))
+        return out
 
     # ------------------------------------------------------------------ query
     def set_query(self, t: np.ndarray):
