@@ -46,6 +46,7 @@ PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.29 TB/s measured achievable pe
 B_CLIPS, T_SEG, CH = 32, 3, 3     # configs[1]
 PROFILE_EVERY = 5                 # every 5th timed step carries per-launch events (~3 us per launch of signal handling)
 SIM_N, SIM_S, SIM_E, SIM_D = 1_000_000, 2, 5, 1024   # configs[3]
+TILED_GROUP = 4                   # csrc/vq_sim.hip: kTiledGroup
 
 
 class _DevArray:
@@ -366,58 +367,76 @@ def cpu_baseline_tsn(crops_u8, weights_graph, seconds_target=12.0):
 
 
 def bench_sim(args, rank, world, device, stream):
+    """configs[3]: 1 query x 1M clips x (2 streams x 5 splits) x 1024 fp32, row-sharded over the ranks through the product's own
+    ShardedFeatureDB (N > 1) / FeatureDB (N = 1), tiled in place after loading.  A step = one scan launch per rank (dots, ensemble
+    mean, weighted score) + the all-gather of the score slices into global order on every rank's device."""
     import torch.distributed as dist
-    row0, rows = shard_range(SIM_N, world, rank)
-    db = vqa.FeatureDB.synthetic(rows, SIM_S, SIM_E, SIM_D, seed=17, scales=(4.0, 1.0), row0=row0, device=device.index)
-    db.set_stream(stream.cuda_stream)
-    # query = scaled features of global row 12345 (rank 0 holds it); broadcast t to every rank
-    t = torch.zeros((SIM_S, SIM_E, SIM_D), dtype=torch.float64, device=device)
-    if rank == 0:
-        t.copy_(torch.from_numpy(db.set_query_from_row(12345)))
+    rehearse = world > 1 and dist.get_backend() != "nccl"
+    sdb = None
     if world > 1:
-        dist.broadcast(t, 0)
-    db.set_query(t.cpu().numpy())
+        from video_query_algorithms_amd.sharded_db import ShardedFeatureDB
+        sdb = ShardedFeatureDB.synthetic(SIM_N, SIM_S, SIM_E, SIM_D, seed=17, scales=(4.0, 1.0), device=device.index,
+                                         stream=None if rehearse else stream)
+        db, row0, rows = sdb.local, sdb.row0, sdb.local.n
+        if rehearse:
+            db.set_stream(stream.cuda_stream)
+    else:
+        row0, rows = 0, SIM_N
+        db = vqa.FeatureDB.synthetic(rows, SIM_S, SIM_E, SIM_D, seed=17, scales=(4.0, 1.0), row0=row0, device=device.index)
+        db.set_stream(stream.cuda_stream)
+    front = sdb if sdb is not None else db
     w = [1.0, 1.5]
-    scores = dev_tensor(db.scores_devptr(), (rows,), "<f8", device)
     tm = C.c_void_p()
     call("vq_timer_create", C.byref(tm))
-    steps, warm = max(args.steps, 5), max(args.warmup, 2)
-    with torch.cuda.stream(stream):
-        for _ in range(warm):
-            db.scan(weights=w)
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        kern_ms = 0.0
-        sim_gather = []
+    sptr = C.c_void_p(stream.cuda_stream)
+
+    def timed_scans(n_steps, gather):
+        kern, gath = 0.0, []
         t0 = time.perf_counter()
-        for _ in range(steps):
-            call("vq_timer_start", tm, C.c_void_p(stream.cuda_stream))
-            db.scan(weights=w)                               # one launch: dots, ensemble mean, weighted score
-            call("vq_timer_stop", tm, C.c_void_p(stream.cuda_stream))
-            if world > 1:
+        for _ in range(n_steps):
+            call("vq_timer_start", tm, sptr)
+            front.scan(weights=w)                            # one launch per rank: dots, ensemble mean, weighted score
+            call("vq_timer_stop", tm, sptr)
+            if gather and sdb is not None:
                 g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 g0.record(stream)
-                all_scores = all_gather_rows(scores, SIM_N)      # score slices -> every rank (N x 8 B, RCCL)
+                sdb.scores_tensor()                          # score slices -> global order on every rank (N x 8 B; RCCL)
                 g1.record(stream)
-                sim_gather.append((g0, g1))
+                gath.append((g0, g1))
             ms = C.c_float()
             call("vq_timer_elapsed_ms", tm, C.byref(ms))
-            kern_ms += ms.value
+            kern += ms.value
         torch.cuda.synchronize(device)
+        return time.perf_counter() - t0, kern / n_steps, gath
+
+    steps, warm = max(args.steps, 5), max(args.warmup, 2)
+    with torch.cuda.stream(stream):
+        t = front.set_query_from_row(12345)                  # the owner's GPU scales the row; the others receive 80 KB
+        # for the record: the row-major block as loaded (what rounds 1-3 measured), then the SAME block tiled in place
+        timed_scans(2, False)
+        _, rows_ms, _ = timed_scans(3, False)
+        torch.cuda.synchronize(device)
+        tp = time.perf_counter()
+        front.set_layout("tiled")
+        torch.cuda.synchronize(device)
+        prepare_ms = (time.perf_counter() - tp) * 1e3
+        timed_scans(warm, True)
         if world > 1:
             dist.barrier()
-        dt = time.perf_counter() - t0
-    kern_ms /= steps
-    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in sim_gather])) if sim_gather else None
+        dt, kern_ms, sim_gather = timed_scans(steps, True)
+        if world > 1:
+            dist.barrier()
+    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in sim_gather])) if sim_gather and not rehearse else None
     nbytes = rows * SIM_S * SIM_E * SIM_D * 4 + rows * 8
-    roof = {"bound": "hbm", "kernel": "scan_kernel<float,2,5,4>", "achieved": nbytes / kern_ms / 1e6, "peak": PEAK_HBM_GBS,
+    roof = {"bound": "hbm", "kernel": "scan_tiled_kernel<2,5,4,%d>" % TILED_GROUP, "achieved": nbytes / kern_ms / 1e6, "peak": PEAK_HBM_GBS,
             "unit": "GB/s", "frac": nbytes / kern_ms / 1e6 / PEAK_HBM_GBS, "traffic": None, "avg_launch_ms": kern_ms,
-            "bytes_per_launch": nbytes, "score_all_gather_ms_per_query": gather_ms}
+            "bytes_per_launch": nbytes, "score_all_gather_ms_per_query": gather_ms,
+            "row_major": {"kernel": "scan_kernel<float,2,5,4>", "avg_launch_ms": rows_ms, "frac": nbytes / rows_ms / 1e6 / PEAK_HBM_GBS},
+            "tile_in_place_ms": prepare_ms}
     # HBM bytes per launch from the PMC counters (collected off-line by tools/pmc_sim.sh on the full 1M-row launch and
     # committed; FETCH_SIZE doubled as the microarchitecture guide prescribes for gfx950); scaled to this rank's rows
     scan_traffic = None
-    for name in ("r03_scan_traffic.json", "r01_scan_traffic.json"):
+    for name in ("r04_scan_traffic.json", "r03_scan_traffic.json", "r01_scan_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):
             with open(tpath) as f:
@@ -425,55 +444,45 @@ def bench_sim(args, rank, world, device, stream):
             roof["traffic"] = scan_traffic["hbm_bytes_per_launch"] * rows / SIM_N
             roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch; committed, not collected in this run)" % name
             break
-    # batched form (N = 1 only, reported beside the single-query metric): 16 queries per pass over the database on the
-    # fp64 matrix cores -- the pass stays HBM-bound, so its roofline is the same byte count over its own duration
-    batched = None
-    if world == 1:
-        Q = 16
-        tb = np.stack([db.set_query_from_row(12345 + 1000 * i) for i in range(Q)])
-        wb = np.stack([[1.0, 1.5 + 0.05 * i] for i in range(Q)])
-        db.set_query(t.cpu().numpy())                       # leave the single-query state as the checks below expect it
-        db.scan(weights=w)
-        with torch.cuda.stream(stream):
-            # the first pass since the database was written reads the rows themselves; the second builds the tile-interleaved mirror (one more
-            # sweep: database read and written once) and runs on it, like every later one -- both are reported, neither is in the timed region
-            setup_ms = []
-            for _ in range(2):
-                torch.cuda.synchronize(device)
-                t_s = time.perf_counter()
-                db.scan_batch(tb, wb, want=False)
-                torch.cuda.synchronize(device)
-                setup_ms.append((time.perf_counter() - t_s) * 1e3)
-            tb0 = time.perf_counter()
-            reps = max(3, steps // 4)
-            ev_ms = 0.0
-            for _ in range(reps):
-                call("vq_timer_start", tm, C.c_void_p(stream.cuda_stream))
-                db.scan_batch(tb, wb, want=False)
-                call("vq_timer_stop", tm, C.c_void_p(stream.cuda_stream))
-                ms = C.c_float()
-                call("vq_timer_elapsed_ms", tm, C.byref(ms))
-                ev_ms += ms.value
-            torch.cuda.synchronize(device)
-            bdt = (time.perf_counter() - tb0) / reps
-            ev_ms /= reps
-        # one launch reads the database once and writes Q score vectors: no intermediate matrix since round 3
-        bbytes = rows * SIM_S * SIM_E * SIM_D * 4 + Q * rows * 8
-        batched = {"queries_per_pass": Q, "value": Q / bdt, "unit": "queries/s", "ms_per_pass": bdt * 1e3,
-                   "kernel": "batch_fused_kernel<float,4,2,false,8,tiled> (one launch per pass, on the tile-interleaved mirror of the database)",
-                   "pass_ms_by_hip_events": ev_ms, "first_pass_on_the_rows_ms": setup_ms[0], "pass_that_builds_the_mirror_ms": setup_ms[1],
-                   "bytes_per_pass": bbytes, "hbm_GBps": bbytes / ev_ms / 1e6, "hbm_frac": bbytes / ev_ms / 1e6 / PEAK_HBM_GBS,
-                   "traffic": (scan_traffic or {}).get("batch_fused_kernel", {}).get("hbm_bytes_per_launch"),
-                   "mfma_f64_tflops": 2.0 * Q * rows * SIM_S * SIM_E * SIM_D / ev_ms / 1e9, "mfma_f64_peak_tflops": 78.6,
-                   "note": "vq_db_scan_batch: the database is read ONCE for 16 queries by a single launch (a workgroup walks the (stream, "
-                           "split) slices itself: the slice's 16 query rows in LDS, dots on v_mfma_f64_16x16x4, per-tile sums in registers; "
-                           "no [slice][query][clip] matrix in memory; from the second pass since the last write the features come from a tile-interleaved "
-                           "copy of the database -- [tile of 16 clips][slice][k / 4][clip][4], as much memory again -- so that a wave's load "
-                           "instruction takes 1 KB of contiguous memory with the non-temporal hint); scores within 1e-12 of 16 single scans, bit-identical to the round-2 "
-                           "two-kernel form; value = wall clock over the passes incl. the 1.3 MB query upload of each; hbm_* from the HIP "
-                           "events around the pass"}
-    roof["batched"] = batched
-    return dt, steps, roof, db, row0, rows
+    # batched form (reported beside the single-query metric): 16 queries per pass over the database on the fp64 matrix cores
+    # -- the pass stays HBM-bound, so its roofline is the same byte count over its own duration
+    Q = 16
+    tb = np.stack([front.set_query_from_row(12345 + 1000 * i) for i in range(Q)])
+    wb = np.stack([[1.0, 1.5 + 0.05 * i] for i in range(Q)])
+    front.set_query(t)                                      # leave the single-query state as the checks below expect it
+    front.scan(weights=w)
+    with torch.cuda.stream(stream):
+        front.scan_batch(tb, wb, want=False)
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        tb0 = time.perf_counter()
+        reps = max(3, steps // 4)
+        ev_ms = 0.0
+        for _ in range(reps):
+            call("vq_timer_start", tm, sptr)
+            front.scan_batch(tb, wb, want=False)
+            call("vq_timer_stop", tm, sptr)
+            ms = C.c_float()
+            call("vq_timer_elapsed_ms", tm, C.byref(ms))
+            ev_ms += ms.value
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        bdt = (time.perf_counter() - tb0) / reps
+        ev_ms /= reps
+    # one launch reads the database once and writes Q score vectors
+    bbytes = rows * SIM_S * SIM_E * SIM_D * 4 + Q * rows * 8
+    roof["batched"] = {"queries_per_pass": Q, "value": Q / bdt, "unit": "queries/s", "ms_per_pass": bdt * 1e3,
+                       "kernel": "batch_fused_kernel<float,4,2,false,8,tiled>", "pass_ms_by_hip_events": ev_ms, "bytes_per_pass": bbytes,
+                       "hbm_GBps": bbytes / ev_ms / 1e6, "hbm_frac": bbytes / ev_ms / 1e6 / PEAK_HBM_GBS,
+                       "traffic": (scan_traffic or {}).get("batch_fused_kernel", {}).get("hbm_bytes_per_launch"),
+                       "mfma_f64_tflops": 2.0 * Q * rows * SIM_S * SIM_E * SIM_D / ev_ms / 1e9, "mfma_f64_peak_tflops": 78.6,
+                       "database_bytes_resident": rows * SIM_S * SIM_E * SIM_D * 4,
+                       "note": "vq_db_scan_batch on the block tiled in place (no second copy): the database is read ONCE for 16 queries by a single "
+                               "launch; value = wall clock over the passes incl. the 1.3 MB query upload of each; hbm_* from the HIP events around the pass"}
+    call("vq_timer_destroy", tm)
+    return dt, steps, roof, front, row0, rows
 
 
 def cpu_baseline_sim(db, row0):
@@ -811,6 +820,109 @@ def bench_e2e_wof(device_index):
                     "GPU, 768 JPEG encodings on 16 host threads, the clip regrouping"}
 
 
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _r(x, nd=4):
+    """Round floats (recursively) so that the line stays short; 4 significant decimals are what the numbers are good for."""
+    if isinstance(x, float):
+        return float("%.*g" % (nd + 2, x))
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def compact(out):
+    """The ONE line the driver records: every number of DESIGN.md section 5, kernel names and config.workload -- no prose (the notes
+    live in DESIGN.md and behind --verbose).  Stays under 4 KB so that the driver's record keeps all of it."""
+    line = _pick(out, ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"])
+    line["vs_baseline"] = out.get("vs_baseline")
+    cfg = out["config"]
+    line["config"] = {"workload": "configs[1]: TSN BN-Inception RGB, 224x224x3, T=3, B=32/GPU (96 crops/step), crops in HBM",
+                      "global_batch": cfg["global_batch"], "parallelism": cfg["parallelism"]}
+    if cfg.get("distributed"):
+        line["config"]["distributed"] = _pick(cfg["distributed"], ["backend", "world_size", "rccl_version", "rehearsal_on_one_gpu"])
+    roof = out["roofline"]
+    line["roofline"] = _pick(roof, ["bound", "achieved", "peak", "unit", "frac", "traffic", "effective_frac", "avg_launch_ms", "launches_per_step",
+                                    "conv_ms_per_step", "other_kernels_ms_per_step", "all_gather_ms_per_step", "graph"])
+    line["roofline"].setdefault("traffic", None)
+    line["roofline"]["kernel"] = "36 conv launches/step: conv_igemm(_pipe)_kernel + wino_f2x2_3x3_kernel, v_mfma_f32_32x32x2"
+    line["roofline"]["families"] = {k: _pick(v, ["frac", "ms_per_step", "launches"]) for k, v in roof.get("families", {}).items()}
+    if isinstance(roof.get("rank_ms_per_step"), dict):
+        line["roofline"]["rank_ms_per_step"] = _pick(roof["rank_ms_per_step"], ["min", "max"])
+    if "pmc_matrix_pipe_utilisation" in roof:
+        line["roofline"]["pmc_matrix_pipe"] = roof["pmc_matrix_pipe_utilisation"]
+    if "production_mode" in out:
+        line["production_mode"] = _pick(out["production_mode"], ["value", "ms_per_step"])
+    if "cpu_baseline" in out:
+        cb = out["cpu_baseline"]
+        line["cpu_baseline"] = _pick(cb, ["value", "unit", "cores", "kind"])
+        line["cpu_baseline"]["sample"] = cb["sample"].split(",")[0]
+        if "ten_crop_variant" in cb:
+            line["cpu_baseline"]["ten_crop_value"] = cb["ten_crop_variant"]["value"]
+    if "parity_vs_oracle_rel_err" in out:
+        line["parity_vs_oracle_rel_err"] = out["parity_vs_oracle_rel_err"]
+    ts = out.get("two_stream")
+    if ts:
+        line["two_stream"] = _pick(ts, ["value", "unit", "ms_per_step", "parity_vs_oracle_rel_err"])
+        line["two_stream"]["config"] = {"workload": "configs[2]: two-stream RGB + 10-ch flow stack, T=7, B=64 (448+448 crops)"}
+        line["two_stream"]["roofline"] = _pick(ts["roofline"], ["bound", "frac", "effective_frac", "conv_ms_per_step"])
+        if "production_mode" in ts:
+            line["two_stream"]["production_mode"] = ts["production_mode"]["value"]
+        if "cpu_baseline" in ts:
+            line["two_stream"]["cpu_baseline"] = _pick(ts["cpu_baseline"], ["value", "cores", "kind"])
+    sim = out.get("similarity")
+    if sim:
+        c = _pick(sim, ["metric", "value", "unit", "ms_per_query", "steps", "scaling"])
+        c["config"] = {"workload": "configs[3]: 1 query x 1M clips x (2 x 5) x 1024 fp32 = 40.96 GB, row-sharded, tiled in place",
+                       "rows_per_gpu": sim["config"]["rows_per_gpu"]}
+        c["roofline"] = _pick(sim["roofline"], ["bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms",
+                                                "score_all_gather_ms_per_query", "tile_in_place_ms"])
+        c["roofline"]["row_major_frac"] = sim["roofline"]["row_major"]["frac"]
+        if "batched" in sim:
+            c["batched"] = _pick(sim["batched"], ["value", "ms_per_pass", "pass_ms_by_hip_events", "hbm_frac", "traffic", "database_bytes_resident"])
+        if "cpu_baseline" in sim:
+            c["cpu_baseline"] = _pick(sim["cpu_baseline"], ["value", "unit", "cores", "kind"])
+            c["cpu_baseline"]["single_thread"] = sim["cpu_baseline"]["single_thread"]["value"]
+        line["similarity"] = c
+    fl = out.get("flow")
+    if fl:
+        c = _pick(fl, ["value", "unit", "ms_per_batch", "inner_loops_device_ms_per_batch", "iteration_launches_per_batch"])
+        c["warped"] = fl["warped"]["value"]
+        c["roofline"] = _pick(fl["roofline"], ["bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac"])
+        if "cpu_baseline" in fl:
+            c["cpu_baseline"] = _pick(fl["cpu_baseline"], ["value", "cores", "kind"])
+        line["flow"] = c
+    jp = out.get("jpeg")
+    if jp:
+        c = _pick(jp, ["value", "unit", "ms_per_batch", "bit_identical_to_libjpeg_turbo"])
+        c["small_batch"] = jp["small_batch"]["value"]
+        c["large"] = {k: v["value"] for k, v in jp["large_batches"].items()}
+        c["cpu_baseline"] = jp["cpu_baseline"]["value"]
+        line["jpeg"] = c
+    e2e = out.get("e2e_cli")
+    if e2e:
+        line["e2e_cli"] = _pick(e2e, ["value", "unit", "seconds", "ensemble3"])
+        line["e2e_cli"]["steady"] = e2e["steady_state"]["value"]
+    wof = out.get("e2e_wof_cli")
+    if wof:
+        line["e2e_wof_cli"] = _pick(wof, ["value", "unit", "seconds"])
+    return _r(line)
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` with no launcher: start N fresh children -- one rank per GPU over 127.0.0.1 -- BEFORE this process makes
+    any GPU call, let rank 0 print the line, return the first non-zero exit code.  (Under torchrun / as a child: do the work.)"""
+    from video_query_algorithms_amd import fanout
+    if args.gpus <= 1 or "RANK" in os.environ or fanout.is_child():
+        return None
+    envs = fanout.rank_envs(args.gpus, max(1, host_cores() // args.gpus))
+    return fanout.run_children(os.path.abspath(__file__), sys.argv[1:], envs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -820,6 +932,9 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-flow", action="store_true")
     ap.add_argument("--skip-two-stream", action="store_true")
+    ap.add_argument("--verbose", action="store_true", help="print the full object (every note, per-stream rooflines, sub-benchmarks' samples) instead of the "
+                                                          "compact line the driver records")
+    ap.add_argument("--details", default=None, help="also write the full object to this JSON file")
     ap.add_argument("--profile-two-stream", action="store_true",
                     help="with --profile-only: keep the configs[2] section in the process (for a rocprofv3 summary of the 448-crop launches); "
                          "by default --profile-only runs configs[1] (and the scan) only, so that the profiler's per-kernel averages are those "
@@ -829,12 +944,14 @@ def main():
                          "VQ_TSN_SPLIT=1) and the un-profiled production-mode pass is skipped")
     ap.add_argument("--tiles", default=None, help="JSON file: load the conv tiling table if it exists, else write it")
     args = ap.parse_args()
+    rc = self_launch(args)                                   # before ANY GPU call of this process
+    if rc is not None:
+        sys.exit(rc)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # VQ_BENCH_REHEARSE=1: every rank on cuda:0 with the gloo backend -- rehearses the N > 1 control flow (sharding,
     # barriers, gathers, max-over-ranks timing) on a one-GPU box; the numbers of such a run mean nothing.
     rehearse = os.environ.get("VQ_BENCH_REHEARSE") == "1"
@@ -917,6 +1034,11 @@ def main():
                "roofline": sroof}
         batched = sroof.pop("batched", None)
         if batched:
+            if world > 1:                                     # per-rank passes run side by side: the job's rate is that of the slowest
+                bt = torch.tensor([batched["ms_per_pass"]], dtype=torch.float64, device=device)
+                dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+                batched["ms_per_pass"] = float(bt.item())
+                batched["value"] = batched["queries_per_pass"] / batched["ms_per_pass"] * 1e3
             sim["batched"] = batched
         if rank == 0 and world == 1 and not args.skip_cpu:
             sim["cpu_baseline"] = cpu_baseline_sim(db, row0)
@@ -934,7 +1056,11 @@ def main():
         if wof:
             out["e2e_wof_cli"] = wof
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        if args.details:
+            os.makedirs(os.path.dirname(os.path.abspath(args.details)) or ".", exist_ok=True)
+            with open(args.details, "w") as f:
+                json.dump(out, f)
+        print(json.dumps(out if args.verbose else compact(out), separators=(",", ":")), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

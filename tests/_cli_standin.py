@@ -21,6 +21,7 @@ class StandInNet:
 
     def __init__(self, net_proto, net_weights, device_id=0, max_crops=96, feature_blob="global_pool", resize_rule="cv2"):
         self.device, self.max_crops = device_id, max_crops
+        self.salt = hashlib.sha256(str(net_weights).encode()).digest()      # different weights -> different "features" (ensemble members)
         log = os.environ.get("STANDIN_DEVICE_LOG")
         if log:                                            # which rank built a net on which device (one line per net)
             with open(log + ".%s" % os.environ.get("RANK", "0"), "a") as f:
@@ -28,9 +29,8 @@ class StandInNet:
         if os.environ.get("STANDIN_FAIL_RANK") == os.environ.get("RANK", "0"):
             raise RuntimeError("stand-in extractor told to fail on this rank")
 
-    @staticmethod
-    def _clip_feature(crops):
-        seed = int.from_bytes(hashlib.sha256(np.ascontiguousarray(crops).tobytes()).digest()[:8], "little")
+    def _clip_feature(self, crops):
+        seed = int.from_bytes(hashlib.sha256(self.salt + np.ascontiguousarray(crops).tobytes()).digest()[:8], "little")
         return np.random.default_rng(seed).random(1024) * 10.0
 
     def extract_clips(self, crops, T, on_device=False):

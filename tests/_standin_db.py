@@ -22,6 +22,9 @@ class OracleFeatureDB:
     def set_stream(self, _s):
         pass
 
+    def set_layout(self, layout):
+        self.layout = layout
+
     def restrict_slots(self, slot_used):
         used = None if slot_used is None else np.asarray(slot_used, dtype=bool)
         self._hidden = None if used is None or used.all() else ~used

@@ -152,3 +152,54 @@ def test_a_failing_rank_fails_the_command(tmp_path):
     r = _run_cli(_argv(frames_root, str(tmp_path / "o"), gpus=("0", "1"), workers="2"), {"STANDIN_FAIL_RANK": "1"}, timeout=120)
     assert r.returncode != 0
     assert "told to fail" in r.stdout
+
+
+def test_one_pass_ensemble_writes_the_bytes_of_three_runs(tmp_path):
+    """calcSig_wOF_ensemble.sh:13-37 runs the command line three times over the SAME frame tree (split1 / split2 / split3 weights).
+    With two ``--ensemble`` options ONE run reads, decodes and resizes every frame once and feeds all three weight sets; the three
+    <modelname> trees must be byte-identical to three separate runs -- on one GPU and fanned out over two (global clip shards:
+    11 clips of 3 videos over 2 ranks, batches that straddle videos)."""
+    frames_root = str(tmp_path / "frames")
+    _make_tree(frames_root)
+    names = ["UCF101_split%d" % k for k in (1, 2, 3)]
+    weights = [("ucf101_split%d_tsn_rgb_bn_inception_wOF.caffemodel" % k, "ucf101_split%d_tsn_flow_bn_inception_wOF.caffemodel" % k) for k in (1, 2, 3)]
+    want = {}
+    for name, (w_rgb, w_flow) in zip(names, weights):
+        out = str(tmp_path / ("sep_" + name))
+        argv = _argv(frames_root, out, gpus=("0",))
+        argv[2], argv[4] = w_rgb, w_flow
+        argv[argv.index("--modelname") + 1] = name
+        r = _run_cli(argv, {})
+        assert r.returncode == 0, r.stdout
+        want.update(_tree_bytes(out))
+    assert len(want) == 18                                              # 3 videos x 3 members x 2 streams
+    assert len({v for v in want.values()}) == 18                        # the members' features differ
+    for gpus in (("0",), ("0", "1")):
+        out = str(tmp_path / ("ens%d" % len(gpus)))
+        argv = _argv(frames_root, out, gpus=gpus)
+        for name, (w_rgb, w_flow) in list(zip(names, weights))[1:]:
+            argv += ["--ensemble", name, w_rgb, w_flow]
+        r = _run_cli(argv, {})
+        assert r.returncode == 0, r.stdout
+        assert _tree_bytes(out) == want
+        # every clip was announced once per stream, not once per member: the frames were read once
+        assert r.stdout.count("for rgb modality done") == 11
+    bad = _run_cli(_argv(frames_root, str(tmp_path / "bad"), gpus=("0",)) + ["--ensemble", "UCF101_split1", "a", "b"], {})
+    assert bad.returncode != 0 and "modelname" in bad.stdout
+
+
+def test_more_ranks_than_clips(tmp_path):
+    """Two clips, three GPUs: the third rank owns no clip, builds no extractor, and still takes part in the gathers."""
+    from video_query_algorithms_amd.tsn import frames
+    rng = np.random.default_rng(5)
+    root = str(tmp_path / "frames")
+    for clip in ("clip_0001", "clip_0002"):
+        d = os.path.join(root, "v", clip)
+        os.makedirs(d)
+        for i in range(1, 7):
+            for pre, shape in (("img", (24, 32, 3)), ("flow_x", (24, 32)), ("flow_y", (24, 32))):
+                frames.write_pnm(os.path.join(d, "%s_%05d.ppm" % (pre, i)), rng.integers(0, 256, shape, dtype=np.uint8))
+    r1 = _run_cli(_argv(root, str(tmp_path / "one"), gpus=("0",)), {})
+    r3 = _run_cli(_argv(root, str(tmp_path / "three"), gpus=("0", "1", "2"), workers="3"), {})
+    assert r1.returncode == 0 and r3.returncode == 0, r1.stdout + r3.stdout
+    assert _tree_bytes(str(tmp_path / "three")) == _tree_bytes(str(tmp_path / "one")) and len(_tree_bytes(str(tmp_path / "one"))) == 2

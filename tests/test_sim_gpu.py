@@ -378,15 +378,16 @@ def test_fused_batched_scan_has_the_bits_of_the_two_kernel_form(vqa, monkeypatch
     db.close()
 
 
-@pytest.mark.parametrize("n,s,e,d,q,masked", [(70_003, 2, 3, 256, 16, False), (5_001, 1, 2, 512, 7, True), (33, 2, 5, 1024, 16, False),
-                                              (140_007, 2, 1, 1024, 16, True), (4_100, 3, 2, 768, 9, False)])
-def test_batched_scan_on_the_tiled_mirror_has_the_bits_of_the_scan_on_the_rows(vqa, monkeypatch, n, s, e, d, q, masked):
-    """From its second pass on, the 16-query pass of an fp32 database reads a tile-interleaved copy ([tile][slice][k / 4][clip][4],
-    built on the device behind the first pass).  Same operands per MFMA in the same order: the scores of the first pass (rows), of the
-    pass that builds the copy and of the passes on it are identical, and identical to a handle that never builds one
-    (VQ_BATCH_MIRROR=0) -- ragged last tiles, presence masks, every D.  A write through vq_db_upload invalidates the copy: the
-    next passes follow the new rows."""
-    rng = np.random.default_rng(n + d)
+@pytest.mark.parametrize("n,s,e,q,masked", [(70_003, 2, 3, 16, False), (5_001, 1, 2, 7, True), (33, 2, 5, 16, False), (140_007, 2, 1, 16, True),
+                                            (16, 1, 1, 1, False), (4_100, 2, 4, 9, True)])
+def test_tiled_layout_in_place(vqa, n, s, e, q, masked):
+    """vq_db_set_layout(TILED) turns the handle's block into [tile of 16 clips][slice][k / 4][clip][4] IN PLACE (no second copy).  On it:
+    the 16-query pass has the bits of the pass on the rows (same operands per MFMA in the same order); the one-query scan
+    (scan_tiled_kernel: a wave per tile) agrees with the row-major scan and with the oracle to <= 1e-12 and is bit-reproducible;
+    rows read back, the query made from a row, uploads into the middle and the ragged end, and target bootstrapping see the same
+    data; converting back restores the block bit for bit -- ragged last tiles, presence masks, 1-2 streams, 1-5 splits."""
+    d = 1024
+    rng = np.random.default_rng(n + e)
     targets = rng.standard_normal((q, s, e, d)) / d
     weights = 0.5 + rng.random((q, s))
     present = None
@@ -395,43 +396,82 @@ def test_batched_scan_on_the_tiled_mirror_has_the_bits_of_the_scan_on_the_rows(v
         present[::5, 0, 0] = 0
         present[n - 1, :, e - 1] = 0
         present[..., 0] |= (present.sum(axis=2) == 0).astype(np.uint8)
-    monkeypatch.setenv("VQ_BATCH_MIRROR", "0")
-    plain = vqa.FeatureDB.synthetic(n, s, e, d, seed=29, scales=(4.0, 1.0, 2.0)[:s])
-    plain.set_present(present)
-    want = plain.scan_batch(targets, weights)
-    monkeypatch.delenv("VQ_BATCH_MIRROR")
-    db = vqa.FeatureDB.synthetic(n, s, e, d, seed=29, scales=(4.0, 1.0, 2.0)[:s])
-    db.set_present(present)
-    for _ in range(4):                                            # rows, build + mirror, mirror, mirror
-        assert (db.scan_batch(targets, weights) == want).all()
-    # new rows in the middle and at the ragged end: both handles see them
+    scales = (4.0, 1.0)[:s]
+    plain = vqa.FeatureDB.synthetic(n, s, e, d, seed=29, scales=scales)
+    db = vqa.FeatureDB.synthetic(n, s, e, d, seed=29, scales=scales)
+    for h in (plain, db):
+        h.set_present(present)
+    assert db.layout == "rows"
+    db.set_layout("tiled")
+    assert db.layout == "tiled" and plain.layout == "rows"
+    pick = np.array(sorted({0, n - 1, n // 2, min(17, n - 1), (n // 16) * 16 - 1 if n >= 16 else 0}))
+    assert (db.read_rows(pick) == plain.read_rows(pick)).all()
+
+    def both(fn):
+        return fn(plain), fn(db)
+    want, got = both(lambda h: h.scan_batch(targets, weights))
+    assert (got == want).all() and (db.scan_batch(targets, weights) == got).all()
+    t_rows, t_tiled = both(lambda h: h.set_query_from_row(int(pick[-1])))
+    assert (t_rows == t_tiled).all()
+    for h in (plain, db):
+        h.scan(weights=[1.0, 1.5][:s], keep_sims=True)
+    (avg_r, ne_r, sims_r), (avg_t, ne_t, sims_t) = both(lambda h: h.similarities(sims=True))
+    x = so.synth_features(29, 0, n, s, e, d, scales) if n <= 6000 else None
+    assert (ne_r == ne_t).all() and np.abs(avg_r - avg_t).max() <= 1e-12 and np.abs(sims_r - sims_t).max() <= 1e-12
+    if x is not None:
+        o_sims, o_avg, o_ne = so.dense_similarities(x, t_rows, present)
+        assert (ne_t == o_ne).all() and np.abs(avg_t - o_avg).max() <= 1e-12 and np.abs(sims_t - o_sims).max() <= 1e-12
+    sc_t = db.scores()
+    assert (sc_t == so.dense_scores(avg_t, [1.0, 1.5][:s])).all()           # scores bit-exact given the averages, as on the rows
+    db.scan(weights=[1.0, 1.5][:s], keep_sims=True)
+    assert (db.scores() == sc_t).all() and (db.similarities()[0] == avg_t).all()
+    if n >= 40 and not masked:
+        v, iv = [int(pick[1]), 3, 20], [5, 30]
+        b_r, b_t = both(lambda h: h.bootstrap_target(v, iv, mu=0.3, set_query=False))
+        assert (b_r == b_t).all()
+    # new rows in the middle and at the ragged end, through vq_db_upload: dealt into their tiles
     rows = (rng.random((40, s, e, d)) * 3).astype(np.float32)
-    for handle in (plain, db):
-        handle.upload(max(0, n // 2 - 10), rows[:25])
-        handle.upload(max(0, n - 15), rows[25:25 + min(15, n)])
-    monkeypatch.setenv("VQ_BATCH_MIRROR", "0")
-    want2 = plain.scan_batch(targets, weights)
-    monkeypatch.delenv("VQ_BATCH_MIRROR")
-    assert not (want2 == want).all()
-    for _ in range(3):
-        assert (db.scan_batch(targets, weights) == want2).all()
+    for h in (plain, db):
+        h.upload(max(0, n // 2 - 10), rows[:min(25, n)])
+        h.upload(max(0, n - 15), rows[25:25 + min(15, n)])
+    want2, got2 = both(lambda h: h.scan_batch(targets, weights))
+    assert not (want2 == want).all() and (got2 == want2).all()
+    with pytest.raises(vqa.VqError):
+        db.feats_devptr()                                              # a tiled block is not [N][S][E][D]
+    db.set_layout("rows")
+    assert (db.read_rows(np.arange(min(n, 64))) == plain.read_rows(np.arange(min(n, 64)))).all()
+    assert (db.read_rows(np.arange(max(0, n - 40), n)) == plain.read_rows(np.arange(max(0, n - 40), n))).all()
+    for h in (plain, db):
+        h.set_query(t_rows)
+        h.scan(weights=[1.0, 1.5][:s])
+    assert (plain.scores() == db.scores()).all()                       # back on the rows: the row-major scan's own bits
     plain.close()
     db.close()
 
 
-def test_a_database_whose_memory_others_can_write_is_never_mirrored(vqa):
-    """Once the raw device pointer of the features has been handed out (or the memory is the caller's own: adopt_device), writes cannot
-    be seen, so the 16-query pass must keep reading the rows themselves: values written through the pointer show up in every pass."""
+def test_tiled_layout_is_refused_where_it_cannot_hold(vqa):
+    """fp64 databases, shapes without a tiled scan kernel, and blocks somebody else may write (adopted memory, a handed-out
+    pointer) stay row-major: VQ_E_UNSUPPORTED / VQ_E_STATE, and the handle keeps working."""
     import torch
-    n, s, e, d = 2_000, 2, 2, 256
-    db = vqa.FeatureDB.synthetic(n, s, e, d, seed=31, scales=(2.0, 1.0))
     rng = np.random.default_rng(8)
+    for kw in ({"dim": 256}, {"dtype": np.float64}, {"n_streams": 3}):
+        args = dict(n=200, n_streams=2, n_splits=2, dim=1024, dtype=np.float32)
+        args.update(kw)
+        db = vqa.FeatureDB.synthetic(args["n"], args["n_streams"], args["n_splits"], args["dim"], seed=3, scales=(2.0, 1.0, 1.0)[:args["n_streams"]],
+                                     dtype=args["dtype"])
+        with pytest.raises(vqa.VqError) as ei:
+            db.set_layout("tiled")
+        assert ei.value.code == -5 and db.layout == "rows"
+        db.close()
+    n, s, e, d = 2_000, 2, 2, 1024
+    db = vqa.FeatureDB.synthetic(n, s, e, d, seed=31, scales=(2.0, 1.0))
     targets = rng.standard_normal((4, s, e, d)) / d
     weights = 0.5 + rng.random((4, s))
     first = db.scan_batch(targets, weights)
-    assert (db.scan_batch(targets, weights) == first).all()       # a mirror exists by now
-    ptr = db.feats_devptr()                                       # ... and must be dropped here
-    # write through the raw pointer with a plain device copy
+    ptr = db.feats_devptr()                                            # from here on others may write the rows
+    with pytest.raises(vqa.VqError) as ei:
+        db.set_layout("tiled")
+    assert ei.value.code == -4
     new = (rng.random((n, s, e, d)) * 2).astype(np.float32)
     src = torch.from_numpy(new).cuda()
     import ctypes as C
@@ -441,9 +481,7 @@ def test_a_database_whose_memory_others_can_write_is_never_mirrored(vqa):
     fresh = vqa.FeatureDB(n, s, e, d)
     fresh.upload(0, new)
     want = fresh.scan_batch(targets, weights)
-    assert not (want == first).all()
-    for _ in range(3):
-        assert (db.scan_batch(targets, weights) == want).all()
+    assert not (want == first).all() and (db.scan_batch(targets, weights) == want).all()     # writes through the pointer are seen
     fresh.close()
     db.close()
 
@@ -478,6 +516,28 @@ def test_cfg4_full_size_scan_one_million_clips(vqa):
     assert amax == int(r[np.argmax(sc[r])])
     db.scan(weights=[1.0, 1.5])
     assert (db.scores() == sc).all() and (db.similarities()[0] == avg).all()
+    # the 16-query pass at this size (62 500 tiles: about eight rounds per workgroup) on the rows, then the SAME block tiled in place
+    # (no second copy: 41 GB stay 41 GB): every query within 1e-12 of a single scan on the four oracle slices, the two layouts
+    # bit-identical, and the one-query scan on the tiled block within 1e-12 of the row-major one everywhere
+    q_rows = [ref_row] + [12_345 + 61_111 * i for i in range(15)]
+    tb = np.stack([db.set_query_from_row(r) for r in q_rows])
+    wb = np.stack([[1.0, 1.5 + 0.05 * i] for i in range(16)])
+    on_rows = db.scan_batch(tb, wb)
+    assert np.abs(on_rows[0] - sc).max() <= 1e-12 and np.isfinite(on_rows).all()
+    for row0 in (0, 333_333, ref_row - 100, n - 4096):
+        x = so.synth_features(23, row0, 4096, s, e, d, scales)
+        for qi in (0, 7, 15):
+            _, o_avg, _ = so.dense_similarities(x, tb[qi])
+            assert np.abs(on_rows[qi, row0:row0 + 4096] - so.dense_scores(o_avg, wb[qi])).max() <= 1e-12
+    assert all(abs(on_rows[i, r] - 1.0) <= 1e-12 and on_rows[i].argmax() == r for i, r in enumerate(q_rows))
+    db.set_layout("tiled")
+    assert (db.scan_batch(tb, wb) == on_rows).all()
+    db.set_query(t)
+    db.scan(weights=[1.0, 1.5])
+    avg_t = db.similarities()[0]
+    assert np.abs(avg_t - avg).max() <= SIM_TOL and (db.scores() == so.dense_scores(avg_t, [1.0, 1.5])).all()
+    sc_t = db.scores()
+    assert np.array_equal(db.topk(20)[0], so.dense_topk(sc_t, 20)[0]) and sc_t.argmax() == ref_row
     db.close()
 
 

@@ -71,6 +71,10 @@ def build_parser():
     parser.add_argument('--device_jpeg', action='store_true',
                         help='decode the .jpg frames with the library (Huffman on host threads, IDCT / upsampling / colour on the '
                              'GPU; the pixels libjpeg gives cv2.imread) and resize them where they land -- no host image library')
+    parser.add_argument('--ensemble', nargs=3, action='append', metavar=('MODELNAME', 'WEIGHTS_RGB', 'WEIGHTS_FLOW'),
+                        help="a further ensemble member (repeatable): the SAME pass over the frame tree -- every frame read, decoded and resized "
+                             "once -- also runs these weights and writes their <modelname> directories; the three runs of "
+                             "calcSig_wOF_ensemble.sh:13-37 become one command with two --ensemble options, byte-identical files")
     parser.add_argument('--number_format', choices=('repr', 'g12'), default='repr',
                         help="how str(numpy.float64) printed under the numpy the reference ran with: shortest round-trip "
                              "(numpy >= 1.14, lossless) or 12 significant digits (numpy < 1.14); the reference ships files of both kinds")
@@ -155,99 +159,131 @@ def main(argv=None, net_factory=None, program=None):
             import torch
             backend_device = torch.device("cuda", device)
     frame_path = args.frame_path if args.frame_path[-1] == '/' else args.frame_path + '/'
-    streamCNN = [{'modality': 'rgb', 'mode': 'rgb', 'net_proto': args.net_proto_rgb, 'net_weights': args.net_weights_rgb,
-                  'cnt_indexer': 1, 'stack_depth': 1},
-                 {'modality': 'flow', 'mode': 'warped_optical_flow', 'net_proto': args.net_proto_flow,
-                  'net_weights': args.net_weights_flow, 'cnt_indexer': 2, 'stack_depth': 5}]   # calcSig_wOF.py:185-189
-    nets = {}
+    streamCNN = [{'modality': 'rgb', 'mode': 'rgb', 'net_proto': args.net_proto_rgb, 'cnt_indexer': 1, 'stack_depth': 1},
+                 {'modality': 'flow', 'mode': 'warped_optical_flow', 'net_proto': args.net_proto_flow, 'cnt_indexer': 2,
+                  'stack_depth': 5}]                                                   # calcSig_wOF.py:185-189
+    # the ensemble: the command line's own weights first, then every --ensemble member; ONE pass over the frame tree feeds them all
+    members = [{'modelname': args.modelname, 'rgb': args.net_weights_rgb, 'flow': args.net_weights_flow}]
+    for name, w_rgb, w_flow in args.ensemble or []:
+        members.append({'modelname': name, 'rgb': w_rgb, 'flow': w_flow})
+    if len({m['modelname'] for m in members}) != len(members):
+        raise SystemExit("--ensemble: every member needs its own --modelname (they name the output directories)")
     rule = "exact" if args.exact_resize else "cv2"
     device_jpeg = args.device_jpeg and args.frame_ext.lower() in ('.jpg', '.jpeg') and not args.host_resize
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=max(1, args.num_worker))
     prep_pool = ThreadPoolExecutor(max_workers=2)        # --device_jpeg: the stages in front of the network (see the batch loop)
-    io_pool = ThreadPoolExecutor(max_workers=len(streamCNN))             # feature files are formatted and written here
+    io_pool = ThreadPoolExecutor(max_workers=2)          # feature files are formatted and written here
     csv_jobs = []
-    build_pool = ThreadPoolExecutor(max_workers=len(streamCNN))
-    net_jobs = {}                                        # both extractors are built side by side when the first video turns up: the flow
-                                                         # net's weights are folded and uploaded while the RGB stream is already running
+    build_pool = ThreadPoolExecutor(max_workers=2)
+
+    # The clips of ALL videos of the tree form one list (video order, then clip number: calcSig_wOF.py:193-200) and THAT is what the
+    # ranks share out: contiguous ranges of it, whole batches of --batch_clips whatever the videos' sizes (the reference's fixtures
+    # are 87- and 114-clip videos: per-video sharding left 11-14 clips per rank on 8 GPUs and one collective per video and stream),
+    # one all-gather per stream (and ensemble member); the files are still one per video, stream and member.
+    videos = []
     for video_path in sorted(glob.glob(frame_path + '*/')):                            # calcSig_wOF.py:193-195
         f_info = frames.parse_directory(video_path, args.rgb_prefix, args.flow_x_prefix, args.flow_y_prefix)
         clip_list = sorted(list(f_info[0]), key=lambda clip: int(clip[-4:]))           # calcSig_wOF.py:199-200
-        first, count = shard_range(len(clip_list), world, rank)
-        features = {}
-        if not net_jobs:
-            for s in streamCNN:
-                net_jobs[s['modality']] = build_pool.submit(net_factory, s['net_proto'], s['net_weights'], device, max_crops=args.batch_clips * T,
-                                                            feature_blob=args.featureBlob, resize_rule=rule)
-        for s in streamCNN:
-            if s['modality'] not in nets:
-                nets[s['modality']] = net_jobs[s['modality']].result()
-            net = nets[s['modality']]
-            mine = []
+        videos.append((video_path, f_info, clip_list))
+    units = [(vi, vid) for vi, (_p, _f, clip_list) in enumerate(videos) for vid in clip_list]
+    first, count = shard_range(len(units), world, rank)
+    on_gpu = world > 1                                   # blocks that will be all-gathered never visit the host
+    host_rule = {'rule': rule} if args.host_resize else {}             # the host loaders resize; the others hand frames to the GPU
 
-            host_rule = {'rule': rule} if args.host_resize else {}         # the host loaders resize; the others hand frames to the GPU
+    def build(s, m):
+        return net_factory(s['net_proto'], m[s['modality']], device, max_crops=args.batch_clips * T, feature_blob=args.featureBlob, resize_rule=rule)
+    # both streams' extractors are built side by side: the flow nets' weights are folded and uploaded while the RGB stream is running
+    net_jobs = {(s['modality'], mi): build_pool.submit(build, s, m) for s in streamCNN for mi, m in enumerate(members)} if count else {}
 
-            def load_clip(vid, s=s):
-                frame_cnt = f_info[s['cnt_indexer']][vid]
-                ticks = frames.frame_ticks(frame_cnt, T, s['stack_depth'])
-                if s['modality'] == 'rgb':
-                    load = frames.load_rgb_jpegs if device_jpeg else frames.load_rgb_snippets if args.host_resize else frames.load_rgb_frames
-                    return load(f_info[0][vid], ticks, args.rgb_prefix, args.frame_ext, **host_rule)
-                load = frames.load_flow_jpegs if device_jpeg else frames.load_flow_snippets if args.host_resize else frames.load_flow_frames
-                return load(f_info[0][vid], ticks, frame_cnt, s['stack_depth'], args.flow_x_prefix, args.flow_y_prefix, args.frame_ext, **host_rule)
+    for s in streamCNN:
+        nets = [net_jobs[(s['modality'], mi)].result() for mi in range(len(members))] if count else []
+        mine = [[] for _ in members]
 
-            # --num_worker decoder threads (the reference runs that many worker PROCESSES, each with its own net,
-            # calcSig_wOF.py:204-210); the batch after the one on the GPU is decoded meanwhile
-            batches = [clip_list[b0:min(b0 + args.batch_clips, first + count)] for b0 in range(first, first + count, args.batch_clips)]
-            pending = [pool.submit(load_clip, vid) for vid in batches[0]] if batches else []
-            on_gpu = world > 1                           # blocks that will be all-gathered never visit the host
-            staged = []                                  # --device_jpeg: the crops of the batches in front of the network, being made by prep_pool
-            for bi, vids in enumerate(batches):
-                crops = [f.result() for f in pending]
-                pending = [pool.submit(load_clip, vid) for vid in batches[bi + 1]] if bi + 1 < len(batches) else []
-                for vid in vids:
-                    print('video {} for {} modality done'.format(vid, s['modality']))
-                if not crops:
-                    continue
-                if device_jpeg:
-                    # Three stages: two threads read, decode, resize and crop batches b + 1 and b + 2 on the GPU (lists of undecoded files in,
-                    # device crops out; the library's calls release the interpreter; each thread has a decoder and a stream of its own, so
-                    # one batch's host half -- reading the files, stripping the byte stuffing -- overlaps the other's device half) while
-                    # this one runs batch b through the network
-                    staged.append(prep_pool.submit(net.crops_from_jpegs, [f for c in crops for f in c], lane=bi % 2))
-                    if len(staged) > 2:
-                        mine.append(net.extract_clips_from_crops(staged.pop(0).result(), T, on_device=on_gpu))
-                elif args.host_resize:
-                    mine.append(net.extract_clips(np.concatenate(crops, axis=0), T, on_device=on_gpu))
-                elif len({c.shape[1:] for c in crops}) == 1:
-                    mine.append(net.extract_clips_from_frames(np.concatenate(crops, axis=0), T, on_device=on_gpu))   # resize + crop on the GPU
-                else:                                        # clips of different frame sizes in one batch
-                    mine += [net.extract_clips_from_frames(c, T, on_device=on_gpu) for c in crops]
-            for job in staged:
-                mine.append(net.extract_clips_from_crops(job.result(), T, on_device=on_gpu))
-            local_feat = _stack_rows(mine, net.feature_dim)
+        def load_clip(unit, s=s):
+            f_info, vid = videos[unit[0]][1], unit[1]
+            frame_cnt = f_info[s['cnt_indexer']][vid]
+            ticks = frames.frame_ticks(frame_cnt, T, s['stack_depth'])
+            if s['modality'] == 'rgb':
+                load = frames.load_rgb_jpegs if device_jpeg else frames.load_rgb_snippets if args.host_resize else frames.load_rgb_frames
+                return load(f_info[0][vid], ticks, args.rgb_prefix, args.frame_ext, **host_rule)
+            load = frames.load_flow_jpegs if device_jpeg else frames.load_flow_snippets if args.host_resize else frames.load_flow_frames
+            return load(f_info[0][vid], ticks, frame_cnt, s['stack_depth'], args.flow_x_prefix, args.flow_y_prefix, args.frame_ext, **host_rule)
+
+        def through_the_nets(make):
+            """One batch through every member's network: ``make(net)`` hands a net the batch (the first net's call also does the
+            decode / resize / crop once; the others take the device crops it produced)."""
+            for mi, net in enumerate(nets):
+                mine[mi].append(make(net))
+
+        # --num_worker decoder threads (the reference runs that many worker PROCESSES, each with its own net,
+        # calcSig_wOF.py:204-210); the batch after the one on the GPU is decoded meanwhile
+        batches = [units[b0:min(b0 + args.batch_clips, first + count)] for b0 in range(first, first + count, args.batch_clips)]
+        pending = [pool.submit(load_clip, u) for u in batches[0]] if batches else []
+        staged = []                                  # --device_jpeg: the crops of the batches in front of the network, being made by prep_pool
+        for bi, batch in enumerate(batches):
+            crops = [f.result() for f in pending]
+            pending = [pool.submit(load_clip, u) for u in batches[bi + 1]] if bi + 1 < len(batches) else []
+            for _vi, vid in batch:
+                print('video {} for {} modality done'.format(vid, s['modality']))
+            if not crops:
+                continue
+            if device_jpeg:
+                # Three stages: two threads read, decode, resize and crop batches b + 1 and b + 2 on the GPU (lists of undecoded files in,
+                # device crops out; the library's calls release the interpreter; each thread has a decoder and a stream of its own, so
+                # one batch's host half -- reading the files, stripping the byte stuffing -- overlaps the other's device half) while
+                # this one runs batch b through the network(s)
+                staged.append(prep_pool.submit(nets[0].crops_from_jpegs, [f for c in crops for f in c], lane=bi % 2))
+                if len(staged) > 2:
+                    dev_crops = staged.pop(0).result()
+                    through_the_nets(lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu))
+            elif args.host_resize:
+                block = np.concatenate(crops, axis=0)
+                through_the_nets(lambda net: net.extract_clips(block, T, on_device=on_gpu))
+            else:
+                # resize + crop on the GPU, once per batch; clips of different frame sizes in one batch go one by one
+                groups = [np.concatenate(crops, axis=0)] if len({c.shape[1:] for c in crops}) == 1 else crops
+                for g in groups:
+                    if len(nets) == 1:
+                        through_the_nets(lambda net: net.extract_clips_from_frames(g, T, on_device=on_gpu))
+                    else:
+                        per = args.batch_clips * T                      # = max_crops of the extractors
+                        for i in range(0, g.shape[0], per):
+                            dev_crops = nets[0].crops_from_frames(g[i:i + per])
+                            nets[0].sync_ingest()
+                            through_the_nets(lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu))
+        for job in staged:
+            dev_crops = job.result()
+            through_the_nets(lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu))
+        for mi, m in enumerate(members):
+            width = nets[mi].feature_dim if nets else args.featureBlob_size
+            local_feat = _stack_rows(mine[mi], width)
             if world > 1:
                 import torch
-                if isinstance(local_feat, np.ndarray):       # host blocks, or a rank that owns no clip of this video
+                if isinstance(local_feat, np.ndarray):       # host blocks, or a rank that owns no clip
                     local_feat = torch.from_numpy(np.ascontiguousarray(local_feat, dtype=np.float64))
                 if backend_device is not None and local_feat.device != backend_device:
                     local_feat = local_feat.to(backend_device)
-                local_feat = all_gather_rows(local_feat, len(clip_list)).cpu().numpy()
-            features[s['mode']] = local_feat
-            numFeatures = local_feat.shape[1] if len(clip_list) else args.featureBlob_size
+                local_feat = all_gather_rows(local_feat, len(units)).cpu().numpy()
+            numFeatures = local_feat.shape[1] if len(units) else args.featureBlob_size
             assert numFeatures == args.featureBlob_size                                  # calcSig_wOF.py:219-220
-            if rank == 0 and clip_list:
+            if rank != 0:
+                continue
+            row = 0
+            for video_path, _f, clip_list in videos:
+                block, row = local_feat[row:row + len(clip_list)], row + len(clip_list)
+                if not clip_list:
+                    continue
                 # a stream's file is formatted and written (half a million float reprs per 256 clips) by a thread of its own while the
-                # next stream -- or the next video -- is on the GPU; the same two files as writing both at the end (:116-134)
-                video = video_path.split('/')[-2]
-                csv_jobs.append(io_pool.submit(write_features, args.outFeatures_dir, video, video_path, args.modelname, args.featureBlob, clip_list,
-                                               {s['mode']: local_feat}, {'rgb': args.net_weights_rgb, 'warped_optical_flow': args.net_weights_flow},
-                                               args.number_format))
+                # next stream is on the GPU; the same files as writing both at the end (:116-134)
+                csv_jobs.append(io_pool.submit(write_features, args.outFeatures_dir, video_path.split('/')[-2], video_path, m['modelname'],
+                                               args.featureBlob, clip_list, {s['mode']: block},
+                                               {'rgb': m['rgb'], 'warped_optical_flow': m['flow']}, args.number_format))
+        for n in nets:                               # this stream's device buffers go back to the pool: the next stream's nets take them
+            n.close()
     pool.shutdown()
     prep_pool.shutdown()
     build_pool.shutdown()
-    for n in nets.values():                                              # releasing the device buffers overlaps the last file's formatting
-        n.close()
     for job in csv_jobs:
         job.result()                                                     # a writer's exception is the command's
     io_pool.shutdown()

@@ -39,7 +39,7 @@ import numpy as np
 from .shard import all_gather_rows, merge_topk, shard_range
 
 OP_CLOSE, OP_RESTRICT, OP_SET_QUERY, OP_QUERY_FROM_ROW, OP_SCAN, OP_RESCORE, OP_SIMS, OP_SCORES, OP_GRID, OP_SELECT, OP_TOPK, \
-    OP_MIN, OP_FETCH, OP_SCAN_BATCH = range(14)
+    OP_MIN, OP_FETCH, OP_SCAN_BATCH, OP_LAYOUT = range(15)
 
 
 class ShardError(RuntimeError):
@@ -51,7 +51,7 @@ class ShardedFeatureDB:
     surface).  ``clip_ids``: the GLOBAL id list (every rank holds it: N x 8 bytes).  ``served``: rank ``root`` drives,
     the others must be inside :meth:`serve`."""
 
-    def __init__(self, local, n_total: int, row0: int, clip_ids: Sequence[int], group=None, root: int = 0, served: bool = False):
+    def __init__(self, local, n_total: int, row0: int, clip_ids: Sequence[int], group=None, root: int = 0, served: bool = False, stream=None):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -75,7 +75,7 @@ class ShardedFeatureDB:
         self._cdev = torch.device("cuda", self.device) if backend == "nccl" else torch.device("cpu")
         self._stream = None
         if self._cdev.type == "cuda":
-            self._stream = torch.cuda.Stream(device=self._cdev)
+            self._stream = stream if stream is not None else torch.cuda.Stream(device=self._cdev)
             local.set_stream(self._stream.cuda_stream)           # scans and collectives are ordered on one stream
         flag = torch.tensor([0 if getattr(local, "present", None) is None else 1], dtype=torch.int64, device=self._cdev)
         self._coll(lambda: dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group))
@@ -98,13 +98,13 @@ class ShardedFeatureDB:
 
     @classmethod
     def synthetic(cls, n: int, n_streams: int, n_splits: int, dim: int = 1024, seed: int = 0, scales=(4.0, 1.0), dtype=np.float32,
-                  device: int = 0, group=None, root: int = 0):
+                  device: int = 0, group=None, root: int = 0, stream=None):
         """Rows generated on each rank's device by the counter-based hash (BASELINE configs[3]: too big to ship)."""
         import torch.distributed as dist
         from .feature_db import FeatureDB
         row0, rows = shard_range(n, dist.get_world_size(group), dist.get_rank(group))
         local = FeatureDB.synthetic(rows, n_streams, n_splits, dim, seed=seed, scales=scales, row0=row0, dtype=dtype, device=device)
-        return cls(local, n, row0, np.arange(1, n + 1, dtype=np.int64), group=group, root=root)
+        return cls(local, n, row0, np.arange(1, n + 1, dtype=np.int64), group=group, root=root, stream=stream)
 
     @classmethod
     def open(cls, store_path: str, gpus: Sequence[int], backend: Optional[str] = None, timeout_s: float = 600.0):
@@ -226,6 +226,11 @@ class ShardedFeatureDB:
         return pos, rows_global[pos] - self.row0
 
     # ------------------------------------------------------------------ query
+    def set_layout(self, layout: str):
+        """Every rank re-tiles its own rows in place (FeatureDB.set_layout): once, after loading."""
+        self._announce(OP_LAYOUT, ints=[1 if layout == "tiled" else 0])
+        self._local_step(lambda: self.local.set_layout(layout))
+
     def restrict_slots(self, slot_used):
         used = None if slot_used is None else np.asarray(slot_used, dtype=bool)
         if used is not None and used.shape != (self.S, self.E):
@@ -494,6 +499,8 @@ class ShardedFeatureDB:
             self.min_score(ints)
         elif op == OP_FETCH:
             self.read_rows(ints)
+        elif op == OP_LAYOUT:
+            self.set_layout("tiled" if ints[0] else "rows")
         else:
             raise RuntimeError("unknown operation %d announced" % op)
 

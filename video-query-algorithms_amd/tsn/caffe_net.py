@@ -144,6 +144,12 @@ class CaffeNet:
                      crop, frames.RESIZE_RULES[self._resize_rule], C.c_void_p(out.data_ptr()), self._channels, k, self._model.device, C.c_void_p(stream))
         return out
 
+    def sync_ingest(self):
+        """Wait for the resize / crop work of ``crops_from_frames`` (queued on torch's current stream) before another extractor's
+        stream reads the crops (an ensemble: one decode feeds several networks)."""
+        import torch
+        torch.cuda.current_stream(torch.device("cuda", self._model.device)).synchronize()
+
     def crops_from_jpegs(self, files, frame_size=(340, 256), crop=224, lane=0):
         """JPEG file contents -> device crops (torch uint8 [n, crop, crop, C]) without the frames ever visiting the host:
         entropy decoding on the library's host threads, IDCT / upsampling / colour on the device (tsn/jpeg.py), resize +
