@@ -673,8 +673,18 @@ def test_bench_two_rank_control_flow_rehearsal(tsn):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["scaling"] == "weak" and out["value"] > 0
-    assert out["roofline"]["launches_per_step"] == 36 and out["roofline"]["all_launches_per_step"] == 38
+    assert out["roofline"]["launches_per_step"] == 36 and out["config"]["distributed"]["world_size"] == 2
     assert 0 < out["roofline"]["frac"] < 1 and out["roofline"]["frac"] < out["roofline"]["effective_frac"] < 2
+    assert len(lines[0]) < 4096                                     # the driver's record keeps the whole line
+    # ``python bench.py --gpus 2`` with NO launcher starts its own ranks (before any GPU call) and prints the same one line
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--skip-cpu"]
+    p = subprocess.run(cmd, env={k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["similarity"]["config"]["rows_per_gpu"] == 500_000 and out["similarity"]["value"] > 0
+    assert out["similarity"]["roofline"]["kernel"].startswith("scan_tiled_kernel") and out["similarity"]["batched"]["value"] > 0
 
 
 def test_tiling_tables_survive_the_process(tsn, monkeypatch, tmp_path):

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <type_traits>
 #include <vector>
 
@@ -66,6 +67,43 @@ __global__ void preprocess_s2d_kernel(const uint8_t* __restrict__ src, float* __
         v[e] = in ? (float)src[((n * H + y) * W + x) * C + c] - mean[c] : 0.0f;
     }
     *reinterpret_cast<floatx4*>(dst + cell * (4 * C) + j0) = v;
+}
+
+// The RGB stem's form (C = 3): one thread per CELL -- its 2 x 2 pixels are two runs of 6 bytes, its 12 floats three 16-byte
+// stores; two divisions per thread instead of a dozen per chunk (32 us -> 17 us per 96-crop step).  Same values.
+__global__ __launch_bounds__(256) void preprocess_s2d3_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int64_t ncell, int H, int W,
+                                                              int Hs, int Ws, int pad, const float* __restrict__ mean) {
+    const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= ncell) return;
+    const int X = (int)(cell % Ws);
+    const int64_t ny = cell / Ws;
+    const int Y = (int)(ny % Hs);
+    const int64_t n = ny / Hs;
+    const float m0 = mean[0], m1 = mean[1], m2 = mean[2];
+    float v[12];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int y = 2 * Y + p - pad;
+        const bool row_in = (unsigned)y < (unsigned)H;
+        const uint8_t* r = src + ((n * H + (row_in ? y : 0)) * W) * 3;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int x = 2 * X + q - pad;
+            const bool in = row_in && (unsigned)x < (unsigned)W;
+            const uint8_t* px = r + (in ? x : 0) * 3;
+            const float a = (float)px[0] - m0, b = (float)px[1] - m1, c = (float)px[2] - m2;
+            v[(p * 2 + q) * 3 + 0] = in ? a : 0.0f;
+            v[(p * 2 + q) * 3 + 1] = in ? b : 0.0f;
+            v[(p * 2 + q) * 3 + 2] = in ? c : 0.0f;
+        }
+    }
+    floatx4* o = reinterpret_cast<floatx4*>(dst + cell * 12);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        floatx4 t;
+        t[0] = v[4 * k], t[1] = v[4 * k + 1], t[2] = v[4 * k + 2], t[3] = v[4 * k + 3];
+        o[k] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -675,8 +713,17 @@ __global__ void gavgpool_consensus_kernel(const float* __restrict__ in, float* _
     if (c < C) {
         const int img = b * T + t;
         const float* p = in + (size_t)img * HW * Cs_in + coff_in + c;
+        // the sum keeps Caffe's order (h, then w: one sequential fp32 chain); the LOADS of seven pixels are issued together
         float acc = 0.f;
-        for (int q = 0; q < HW; ++q) acc += p[(size_t)q * Cs_in];
+        int q = 0;
+        for (; q + 7 <= HW; q += 7) {
+            float x[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) x[u] = p[(size_t)(q + u) * Cs_in];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) acc += x[u];
+        }
+        for (; q < HW; ++q) acc += p[(size_t)q * Cs_in];
         v = acc / (float)HW;
         out[(size_t)img * Cs_out + coff_out + c] = v;
     }
@@ -779,6 +826,21 @@ struct vq_tsn {
     hipStream_t ls = nullptr;             // stream the next launch goes to
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // profiling: events of the next launch
     std::vector<hipStream_t> split_streams;       // [n_split]; entry 0 unused (caller's stream)
+    // Captured forwards: the whole launch list of a (crops address, batch, T, mode) as ONE hipGraph, replayed by later forwards of the
+    // same key (VQ_TSN_GRAPH=0: off).  A step is 38 dependent launches of ~70 us: replayed as a graph they are queued in one go.
+    struct GraphKey {
+        const void* src;
+        int n_crops, T, n_split;
+        bool operator<(const GraphKey& o) const { return std::tie(src, n_crops, T, n_split) < std::tie(o.src, o.n_crops, o.T, o.n_split); }
+    };
+    struct GraphEntry {
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        uint64_t used;
+    };
+    std::map<GraphKey, GraphEntry> graphs;
+    uint64_t graph_clock = 0;
+    bool use_graph = true;
     hipEvent_t fork_ev = nullptr;
     std::vector<hipEvent_t> join_ev;              // per extra stream
 };
@@ -841,7 +903,16 @@ static void pool_free(int device, void* p, size_t bytes) {
     (void)hipFree(p);
 }
 
+static void drop_graphs(vq_tsn* net) {
+    for (auto& kv : net->graphs) {
+        (void)hipGraphExecDestroy(kv.second.exec);
+        (void)hipGraphDestroy(kv.second.graph);
+    }
+    net->graphs.clear();
+}
+
 static void tsn_free(vq_tsn* net) {
+    drop_graphs(net);
     for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
     net->events.clear();
     for (hipEvent_t e : net->join_ev)
@@ -1580,6 +1651,8 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
                 for (int i = 0; i < kNumTiles; ++i)
                     if (kTiles[i].bm == bm && kTiles[i].bn == bn && kTiles[i].bk == bk && kTiles[i].pipe == pipe) net->forced_tile = i;
         }
+        const char* gr = getenv("VQ_TSN_GRAPH");
+        net->use_graph = !(gr && *gr == '0');
         const char* sp = getenv("VQ_TSN_SPLIT");
         if (sp && strchr(sp, ',')) {                   // "2,1": sub-batches of 2/3 and 1/3 of the crops
             for (const char* q = sp; *q;) {
@@ -1636,80 +1709,26 @@ int vq_tsn_set_stream(vq_tsn* net, void* s) {
     return VQ_OK;
 }
 
-int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, int32_t n_crops, int32_t T,
-                   const float* mean_host, double* feat_host, float* per_snippet_host) {
-    VQ_REQUIRE(net && crops && mean_host, "NULL argument");
-    VQ_REQUIRE(n_crops > 0 && n_crops <= net->max_crops, "n_crops %d outside (0,%d]", n_crops, net->max_crops);
-    VQ_REQUIRE(T > 0 && n_crops % T == 0, "n_crops (%d) must be a multiple of T (%d)", n_crops, T);
-    std::lock_guard<std::mutex> lk(net->mu);
-    DeviceGuard g(net->device);
+// The launches of one forward, in order, on net->stream (and the sub-batch streams): preprocess, the launch items, the consensus.
+static int forward_launches(vq_tsn* net, const uint8_t* src, int n_crops, int T, int n_split, const std::vector<int>& sub,
+                            const std::vector<int>& sub_off, hipEvent_t* ev) {
     const vq_tensor_desc& t0 = net->tensors[0];
     const int in_c = net->in_channels;
     const int64_t npix = (int64_t)n_crops * net->input.h * net->input.w;
-    const uint8_t* src = crops;
-    if (!crops_on_device) {
-        const size_t bytes = (size_t)npix * in_c;
-        if (net->crops_cap < bytes) {
-            if (net->crops_dev) VQ_HIP(hipFree(net->crops_dev));
-            net->crops_dev = nullptr;
-            net->crops_cap = 0;
-            VQ_HIP(hipMalloc((void**)&net->crops_dev, bytes));
-            net->crops_cap = bytes;
-        }
-        VQ_HIP(hipMemcpyAsync(net->crops_dev, crops, bytes, hipMemcpyHostToDevice, net->stream));
-        src = net->crops_dev;
-    }
-    if (net->mean_cached.size() != (size_t)in_c || memcmp(net->mean_cached.data(), mean_host, in_c * sizeof(float)) != 0) {
-        net->mean_cached.assign(mean_host, mean_host + in_c);     // pageable copy from a buffer that outlives this call
-        VQ_HIP(hipMemcpyAsync(net->mean_dev, net->mean_cached.data(), in_c * sizeof(float), hipMemcpyHostToDevice, net->stream));
-        VQ_HIP(hipStreamSynchronize(net->stream));
-    }
-    if (net->poison)
-        for (size_t i = 0; i < net->slots.size(); ++i) {
-            const vq_tensor_desc& t = net->tensors[i];
-            VQ_HIP(hipMemsetAsync(net->slots[i], 0xFF, (size_t)net->max_crops * t.h * t.w * t.c * sizeof(float), net->stream));
-        }
+    const int n_items = (int)net->items.size();
     if (net->input.s2d_pad < 0) {
         const int64_t nchunk = npix * (t0.c / 4);
         preprocess_kernel<<<cdiv(nchunk, 256), 256, 0, net->stream>>>(src, net->slots[0], nchunk, in_c, t0.c, net->mean_dev);
     } else {
         const int64_t nchunk = (int64_t)n_crops * t0.h * t0.w * in_c;
-        preprocess_s2d_kernel<<<cdiv(nchunk, 256), 256, 0, net->stream>>>(src, net->slots[0], nchunk, net->input.h, net->input.w, in_c,
-                                                                        t0.h, t0.w, net->input.s2d_pad, net->mean_dev);
+        if (in_c == 3 && t0.c == 12)
+            preprocess_s2d3_kernel<<<cdiv(nchunk / 3, 256), 256, 0, net->stream>>>(src, net->slots[0], nchunk / 3, net->input.h, net->input.w, t0.h, t0.w,
+                                                                                   net->input.s2d_pad, net->mean_dev);
+        else
+            preprocess_s2d_kernel<<<cdiv(nchunk, 256), 256, 0, net->stream>>>(src, net->slots[0], nchunk, net->input.h, net->input.w, in_c,
+                                                                            t0.h, t0.w, net->input.s2d_pad, net->mean_dev);
     }
     VQ_CHECK_LAUNCH();
-    net->cur_T = T;
-    const int n_items = (int)net->items.size();
-    hipEvent_t* ev = nullptr;
-    const bool profiling = net->profile_depth > 0;
-    if (profiling && net->profile_tick++ % net->profile_every == 0)
-        ev = net->events.data() + (size_t)(net->profile_count % net->profile_depth) * (2 * n_items);
-    // While profiling everything stays on the caller's stream (each duration is then the launch alone, and the forwards
-    // between two sampled ones issue exactly the same launches).
-    int parts_sum = 0;
-    for (int v : net->split_parts) parts_sum += v;
-    int n_split = (!profiling && net->n_split > 1 && n_crops % parts_sum == 0) ? net->n_split : 1;
-    std::vector<int> sub(n_split, n_crops), sub_off(n_split, 0);
-    if (n_split > 1) {
-        for (int sb = 0, o = 0; sb < n_split; ++sb) {
-            sub[sb] = n_crops / parts_sum * net->split_parts[sb];
-            sub_off[sb] = o;
-            o += sub[sb];
-        }
-    }
-    {   // the consensus rides in the global-pool launch when every launch of that layer covers whole clips
-        bool whole = net->consensus_layer >= 0 && T <= kMaxFusedT;
-        if (whole) {
-            const int cap = net->items[net->item_of_layer[net->consensus_layer]].max_crops;
-            for (int sb = 0; sb < n_split; ++sb)
-                if (sub[sb] % T != 0 || sub_off[sb] % T != 0 || (sub[sb] > cap && cap % T != 0)) whole = false;
-        }
-        net->fused_consensus = whole;
-    }
-    for (int sb = 0; sb < n_split; ++sb) {      // n_split == 1: sub[0] is the whole batch
-        const int rc = ensure_tuned(net, sub[sb]);
-        if (rc != VQ_OK) return rc;
-    }
     if (n_split > 1) {
         // Batch split: the sub-batches are independent, so each runs the whole launch list on its own stream with no
         // synchronisation in between; one sub-batch's launch ramp and tail overlap the other's steady state.
@@ -1744,7 +1763,123 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
                                                                                   net->D, net->D);
         VQ_CHECK_LAUNCH();
     }
+    return VQ_OK;
+}
+
+int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, int32_t n_crops, int32_t T,
+                   const float* mean_host, double* feat_host, float* per_snippet_host) {
+    VQ_REQUIRE(net && crops && mean_host, "NULL argument");
+    VQ_REQUIRE(n_crops > 0 && n_crops <= net->max_crops, "n_crops %d outside (0,%d]", n_crops, net->max_crops);
+    VQ_REQUIRE(T > 0 && n_crops % T == 0, "n_crops (%d) must be a multiple of T (%d)", n_crops, T);
+    std::lock_guard<std::mutex> lk(net->mu);
+    DeviceGuard g(net->device);
+    const vq_tensor_desc& t0 = net->tensors[0];
+    const int in_c = net->in_channels;
+    const int64_t npix = (int64_t)n_crops * net->input.h * net->input.w;
+    const uint8_t* src = crops;
+    if (!crops_on_device) {
+        const size_t bytes = (size_t)npix * in_c;
+        if (net->crops_cap < bytes) {
+            if (net->crops_dev) VQ_HIP(hipFree(net->crops_dev));
+            net->crops_dev = nullptr;
+            net->crops_cap = 0;
+            VQ_HIP(hipMalloc((void**)&net->crops_dev, bytes));
+            net->crops_cap = bytes;
+        }
+        VQ_HIP(hipMemcpyAsync(net->crops_dev, crops, bytes, hipMemcpyHostToDevice, net->stream));
+        src = net->crops_dev;
+    }
+    if (net->mean_cached.size() != (size_t)in_c || memcmp(net->mean_cached.data(), mean_host, in_c * sizeof(float)) != 0) {
+        net->mean_cached.assign(mean_host, mean_host + in_c);     // pageable copy from a buffer that outlives this call
+        VQ_HIP(hipMemcpyAsync(net->mean_dev, net->mean_cached.data(), in_c * sizeof(float), hipMemcpyHostToDevice, net->stream));
+        VQ_HIP(hipStreamSynchronize(net->stream));
+    }
+    if (net->poison)
+        for (size_t i = 0; i < net->slots.size(); ++i) {
+            const vq_tensor_desc& t = net->tensors[i];
+            VQ_HIP(hipMemsetAsync(net->slots[i], 0xFF, (size_t)net->max_crops * t.h * t.w * t.c * sizeof(float), net->stream));
+        }
+    net->cur_T = T;
+    const int n_items = (int)net->items.size();
+    hipEvent_t* ev = nullptr;
+    const bool profiling = net->profile_depth > 0;
+    if (profiling && net->profile_tick++ % net->profile_every == 0)
+        ev = net->events.data() + (size_t)(net->profile_count % net->profile_depth) * (2 * n_items);
+    // While profiling everything stays on the caller's stream (each duration is then the launch alone, and the forwards
+    // between two sampled ones issue exactly the same launches).
+    int parts_sum = 0;
+    for (int v : net->split_parts) parts_sum += v;
+    int n_split = (!profiling && net->n_split > 1 && n_crops % parts_sum == 0) ? net->n_split : 1;
+    std::vector<int> sub(n_split, n_crops), sub_off(n_split, 0);
+    if (n_split > 1) {
+        for (int sb = 0, o = 0; sb < n_split; ++sb) {
+            sub[sb] = n_crops / parts_sum * net->split_parts[sb];
+            sub_off[sb] = o;
+            o += sub[sb];
+        }
+    }
+    {   // the consensus rides in the global-pool launch when every launch of that layer covers whole clips
+        bool whole = net->consensus_layer >= 0 && T <= kMaxFusedT;
+        if (whole) {
+            const int cap = net->items[net->item_of_layer[net->consensus_layer]].max_crops;
+            for (int sb = 0; sb < n_split; ++sb)
+                if (sub[sb] % T != 0 || sub_off[sb] % T != 0 || (sub[sb] > cap && cap % T != 0)) whole = false;
+        }
+        net->fused_consensus = whole;
+    }
+    for (int sb = 0; sb < n_split; ++sb) {      // n_split == 1: sub[0] is the whole batch
+        const int rc = ensure_tuned(net, sub[sb]);
+        if (rc != VQ_OK) return rc;
+    }
+    // A forward that carries no events and moves nothing to or from the host is a fixed list of launches: the second time its key is
+    // seen it is captured into a hipGraph (forks to the sub-batch streams included), from then on it is replayed.
+    bool capturing = false;
+    vq_tsn::GraphKey key{src, n_crops, T, n_split};
+    if (net->use_graph && !ev && crops_on_device && !feat_host && !per_snippet_host && !net->poison && net->stream != nullptr) {
+        auto it = net->graphs.find(key);
+        if (it != net->graphs.end() && it->second.exec) {
+            it->second.used = ++net->graph_clock;
+            VQ_HIP(hipGraphLaunch(it->second.exec, net->stream));
+            net->last_crops = n_crops;
+            return VQ_OK;
+        }
+        if (it == net->graphs.end()) {
+            net->graphs[key] = vq_tsn::GraphEntry{nullptr, nullptr, ++net->graph_clock};      // seen once: the next one is captured
+            if (net->graphs.size() > 8) {                                                    // least recently used key goes
+                auto old = net->graphs.begin();
+                for (auto j = net->graphs.begin(); j != net->graphs.end(); ++j)
+                    if (j->second.used < old->second.used) old = j;
+                if (old->second.exec) (void)hipGraphExecDestroy(old->second.exec);
+                if (old->second.graph) (void)hipGraphDestroy(old->second.graph);
+                net->graphs.erase(old);
+            }
+        } else {
+            VQ_HIP(hipStreamBeginCapture(net->stream, hipStreamCaptureModeThreadLocal));
+            capturing = true;
+        }
+    }
+    const int frc = forward_launches(net, src, n_crops, T, n_split, sub, sub_off, ev);
+    if (capturing) {
+        hipGraph_t graph = nullptr;
+        const hipError_t e = hipStreamEndCapture(net->stream, &graph);
+        if (frc != VQ_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return frc;
+        }
+        if (e != hipSuccess || !graph) return fail(VQ_E_HIP, "capturing the forward failed: %s", hipGetErrorString(e));
+        hipGraphExec_t exec = nullptr;
+        const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (e2 != hipSuccess) {
+            (void)hipGraphDestroy(graph);
+            return fail(VQ_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e2));
+        }
+        net->graphs[key] = vq_tsn::GraphEntry{graph, exec, ++net->graph_clock};
+        VQ_HIP(hipGraphLaunch(exec, net->stream));               // nothing ran while capturing
+    } else if (frc != VQ_OK) {
+        return frc;
+    }
     net->last_crops = n_crops;
+    const int B = n_crops / T;
     if (feat_host)
         VQ_HIP(hipMemcpyAsync(feat_host, net->feat_dev, (size_t)B * net->D * sizeof(double), hipMemcpyDeviceToHost, net->stream));
     if (per_snippet_host)
@@ -1915,6 +2050,7 @@ int vq_tsn_set_layer_tiles(vq_tsn* net, int32_t n_crops, const int32_t* tiles, i
     }
     std::lock_guard<std::mutex> lk(net->mu);
     net->tuned[n_crops] = choice;
+    drop_graphs(net);                             // captured forwards hold the old tilings' launches
     return VQ_OK;
 }
 
