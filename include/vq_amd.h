@@ -49,6 +49,13 @@ int vq_timer_stop(void* timer, void* stream);
 int vq_timer_elapsed_ms(void* timer, float* ms);       /* synchronises on the stop event */
 int vq_timer_destroy(void* timer);
 
+/* Feature rows as the text the reference's writer produces (src/features_GPU_compute/calcSig_wOF.py:128-133): per clip
+ * "<clip number>,<v0>,...,<vD-1>\n" with every value printed like str(numpy.float64) -- number_format 0: Python's float repr
+ * (shortest round-trip digits; numpy >= 1.14), 1: '%.12g' with ".0" kept for integral values (numpy < 1.14); the reference
+ * ships feature files of both kinds.  out must hold n_rows * (dim * 26 + 22) bytes; *written = bytes produced.  Host only. */
+int vq_format_feature_rows(const double* feats, int64_t n_rows, int32_t dim, const int64_t* clip_numbers, int32_t number_format,
+                           char* out, int64_t cap, int64_t* written);
+
 /* ------------------------------------------------------------------------------------------
  * Hot path B: feature database, similarity scan, scoring, selection
  * ------------------------------------------------------------------------------------------ */

@@ -413,3 +413,26 @@ def test_packed_weight_cache_skips_the_loader_and_returns_the_same_blob(tmp_path
         f.write_bytes(f.read_bytes()[:1000])
     tnet.TsnNet(g, loader(2), cache_key="synthetic:2")
     assert loads[-1] == 2 and len(loads) == 5 and (seen["blob"] == first["blob"]).all()
+
+
+def test_native_row_formatter_prints_like_str_of_numpy_float64():
+    """The feature rows are formatted by the library (csrc/host/vq_csv.cc: shortest round-trip digits laid out by repr's rule, or
+    '%.12g' + '.0').  Against Python's own ``repr`` / the numpy < 1.14 rule on values that exercise every branch: the
+    fixed / scientific boundaries (1e-4, 1e16), integral values, denormals, the largest double, signed zeros, inf / nan, 17-digit
+    values, fp64 means of 25 fp32 numbers (what the command line writes), wide random exponents."""
+    from video_query_algorithms_amd.tsn.feature_csv import NUMBER_FORMATS, format_rows
+    rng = np.random.default_rng(0)
+    special = [0.0, -0.0, 1.0, 100000.0, 1e16, 1e15, 9999999999999998.0, 1e-4, 9.999e-5, 1e-5, 1.5e-7, 123456789012345678.0, 5e-324,
+               2.2250738585072014e-308, 1.7976931348623157e308, float("inf"), float("-inf"), float("nan"), 2.0 ** 53, 0.1, 0.30000000000000004,
+               1e22, 1e21, 12345.0, 0.5, 999999999999999.9, 0.0001234, 1e100, 1.2345e-100]
+    vals = np.concatenate([rng.random(40_000) * 3, 10.0 ** rng.uniform(-320, 308, 40_000), -rng.random(1_000), special,
+                           np.float32(rng.random(20_000) * 5).astype(np.float64),
+                           np.float32(rng.random((8_000, 25)) * 4).astype(np.float64).mean(axis=1)])
+    vals = vals[:vals.size // 8 * 8].reshape(-1, 8)
+    nos = np.arange(7, 7 + vals.shape[0])
+    for name, fmt in NUMBER_FORMATS.items():
+        want = "".join(str(int(c)) + "," + ",".join(map(fmt, row.tolist())) + "\n" for c, row in zip(nos, vals)).encode()
+        assert format_rows(vals, nos, name) == want, name
+    assert format_rows(np.zeros((0, 4)), np.zeros(0, dtype=np.int64)) == b""
+    with pytest.raises(KeyError):
+        format_rows(vals, nos, "g7")

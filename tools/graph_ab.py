@@ -1,4 +1,4 @@
-"""A/B of the captured forward (VQ_TSN_GRAPH) at cfg 2 (96 crops) and cfg 3 (448): wall clock of K back-to-back forwards on a stream, with
+"""A/B of the captured forward (VQ_TSN_GRAPH=1, opt-in) at cfg 2 (96 crops) and cfg 3 (448): wall clock of K back-to-back forwards on a stream, with
 and without the graph, on one stream and split over two; the features must have the same bits."""
 import os
 import sys

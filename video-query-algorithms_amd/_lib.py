@@ -60,6 +60,7 @@ _pI32, _pI64, _pF32, _pF64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINT
 # name -> argtypes; every function returns int (status) unless listed in _SPECIAL
 SIGNATURES = {
     "vq_device_count": [_pI32],
+    "vq_format_feature_rows": [_P, _I64, _I32, _P, _I32, _P, _I64, _pI64],
     "vq_timer_create": [_PP], "vq_timer_start": [_P, _P], "vq_timer_stop": [_P, _P],
     "vq_timer_elapsed_ms": [_P, _pF32], "vq_timer_destroy": [_P],
     "vq_db_create": [_I64, _I32, _I32, _I32, _I32, _I32, _PP],

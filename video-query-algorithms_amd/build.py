@@ -10,7 +10,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SOURCES = ["csrc/vq_sim.hip", "csrc/vq_tsn.hip", "csrc/vq_wino.hip", "csrc/vq_boot.hip", "csrc/vq_frames.hip", "csrc/vq_comm.hip", "csrc/vq_flow.hip",
            "csrc/vq_jpeg.hip"]
-HEADERS = ["csrc/vq_common.h", "csrc/vq_tsn_kernels.h", "../include/vq_amd.h"]
+# host-only translation units (no HIP include): plain C++, also built with sanitizers by tests/sanitize/Makefile
+HOST_SOURCES = ["csrc/host/vq_csv.cc"]
+HEADERS = ["csrc/vq_common.h", "csrc/vq_tsn_kernels.h", "csrc/host/vq_host.h", "../include/vq_amd.h"]
 OUT = os.path.join(HERE, "libvqamd.so")
 # -ffp-contract=off: score arithmetic must round like the reference's numpy scalars; FMAs are explicit
 # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in architectural VGPRs.  Left to itself the register allocator parks part of
@@ -25,7 +27,7 @@ def _stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(os.path.join(HERE, p)) > t for p in SOURCES + HEADERS + ["build.py"])
+    return any(os.path.getmtime(os.path.join(HERE, p)) > t for p in SOURCES + HOST_SOURCES + HEADERS + ["build.py"])
 
 
 def build(force=False, verbose=True):
@@ -42,9 +44,18 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append(subprocess.Popen(cmd))
+    host_flags = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
+                  "-I" + os.path.join(HERE, "csrc", "host")]
+    for src in HOST_SOURCES:
+        obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
+        objs.append(obj)
+        cmd = [os.environ.get("CXX", "g++"), "-c"] + host_flags + [os.path.join(HERE, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append(subprocess.Popen(cmd))
     for p in procs:
         if p.wait() != 0:
-            raise RuntimeError("hipcc failed")
+            raise RuntimeError("compilation failed")
     cmd = [hipcc, "-shared", "--offload-arch=gfx950", "-fPIC"] + objs + ["-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -23,6 +23,7 @@ import argparse
 import glob
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -31,6 +32,7 @@ if __package__ in (None, ""):
     import video_query_algorithms_amd  # noqa: F401
     from video_query_algorithms_amd.tsn import frames
     from video_query_algorithms_amd.tsn.caffe_net import CaffeNet
+    from video_query_algorithms_amd.tsn.ingest import FrameIngest
     from video_query_algorithms_amd.tsn.feature_csv import write_features
     from video_query_algorithms_amd.shard import all_gather_rows, shard_range
     from video_query_algorithms_amd import fanout
@@ -38,6 +40,7 @@ else:
     from . import fanout
     from .tsn import frames
     from .tsn.caffe_net import CaffeNet
+    from .tsn.ingest import FrameIngest
     from .tsn.feature_csv import write_features
     from .shard import all_gather_rows, shard_range
 
@@ -128,6 +131,46 @@ def _fan_out(args, argv, program):
     return fanout.run_children(program, argv, envs)
 
 
+class _CropPipeline:
+    """--device_jpeg: the device crops of the batches AHEAD of the network, across the streams.  The batches of all streams form one
+    work list (RGB batches, then flow batches); up to ``ahead`` of them beyond the one the network asks for are in preparation on
+    two threads -- lists of undecoded files in, device crops out (tsn/ingest.py; the library's calls release the interpreter; the two
+    lanes own a decoder and a HIP stream each, so one batch's host half -- reading the files, stripping the byte stuffing --
+    overlaps the other's device half).  Nothing here needs an extractor: the first batches are prepared while the extractors are
+    still being built, and the flow stream's first batches while the RGB stream's last ones are in the network."""
+
+    def __init__(self, ingests, batches, load_clip, file_pool, ahead=2):
+        from concurrent.futures import ThreadPoolExecutor
+        self.ingests, self.batches, self.load_clip, self.file_pool, self.ahead = ingests, batches, load_clip, file_pool, ahead
+        self.order = [(si, bi) for si in range(len(batches)) for bi in range(len(batches[si]))]
+        self.index = {key: k for k, key in enumerate(self.order)}
+        self.pool = ThreadPoolExecutor(max_workers=2)
+        self.jobs, self.submitted = {}, 0
+
+    def _prepare(self, k):
+        si, bi = self.order[k]
+        lists = [f.result() for f in [self.file_pool.submit(self.load_clip, si, u) for u in self.batches[si][bi]]]
+        return self.ingests[si].crops_from_jpegs([f for c in lists for f in c], lane=k % 2)
+
+    def start(self):
+        self._fill(0)
+
+    def _fill(self, k):
+        while self.submitted < min(k + self.ahead + 1, len(self.order)):
+            self.jobs[self.submitted] = self.pool.submit(self._prepare, self.submitted)
+            self.submitted += 1
+
+    def get(self, si, bi):
+        k = self.index[(si, bi)]
+        self._fill(k)
+        return self.jobs.pop(k).result()
+
+    def close(self):
+        self.pool.shutdown()
+        for ing in self.ingests:
+            ing.close()
+
+
 def main(argv=None, net_factory=None, program=None):
     """``net_factory(net_proto, net_weights, device, max_crops=, feature_blob=, resize_rule=)`` builds the per-stream extractor
     (default: the HIP ``CaffeNet``; the CPU tests of the sharding logic pass a stand-in).  ``program``: the script the
@@ -172,7 +215,6 @@ def main(argv=None, net_factory=None, program=None):
     device_jpeg = args.device_jpeg and args.frame_ext.lower() in ('.jpg', '.jpeg') and not args.host_resize
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=max(1, args.num_worker))
-    prep_pool = ThreadPoolExecutor(max_workers=2)        # --device_jpeg: the stages in front of the network (see the batch loop)
     io_pool = ThreadPoolExecutor(max_workers=2)          # feature files are formatted and written here
     csv_jobs = []
     build_pool = ThreadPoolExecutor(max_workers=2)
@@ -196,47 +238,57 @@ def main(argv=None, net_factory=None, program=None):
     # both streams' extractors are built side by side: the flow nets' weights are folded and uploaded while the RGB stream is running
     net_jobs = {(s['modality'], mi): build_pool.submit(build, s, m) for s in streamCNN for mi, m in enumerate(members)} if count else {}
 
-    for s in streamCNN:
+    def load_clip(si, unit):
+        s = streamCNN[si]
+        f_info, vid = videos[unit[0]][1], unit[1]
+        frame_cnt = f_info[s['cnt_indexer']][vid]
+        ticks = frames.frame_ticks(frame_cnt, T, s['stack_depth'])
+        if s['modality'] == 'rgb':
+            load = frames.load_rgb_jpegs if device_jpeg else frames.load_rgb_snippets if args.host_resize else frames.load_rgb_frames
+            return load(f_info[0][vid], ticks, args.rgb_prefix, args.frame_ext, **host_rule)
+        load = frames.load_flow_jpegs if device_jpeg else frames.load_flow_snippets if args.host_resize else frames.load_flow_frames
+        return load(f_info[0][vid], ticks, frame_cnt, s['stack_depth'], args.flow_x_prefix, args.flow_y_prefix, args.frame_ext, **host_rule)
+
+    batches = [units[b0:min(b0 + args.batch_clips, first + count)] for b0 in range(first, first + count, args.batch_clips)]
+    crop_pipe = None
+    if device_jpeg and count:
+        crop_pipe = _CropPipeline([FrameIngest(3 if s['modality'] == 'rgb' else 2 * s['stack_depth'], device, rule) for s in streamCNN],
+                                  [batches] * len(streamCNN), load_clip, pool)
+        crop_pipe.start()                            # the first batches are read and decoded while the extractors are being built
+
+    for si, s in enumerate(streamCNN):
         nets = [net_jobs[(s['modality'], mi)].result() for mi in range(len(members))] if count else []
         mine = [[] for _ in members]
-
-        def load_clip(unit, s=s):
-            f_info, vid = videos[unit[0]][1], unit[1]
-            frame_cnt = f_info[s['cnt_indexer']][vid]
-            ticks = frames.frame_ticks(frame_cnt, T, s['stack_depth'])
-            if s['modality'] == 'rgb':
-                load = frames.load_rgb_jpegs if device_jpeg else frames.load_rgb_snippets if args.host_resize else frames.load_rgb_frames
-                return load(f_info[0][vid], ticks, args.rgb_prefix, args.frame_ext, **host_rule)
-            load = frames.load_flow_jpegs if device_jpeg else frames.load_flow_snippets if args.host_resize else frames.load_flow_frames
-            return load(f_info[0][vid], ticks, frame_cnt, s['stack_depth'], args.flow_x_prefix, args.flow_y_prefix, args.frame_ext, **host_rule)
+        waited = {'files': 0.0, 'crops': 0.0, 'nets': 0.0}     # VQ_CLI_TRACE=1: where this stream's loop waited
 
         def through_the_nets(make):
-            """One batch through every member's network: ``make(net)`` hands a net the batch (the first net's call also does the
-            decode / resize / crop once; the others take the device crops it produced)."""
+            """One batch through every member's network: ``make(net)`` hands a net the batch (decoded, resized and cropped once,
+            whatever the number of members)."""
+            t0 = time.perf_counter()
             for mi, net in enumerate(nets):
                 mine[mi].append(make(net))
+            waited['nets'] += time.perf_counter() - t0
 
         # --num_worker decoder threads (the reference runs that many worker PROCESSES, each with its own net,
         # calcSig_wOF.py:204-210); the batch after the one on the GPU is decoded meanwhile
-        batches = [units[b0:min(b0 + args.batch_clips, first + count)] for b0 in range(first, first + count, args.batch_clips)]
-        pending = [pool.submit(load_clip, u) for u in batches[0]] if batches else []
-        staged = []                                  # --device_jpeg: the crops of the batches in front of the network, being made by prep_pool
+        pending = [pool.submit(load_clip, si, u) for u in batches[0]] if batches and not crop_pipe else []
+        t_stream = time.perf_counter()
         for bi, batch in enumerate(batches):
-            crops = [f.result() for f in pending]
-            pending = [pool.submit(load_clip, u) for u in batches[bi + 1]] if bi + 1 < len(batches) else []
+            crops = []
+            if not crop_pipe:
+                t0 = time.perf_counter()
+                crops = [f.result() for f in pending]
+                waited['files'] += time.perf_counter() - t0
+                pending = [pool.submit(load_clip, si, u) for u in batches[bi + 1]] if bi + 1 < len(batches) else []
             for _vi, vid in batch:
                 print('video {} for {} modality done'.format(vid, s['modality']))
-            if not crops:
+            if crop_pipe:
+                t0 = time.perf_counter()
+                dev_crops = crop_pipe.get(si, bi)
+                waited['crops'] += time.perf_counter() - t0
+                through_the_nets(lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu))
+            elif not crops:
                 continue
-            if device_jpeg:
-                # Three stages: two threads read, decode, resize and crop batches b + 1 and b + 2 on the GPU (lists of undecoded files in,
-                # device crops out; the library's calls release the interpreter; each thread has a decoder and a stream of its own, so
-                # one batch's host half -- reading the files, stripping the byte stuffing -- overlaps the other's device half) while
-                # this one runs batch b through the network(s)
-                staged.append(prep_pool.submit(nets[0].crops_from_jpegs, [f for c in crops for f in c], lane=bi % 2))
-                if len(staged) > 2:
-                    dev_crops = staged.pop(0).result()
-                    through_the_nets(lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu))
             elif args.host_resize:
                 block = np.concatenate(crops, axis=0)
                 through_the_nets(lambda net: net.extract_clips(block, T, on_device=on_gpu))
@@ -252,9 +304,9 @@ def main(argv=None, net_factory=None, program=None):
                             dev_crops = nets[0].crops_from_frames(g[i:i + per])
                             nets[0].sync_ingest()
                             through_the_nets(lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu))
-        for job in staged:
-            dev_crops = job.result()
-            through_the_nets(lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu))
+        if os.environ.get("VQ_CLI_TRACE") == "1":
+            print("trace: %s stream, %d batches in %.3f s: waited %.3f s for file lists, %.3f s for device crops, %.3f s in the networks"
+                  % (s['modality'], len(batches), time.perf_counter() - t_stream, waited['files'], waited['crops'], waited['nets']), file=sys.stderr, flush=True)
         for mi, m in enumerate(members):
             width = nets[mi].feature_dim if nets else args.featureBlob_size
             local_feat = _stack_rows(mine[mi], width)
@@ -281,8 +333,9 @@ def main(argv=None, net_factory=None, program=None):
                                                {'rgb': m['rgb'], 'warped_optical_flow': m['flow']}, args.number_format))
         for n in nets:                               # this stream's device buffers go back to the pool: the next stream's nets take them
             n.close()
+    if crop_pipe:
+        crop_pipe.close()
     pool.shutdown()
-    prep_pool.shutdown()
     build_pool.shutdown()
     for job in csv_jobs:
         job.result()                                                     # a writer's exception is the command's

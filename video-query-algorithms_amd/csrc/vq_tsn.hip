@@ -826,8 +826,11 @@ struct vq_tsn {
     hipStream_t ls = nullptr;             // stream the next launch goes to
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // profiling: events of the next launch
     std::vector<hipStream_t> split_streams;       // [n_split]; entry 0 unused (caller's stream)
-    // Captured forwards: the whole launch list of a (crops address, batch, T, mode) as ONE hipGraph, replayed by later forwards of the
-    // same key (VQ_TSN_GRAPH=0: off).  A step is 38 dependent launches of ~70 us: replayed as a graph they are queued in one go.
+    // Captured forwards (VQ_TSN_GRAPH=1; off by default): the whole launch list of a (crops address, batch, T, mode) as ONE hipGraph,
+    // replayed by later forwards of the same key.  Measured in round 4 (tools/graph_ab.py): same bits, and NO gain where the host keeps
+    // up -- 2.761 vs 2.768 ms per 96-crop step on one stream, 12 110 vs 12 050 clips/s with two sub-batch streams: the ~3 us between
+    // two dependent launches is the command processor's, not the host's, and a graph's kernel nodes pay it too.  It helps only a host
+    // that is late with its launches (3.21 -> 2.66 ms in a process whose other threads hold the interpreter).
     struct GraphKey {
         const void* src;
         int n_crops, T, n_split;
@@ -1652,7 +1655,7 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
                     if (kTiles[i].bm == bm && kTiles[i].bn == bn && kTiles[i].bk == bk && kTiles[i].pipe == pipe) net->forced_tile = i;
         }
         const char* gr = getenv("VQ_TSN_GRAPH");
-        net->use_graph = !(gr && *gr == '0');
+        net->use_graph = gr && *gr == '1';        // opt-in: measured, no gain (see the struct)
         const char* sp = getenv("VQ_TSN_SPLIT");
         if (sp && strchr(sp, ',')) {                   // "2,1": sub-batches of 2/3 and 1/3 of the crops
             for (const char* q = sp; *q;) {
@@ -1773,7 +1776,6 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
     VQ_REQUIRE(T > 0 && n_crops % T == 0, "n_crops (%d) must be a multiple of T (%d)", n_crops, T);
     std::lock_guard<std::mutex> lk(net->mu);
     DeviceGuard g(net->device);
-    const vq_tensor_desc& t0 = net->tensors[0];
     const int in_c = net->in_channels;
     const int64_t npix = (int64_t)n_crops * net->input.h * net->input.w;
     const uint8_t* src = crops;
@@ -1874,6 +1876,7 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
             return fail(VQ_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e2));
         }
         net->graphs[key] = vq_tsn::GraphEntry{graph, exec, ++net->graph_clock};
+        (void)hipGetLastError();                                 // whatever the capture left behind must not meet the next launch check
         VQ_HIP(hipGraphLaunch(exec, net->stream));               // nothing ran while capturing
     } else if (frc != VQ_OK) {
         return frc;

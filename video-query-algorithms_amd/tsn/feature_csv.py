@@ -32,10 +32,31 @@ def _g12(v: float) -> str:
 NUMBER_FORMATS = {"repr": repr, "g12": _g12}
 
 
+def format_rows(feat: np.ndarray, clip_numbers: np.ndarray, number_format: str = "repr") -> bytes:
+    """``"<clip>,<v0>,...\\n"`` per row, every value printed like ``str(numpy.float64)`` -- by the library (a C loop that holds
+    no interpreter lock: the writer thread of the command line runs beside the threads that feed the GPU).  ``NUMBER_FORMATS``
+    above are the same two rules in Python; the tests hold one against the other."""
+    import ctypes as C
+    from .._lib import call
+    if number_format not in NUMBER_FORMATS:
+        raise KeyError(number_format)
+    feat = np.ascontiguousarray(feat, dtype=np.float64)
+    nos = np.ascontiguousarray(clip_numbers, dtype=np.int64)
+    if feat.ndim != 2 or nos.shape != (feat.shape[0],):
+        raise ValueError("feat must be [n, D] with one clip number per row")
+    if feat.shape[0] == 0:
+        return b""
+    cap = feat.shape[0] * (feat.shape[1] * 26 + 22)
+    buf = C.create_string_buffer(cap)
+    n = C.c_int64()
+    call("vq_format_feature_rows", feat.ctypes.data_as(C.c_void_p), feat.shape[0], feat.shape[1], nos.ctypes.data_as(C.c_void_p),
+         0 if number_format == "repr" else 1, buf, cap, C.byref(n))
+    return buf.raw[:n.value]
+
+
 def write_features(out_dir: str, video: str, video_path: str, modelname: str, blob: str, clip_names: Sequence[str],
                    features: Dict[str, np.ndarray], weights_files: Dict[str, str], number_format: str = "repr") -> List[str]:
     """features[mode] is [n_clips, D] float64 in clip order; returns the files written."""
-    fmt = NUMBER_FORMATS[number_format]
     f_output_dir = os.path.join(out_dir, video, modelname)
     os.makedirs(f_output_dir, exist_ok=True)
     written = []
@@ -45,12 +66,11 @@ def write_features(out_dir: str, video: str, video_path: str, modelname: str, bl
         header_txt = 'video =' + video + ', video url =' + video_path + ', CNN stream =' + mode \
                      + ', feature blob =' + blob + ', caffe model =' + weights_files[mode]
         outfile = os.path.join(f_output_dir, mode + "_" + blob + "_features.csv")
-        feat = np.asarray(features[mode], dtype=np.float64)
-        with open(outfile, mode='w', newline='\n') as fout:
-            fout.write(header_txt + "\n")
-            for i, vid in enumerate(clip_names):
-                clip_no = int(vid[-4:])
-                fout.write(str(clip_no) + "," + ",".join(map(fmt, feat[i].tolist())) + "\n")
+        feat = np.ascontiguousarray(features[mode], dtype=np.float64)
+        clip_nos = np.asarray([int(vid[-4:]) for vid in clip_names], dtype=np.int64)          # calcSig_wOF.py:131
+        with open(outfile, mode='wb') as fout:
+            fout.write((header_txt + "\n").encode())
+            fout.write(format_rows(feat, clip_nos, number_format))
         written.append(outfile)
     return written
 
