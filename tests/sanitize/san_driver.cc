@@ -1,0 +1,245 @@
+// Test program (CPU container): the host-only translation units of the library (video-query-algorithms_amd/csrc/host/*.cc -- JPEG
+// marker / table parsing, host entropy decoder, unstuffing, device table forms, the worker-thread stages of a batch, the CSV row
+// formatter) linked with a sanitizer runtime and driven over a corpus of valid and DAMAGED files.  Built three ways by the
+// Makefile next to it (-fsanitize=address,undefined / -fsanitize=thread); tests/test_sanitizers.py makes the corpus and runs them.
+//
+//   san_driver single <dir>    every file alone: parse, decode, unstuff (what a worker thread does with one file)
+//   san_driver batch  <dir>    the files that parse, grouped by size, through parse_batch / decode_batch / unstuff_batch / read_files
+//                              on 8 threads, several rounds
+//   san_driver csv             vq_format_feature_rows on values of every kind
+//   san_driver corners         the corner selection of the warped-flow step, 24 frames over host threads
+//   san_driver pool            the device-block pool's bookkeeping hammered from 8 threads
+#include <dirent.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "vq_block_pool.h"
+#include "vq_corners.h"
+#include "vq_jpeg_host.h"
+
+namespace vq {
+std::string& last_error_ref() {
+    thread_local std::string e;
+    return e;
+}
+}  // namespace vq
+
+using namespace vq::jpeg;
+
+static std::vector<std::string> list_dir(const char* dir) {
+    std::vector<std::string> out;
+    if (DIR* d = opendir(dir)) {
+        while (dirent* e = readdir(d))
+            if (e->d_name[0] != '.') out.push_back(std::string(dir) + "/" + e->d_name);
+        closedir(d);
+    }
+    std::sort(out.begin(), out.end());
+    return out;
+}
+
+static std::vector<uint8_t> slurp(const std::string& path) {
+    std::vector<uint8_t> v;
+    if (FILE* f = fopen(path.c_str(), "rb")) {
+        fseek(f, 0, SEEK_END);
+        const long n = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        v.resize(n > 0 ? (size_t)n : 0);
+        if (n > 0 && fread(v.data(), 1, (size_t)n, f) != (size_t)n) v.clear();
+        fclose(f);
+    }
+    return v;
+}
+
+// one file the way a worker treats it; returns 1 decoded, 0 refused
+static int one_file(const std::vector<uint8_t>& d) {
+    Frame f;
+    if (d.empty() || parse_headers(d.data(), d.size(), f) != VQ_OK) return 0;
+    if ((long long)f.H * f.W > 4096ll * 4096ll) return 0;                 // the library sizes its buffers by the CALL's h x w
+    size_t comp_off[3] = {0, 0, 0};
+    const size_t blocks = place_blocks(f, f.H, f.W);
+    size_t o = 0;
+    for (int c = 0; c < f.nc; ++c) {
+        comp_off[c] = o;
+        o += (size_t)f.comp[c].bw * f.comp[c].bh;
+    }
+    std::vector<int16_t> coef(blocks * 64, 0);                            // exactly the frame's blocks: an overrun is a finding
+    const int rc = decode_scan(d.data(), d.size(), f, coef.data(), comp_off);
+    // the device path's host stage on the same file
+    std::vector<int> n_mcu, want;
+    std::vector<size_t> region;
+    const int64_t size = (int64_t)d.size();
+    stream_regions(&f, &size, 1, f.H, f.W, n_mcu, want, region);
+    std::vector<uint8_t> stream(region[1]);                               // exactly the region the product reserves
+    std::vector<uint32_t> off((size_t)want[0]), len((size_t)want[0]);
+    (void)unstuff_scan(d.data(), d.size(), f.scan, stream.data(), want[0], off.data(), len.data());
+    for (int c = 0; c < f.nc; ++c) {
+        DevHuff dh;
+        fill_dev_huff(f.dc[f.comp[c].td], dh);
+        fill_dev_huff(f.ac[f.comp[c].ta], dh);
+    }
+    return rc == VQ_OK;
+}
+
+static int run_single(const char* dir) {
+    int decoded = 0, refused = 0;
+    for (const std::string& p : list_dir(dir)) (one_file(slurp(p)) ? decoded : refused)++;
+    printf("single: %d decoded, %d refused\n", decoded, refused);
+    return decoded > 0 && refused > 0 ? 0 : 3;
+}
+
+static int run_batch(const char* dir) {
+    // files whose headers parse, by frame size; every group repeated to a batch of >= 48 frames
+    std::map<std::pair<int, int>, std::vector<std::string>> by_size;
+    for (const std::string& p : list_dir(dir)) {
+        const std::vector<uint8_t> d = slurp(p);
+        Frame f;
+        if (!d.empty() && parse_headers(d.data(), d.size(), f) == VQ_OK && (long long)f.H * f.W <= 1024 * 1024) by_size[{f.H, f.W}].push_back(p);
+    }
+    int ok = 0, bad = 0;
+    for (auto& kv : by_size) {
+        const int h = kv.first.first, w = kv.first.second;
+        std::vector<std::string> paths;
+        while (paths.size() < 48) paths.insert(paths.end(), kv.second.begin(), kv.second.end());
+        const int n = (int)paths.size(), workers = 8;
+        std::vector<const char*> cpaths;
+        for (const std::string& p : paths) cpaths.push_back(p.c_str());
+        for (int round = 0; round < 3; ++round) {
+            std::vector<std::vector<uint8_t>> data;
+            if (read_files(cpaths.data(), n, data, workers) != VQ_OK) return 4;
+            std::vector<const uint8_t*> ptrs;
+            std::vector<int64_t> sizes;
+            for (auto& v : data) {
+                ptrs.push_back(v.data());
+                sizes.push_back((int64_t)v.size());
+            }
+            std::vector<Frame> fr((size_t)n);
+            if (parse_batch(ptrs.data(), sizes.data(), n, h, w, fr.data(), workers) != VQ_OK) return 5;      // they all parsed alone
+            std::vector<size_t> comp_off((size_t)n * 3, 0);
+            size_t blocks = 0;
+            for (int i = 0; i < n; ++i) {
+                place_blocks(fr[i], h, w);
+                for (int c = 0; c < fr[i].nc; ++c) {
+                    comp_off[(size_t)i * 3 + c] = blocks;
+                    blocks += (size_t)fr[i].comp[c].bw * fr[i].comp[c].bh;
+                }
+            }
+            std::vector<int16_t> coef(blocks * 64), device(blocks * 64);
+            size_t copied = 0;
+            const int rc = decode_batch(ptrs.data(), sizes.data(), n, fr.data(), coef.data(), comp_off.data(), blocks, workers, 4, [&](size_t b0, size_t b1) {
+                memcpy(device.data() + b0 * 64, coef.data() + b0 * 64, (b1 - b0) * 64 * sizeof(int16_t));    // the copy the product queues per piece
+                copied += b1 - b0;
+            });
+            if (copied != blocks) return 6;
+            (rc == VQ_OK ? ok : bad)++;
+            std::vector<int> n_mcu, want;
+            std::vector<size_t> region;
+            stream_regions(fr.data(), sizes.data(), n, h, w, n_mcu, want, region);
+            std::vector<uint8_t> stream(region[(size_t)n]);
+            std::vector<std::vector<uint32_t>> off, len;
+            (void)unstuff_batch(ptrs.data(), sizes.data(), n, fr.data(), stream.data(), region.data(), want.data(), off, len, workers);
+        }
+    }
+    printf("batch: %zu sizes, %d batches decoded, %d with a damaged scan\n", by_size.size(), ok, bad);
+    return ok > 0 ? 0 : 7;
+}
+
+static int run_csv() {
+    std::vector<double> v = {0.0, -0.0, 1.0, 1e16, 1e15, 1e-4, 9.999e-5, 5e-324, 1.7976931348623157e308, INFINITY, -INFINITY, NAN, 0.1, 123456789012345678.0,
+                             2.2250738585072014e-308, 1e22, 0.30000000000000004, -12345.678};
+    unsigned long long z = 88172645463325252ull;
+    while (v.size() % 6 || v.size() < 6000) {
+        z ^= z << 13, z ^= z >> 7, z ^= z << 17;
+        double x;
+        memcpy(&x, &z, 8);                                            // every bit pattern: denormals, NaN payloads, huge exponents
+        v.push_back(x);
+    }
+    const int dim = 6, rows = (int)(v.size() / dim);
+    std::vector<int64_t> clips((size_t)rows);
+    for (int i = 0; i < rows; ++i) clips[i] = i % 2 ? 9223372036854775807ll : -(long long)i;
+    for (int fmt = 0; fmt < 2; ++fmt) {
+        const int64_t need = (int64_t)rows * (dim * 26 + 22);
+        std::vector<char> out((size_t)need);                             // exactly the documented capacity
+        int64_t written = 0;
+        if (vq_format_feature_rows(v.data(), rows, dim, clips.data(), fmt, out.data(), need, &written) != VQ_OK || written <= 0 || written > need) return 8;
+        if (vq_format_feature_rows(v.data(), rows, dim, clips.data(), fmt, out.data(), need - 1, &written) == VQ_OK) return 9;   // too small: refused
+    }
+    printf("csv: ok\n");
+    return 0;
+}
+
+// corner selection of 24 frames on host threads: random strength maps with plateaus (equal strengths) and empty frames
+static int run_corners() {
+    const int n = 24, h = 61, w = 83, max_corners = 200;
+    std::vector<float> peaks((size_t)n * h * w, 0.f);
+    std::vector<unsigned> top((size_t)n, 0);
+    unsigned long long z = 1234567ull;
+    for (int p = 0; p < n; ++p) {
+        float best = 0.f;
+        for (int i = 0; i < h * w && p % 5 != 4; ++i) {                 // every fifth frame has no corner at all
+            z ^= z << 13, z ^= z >> 7, z ^= z << 17;
+            if (z % 7 == 0) {
+                const float v = (float)((z >> 8) % 64) / 8.0f;          // few distinct values: many ties
+                peaks[(size_t)p * h * w + i] = v;
+                best = std::max(best, v);
+            }
+        }
+        memcpy(&top[p], &best, 4);
+    }
+    std::vector<float> xy((size_t)n * max_corners * 2);
+    std::vector<int> counts((size_t)n, -1);
+    for (float md : {0.f, 3.f, 7.5f}) {
+        vq::select_corners_batch(peaks.data(), top.data(), n, h, w, max_corners, 0.01f, md, xy.data(), counts.data());
+        for (int p = 0; p < n; ++p)
+            if (counts[p] < 0 || counts[p] > max_corners || (p % 5 == 4 && counts[p] != 0)) return 10;
+    }
+    printf("corners: ok\n");
+    return 0;
+}
+
+// the device-block pool's bookkeeping from 8 threads: give / take / drain with fake addresses; every block is accounted for once
+static int run_pool() {
+    vq::BlockPool pool(64u << 20);
+    std::vector<std::thread> th;
+    std::vector<long long> balance(8, 0);
+    for (int t = 0; t < 8; ++t)
+        th.emplace_back([&, t] {
+            unsigned long long z = 99 + t;
+            for (int i = 0; i < 20000; ++i) {
+                z ^= z << 13, z ^= z >> 7, z ^= z << 17;
+                const size_t bytes = (size_t)(1 + z % 4) << 20;
+                const int dev = (int)(z >> 20) % 2;
+                if (z % 3) {
+                    void* fake = (void*)(uintptr_t)(0x1000 + ((unsigned long long)t << 32) + (unsigned)i * 16);
+                    if (pool.give(dev, fake, bytes)) balance[t] += (long long)bytes;
+                } else if (z % 3 == 0 && (z >> 40) % 50 == 0) {
+                    (void)pool.drain().size();
+                } else if (pool.take(dev, bytes)) {
+                    balance[t] -= (long long)bytes;
+                }
+            }
+        });
+    for (auto& x : th) x.join();
+    if (pool.held() > (64u << 20)) return 11;
+    (void)pool.drain();
+    if (pool.held() != 0) return 12;
+    printf("pool: ok\n");
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    const std::string mode = argc > 1 ? argv[1] : "";
+    if (mode == "single" && argc > 2) return run_single(argv[2]);
+    if (mode == "batch" && argc > 2) return run_batch(argv[2]);
+    if (mode == "csv") return run_csv();
+    if (mode == "corners") return run_corners();
+    if (mode == "pool") return run_pool();
+    fprintf(stderr, "usage: san_driver single|batch <dir> | csv\n");
+    return 2;
+}

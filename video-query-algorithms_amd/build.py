@@ -11,8 +11,8 @@ ROOT = os.path.dirname(HERE)
 SOURCES = ["csrc/vq_sim.hip", "csrc/vq_tsn.hip", "csrc/vq_wino.hip", "csrc/vq_boot.hip", "csrc/vq_frames.hip", "csrc/vq_comm.hip", "csrc/vq_flow.hip",
            "csrc/vq_jpeg.hip"]
 # host-only translation units (no HIP include): plain C++, also built with sanitizers by tests/sanitize/Makefile
-HOST_SOURCES = ["csrc/host/vq_csv.cc"]
-HEADERS = ["csrc/vq_common.h", "csrc/vq_tsn_kernels.h", "csrc/host/vq_host.h", "../include/vq_amd.h"]
+HOST_SOURCES = ["csrc/host/vq_csv.cc", "csrc/host/vq_jpeg_host.cc", "csrc/host/vq_corners.cc", "csrc/host/vq_block_pool.cc"]
+HEADERS = ["csrc/vq_common.h", "csrc/vq_tsn_kernels.h", "csrc/host/vq_host.h", "csrc/host/vq_jpeg_host.h", "csrc/host/vq_corners.h", "csrc/host/vq_block_pool.h", "../include/vq_amd.h"]
 OUT = os.path.join(HERE, "libvqamd.so")
 # -ffp-contract=off: score arithmetic must round like the reference's numpy scalars; FMAs are explicit
 # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in architectural VGPRs.  Left to itself the register allocator parks part of
@@ -44,7 +44,7 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append(subprocess.Popen(cmd))
-    host_flags = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
+    host_flags = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
                   "-I" + os.path.join(HERE, "csrc", "host")]
     for src in HOST_SOURCES:
         obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")

@@ -9,6 +9,8 @@
 namespace vq {
 std::string& last_error_ref();
 
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
 inline int host_fail(int code, const char* fmt, ...) {
     char buf[1024];
     va_list ap;

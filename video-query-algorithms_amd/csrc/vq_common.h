@@ -9,10 +9,9 @@
 #include <vector>
 
 #include "vq_amd.h"
+#include "host/vq_host.h"      // cdiv, the error string shared with the host-only translation units
 
 namespace vq {
-
-std::string& last_error_ref();
 
 inline int fail(int code, const char* fmt, ...) {
     char buf[1024];
@@ -83,7 +82,6 @@ struct PerDeviceOnce {
         }                                                                                                                        \
     } while (0)
 
-inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // csrc/vq_boot.hip: closed-form target bootstrapping on rows that already live on the device.  row_off [P][stride]
 // element offsets into base_dev (the n_valid[p] validated matches first, then the n_invalid[p] non-matches).

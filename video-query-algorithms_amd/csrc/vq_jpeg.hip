@@ -36,320 +36,16 @@
 #include <vector>
 
 #include "vq_common.h"
+#include "host/vq_jpeg_host.h"      // the host half: parsing, host entropy decoder, unstuffing, the worker-thread stages
 
 using namespace vq;
+using namespace vq::jpeg;
 
 namespace {
-
-const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-
-struct Huff {
-    // lookup of the first 9 bits -> (symbol, code length), 0 length = longer code; canonical tables for the rest (T.81 F.2.2.3)
-    uint8_t look_sym[512], look_len[512];
-    int maxcode[18], valptr[17], mincode[17];
-    uint8_t vals[256];
-    bool present = false;
-};
-
-bool build_huff(const uint8_t* counts, const uint8_t* symbols, int n_symbols, Huff& h) {
-    int code = 0, k = 0;
-    memset(&h, 0, sizeof h);             // every byte defined: identical tables of different files compare equal
-    for (int ln = 1; ln <= 16; ++ln) {
-        h.valptr[ln] = k;
-        h.mincode[ln] = code;
-        for (int i = 0; i < counts[ln - 1]; ++i) {
-            if (k >= n_symbols || k >= 256) return false;
-            h.vals[k] = symbols[k];
-            if (ln <= 9) {
-                const int first = code << (9 - ln), span = 1 << (9 - ln);
-                if (first + span > 512) return false;
-                for (int q = 0; q < span; ++q) {
-                    h.look_sym[first + q] = symbols[k];
-                    h.look_len[first + q] = (uint8_t)ln;
-                }
-            }
-            ++code;
-            ++k;
-        }
-        h.maxcode[ln] = counts[ln - 1] ? code - 1 : -1;
-        if (code > (1 << ln)) return false;
-        code <<= 1;
-    }
-    h.maxcode[17] = 0x7fffffff;
-    h.present = true;
-    return true;
-}
-
-struct Comp {
-    int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
-    int bw = 0, bh = 0;        // blocks per row / column of the decoded plane
-};
-
-struct Frame {
-    int H = 0, W = 0, nc = 0, hmax = 1, vmax = 1, ri = 0;
-    Comp comp[3];
-    uint16_t qt[4][64];
-    bool qt_present[4] = {false, false, false, false};
-    Huff dc[4], ac[4];
-    size_t scan = 0;
-};
-
-struct BitReader {
-    const uint8_t* d;
-    size_t n, p;
-    uint64_t acc = 0;
-    int bits = 0;
-    bool hit_marker = false;
-    void fill() {                       // keep at least 25 bits; behind a marker the stream continues with zeros
-        if (!hit_marker && p + 8 <= n) {
-            // fast path: as many whole bytes as fit, in one go, unless one of them is 0xFF (stuffing or a marker: the byte loop below)
-            const int take = (64 - bits) >> 3;
-            uint64_t wd;
-            memcpy(&wd, d + p, 8);                                    // little-endian: the first stream byte is the lowest
-            const uint64_t x = ~wd;                                    // a zero byte of x = a 0xFF byte of the stream
-            uint64_t ff = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
-            if (take < 8) ff &= (1ull << (8 * take)) - 1;
-            if (!ff && take > 0) {
-                const uint64_t be = __builtin_bswap64(wd);
-                acc = take == 8 ? be : (acc << (8 * take)) | (be >> (64 - 8 * take));
-                bits += 8 * take;
-                p += (size_t)take;
-                return;
-            }
-        }
-        while (bits <= 56) {
-            uint32_t b = 0;
-            if (!hit_marker && p < n) {
-                b = d[p];
-                if (b == 0xFF) {
-                    const uint8_t nx = p + 1 < n ? d[p + 1] : 0xD9;
-                    if (nx == 0) {
-                        p += 2;
-                    } else {
-                        hit_marker = true;
-                        b = 0;
-                    }
-                } else {
-                    ++p;
-                }
-            }
-            acc = (acc << 8) | b;
-            bits += 8;
-        }
-    }
-    inline uint32_t peek(int k) { return (uint32_t)((acc >> (bits - k)) & ((1u << k) - 1)); }
-    inline void skip(int k) { bits -= k; }
-    inline uint32_t get(int k) {
-        if (k == 0) return 0;
-        if (bits < k) fill();
-        const uint32_t v = peek(k);
-        bits -= k;
-        return v;
-    }
-    bool restart() {                    // discard padding, consume the RSTn marker
-        acc = 0;
-        bits = 0;
-        hit_marker = false;
-        while (p + 1 < n && !(d[p] == 0xFF && d[p + 1] >= 0xD0 && d[p + 1] <= 0xD7)) ++p;
-        if (p + 1 >= n) return false;
-        p += 2;
-        return true;
-    }
-};
-
-inline int decode_symbol(BitReader& br, const Huff& h) {
-    if (br.bits < 16) br.fill();
-    const uint32_t look = br.peek(9);
-    const int ln = h.look_len[look];
-    if (ln) {
-        br.skip(ln);
-        return h.look_sym[look];
-    }
-    int code = (int)br.peek(10);
-    int l = 10;
-    while (l <= 16 && code > h.maxcode[l]) {
-        ++l;
-        code = (int)br.peek(l);
-    }
-    if (l > 16) return -1;
-    br.skip(l);
-    const int idx = h.valptr[l] + code - h.mincode[l];
-    return idx >= 0 && idx < 256 ? h.vals[idx] : -1;
-}
-
-inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
-
-inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
-
-// Marker segments up to the start of the (single) scan.  Returns VQ_OK or an error code with the message set.
-int parse_headers(const uint8_t* d, size_t n, Frame& f) {
-    if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return fail(VQ_E_INVALID, "not a JPEG file (no SOI marker)");
-    size_t p = 2;
-    bool have_sof = false;
-    for (;;) {
-        while (p < n && d[p] != 0xFF) ++p;
-        while (p < n && d[p] == 0xFF) ++p;
-        if (p >= n) return fail(VQ_E_INVALID, "JPEG: no scan found");
-        const int m = d[p++];
-        if (m == 0xD9) return fail(VQ_E_INVALID, "JPEG: end of image before any scan");
-        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;      // markers without a length
-        if (p + 2 > n) return fail(VQ_E_INVALID, "JPEG: truncated marker segment");
-        const int ln = be16(d + p);
-        if (ln < 2 || p + ln > n) return fail(VQ_E_INVALID, "JPEG: marker segment runs past the end of the file");
-        const uint8_t* s = d + p + 2;
-        const int sl = ln - 2;
-        p += ln;
-        if (m == 0xDB) {
-            for (int q = 0; q < sl;) {
-                const int prec = s[q] >> 4, tid = s[q] & 15;
-                ++q;
-                if (tid > 3 || q + (prec ? 128 : 64) > sl) return fail(VQ_E_INVALID, "JPEG: bad quantisation table");
-                for (int k = 0; k < 64; ++k) f.qt[tid][kZigzag[k]] = prec ? (uint16_t)be16(s + q + 2 * k) : s[q + k];
-                f.qt_present[tid] = true;
-                q += prec ? 128 : 64;
-            }
-        } else if (m == 0xC0 || m == 0xC1) {
-            if (sl < 6) return fail(VQ_E_INVALID, "JPEG: bad frame header");
-            if (s[0] != 8) return fail(VQ_E_UNSUPPORTED, "JPEG: %d-bit samples (only 8-bit files are decoded)", s[0]);
-            f.H = be16(s + 1);
-            f.W = be16(s + 3);
-            f.nc = s[5];
-            if (f.nc != 1 && f.nc != 3) return fail(VQ_E_UNSUPPORTED, "JPEG: %d components (1 or 3 are decoded)", f.nc);
-            if (sl < 6 + 3 * f.nc || f.H <= 0 || f.W <= 0) return fail(VQ_E_INVALID, "JPEG: bad frame header");
-            for (int i = 0; i < f.nc; ++i) {
-                Comp& c = f.comp[i];
-                c.id = s[6 + 3 * i];
-                c.h = s[7 + 3 * i] >> 4;
-                c.v = s[7 + 3 * i] & 15;
-                c.tq = s[8 + 3 * i];
-                if (c.h < 1 || c.h > 2 || c.v < 1 || c.v > 2 || c.tq > 3) return fail(VQ_E_UNSUPPORTED, "JPEG: sampling factors %dx%d", c.h, c.v);
-                f.hmax = std::max(f.hmax, c.h);
-                f.vmax = std::max(f.vmax, c.v);
-            }
-            have_sof = true;
-        } else if (m == 0xC2 || m == 0xC3 || (m >= 0xC5 && m <= 0xC7) || (m >= 0xC9 && m <= 0xCB) || (m >= 0xCD && m <= 0xCF)) {
-            return fail(VQ_E_UNSUPPORTED, "JPEG process with marker FF%02X (progressive / lossless / arithmetic): baseline Huffman files only", m);
-        } else if (m == 0xC4) {
-            for (int q = 0; q < sl;) {
-                if (q + 17 > sl) return fail(VQ_E_INVALID, "JPEG: bad Huffman table");
-                const int tc = s[q] >> 4, th = s[q] & 15;
-                int cnt = 0;
-                for (int k = 0; k < 16; ++k) cnt += s[q + 1 + k];
-                if (tc > 1 || th > 3 || cnt > 256 || q + 17 + cnt > sl) return fail(VQ_E_INVALID, "JPEG: bad Huffman table");
-                if (!build_huff(s + q + 1, s + q + 17, cnt, tc ? f.ac[th] : f.dc[th])) return fail(VQ_E_INVALID, "JPEG: inconsistent Huffman table");
-                q += 17 + cnt;
-            }
-        } else if (m == 0xDD) {
-            if (sl < 2) return fail(VQ_E_INVALID, "JPEG: bad restart interval");
-            f.ri = be16(s);
-        } else if (m == 0xDA) {
-            if (!have_sof) return fail(VQ_E_INVALID, "JPEG: scan before the frame header");
-            if (sl < 1 || s[0] != f.nc || sl < 1 + 2 * f.nc + 3) return fail(VQ_E_UNSUPPORTED, "JPEG: multi-scan files are not decoded");
-            for (int i = 0; i < f.nc; ++i) {
-                Comp* c = nullptr;
-                for (int k = 0; k < f.nc; ++k)
-                    if (f.comp[k].id == s[1 + 2 * i]) c = &f.comp[k];
-                if (!c || c != &f.comp[i]) return fail(VQ_E_UNSUPPORTED, "JPEG: scan components out of frame order");
-                c->td = s[2 + 2 * i] >> 4;
-                c->ta = s[2 + 2 * i] & 15;
-                if (c->td > 3 || c->ta > 3 || !f.dc[c->td].present || !f.ac[c->ta].present || !f.qt_present[c->tq])
-                    return fail(VQ_E_INVALID, "JPEG: scan refers to a table the file does not define");
-            }
-            f.scan = p;
-            if (f.nc == 3) {
-                for (int i = 1; i < 3; ++i)
-                    if (f.hmax % f.comp[i].h || f.vmax % f.comp[i].v) return fail(VQ_E_UNSUPPORTED, "JPEG: fractional sampling ratios");
-                if (f.comp[0].h != f.hmax || f.comp[0].v != f.vmax || f.comp[1].h != f.comp[2].h || f.comp[1].v != f.comp[2].v ||
-                    (f.vmax / f.comp[1].v == 2 && f.hmax / f.comp[1].h == 1))
-                    return fail(VQ_E_UNSUPPORTED, "JPEG: chroma layout other than 4:4:4, 4:2:2 (h2v1) or 4:2:0 (h2v2)");
-            }
-            return VQ_OK;
-        }
-        // APPn, COM and the rest: skipped
-    }
-}
-
-// Entropy decoding of the scan into natural-order coefficient blocks: [component][block row][block col][64] int16, the
-// components back to back at comp_off[] (in blocks).
-int decode_scan(const uint8_t* d, size_t n, Frame& f, int16_t* coef, const size_t* comp_off) {
-    const bool single = f.nc == 1;
-    const int mx = single ? cdiv(f.W, 8) : cdiv(f.W, 8 * f.hmax), my = single ? cdiv(f.H, 8) : cdiv(f.H, 8 * f.vmax);
-    BitReader br{d, n, f.scan};
-    int pred[3] = {0, 0, 0};
-    int count = 0;
-    for (int mcu = 0; mcu < mx * my; ++mcu) {
-        if (f.ri && count == f.ri) {
-            if (!br.restart()) return fail(VQ_E_INVALID, "JPEG: restart marker missing");
-            pred[0] = pred[1] = pred[2] = 0;
-            count = 0;
-        }
-        ++count;
-        const int my_ = mcu / mx, mx_ = mcu - my_ * mx;
-        for (int ci = 0; ci < f.nc; ++ci) {
-            const Comp& c = f.comp[ci];
-            const int hh = single ? 1 : c.h, vv = single ? 1 : c.v;
-            const Huff &hd = f.dc[c.td], &ha = f.ac[c.ta];
-            for (int by = 0; by < vv; ++by)
-                for (int bx = 0; bx < hh; ++bx) {
-                    int16_t* blk = coef + (comp_off[ci] + (size_t)(my_ * vv + by) * c.bw + (size_t)(mx_ * hh + bx)) * 64;
-                    int s = decode_symbol(br, hd);
-                    if (s < 0 || s > 11) return fail(VQ_E_INVALID, "JPEG: corrupt entropy-coded data (DC)");
-                    if (s) pred[ci] += extend((int)br.get(s), s);
-                    blk[0] = (int16_t)pred[ci];
-                    for (int k = 1; k < 64;) {
-                        const int rs = decode_symbol(br, ha);
-                        if (rs < 0) return fail(VQ_E_INVALID, "JPEG: corrupt entropy-coded data (AC)");
-                        const int r = rs >> 4;
-                        s = rs & 15;
-                        if (s == 0) {
-                            if (r == 15) {
-                                k += 16;
-                                continue;
-                            }
-                            break;
-                        }
-                        k += r;
-                        if (k > 63) return fail(VQ_E_INVALID, "JPEG: corrupt entropy-coded data (run past the block)");
-                        blk[kZigzag[k]] = (int16_t)extend((int)br.get(s), s);
-                        ++k;
-                    }
-                }
-        }
-    }
-    return VQ_OK;
-}
 
 // ---- device side ------------------------------------------------------------------------------------------------------
 
 // ---- entropy decoding on the device -----------------------------------------------------------------------------------
-
-constexpr int kFastBits = 11;
-struct DevHuff {               // one Huffman table as the decoder wants it
-    uint16_t fast[1 << kFastBits];   // the next 11 bits -> (code length << 8) | symbol, 0 = the code is longer
-    uint32_t lim[8];           // codes of 12..16 bits without a loop: lim[l - 12] = first left-aligned 16-bit pattern that is NOT a code of
-                               // <= l bits (non-decreasing); the length is 12 + the number of limits the next 16 bits reach
-    int32_t valptr[17];        // canonical decoding (T.81 F.2.2.3): index of the first symbol of every length ...
-    int32_t mincode[17];       // ... and its code
-    uint8_t vals[256];
-    uint8_t pad[8];
-};
-static_assert(sizeof(DevHuff) == 4096 + 32 + 68 + 68 + 256 + 8 && sizeof(DevHuff) % 16 == 0, "DevHuff layout");
-struct DevTableSet {           // the tables a frame's components use: DC, AC of component 0, 1, 2
-    DevHuff t[6];
-};
-struct SegDesc {               // one stream: a frame's scan, or one restart interval of it
-    uint32_t word_off, n_words;          // its unstuffed bytes inside the batch's stream buffer (32-bit words, zero padded)
-    int32_t frame;                       // -1: padding of a wave
-    int32_t mcu0, mcu1;                  // MCUs [mcu0, mcu1) of the frame
-    int32_t set;                         // its table set (the same for all 64 streams of a wave)
-};
-struct EntFrame {              // what the decoder needs to place a frame's blocks
-    int32_t nc, mx;                      // components, MCUs per row
-    int32_t h[3], v[3], bw[3];           // blocks per MCU in x / y, blocks per plane row
-    uint32_t coef_off[3];                // first block of each component in the coefficient buffer
-};
 
 struct DevBits {
     const uint32_t* w;
@@ -774,72 +470,6 @@ __global__ void jpeg_pixels_kernel(const FrameDesc* __restrict__ frames, const u
     o[2] = (uint8_t)r;
 }
 
-// One pass over a file's scan: byte stuffing removed (FF 00 -> FF), cut at the RSTn markers, every piece zero-padded to whole
-// 32-bit words + two words (the decoder reads zeros behind a stream, like the host reader behind a marker).  dst has room for
-// n - scan + 16 * (max_segs + 1) bytes.  Returns the number of pieces found (<= max_segs are recorded).
-int unstuff_scan(const uint8_t* d, size_t n, size_t scan, uint8_t* dst, int max_segs, uint32_t* seg_off_bytes, uint32_t* seg_len_bytes) {
-    size_t p = scan, o = 0;
-    int segs = 0;
-    size_t start = 0;
-    auto close = [&]() {
-        if (segs < max_segs) {
-            seg_off_bytes[segs] = (uint32_t)start;
-            seg_len_bytes[segs] = (uint32_t)(o - start);
-        }
-        ++segs;
-        const size_t padded = ((o + 3) & ~(size_t)3) + 8;
-        memset(dst + o, 0, padded - o);
-        o = padded;
-        start = o;
-    };
-    while (p < n) {
-        const uint8_t* q = (const uint8_t*)memchr(d + p, 0xFF, n - p);
-        const size_t run = q ? (size_t)(q - (d + p)) : n - p;
-        memcpy(dst + o, d + p, run);
-        o += run;
-        p += run;
-        if (!q) break;
-        const uint8_t nx = p + 1 < n ? d[p + 1] : 0xD9;
-        if (nx == 0) {
-            dst[o++] = 0xFF;
-            p += 2;
-        } else if (nx >= 0xD0 && nx <= 0xD7) {
-            if (segs + 1 >= max_segs) break;  // more restart markers than the frame has intervals: the rest is not decoded
-            close();
-            p += 2;
-        } else if (nx == 0xFF) {              // fill byte before a marker
-            ++p;
-        } else {
-            break;                            // EOI or any other marker: the entropy-coded data ends here
-        }
-    }
-    close();
-    return segs;
-}
-
-void fill_dev_huff(const Huff& h, DevHuff& d) {
-    memset(&d, 0, sizeof d);
-    // every code of <= kFastBits bits fills its span of the look-up (codes are left-aligned in the index)
-    for (int ln = 1; ln <= kFastBits; ++ln) {
-        if (h.maxcode[ln] < 0) continue;
-        for (int code = h.mincode[ln]; code <= h.maxcode[ln]; ++code) {
-            const int sym = h.vals[h.valptr[ln] + code - h.mincode[ln]];
-            const int first = code << (kFastBits - ln), span = 1 << (kFastBits - ln);
-            for (int q = 0; q < span && first + q < (1 << kFastBits); ++q) d.fast[first + q] = (uint16_t)((ln << 8) | sym);
-        }
-    }
-    uint32_t run = 0;
-    for (int ln = 1; ln <= 16; ++ln) {
-        if (h.maxcode[ln] >= 0) run = std::max(run, (uint32_t)(h.maxcode[ln] + 1) << (16 - ln));
-        if (ln > kFastBits) d.lim[ln - kFastBits - 1] = run;
-    }
-    for (int i = 0; i < 17; ++i) {
-        d.valptr[i] = h.valptr[i];
-        d.mincode[i] = h.mincode[i];
-    }
-    memcpy(d.vals, h.vals, 256);
-}
-
 }  // namespace
 
 struct vq_jpeg {
@@ -980,35 +610,10 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
     //      did it), then sizes, layouts and where everything goes (serial, cheap)
     if (j->frames.size() < (size_t)n) j->frames.resize((size_t)n);
     Frame* fr = j->frames.data();
-    const int workers = std::max(1, std::min<int>({n, 16, (int)std::thread::hardware_concurrency()}));
-    std::vector<int> status((size_t)n, VQ_OK);
-    std::vector<std::string> message((size_t)n);
+    const int workers = batch_workers(n);
     {
-        auto parse = [&](int first) {
-            for (int i = first; i < n; i += workers) {
-                fr[i] = Frame();
-                if (!files[i] || sizes[i] <= 0) {
-                    status[i] = VQ_E_INVALID;
-                    message[i] = "file is empty";
-                    continue;
-                }
-                status[i] = parse_headers(files[i], (size_t)sizes[i], fr[i]);
-                if (status[i] != VQ_OK) {
-                    message[i] = last_error_ref();                        // thread-local message of this worker
-                } else if (fr[i].H != h || fr[i].W != w) {
-                    status[i] = VQ_E_INVALID;
-                    char buf[96];
-                    snprintf(buf, sizeof buf, "is %dx%d, the call decodes %dx%d frames", fr[i].W, fr[i].H, w, h);
-                    message[i] = buf;
-                }
-            }
-        };
-        std::vector<std::thread> pool;
-        for (int k = 1; k < workers; ++k) pool.emplace_back(parse, k);
-        parse(0);
-        for (std::thread& th : pool) th.join();
-        for (int i = 0; i < n; ++i)
-            if (status[i] != VQ_OK) return fail(status[i], "file %d: %s", i, message[i].c_str());
+        const int rc = parse_batch(files, sizes, n, h, w, fr, workers);
+        if (rc != VQ_OK) return rc;
     }
     std::vector<FrameDesc> desc((size_t)n);
     std::vector<uint16_t> qts((size_t)n * 4 * 64, 0);
@@ -1020,12 +625,9 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
         memset(&fd, 0, sizeof fd);
         fd.nc = f.nc;
         fd.mode = f.nc == 3 ? (f.hmax / f.comp[1].h == 2 ? (f.vmax / f.comp[1].v == 2 ? 2 : 1) : 0) : 0;
-        const bool single = f.nc == 1;
-        const int mx = single ? cdiv(w, 8) : cdiv(w, 8 * f.hmax), my = single ? cdiv(h, 8) : cdiv(h, 8 * f.vmax);
+        place_blocks(f, h, w);                        // blocks per row / column of every component plane
         for (int c = 0; c < f.nc; ++c) {
             Comp& cp = f.comp[c];
-            cp.bw = single ? mx : mx * cp.h;
-            cp.bh = single ? my : my * cp.v;
             PlaneDesc& pd = fd.pl[c];
             pd.coef_off = (unsigned)blocks;
             pd.first_block = (unsigned)blocks;
@@ -1086,38 +688,13 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
     // The coefficients travel in kCopyGroups pieces (frames [g n / G, (g + 1) n / G)): a piece is queued as soon as its frames are decoded
     // -- the workers walk the frames in index order, so the pieces finish roughly in order -- and the copies (4 ms for the 800 RGB
     // frames of a command-line batch) overlap the decoding of the later pieces instead of following it.
-    constexpr int kCopyGroups = 4;
-    std::atomic<int> group_done[kCopyGroups];
-    for (auto& g2 : group_done) g2.store(0);
-    auto group_of = [&](int i) { return (int)((long long)i * kCopyGroups / n); };
-    auto work = [&](int first) {
-        for (int i = first; i < n; i += workers) {
-            // the frame's blocks start from zero (only non-zero coefficients are written): cleared here, by the frame's own thread
-            const size_t b0 = comp_off[(size_t)i * 3], b1 = i + 1 < n ? comp_off[(size_t)(i + 1) * 3] : blocks;
-            memset(j->coef_host + b0 * 64, 0, (b1 - b0) * 64 * sizeof(int16_t));
-            status[i] = decode_scan(files[i], (size_t)sizes[i], fr[i], j->coef_host, &comp_off[(size_t)i * 3]);
-            if (status[i] != VQ_OK) message[i] = last_error_ref();       // thread-local message of this worker
-            group_done[group_of(i)].fetch_add(1, std::memory_order_release);
-        }
-    };
-    std::vector<std::thread> pool;
-    for (int k = 0; k < workers; ++k) pool.emplace_back(work, k);
     hipError_t copy_err = hipSuccess;
-    for (int g2 = 0; g2 < kCopyGroups; ++g2) {
-        int i0 = 0, i1 = 0;                                           // the group's frames
-        while (i0 < n && group_of(i0) < g2) ++i0;
-        i1 = i0;
-        while (i1 < n && group_of(i1) == g2) ++i1;
-        if (i1 == i0) continue;
-        while (group_done[g2].load(std::memory_order_acquire) < i1 - i0) std::this_thread::yield();
-        const size_t b0 = comp_off[(size_t)i0 * 3], b1 = i1 < n ? comp_off[(size_t)i1 * 3] : blocks;
+    const int drc = decode_batch(files, sizes, n, fr, j->coef_host, comp_off.data(), blocks, workers, 4, [&](size_t b0, size_t b1) {
         if (copy_err == hipSuccess)
             copy_err = hipMemcpyAsync(j->coef_dev + b0 * 64, j->coef_host + b0 * 64, (b1 - b0) * 64 * sizeof(int16_t), hipMemcpyHostToDevice, st);
-    }
-    for (std::thread& th : pool) th.join();
+    });
     VQ_HIP(copy_err);
-    for (int i = 0; i < n; ++i)
-        if (status[i] != VQ_OK) return fail(status[i], "file %d: %s", i, message[i].c_str());
+    if (drc != VQ_OK) return drc;
     lap("entropy decoding (threads) + copies queued");
     if (host_stamps) {
         VQ_HIP(hipStreamSynchronize(st));
@@ -1125,15 +702,9 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
     }
     } else {
     // ---- entropy decoding on the device: the host strips the byte stuffing and cuts the scans at the restart markers
-    std::vector<int> n_mcu((size_t)n), want_segs((size_t)n);
-    std::vector<size_t> region((size_t)n + 1, 0);                   // byte offset of every frame's region in the stream buffer
-    for (int i = 0; i < n; ++i) {
-        const Frame& f = fr[i];
-        const bool single = f.nc == 1;
-        n_mcu[i] = (single ? cdiv(w, 8) : cdiv(w, 8 * f.hmax)) * (single ? cdiv(h, 8) : cdiv(h, 8 * f.vmax));
-        want_segs[i] = f.ri ? cdiv(n_mcu[i], f.ri) : 1;
-        region[i + 1] = region[i] + (((size_t)sizes[i] - f.scan + 16 * ((size_t)want_segs[i] + 2)) + 3) / 4 * 4;
-    }
+    std::vector<int> n_mcu, want_segs;
+    std::vector<size_t> region;                                     // byte offset of every frame's region in the stream buffer
+    stream_regions(fr, sizes, n, h, w, n_mcu, want_segs, region);
     const size_t need_words = region[n] / 4 + 4;
     if (j->stream_words < need_words) {
         if (j->stream_host) (void)hipHostFree(j->stream_host);
@@ -1180,25 +751,11 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
         set_of[i] = found;
     }
     lap("table sets");
-    std::vector<std::vector<uint32_t>> seg_off((size_t)n), seg_len((size_t)n);
-    auto work = [&](int first) {
-        for (int i = first; i < n; i += workers) {
-            seg_off[i].assign((size_t)want_segs[i], 0);
-            seg_len[i].assign((size_t)want_segs[i], 0);
-            const int got = unstuff_scan(files[i], (size_t)sizes[i], fr[i].scan, reinterpret_cast<uint8_t*>(j->stream_host) + region[i], want_segs[i],
-                                         seg_off[i].data(), seg_len[i].data());
-            if (got < want_segs[i]) {
-                status[i] = VQ_E_INVALID;
-                message[i] = "JPEG: restart marker missing";
-            }
-        }
-    };
-    std::vector<std::thread> pool;
-    for (int k = 1; k < workers; ++k) pool.emplace_back(work, k);
-    work(0);
-    for (std::thread& th : pool) th.join();
-    for (int i = 0; i < n; ++i)
-        if (status[i] != VQ_OK) return fail(status[i], "file %d: %s", i, message[i].c_str());
+    std::vector<std::vector<uint32_t>> seg_off, seg_len;
+    {
+        const int rc = unstuff_batch(files, sizes, n, fr, reinterpret_cast<uint8_t*>(j->stream_host), region.data(), want_segs.data(), seg_off, seg_len, workers);
+        if (rc != VQ_OK) return rc;
+    }
     lap("unstuffing (threads)");
     // streams grouped by table set, every group padded to whole waves
     std::vector<SegDesc> segs;
@@ -1305,38 +862,14 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
 int vq_jpeg_decode_files(vq_jpeg* j, const char* const* paths, int32_t n, int32_t color, int32_t h, int32_t w, uint8_t* out_host, uint8_t** out_dev,
                          void* hip_stream) {
     VQ_REQUIRE(j && paths && n > 0, "bad argument");
-    std::vector<std::vector<uint8_t>> data((size_t)n);
-    std::vector<int> bad((size_t)n, 0);
-    const int workers = std::max(1, std::min<int>({n, 16, (int)std::thread::hardware_concurrency()}));
-    auto work = [&](int first) {
-        for (int i = first; i < n; i += workers) {
-            FILE* f = paths[i] ? fopen(paths[i], "rb") : nullptr;
-            if (!f) {
-                bad[i] = 1;
-                continue;
-            }
-            if (fseek(f, 0, SEEK_END) == 0) {
-                const long sz = ftell(f);
-                if (sz > 0 && fseek(f, 0, SEEK_SET) == 0) {
-                    data[i].resize((size_t)sz);
-                    if (fread(data[i].data(), 1, (size_t)sz, f) != (size_t)sz) bad[i] = 1;
-                } else {
-                    bad[i] = 1;
-                }
-            } else {
-                bad[i] = 1;
-            }
-            fclose(f);
-        }
-    };
-    std::vector<std::thread> pool;
-    for (int k = 1; k < workers; ++k) pool.emplace_back(work, k);
-    work(0);
-    for (std::thread& th : pool) th.join();
+    std::vector<std::vector<uint8_t>> data;
+    {
+        const int rc = read_files(paths, n, data, batch_workers(n));
+        if (rc != VQ_OK) return rc;
+    }
     std::vector<const uint8_t*> ptrs((size_t)n);
     std::vector<int64_t> sizes((size_t)n);
     for (int i = 0; i < n; ++i) {
-        if (bad[i]) return fail(VQ_E_INVALID, "cannot read file %d: %s", i, paths[i] ? paths[i] : "(null)");
         ptrs[i] = data[i].data();
         sizes[i] = (int64_t)data[i].size();
     }

@@ -24,6 +24,7 @@
 
 #include "vq_common.h"
 #include "vq_tsn_kernels.h"
+#include "host/vq_block_pool.h"
 
 using namespace vq;
 
@@ -852,37 +853,18 @@ struct vq_tsn {
 // next one of the same shape in the process: on some hosts a hipMalloc of tens of GB right behind the hipFree of as much waits ~1 s for
 // the driver to reclaim the memory (seen as 1.2 s extractor builds in back-to-back command-line runs of one process).  A block is only
 // reused at its exact size on its device; whatever a forward reads it has written before.
-struct DevicePool {
-    std::mutex mu;
-    std::multimap<std::pair<int, size_t>, void*> blocks;
-    size_t held = 0, cap = 0;
-    DevicePool() {
-        const char* e = getenv("VQ_DEVICE_POOL_GB");
-        cap = (size_t)((e ? atof(e) : 40.0) * 1073741824.0);
-    }
-};
-static DevicePool& device_pool() {
-    static DevicePool p;
+// bookkeeping in csrc/host/vq_block_pool.cc (host-only, sanitizer-built); the HIP calls stay here
+static vq::BlockPool& device_pool() {
+    static vq::BlockPool p(vq::BlockPool::cap_from_env());
     return p;
 }
 void vq::device_pool_trim() {
-    DevicePool& dp = device_pool();
-    std::lock_guard<std::mutex> lk(dp.mu);
-    for (auto& kv : dp.blocks) (void)hipFree(kv.second);
-    dp.blocks.clear();
-    dp.held = 0;
+    for (void* blk : device_pool().drain()) (void)hipFree(blk);
 }
 static hipError_t pool_alloc(int device, size_t bytes, void** out) {
-    DevicePool& dp = device_pool();
-    {
-        std::lock_guard<std::mutex> lk(dp.mu);
-        auto it = dp.blocks.find({device, bytes});
-        if (it != dp.blocks.end()) {
-            *out = it->second;
-            dp.blocks.erase(it);
-            dp.held -= bytes;
-            return hipSuccess;
-        }
+    if (void* blk = device_pool().take(device, bytes)) {
+        *out = blk;
+        return hipSuccess;
     }
     hipError_t e = hipMalloc(out, bytes);
     if (e == hipErrorOutOfMemory) {                       // give the pooled blocks back and try once more
@@ -894,16 +876,7 @@ static hipError_t pool_alloc(int device, size_t bytes, void** out) {
 }
 static void pool_free(int device, void* p, size_t bytes) {
     if (!p) return;
-    DevicePool& dp = device_pool();
-    {
-        std::lock_guard<std::mutex> lk(dp.mu);
-        if (bytes >= (1u << 20) && dp.held + bytes <= dp.cap) {
-            dp.blocks.insert({{device, bytes}, p});
-            dp.held += bytes;
-            return;
-        }
-    }
-    (void)hipFree(p);
+    if (!device_pool().give(device, p, bytes)) (void)hipFree(p);
 }
 
 static void drop_graphs(vq_tsn* net) {
@@ -1698,7 +1671,9 @@ int vq_tsn_destroy(vq_tsn* net) {
     if (!net) return VQ_OK;
     {
         DeviceGuard g(net->device);
-        (void)hipStreamSynchronize(net->stream);
+        // everything that may still read or write the blocks must be done before the pool hands them to the next extractor: the
+        // handle's stream, its sub-batch streams, a stream set earlier (the hipFree this replaced waited for the whole device too)
+        (void)hipDeviceSynchronize();
         tsn_free(net);
     }
     delete net;
