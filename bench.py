@@ -578,26 +578,36 @@ def bench_flow(device_index, with_cpu):
         wr = m.warped(f0, f1)
     dw = (time.perf_counter() - t0) / reps
     prof = None
-    ppath = os.path.join(ROOT, "profiles", "r03_flow_summary.json")
-    if os.path.exists(ppath):
-        with open(ppath) as f:
-            prof = json.load(f)
+    for name in ("r04_flow_summary.json", "r03_flow_summary.json"):
+        ppath = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(ppath):
+            with open(ppath) as f:
+                prof = json.load(f)
+            prof["file"] = name
+            break
+    # The blocked kernel is bound by vector-ALU issue, not by bandwidth (five correctly rounded divisions and two square roots per pixel and
+    # iteration; the fields stay on chip between the 4 iterations of a launch).  achieved = wave instructions per second: the committed
+    # PMC pass's SQ_INSTS_VALU per pixel-iteration (the instruction count of an iteration does not depend on the run) x this run's
+    # pixel-iterations / this run's device time of the inner loops; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction.
+    peak_valu = 256 * 4 * 2.4e9 / 4 / 1e9
+    per_pi = (prof or {}).get("valu_wave_insts_per_pixel_iteration")
+    flow_roof = {"kernel": "tvl1_block_kernel<64,1024> (4 inner iterations per launch on tiles resident in registers / LDS)",
+                 "avg_launch_ms": inner_ms / max(launches, 1), "pixel_iterations_per_second": pixel_iters / inner_ms * 1e3,
+                 "traffic": prof.get("hbm_bytes_per_batch") if prof else None, "hbm_GBps_algorithmic": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
+                 "bytes_per_batch": abytes,
+                 "pmc_source": ("profiles/%s (separate rocprofv3 --pmc passes of tools/flow_profile.py: SQ_INSTS_VALU / GRBM_GUI_ACTIVE, FETCH_SIZE x2, "
+                                "WRITE_SIZE; committed, not collected in this run)" % prof["file"]) if prof else None}
+    if per_pi:
+        wips = per_pi * pixel_iters / inner_ms / 1e6                                  # G wave-instructions / s
+        flow_roof.update({"bound": "valu", "achieved": wips, "peak": peak_valu, "unit": "G wave-inst/s", "frac": wips / peak_valu,
+                          "valu_thread_insts_per_pixel_iteration": per_pi * 64, "pmc_valu_issue_utilisation": prof.get("valu_issue_utilisation")})
+    else:                                                                              # no VALU pass committed yet: the byte figure only
+        flow_roof.update({"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS})
     out = {"metric": "frame pairs/sec TV-L1 flow (340x256, OpenCV default parameters)", "value": n / dt, "unit": "pairs/s",
            "batch_pairs": n, "ms_per_batch": dt * 1e3, "mean_inner_iterations_per_warp": float(its.mean()),
            "pixel_iterations_per_batch": pixel_iters, "iteration_launches_per_batch": launches,
            "inner_loops_device_ms_per_batch": inner_ms,
-           "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                        "traffic": prof.get("hbm_bytes_per_batch") if prof else None,
-                        "traffic_source": "profiles/r03_flow_summary.json (separate rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes of "
-                                          "tools/flow_profile.py, committed; not collected in this run)" if prof else None,
-                        "kernel": "tvl1_block_kernel<64,1024> (4 inner iterations per launch on tiles resident in registers / LDS)",
-                        "avg_launch_ms": inner_ms / max(launches, 1), "bytes_per_batch": abytes,
-                        "pixel_iterations_per_second": pixel_iters / inner_ms * 1e3,
-                        "note": "achieved = algorithmic bytes of the blocks actually run / device time of the inner loops (HIP events "
-                                "around every loop: the iteration kernels and the idle gaps between their launches).  The blocked kernel "
-                                "is NOT bandwidth-bound any more: five correctly rounded divisions and two square roots per pixel and "
-                                "iteration on the vector unit set its time; the low fraction says that the fields stay on chip, not "
-                                "that bandwidth is wasted"},
+           "roofline": flow_roof,
            "warped": {"value": n / dw, "unit": "pairs/s", "ms_per_batch": dw * 1e3, "mean_corners": float(wr["matches"].mean()),
                       "mean_inliers": float(wr["inliers"].mean()),
                       "note": "first-pass flow + corners + RANSAC homography + second-pass flow on the compensated frame"},

@@ -413,6 +413,20 @@ def test_packed_weight_cache_skips_the_loader_and_returns_the_same_blob(tmp_path
         f.write_bytes(f.read_bytes()[:1000])
     tnet.TsnNet(g, loader(2), cache_key="synthetic:2")
     assert loads[-1] == 2 and len(loads) == 5 and (seen["blob"] == first["blob"]).all()
+    # ... also when the file keeps its size and only a value changed (the stored checksum no longer matches) ...
+    tnet.TsnNet(g, loader(2), cache_key="synthetic:2")                           # entry rewritten by the handle above: a hit again
+    assert len(loads) == 5
+    for f in (tmp_path / "wc").glob("*.npy"):
+        raw = bytearray(f.read_bytes())
+        raw[-8] ^= 0x40
+        f.write_bytes(bytes(raw))
+    tnet.TsnNet(g, loader(2), cache_key="synthetic:2")
+    assert len(loads) == 6 and (seen["blob"] == first["blob"]).all()
+    # ... and an entry written by OTHER packing code is never found: the key carries a digest of the packing sources
+    n_entries = len(list((tmp_path / "wc").glob("*.json")))
+    monkeypatch.setattr(tnet, "_PACKER_DIGEST", "as if net.py had been edited")
+    tnet.TsnNet(g, loader(2), cache_key="synthetic:2")
+    assert len(loads) == 7 and len(list((tmp_path / "wc").glob("*.json"))) == n_entries + 1
 
 
 def test_native_row_formatter_prints_like_str_of_numpy_float64():

@@ -8,7 +8,9 @@ fam = {}
 for r in csv.DictReader(open(stats)):
     name = r["Name"]
     key = ("conv direct (conv_igemm*)" if "conv_igemm" in name else "conv winograd (wino_f2x2_3x3, incl. the pooling that rides along)" if "wino_f2x2" in name
-           else "scan_kernel" if "scan_kernel" in name else "batch_fused_kernel (16-query pass)" if "batch_fused" in name
+           else "scan_tiled_kernel" if "scan_tiled_kernel" in name else "scan_kernel (row-major block, before the in-place tiling)" if "scan_kernel" in name
+           else "batch_fused_kernel (16-query pass)" if "batch_fused" in name and "true>" in name
+           else "batch_fused_kernel on the row-major block" if "batch_fused" in name
            else "pool/gavgpool/preprocess/consensus" if any(k in name for k in ("pool_kernel", "gavgpool", "preprocess", "consensus"))
            else "other")
     f = fam.setdefault(key, [0, 0.0])
@@ -27,11 +29,11 @@ for k in ("direct", "winograd"):
           % (k, fk[0], fk[1] / fk[0] / 1e6, bf["ms_per_step"] / bf["launches"], bf["launches"]))
 print("conv: rocprof avg launch %.4f ms over %d launches (%d per forward); bench.py HIP-event avg launch %.4f ms"
       % (t / c / 1e6, c, b["roofline"]["launches_per_step"], b["roofline"]["avg_launch_ms"]))
-if "scan_kernel" in fam:
-    c, t = fam["scan_kernel"]
+if "scan_tiled_kernel" in fam:
+    c, t = fam["scan_tiled_kernel"]
     print("scan: rocprof avg launch %.4f ms over %d launches; bench.py HIP-event avg launch %.4f ms"
           % (t / c / 1e6, c, b["similarity"]["roofline"]["avg_launch_ms"]))
-bk = [k for k in fam if k.startswith("batch_fused")]
+bk = [k for k in fam if k.startswith("batch_fused_kernel (16")]
 if bk and b.get("similarity", {}).get("batched"):
     c, t = fam[bk[0]]
     print("batched scan: rocprof avg launch %.4f ms over %d launches; bench.py HIP events around a pass (upload + launch) %.4f ms"

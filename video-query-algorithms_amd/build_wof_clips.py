@@ -194,6 +194,10 @@ def process_video(vid_path: str, out_path: str, flow_for, new_size=(0, 0), seed:
             put('{}/flow_x_{:05d}'.format(out_full_path, k), fx[j])
             put('{}/flow_y_{:05d}'.format(out_full_path, k), fy[j])
         done += len(window)
+        # the encoders are slower than the flow: at most two windows of images wait for them (each pending job holds a frame or a
+        # flow plane), so a long video never sits in host memory as a whole
+        while len(jobs) > 2 * 3 * max_pairs:
+            jobs.pop(0).result()
 
     for i, (frame, g) in enumerate(iter_video_ahead(vid_path)):
         if flow is None:
@@ -280,7 +284,7 @@ def main(argv=None, program=None) -> int:
     writers = ThreadPoolExecutor(max_workers=max(1, args.num_worker // world)) if args.num_worker > 1 else None
     mine = [(vid_id, vid_path) for vid_id, vid_path in enumerate(vid_list) if vid_id % world == rank]
     for vid_id, vid_path in mine:                                               # the seed is the video's GLOBAL index: the
-        n = process_video(vid_path, args.out_dir, flow_for, new_size, seed=vid_id, max_pairs=args.max_pairs, writers=writers)   # files do not depend on --num_gpu
+        n = process_video(vid_path, args.out_dir, flow_for, new_size, seed=(vid_id * 2654435761) & 0xFFFFFFFF, max_pairs=args.max_pairs, writers=writers)   # files do not depend on --num_gpu
         print('warp + rgb for {} {} done ({} frames)'.format(vid_id, os.path.basename(os.path.normpath(vid_path)), n))
         sys.stdout.flush()
     for _, vid_path in mine:                                                    # build_wof_clips.py:188-191

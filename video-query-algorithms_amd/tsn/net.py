@@ -109,8 +109,29 @@ def s2d_stem_weights(W: np.ndarray) -> np.ndarray:
     return out
 
 
+_PACKER_DIGEST = None
+
+
+def packer_digest() -> str:
+    """Names the CODE that turns weights into the packed blob and the layer table: this module (BN folding, Winograd filters, the
+    space-to-depth stem, the LayerDesc fields it fills) and the plan builder (tsn/bn_inception.py: fusion, slots, channel offsets),
+    plus the ctypes layout of the descriptors.  Part of the weight-cache key: a change to any of them makes every cached blob
+    unreachable instead of silently wrong (a stale tiling table costs time; a stale blob would cost the features)."""
+    global _PACKER_DIGEST
+    if _PACKER_DIGEST is None:
+        h = hashlib.sha1()
+        here = os.path.dirname(os.path.abspath(__file__))
+        for name in ("net.py", "bn_inception.py"):
+            with open(os.path.join(here, name), "rb") as f:
+                h.update(f.read())
+        h.update(repr([(n, t.__name__) for n, t in LayerDesc._fields_] + [(n, t.__name__) for n, t in ConvSegment._fields_]).encode())
+        _PACKER_DIGEST = h.hexdigest()
+    return _PACKER_DIGEST
+
+
 def _load_packed(path: str, n_ops: int):
-    """(blob, layers, segments, conv_kp) of a packed network from the weight cache, or None."""
+    """(blob, layers, segments, conv_kp) of a packed network from the weight cache, or None -- also when the blob's bytes do not
+    have the checksum stored with them (a torn or edited file)."""
     try:
         with open(path + ".json") as f:
             meta = json.load(f)
@@ -118,6 +139,9 @@ def _load_packed(path: str, n_ops: int):
             return None
         blob = np.load(path + ".npy", mmap_mode="r", allow_pickle=False)
         if blob.dtype != np.float32 or blob.ndim != 1 or blob.size != meta["blob_floats"]:
+            return None
+        blob = np.ascontiguousarray(blob)
+        if hashlib.sha1(blob.view(np.uint8)).hexdigest() != meta["blob_sha1"]:
             return None
         layers = (LayerDesc * n_ops).from_buffer_copy(bytes.fromhex(meta["layers"]))
         n_seg = meta["n_segments"]
@@ -137,7 +161,8 @@ def _store_packed(path: str, blob, layers, seg_list, conv_kp) -> None:
             np.save(f, blob, allow_pickle=False)
         os.replace(tmp + ".npy", path + ".npy")
         segs = (ConvSegment * max(len(seg_list), 1))(*seg_list)
-        meta = {"n_ops": len(layers), "blob_floats": int(blob.size), "layers": bytes(layers).hex(), "n_segments": len(seg_list),
+        meta = {"n_ops": len(layers), "blob_floats": int(blob.size), "blob_sha1": hashlib.sha1(np.ascontiguousarray(blob).view(np.uint8)).hexdigest(),
+                "layers": bytes(layers).hex(), "n_segments": len(seg_list),
                 "segments": bytes(segs).hex() if seg_list else "", "conv_kp": {str(k): int(v) for k, v in conv_kp.items()}}
         with open(tmp + ".json", "w") as f:
             json.dump(meta, f)
@@ -192,7 +217,7 @@ class TsnNet:
         cache_file = None
         where = os.environ.get("VQ_WEIGHT_CACHE", os.path.join(os.path.dirname(_lib.LIB_PATH), ".weight_cache"))
         if cache_key is not None and where != "0":
-            opts = [_lib.ABI_VERSION, BK, cache_key, repr(plan.ops), repr(plan.tensors), bool(self.winograd), bool(self.stem_s2d), float(bn_eps), cin_pad]
+            opts = [_lib.ABI_VERSION, packer_digest(), BK, cache_key, repr(plan.ops), repr(plan.tensors), bool(self.winograd), bool(self.stem_s2d), float(bn_eps), cin_pad]
             cache_file = os.path.join(where, hashlib.sha1(json.dumps(opts).encode()).hexdigest()[:24])
         cached = _load_packed(cache_file, len(plan.ops)) if cache_file else None
         if cached is not None:
