@@ -132,24 +132,22 @@ def _fan_out(args, argv, program):
 
 
 class _CropPipeline:
-    """--device_jpeg: the device crops of the batches AHEAD of the network, across the streams.  The batches of all streams form one
-    work list (RGB batches, then flow batches); up to ``ahead`` of them beyond the one the network asks for are in preparation on
+    """--device_jpeg: the device crops of the batches AHEAD of the network, across the streams.  The (stream, batch) items form one
+    work list (``order``); up to ``ahead`` of them beyond the one the network asks for are in preparation on
     two threads -- lists of undecoded files in, device crops out (tsn/ingest.py; the library's calls release the interpreter; the two
     lanes own a decoder and a HIP stream each, so one batch's host half -- reading the files, stripping the byte stuffing --
     overlaps the other's device half).  Nothing here needs an extractor: the first batches are prepared while the extractors are
     still being built, and the flow stream's first batches while the RGB stream's last ones are in the network."""
 
-    def __init__(self, ingests, batches, load_clip, file_pool, ahead=2):
+    def __init__(self, ingests, batches, order, load_clip, file_pool, ahead=3):
         from concurrent.futures import ThreadPoolExecutor
-        self.ingests, self.batches, self.load_clip, self.file_pool, self.ahead = ingests, batches, load_clip, file_pool, ahead
-        self.order = [(si, bi) for si in range(len(batches)) for bi in range(len(batches[si]))]
-        self.index = {key: k for k, key in enumerate(self.order)}
+        self.ingests, self.batches, self.order, self.load_clip, self.file_pool, self.ahead = ingests, batches, order, load_clip, file_pool, ahead
         self.pool = ThreadPoolExecutor(max_workers=2)
         self.jobs, self.submitted = {}, 0
 
     def _prepare(self, k):
         si, bi = self.order[k]
-        lists = [f.result() for f in [self.file_pool.submit(self.load_clip, si, u) for u in self.batches[si][bi]]]
+        lists = [f.result() for f in [self.file_pool.submit(self.load_clip, si, u) for u in self.batches[bi]]]
         return self.ingests[si].crops_from_jpegs([f for c in lists for f in c], lane=k % 2)
 
     def start(self):
@@ -160,8 +158,7 @@ class _CropPipeline:
             self.jobs[self.submitted] = self.pool.submit(self._prepare, self.submitted)
             self.submitted += 1
 
-    def get(self, si, bi):
-        k = self.index[(si, bi)]
+    def get(self, k):
         self._fill(k)
         return self.jobs.pop(k).result()
 
@@ -250,66 +247,85 @@ def main(argv=None, net_factory=None, program=None):
         return load(f_info[0][vid], ticks, frame_cnt, s['stack_depth'], args.flow_x_prefix, args.flow_y_prefix, args.frame_ext, **host_rule)
 
     batches = [units[b0:min(b0 + args.batch_clips, first + count)] for b0 in range(first, first + count, args.batch_clips)]
+    n_streams = len(streamCNN)
+    # The order of the work.  Host decoding: stream by stream, as the reference does (all RGB batches, then all flow batches).
+    # --device_jpeg: batch by batch, the RGB and the flow half of a batch behind each other -- the preparation of a flow batch (8 000
+    # files at the reference's defaults) then has a whole batch of BOTH networks to hide behind instead of one flow forward, and a long
+    # job is bound by the networks from its first batch to its last.  Features do not depend on the order.
     crop_pipe = None
     if device_jpeg and count:
+        order = [(si, bi) for bi in range(len(batches)) for si in range(n_streams)]
         crop_pipe = _CropPipeline([FrameIngest(3 if s['modality'] == 'rgb' else 2 * s['stack_depth'], device, rule) for s in streamCNN],
-                                  [batches] * len(streamCNN), load_clip, pool)
+                                  batches, order, load_clip, pool)
         crop_pipe.start()                            # the first batches are read and decoded while the extractors are being built
+    else:
+        order = [(si, bi) for si in range(n_streams) for bi in range(len(batches))]
+    nets = [None] * n_streams
+    mine = [[[] for _ in members] for _ in streamCNN]
+    waited = [{'files': 0.0, 'crops': 0.0, 'nets': 0.0} for _ in streamCNN]     # VQ_CLI_TRACE=1: where the loop waited, per stream
+    pending = {}                                     # host decoding: (si, bi) -> futures of the batch's clips, one batch ahead
+
+    def submit_files(k):
+        if k < len(order) and not crop_pipe:
+            si, bi = order[k]
+            pending[(si, bi)] = [pool.submit(load_clip, si, u) for u in batches[bi]]
+
+    def through_the_nets(si, make):
+        """One batch through every member's network of stream si: ``make(net)`` hands a net the batch (decoded, resized and cropped
+        once, whatever the number of members)."""
+        t0 = time.perf_counter()
+        for mi, net in enumerate(nets[si]):
+            mine[si][mi].append(make(net))
+        waited[si]['nets'] += time.perf_counter() - t0
+
+    t_loop = time.perf_counter()
+    submit_files(0)
+    for k, (si, bi) in enumerate(order):
+        s, batch = streamCNN[si], batches[bi]
+        if nets[si] is None:
+            nets[si] = [net_jobs[(s['modality'], mi)].result() for mi in range(len(members))]
+        crops = []
+        if not crop_pipe:
+            # --num_worker decoder threads (the reference runs that many worker PROCESSES, each with its own net,
+            # calcSig_wOF.py:204-210); the batch after the one on the GPU is decoded meanwhile
+            t0 = time.perf_counter()
+            crops = [f.result() for f in pending.pop((si, bi))]
+            waited[si]['files'] += time.perf_counter() - t0
+            submit_files(k + 1)
+        for _vi, vid in batch:
+            print('video {} for {} modality done'.format(vid, s['modality']))
+        if crop_pipe:
+            t0 = time.perf_counter()
+            dev_crops = crop_pipe.get(k)
+            waited[si]['crops'] += time.perf_counter() - t0
+            through_the_nets(si, lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu))
+        elif not crops:
+            continue
+        elif args.host_resize:
+            block = np.concatenate(crops, axis=0)
+            through_the_nets(si, lambda net: net.extract_clips(block, T, on_device=on_gpu))
+        else:
+            # resize + crop on the GPU, once per batch; clips of different frame sizes in one batch go one by one
+            groups = [np.concatenate(crops, axis=0)] if len({c.shape[1:] for c in crops}) == 1 else crops
+            for g in groups:
+                if len(nets[si]) == 1:
+                    through_the_nets(si, lambda net: net.extract_clips_from_frames(g, T, on_device=on_gpu))
+                else:
+                    per = args.batch_clips * T                      # = max_crops of the extractors
+                    for i in range(0, g.shape[0], per):
+                        dev_crops = nets[si][0].crops_from_frames(g[i:i + per])
+                        nets[si][0].sync_ingest()
+                        through_the_nets(si, lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu))
+    if os.environ.get("VQ_CLI_TRACE") == "1":
+        for si, s in enumerate(streamCNN):
+            print("trace: %s stream, %d batches (loop of both streams: %.3f s): waited %.3f s for file lists, %.3f s for device crops, %.3f s in the networks"
+                  % (s['modality'], len(batches), time.perf_counter() - t_loop, waited[si]['files'], waited[si]['crops'], waited[si]['nets']),
+                  file=sys.stderr, flush=True)
 
     for si, s in enumerate(streamCNN):
-        nets = [net_jobs[(s['modality'], mi)].result() for mi in range(len(members))] if count else []
-        mine = [[] for _ in members]
-        waited = {'files': 0.0, 'crops': 0.0, 'nets': 0.0}     # VQ_CLI_TRACE=1: where this stream's loop waited
-
-        def through_the_nets(make):
-            """One batch through every member's network: ``make(net)`` hands a net the batch (decoded, resized and cropped once,
-            whatever the number of members)."""
-            t0 = time.perf_counter()
-            for mi, net in enumerate(nets):
-                mine[mi].append(make(net))
-            waited['nets'] += time.perf_counter() - t0
-
-        # --num_worker decoder threads (the reference runs that many worker PROCESSES, each with its own net,
-        # calcSig_wOF.py:204-210); the batch after the one on the GPU is decoded meanwhile
-        pending = [pool.submit(load_clip, si, u) for u in batches[0]] if batches and not crop_pipe else []
-        t_stream = time.perf_counter()
-        for bi, batch in enumerate(batches):
-            crops = []
-            if not crop_pipe:
-                t0 = time.perf_counter()
-                crops = [f.result() for f in pending]
-                waited['files'] += time.perf_counter() - t0
-                pending = [pool.submit(load_clip, si, u) for u in batches[bi + 1]] if bi + 1 < len(batches) else []
-            for _vi, vid in batch:
-                print('video {} for {} modality done'.format(vid, s['modality']))
-            if crop_pipe:
-                t0 = time.perf_counter()
-                dev_crops = crop_pipe.get(si, bi)
-                waited['crops'] += time.perf_counter() - t0
-                through_the_nets(lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu))
-            elif not crops:
-                continue
-            elif args.host_resize:
-                block = np.concatenate(crops, axis=0)
-                through_the_nets(lambda net: net.extract_clips(block, T, on_device=on_gpu))
-            else:
-                # resize + crop on the GPU, once per batch; clips of different frame sizes in one batch go one by one
-                groups = [np.concatenate(crops, axis=0)] if len({c.shape[1:] for c in crops}) == 1 else crops
-                for g in groups:
-                    if len(nets) == 1:
-                        through_the_nets(lambda net: net.extract_clips_from_frames(g, T, on_device=on_gpu))
-                    else:
-                        per = args.batch_clips * T                      # = max_crops of the extractors
-                        for i in range(0, g.shape[0], per):
-                            dev_crops = nets[0].crops_from_frames(g[i:i + per])
-                            nets[0].sync_ingest()
-                            through_the_nets(lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu))
-        if os.environ.get("VQ_CLI_TRACE") == "1":
-            print("trace: %s stream, %d batches in %.3f s: waited %.3f s for file lists, %.3f s for device crops, %.3f s in the networks"
-                  % (s['modality'], len(batches), time.perf_counter() - t_stream, waited['files'], waited['crops'], waited['nets']), file=sys.stderr, flush=True)
         for mi, m in enumerate(members):
-            width = nets[mi].feature_dim if nets else args.featureBlob_size
-            local_feat = _stack_rows(mine[mi], width)
+            width = nets[si][mi].feature_dim if nets[si] else args.featureBlob_size
+            local_feat = _stack_rows(mine[si][mi], width)
             if world > 1:
                 import torch
                 if isinstance(local_feat, np.ndarray):       # host blocks, or a rank that owns no clip
@@ -331,7 +347,8 @@ def main(argv=None, net_factory=None, program=None):
                 csv_jobs.append(io_pool.submit(write_features, args.outFeatures_dir, video_path.split('/')[-2], video_path, m['modelname'],
                                                args.featureBlob, clip_list, {s['mode']: block},
                                                {'rgb': m['rgb'], 'warped_optical_flow': m['flow']}, args.number_format))
-        for n in nets:                               # this stream's device buffers go back to the pool: the next stream's nets take them
+    for per_stream in nets:
+        for n in per_stream or []:
             n.close()
     if crop_pipe:
         crop_pipe.close()
