@@ -40,7 +40,7 @@ class ConvSegment(C.Structure):
 
 
 class InputDesc(C.Structure):
-    _fields_ = [("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("s2d_pad", C.c_int32), ("s2d_kernel", C.c_int32)]
+    _fields_ = [("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("s2d_pad", C.c_int32), ("s2d_kernel", C.c_int32), ("s2d_order", C.c_int32)]
 
 
 class Tvl1Params(C.Structure):

@@ -73,7 +73,7 @@ __global__ void preprocess_s2d_kernel(const uint8_t* __restrict__ src, float* __
 // The RGB stem's form (C = 3): one thread per CELL -- its 2 x 2 pixels are two runs of 6 bytes, its 12 floats three 16-byte
 // stores; two divisions per thread instead of a dozen per chunk (32 us -> 17 us per 96-crop step).  Same values.
 __global__ __launch_bounds__(256) void preprocess_s2d3_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int64_t ncell, int H, int W,
-                                                              int Hs, int Ws, int pad, const float* __restrict__ mean) {
+                                                              int Hs, int Ws, int pad, const float* __restrict__ mean, int xmajor) {
     const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= ncell) return;
     const int X = (int)(cell % Ws);
@@ -93,9 +93,10 @@ __global__ __launch_bounds__(256) void preprocess_s2d3_kernel(const uint8_t* __r
             const bool in = row_in && (unsigned)x < (unsigned)W;
             const uint8_t* px = r + (in ? x : 0) * 3;
             const float a = (float)px[0] - m0, b = (float)px[1] - m1, c = (float)px[2] - m2;
-            v[(p * 2 + q) * 3 + 0] = in ? a : 0.0f;
-            v[(p * 2 + q) * 3 + 1] = in ? b : 0.0f;
-            v[(p * 2 + q) * 3 + 2] = in ? c : 0.0f;
+            const int slot = xmajor ? q * 2 + p : p * 2 + q;        // s2d_order 1: (q, p, c) -- the x-taps of a kernel row side by side
+            v[slot * 3 + 0] = in ? a : 0.0f;
+            v[slot * 3 + 1] = in ? b : 0.0f;
+            v[slot * 3 + 2] = in ? c : 0.0f;
         }
     }
     floatx4* o = reinterpret_cast<floatx4*>(dst + cell * 12);
@@ -129,6 +130,9 @@ struct ConvArgs {
     int Ho, Wo, Cs_out, coff_out, Cout;
     int k, stride, pad;  // k kernel rows ...
     int kw;              // ... of kw taps each (= k, or 1 when a kernel row is folded into the channel axis, see launch_conv_layer)
+    int col_off;         // aligned mode: floats between the 16-byte chunk columns of a staged row (4 = consecutive channels), and
+    int c_step;          // floats the channel offset advances per K-step (BK).  The x-major space-to-depth stem stages ROW r of its
+                         // four kernel rows in chunk column r instead: col_off = the slot's row pitch, c_step = 4 (launch_conv_layer)
     int M, Kp, relu;
     int out_row0;        // first output row (pixel) of this launch inside the destination slots (sub-batch launches)
     int pool_k, pool_s;  // POOL kernels: the 1x1 convolution reads max over a pool_k x pool_k window (stride pool_s, no padding,
@@ -273,24 +277,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             } else if (POOL) {                                                                                     \
                 /* 3x3 window: taps outside the image re-read the window's first pixel (max is unchanged) */      \
                 const bool ok = a_ih0[i] >= 0;                                                                     \
-                if (ok) src = a_img[i] + ((size_t)a_ih0[i] * a.W + a_iw0[i]) * a.Cs_in + c0 + a_col[i] * 4;        \
+                if (ok) src = a_img[i] + ((size_t)a_ih0[i] * a.W + a_iw0[i]) * a.Cs_in + c0 + a_col[i] * a.col_off; \
                 _Pragma("unroll") for (int t = 1; t < 9; ++t) {                                                    \
                     const int ih = a_ih0[i] + t / 3, iw = a_iw0[i] + t % 3;                                        \
                     const float* q = src;                                                                          \
-                    if (ok && ih < a.H && iw < a.W) q = a_img[i] + ((size_t)ih * a.W + iw) * a.Cs_in + c0 + a_col[i] * 4; \
+                    if (ok && ih < a.H && iw < a.W) q = a_img[i] + ((size_t)ih * a.W + iw) * a.Cs_in + c0 + a_col[i] * a.col_off; \
                     rp[i][t - 1] = *reinterpret_cast<const floatx4*>(q);                                           \
                 }                                                                                                  \
             } else {                                                                                               \
                 const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;                                                  \
                 if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)                                  \
-                    src = a_img[i] + ((size_t)ih * a.W + iw) * a.Cs_in + c0 + a_col[i] * 4;                        \
+                    src = a_img[i] + ((size_t)ih * a.W + iw) * a.Cs_in + c0 + a_col[i] * a.col_off;                \
             }                                                                                                      \
             ra[i] = *reinterpret_cast<const floatx4*>(src);                                                        \
         }                                                                                                          \
         _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                             \
             rb[i] = *reinterpret_cast<const floatx4*>(b_ok[i] ? b_ptr[i] + (size_t)(KC) * BK : a.zeros);           \
         if (!SMALL_CIN) {                                                                                          \
-            c0 += BK;                                                                                              \
+            c0 += a.c_step ? a.c_step : BK;                                                                        \
             if (c0 >= a.Cin) {                                                                                     \
                 c0 = 0;                                                                                            \
                 if (++kw == a.kw) {                                                                                \
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
         const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
         // aligned mode: the chunk column is a channel offset inside the tap; small-Cin mode: it selects the tap itself
-        a_off[i] = (((n_img * a.H + ih0) * a.W + iw0) * a.Cs_in + a.coff_in + (SMALL_CIN ? 0 : a_col[i] * 4)) * 4;
+        a_off[i] = (((n_img * a.H + ih0) * a.W + iw0) * a.Cs_in + a.coff_in + (SMALL_CIN ? 0 : a_col[i] * a.col_off)) * 4;
         unsigned long long mask = 0;
         for (int th = 0; th < a.k; ++th)
             for (int tw = 0; tw < a.kw; ++tw)
@@ -468,6 +472,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) a_voff[i] = ((a_mask[i] >> tap) & 1ull) ? (unsigned)(a_off[i] + tap_pix0) : 0xFFFFFFFFu;
     }
+    const int c_step = a.c_step ? a.c_step : BK;
     const unsigned cpt = (unsigned)a.Cin >> 2, inv_cpt = 65536u / cpt + 1u, inv_k = 65536u / (unsigned)a.kw + 1u;   // small-Cin decode
 
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     }
 #define VQ_ADVANCE_TAP()                                                                     \
     if (!SMALL_CIN) {                                                                        \
-        c0 += BK;                                                                            \
+        c0 += c_step;                                                                        \
         if (c0 >= a.Cin) {                                                                   \
             c0 = 0;                                                                          \
             ++tap;                                                                           \
@@ -1033,6 +1038,8 @@ static void fill_conv_args(vq_tsn* net, int li, int n_crops, ConvArgs& a) {
     a.Cout = L.cout;
     a.k = L.k;
     a.kw = L.k;
+    a.col_off = 4;
+    a.c_step = 0;        // 0: the kernel's BK
     a.stride = L.stride;
     a.pad = L.pad;
     a.M = n_crops * td.h * td.w;
@@ -1057,7 +1064,21 @@ static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
     // row into the channel axis -- k rows of one tap with kw*Cin channels.  The space-to-depth stem (4x4 over 12
     // channels) becomes 4 taps of 48 contiguous floats and, with BK = 16, runs on the aligned path: no per-chunk tap
     // decoding in its K loop.
-    if (L.pad == 0 && L.k > 1 && L.cin == net->tensors[L.src].c && L.src_coff == 0) {
+    const bool stem_rows = L.src == 0 && net->input.s2d_pad >= 0 && net->input.s2d_order == 1;
+    if (stem_rows) {
+        // The x-major space-to-depth stem (vq_input_desc.s2d_order = 1): a kernel row is 7 x-taps x (2 rows x 3 channels) = 42 contiguous
+        // floats of the slot (+ 2 of the next pixel against zero weights = 44), and the weights are packed [Cout][11 steps][4 rows][4]:
+        // chunk column r of a staged row holds kernel row r, every K-step advances 4 floats along all four rows at once.  K = 176
+        // instead of the 192 of the (p,q,c) order (whose zero taps are scattered through every 16-float step): one K-step of twelve
+        // less, with the address arithmetic of the aligned path (a per-lane row offset fixed for the whole loop, a uniform scalar
+        // offset per step).
+        a.k = a.kw = 1;
+        a.Cin = 4 * L.k * L.cin;                       // never reached: the walk stays inside its one "tap"
+        a.col_off = net->tensors[L.src].w * net->tensors[L.src].c;
+        a.c_step = 4;
+        a.Kp = 176;
+        a.w_bytes = (unsigned)((size_t)L.cout * a.Kp * sizeof(float));
+    } else if (L.pad == 0 && L.k > 1 && L.cin == net->tensors[L.src].c && L.src_coff == 0) {
         a.kw = 1;
         a.Cin = L.k * L.cin;
     }
@@ -1067,6 +1088,11 @@ static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
         ConvTile t = kTiles[tile_idx];
         if (!pool_tile_ok(t)) t = ConvTile{t.bm, t.bn, 16, 0};
         return launch_conv_pool(net, a, t);
+    }
+    if (stem_rows) {                                   // four chunk columns = four kernel rows: BK = 16 tilings only (same bits for all)
+        ConvTile t = kTiles[tile_idx];
+        t.bk = 16;
+        return t.pipe ? launch_conv_pipe<false>(net, a, t) : launch_conv<false>(net, a, t);
     }
     const bool small = (a.Cin % kTiles[tile_idx].bk) != 0;
     if (net->ksplit[li] > 1) {
@@ -1439,6 +1465,7 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
     } else {
         VQ_REQUIRE(tensors[0].c == 4 * in_channels, "space-to-depth input slot needs 4 x %d channels (got %d)", in_channels, tensors[0].c);
         VQ_REQUIRE(input->s2d_pad <= 64, "space-to-depth shift out of range");
+        VQ_REQUIRE(input->s2d_order == 0 || input->s2d_order == 1, "s2d_order must be 0 or 1");
     }
     // validate every layer against the tensor table BEFORE anything is launched: a mismatch here would be
     // an out-of-bounds access on the device
@@ -1487,7 +1514,13 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
             } else
             VQ_REQUIRE(td.h == (ts.h + 2 * L.pad - L.k) / L.stride + 1 && td.w == (ts.w + 2 * L.pad - L.k) / L.stride + 1,
                        "layer %d: conv output size mismatch", i);
-            const int64_t kp = (int64_t)(L.k * L.k * L.cin + KPAD - 1) / KPAD * KPAD;
+            int64_t kp = (int64_t)(L.k * L.k * L.cin + KPAD - 1) / KPAD * KPAD;
+            if (L.src == 0 && input->s2d_pad >= 0 && input->s2d_order == 1) {      // x-major stem: [Cout][11][4][4], see launch_conv_layer
+                VQ_REQUIRE(in_channels == 3 && L.k == 4 && L.cin == 12 && L.stride == 1 && L.pad == 0 && L.src_coff == 0 && L.pre_pool_k == 0 &&
+                               L.seg_count == 0 && input->s2d_kernel == 7,
+                           "layer %d: the x-major space-to-depth stem is the 7x7 / stride-2 convolution of a 3-channel crop", i);
+                kp = 176;
+            }
             VQ_REQUIRE(L.w_off >= 0 && L.w_off % 4 == 0 && L.w_off + (int64_t)L.cout * kp <= blob_floats,
                        "layer %d: weights outside the blob", i);
             VQ_REQUIRE(L.b_off >= 0 && L.b_off + L.cout <= blob_floats, "layer %d: bias outside the blob", i);
@@ -1701,7 +1734,7 @@ static int forward_launches(vq_tsn* net, const uint8_t* src, int n_crops, int T,
         const int64_t nchunk = (int64_t)n_crops * t0.h * t0.w * in_c;
         if (in_c == 3 && t0.c == 12)
             preprocess_s2d3_kernel<<<cdiv(nchunk / 3, 256), 256, 0, net->stream>>>(src, net->slots[0], nchunk / 3, net->input.h, net->input.w, t0.h, t0.w,
-                                                                                   net->input.s2d_pad, net->mean_dev);
+                                                                                   net->input.s2d_pad, net->mean_dev, net->input.s2d_order);
         else
             preprocess_s2d_kernel<<<cdiv(nchunk, 256), 256, 0, net->stream>>>(src, net->slots[0], nchunk, net->input.h, net->input.w, in_c,
                                                                             t0.h, t0.w, net->input.s2d_pad, net->mean_dev);

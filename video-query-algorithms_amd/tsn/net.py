@@ -109,6 +109,25 @@ def s2d_stem_weights(W: np.ndarray) -> np.ndarray:
     return out
 
 
+def s2d_stem_weights_xmajor(W: np.ndarray) -> np.ndarray:
+    """[Cout][3][7][7] of the stride-2 stem -> [Cout][176] for the x-major space-to-depth slot (vq_input_desc.s2d_order = 1:
+    slot0[Y][X][(q*2+p)*3 + ch] = crop[2Y+p-pad][2X+q-pad][ch]).  Kernel row r (cell rows r = 0..3) reads ONE run of the slot: x-tap
+    t = 0..6, then (p, ch) -- 42 floats, position 6t + 3p + ch -- plus two floats of the next pixel against zero weights.  The four
+    runs advance together, four floats per K-step: packed index 16 s + 4 r + e for run position 4 s + e.  Zero where 2r + p = 7."""
+    cout, c, k, _ = W.shape
+    if (c, k) != (3, 7):
+        raise ValueError("the x-major stem packing is for 3-channel 7x7 kernels")
+    out = np.zeros((cout, 11, 4, 4), dtype=W.dtype)
+    for r in range(4):
+        for t in range(7):
+            for p in range(2):
+                if 2 * r + p < k:
+                    for ch in range(c):
+                        pos = 6 * t + 3 * p + ch
+                        out[:, pos // 4, r, pos % 4] = W[:, ch, 2 * r + p, t]
+    return out.reshape(cout, 176)
+
+
 _PACKER_DIGEST = None
 
 
@@ -204,6 +223,8 @@ class TsnNet:
             if op.kind == "conv" and op.stride == 2 and not op.segments and op.k >= 3 and \
                     (mode == "2" or _round_up(k2 * k2 * 4 * self.in_channels, BK) <= 1.06 * _round_up(op.k * op.k * cin_pad, BK)):
                 self.stem_s2d = True
+        # x-major cells + row-interleaved packing (K = 176 instead of 192) for the RGB 7x7 stem; VQ_TSN_STEM_ORDER=0 keeps the (p,q,c) order
+        self.stem_xmajor = bool(self.stem_s2d and self.in_channels == 3 and stem[0].k == 7 and os.environ.get("VQ_TSN_STEM_ORDER", "1") != "0")
         in_slot_c = 4 * self.in_channels if self.stem_s2d else cin_pad
         tensors = (TensorDesc * len(plan.tensors))()
         for i, t in enumerate(plan.tensors):
@@ -217,7 +238,7 @@ class TsnNet:
         cache_file = None
         where = os.environ.get("VQ_WEIGHT_CACHE", os.path.join(os.path.dirname(_lib.LIB_PATH), ".weight_cache"))
         if cache_key is not None and where != "0":
-            opts = [_lib.ABI_VERSION, packer_digest(), BK, cache_key, repr(plan.ops), repr(plan.tensors), bool(self.winograd), bool(self.stem_s2d), float(bn_eps), cin_pad]
+            opts = [_lib.ABI_VERSION, packer_digest(), BK, cache_key, repr(plan.ops), repr(plan.tensors), bool(self.winograd), bool(self.stem_s2d), bool(self.stem_xmajor), float(bn_eps), cin_pad]
             cache_file = os.path.join(where, hashlib.sha1(json.dumps(opts).encode()).hexdigest()[:24])
         cached = _load_packed(cache_file, len(plan.ops)) if cache_file else None
         if cached is not None:
@@ -272,8 +293,11 @@ class TsnNet:
                         w2 = s2d_stem_weights(W)
                         cin_dev = in_slot_c
                         kdim = w2.shape[1] * w2.shape[2] * cin_dev
-                        packed = np.zeros((op.cout, _round_up(kdim, BK)), dtype=np.float32)
-                        packed[:, :kdim] = w2.reshape(op.cout, kdim)
+                        if self.stem_xmajor:
+                            packed = np.ascontiguousarray(s2d_stem_weights_xmajor(W), dtype=np.float32)
+                        else:
+                            packed = np.zeros((op.cout, _round_up(kdim, BK)), dtype=np.float32)
+                            packed[:, :kdim] = w2.reshape(op.cout, kdim)
                         if not op.bias:
                             b = np.zeros_like(b)
                         d.k, d.stride, d.pad = w2.shape[1], 1, 0
@@ -306,7 +330,8 @@ class TsnNet:
                 _store_packed(cache_file, blob, layers, seg_list, self.conv_kp)
         segs = (ConvSegment * max(len(seg_list), 1))(*seg_list)
         self._h = C.c_void_p()
-        inp = InputDesc(self.in_h, self.in_w, self.in_channels, stem[0].pad if self.stem_s2d else -1, stem[0].k if self.stem_s2d else 0)
+        inp = InputDesc(self.in_h, self.in_w, self.in_channels, stem[0].pad if self.stem_s2d else -1, stem[0].k if self.stem_s2d else 0,
+                        1 if self.stem_xmajor else 0)
         call("vq_tsn_create", tensors, len(plan.tensors), layers, len(plan.ops), segs, len(seg_list),
              blob.ctypes.data_as(C.c_void_p), blob.size, C.byref(inp), plan.feature_slot, self.max_crops, device,
              C.byref(self._h))
@@ -424,7 +449,8 @@ class TsnNet:
             img = np.zeros((n_crops, 2 * h, 2 * w, ci), dtype=np.float32)
             for p in range(2):
                 for q in range(2):
-                    img[:, p::2, q::2] = buf[..., (p * 2 + q) * ci:(p * 2 + q + 1) * ci]
+                    cell = (q * 2 + p) if self.stem_xmajor else (p * 2 + q)
+                    img[:, p::2, q::2] = buf[..., cell * ci:(cell + 1) * ci]
             return img[:, pad:pad + self.in_h, pad:pad + self.in_w]
         return buf[..., coff:coff + c]
 
