@@ -214,10 +214,10 @@ int run_bootstrap(const void* base_dev, int dtype, const std::vector<int64_t>& r
             return fail(e_ == hipErrorOutOfMemory ? VQ_E_NOMEM : VQ_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
         }                                                                                      \
     } while (0)
-    VQ_BOOT_HIP(hipMalloc((void**)&d_off, row_off_host.size() * sizeof(int64_t)));
-    VQ_BOOT_HIP(hipMalloc((void**)&d_cnt, (size_t)3 * P * sizeof(int32_t)));
-    VQ_BOOT_HIP(hipMalloc((void**)&d_ws, (size_t)P * ws_stride * sizeof(double)));
-    VQ_BOOT_HIP(hipMalloc((void**)&d_out, (size_t)P * D * sizeof(double)));
+    VQ_BOOT_HIP(vq::malloc_trim((void**)&d_off, row_off_host.size() * sizeof(int64_t)));
+    VQ_BOOT_HIP(vq::malloc_trim((void**)&d_cnt, (size_t)3 * P * sizeof(int32_t)));
+    VQ_BOOT_HIP(vq::malloc_trim((void**)&d_ws, (size_t)P * ws_stride * sizeof(double)));
+    VQ_BOOT_HIP(vq::malloc_trim((void**)&d_out, (size_t)P * D * sizeof(double)));
     VQ_BOOT_HIP(hipMemcpyAsync(d_off, row_off_host.data(), row_off_host.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
     VQ_BOOT_HIP(hipMemcpyAsync(d_cnt, n_valid, (size_t)P * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     VQ_BOOT_HIP(hipMemcpyAsync(d_cnt + P, n_invalid, (size_t)P * sizeof(int32_t), hipMemcpyHostToDevice, stream));
@@ -292,7 +292,7 @@ extern "C" int vq_bootstrap_targets(const void* rows_host, int32_t dtype, int32_
         for (int k = 0; k < n_valid[p] + n_invalid[p]; ++k) off[(size_t)p * stride + k] = (row++) * dim;
     const size_t esz = dtype == VQ_F64 ? 8 : 4;
     void* d_rows = nullptr;
-    VQ_HIP(hipMalloc(&d_rows, (size_t)total * dim * esz));
+    VQ_HIP(vq::malloc_trim(&d_rows, (size_t)total * dim * esz));
     hipError_t e = hipMemcpy(d_rows, rows_host, (size_t)total * dim * esz, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         (void)hipFree(d_rows);

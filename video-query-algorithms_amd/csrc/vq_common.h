@@ -97,4 +97,21 @@ int db_copy_scores_ordered(vq_db* db, double* dst_dev, int64_t* n_out, hipStream
 // (VQ_DEVICE_POOL_GB); this gives them back to the driver -- called by the other modules when an allocation of theirs runs out of memory.
 void device_pool_trim();
 
+// hipMalloc for everything the library allocates itself: when the device is out of memory the blocks that closed extractors left in
+// the pool go back to the driver and the allocation is tried once more (the pool must never be the reason another handle cannot grow).
+// Allocations made OUTSIDE the library (torch, the host application) cannot see the pool: VQ_DEVICE_POOL_GB bounds what it may hold.
+inline hipError_t malloc_trim(void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        device_pool_trim();
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+template <typename T>
+inline hipError_t malloc_trim(T** p, size_t bytes) {
+    return malloc_trim(reinterpret_cast<void**>(p), bytes);
+}
+
 }  // namespace vq

@@ -1009,30 +1009,30 @@ int vq_flow_create(int32_t max_pairs, int32_t h, int32_t w, const vq_tvl1_params
     };
     const size_t full = (size_t)max_pairs * h * w;
     hipError_t e;
-    if ((e = hipMalloc((void**)&f->pyr0, off * sizeof(float))) != hipSuccess) return bail("hipMalloc(pyramid)", e);
-    if ((e = hipMalloc((void**)&f->pyr1, off * sizeof(float))) != hipSuccess) return bail("hipMalloc(pyramid)", e);
+    if ((e = vq::malloc_trim((void**)&f->pyr0, off * sizeof(float))) != hipSuccess) return bail("vq::malloc_trim(pyramid)", e);
+    if ((e = vq::malloc_trim((void**)&f->pyr1, off * sizeof(float))) != hipSuccess) return bail("vq::malloc_trim(pyramid)", e);
     for (float*& p : f->plane)
-        if ((e = hipMalloc((void**)&p, full * sizeof(float))) != hipSuccess) return bail("hipMalloc(plane)", e);
+        if ((e = vq::malloc_trim((void**)&p, full * sizeof(float))) != hipSuccess) return bail("vq::malloc_trim(plane)", e);
     for (float*& p : f->tmp)
-        if ((e = hipMalloc((void**)&p, full * sizeof(float))) != hipSuccess) return bail("hipMalloc(plane)", e);
+        if ((e = vq::malloc_trim((void**)&p, full * sizeof(float))) != hipSuccess) return bail("vq::malloc_trim(plane)", e);
     for (float*& p : f->alt)
-        if ((e = hipMalloc((void**)&p, full * sizeof(float))) != hipSuccess) return bail("hipMalloc(plane)", e);
+        if ((e = vq::malloc_trim((void**)&p, full * sizeof(float))) != hipSuccess) return bail("vq::malloc_trim(plane)", e);
     for (int k = 0; k < 2; ++k) {
-        if ((e = hipMalloc((void**)&f->frames_dev[k], full)) != hipSuccess) return bail("hipMalloc(frames)", e);
-        if ((e = hipMalloc((void**)&f->img_dev[k], full)) != hipSuccess) return bail("hipMalloc(images)", e);
+        if ((e = vq::malloc_trim((void**)&f->frames_dev[k], full)) != hipSuccess) return bail("vq::malloc_trim(frames)", e);
+        if ((e = vq::malloc_trim((void**)&f->img_dev[k], full)) != hipSuccess) return bail("vq::malloc_trim(images)", e);
     }
-    if ((e = hipMalloc((void**)&f->st, (size_t)max_pairs * sizeof(PairState))) != hipSuccess) return bail("hipMalloc(state)", e);
-    if ((e = hipMalloc((void**)&f->n_active, sizeof(int))) != hipSuccess) return bail("hipMalloc(state)", e);
-    if ((e = hipMalloc((void**)&f->iters_log, (size_t)f->levels.size() * prm.warps * max_pairs * sizeof(int))) != hipSuccess)
-        return bail("hipMalloc(log)", e);
+    if ((e = vq::malloc_trim((void**)&f->st, (size_t)max_pairs * sizeof(PairState))) != hipSuccess) return bail("vq::malloc_trim(state)", e);
+    if ((e = vq::malloc_trim((void**)&f->n_active, sizeof(int))) != hipSuccess) return bail("vq::malloc_trim(state)", e);
+    if ((e = vq::malloc_trim((void**)&f->iters_log, (size_t)f->levels.size() * prm.warps * max_pairs * sizeof(int))) != hipSuccess)
+        return bail("vq::malloc_trim(log)", e);
     if ((e = hipHostMalloc((void**)&f->live_host, 2 * sizeof(int))) != hipSuccess) return bail("hipHostMalloc(poll)", e);
     for (hipEvent_t& ev : f->poll_ev)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     f->loop_ev.assign((size_t)2 * f->levels.size() * prm.warps, nullptr);
     for (hipEvent_t& ev : f->loop_ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipMalloc((void**)&f->hinv_dev, (size_t)max_pairs * 9 * sizeof(double))) != hipSuccess) return bail("hipMalloc(homographies)", e);
-    if ((e = hipMalloc((void**)&f->frame_max, (size_t)max_pairs * sizeof(unsigned))) != hipSuccess) return bail("hipMalloc(state)", e);
+    if ((e = vq::malloc_trim((void**)&f->hinv_dev, (size_t)max_pairs * 9 * sizeof(double))) != hipSuccess) return bail("vq::malloc_trim(homographies)", e);
+    if ((e = vq::malloc_trim((void**)&f->frame_max, (size_t)max_pairs * sizeof(unsigned))) != hipSuccess) return bail("vq::malloc_trim(state)", e);
     *out = f;
     return VQ_OK;
 }
@@ -1375,7 +1375,7 @@ static int good_features_core(vq_flow* f, const uint8_t* d, int n, int max_corne
     const int h = f->h, w = f->w;
     const int64_t full = (int64_t)n * h * w;
     for (float*& p : f->corner_plane)
-        if (!p) VQ_HIP(hipMalloc((void**)&p, (size_t)f->max_pairs * h * w * sizeof(float)));
+        if (!p) VQ_HIP(vq::malloc_trim((void**)&p, (size_t)f->max_pairs * h * w * sizeof(float)));
     float *strength = f->corner_plane[0], *peaks = f->corner_plane[1];
     VQ_HIP(hipMemsetAsync(f->frame_max, 0, (size_t)n * sizeof(unsigned), st));
     corner_strength_kernel<<<dim3((unsigned)cdiv((int64_t)h * w, 256), (unsigned)n), 256, 0, st>>>(d, strength, f->frame_max, n, h, w);
@@ -1432,7 +1432,7 @@ int vq_flow_ransac_homography(vq_flow* f, const float* src_host, const float* ds
         if (f->match_dev) (void)hipFree(f->match_dev);
         f->match_dev = nullptr;
         f->match_bytes = 0;
-        VQ_HIP(hipMalloc(&f->match_dev, need));
+        VQ_HIP(vq::malloc_trim(&f->match_dev, need));
         f->match_bytes = need;
     }
     char* base = (char*)f->match_dev;
@@ -1513,7 +1513,7 @@ int vq_flow_warped(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, i
         if (f->warp_dev) (void)hipFree(f->warp_dev);
         f->warp_dev = nullptr;
         f->warp_bytes = 0;
-        VQ_HIP(hipMalloc(&f->warp_dev, need));
+        VQ_HIP(vq::malloc_trim(&f->warp_dev, need));
         f->warp_bytes = need;
     }
     float* c_dev = (float*)f->warp_dev;

@@ -107,7 +107,7 @@ extern "C" int vq_resize_crop(const uint8_t* frames, int32_t frames_on_device, i
     uint8_t* staged = nullptr;
     if (!frames_on_device) {
         const size_t bytes = (size_t)n * h * w * c;
-        VQ_HIP(hipMalloc((void**)&staged, bytes));
+        VQ_HIP(vq::malloc_trim((void**)&staged, bytes));
         hipError_t e = hipMemcpyAsync(staged, frames, bytes, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) {
             (void)hipFree(staged);

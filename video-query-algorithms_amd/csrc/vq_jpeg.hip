@@ -523,7 +523,7 @@ int grow_dev(T** p, size_t* cap, size_t need) {
     *p = nullptr;
     *cap = 0;
     const size_t want = need + need / 4;
-    VQ_HIP(hipMalloc((void**)p, want));
+    VQ_HIP(vq::malloc_trim((void**)p, want));
     *cap = want;
     return VQ_OK;
 }
@@ -714,7 +714,7 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
         j->stream_words = 0;
         const size_t cap = need_words + need_words / 4;
         VQ_HIP(hipHostMalloc((void**)&j->stream_host, cap * 4));
-        VQ_HIP(hipMalloc((void**)&j->stream_dev, cap * 4));
+        VQ_HIP(vq::malloc_trim((void**)&j->stream_dev, cap * 4));
         j->stream_words = cap;
     }
     // table sets: the (DC, AC) tables of a frame's components; files of one writer share one set -- found by comparing the parsed
@@ -798,7 +798,7 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
         if (j->ent_dev) (void)hipFree(j->ent_dev);
         j->ent_dev = nullptr;
         j->ent_bytes = 0;
-        VQ_HIP(hipMalloc(&j->ent_dev, ent_need * 2));
+        VQ_HIP(vq::malloc_trim(&j->ent_dev, ent_need * 2));
         j->ent_bytes = ent_need * 2;
     }
     if (j->status_cap < segs.size()) {
@@ -817,7 +817,7 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
     VQ_HIP(hipMemcpyAsync(j->desc_dev, desc.data(), desc.size() * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
     lap("stream lists, copies queued");
     long long* stamps_dev = nullptr;                      // VQ_JPEG_STAMPS=1: where the two waves of a workgroup spend their cycles (stderr)
-    if (getenv("VQ_JPEG_STAMPS")) VQ_HIP(hipMalloc((void**)&stamps_dev, (size_t)n_seg_padded / 64 * 4 * sizeof(long long)));
+    if (getenv("VQ_JPEG_STAMPS")) VQ_HIP(vq::malloc_trim((void**)&stamps_dev, (size_t)n_seg_padded / 64 * 4 * sizeof(long long)));
     jpeg_entropy_idct_kernel<<<n_seg_padded / 64, 128, 0, st>>>(reinterpret_cast<const SegDesc*>(eb), reinterpret_cast<const EntFrame*>(eb + o_fr),
                                                                 j->desc_dev, reinterpret_cast<const DevTableSet*>(eb + o_set), j->stream_dev, j->qt_dev,
                                                                 j->planes_dev, reinterpret_cast<int*>(eb + o_stat), stamps_dev);

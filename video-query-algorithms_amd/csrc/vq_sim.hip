@@ -1226,7 +1226,7 @@ int vq_db_create(int64_t n, int32_t S, int32_t E, int32_t D, int32_t dtype, int3
         if (e_ != hipSuccess) {                           \
             db_free(db);                                  \
             delete db;                                    \
-            return fail(VQ_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", (size_t)(bytes), hipGetErrorString(e_)); \
+            return fail(VQ_E_NOMEM, "vq::malloc_trim(%zu bytes) failed: %s", (size_t)(bytes), hipGetErrorString(e_)); \
         }                                                 \
     } while (0)
     A_(db->feats, fbytes);
@@ -1288,7 +1288,7 @@ int vq_db_upload(vq_db* db, int64_t row0, int64_t nrows, const void* feats_host)
         // rows land in a staging block and are dealt into their tiles by a kernel, a bounded chunk at a time
         const int64_t chunk = std::max<int64_t>(1, (int64_t)(64u << 20) / (int64_t)row_bytes);
         void* stage = nullptr;
-        VQ_HIP(hipMalloc(&stage, (size_t)std::min<int64_t>(chunk, std::max<int64_t>(nrows, 1)) * row_bytes));
+        VQ_HIP(vq::malloc_trim(&stage, (size_t)std::min<int64_t>(chunk, std::max<int64_t>(nrows, 1)) * row_bytes));
         const int NV = db->S * db->E, d4 = db->D / 4;
         for (int64_t r = 0; r < nrows; r += chunk) {
             const int64_t k = std::min(chunk, nrows - r);
@@ -1336,7 +1336,7 @@ int vq_db_set_present(vq_db* db, const uint8_t* present_host) {
         if (db->present) VQ_HIP(hipFree(db->present));
         db->present = nullptr;
     } else {
-        if (!db->present) VQ_HIP(hipMalloc((void**)&db->present, bytes));
+        if (!db->present) VQ_HIP(vq::malloc_trim((void**)&db->present, bytes));
         VQ_HIP(hipMemcpyAsync(db->present, present_host, bytes, hipMemcpyHostToDevice, db->stream));
         VQ_HIP(hipStreamSynchronize(db->stream));
     }
@@ -1516,7 +1516,7 @@ int vq_db_scan(vq_db* db, const double* w_host, int32_t keep_sims) {
     std::lock_guard<std::mutex> lk(db->mu);
     if (!db->have_query) return fail(VQ_E_STATE, "vq_db_scan: no query set (call vq_db_set_query first)");
     DeviceGuard g(db->device);
-    if (keep_sims && !db->sims) VQ_HIP(hipMalloc((void**)&db->sims, (size_t)db->n * db->S * db->E * 8));
+    if (keep_sims && !db->sims) VQ_HIP(vq::malloc_trim((void**)&db->sims, (size_t)db->n * db->S * db->E * 8));
     if (w_host) VQ_HIP(hipMemcpyAsync(db->w, w_host, db->S * 8, hipMemcpyHostToDevice, db->stream));
     ScanArgs a;
     a.feats = db->feats;
@@ -1557,7 +1557,7 @@ int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const d
         if (db->batch_buf) VQ_HIP(hipFree(db->batch_buf));
         db->batch_buf = nullptr;
         db->batch_cap = 0;
-        VQ_HIP(hipMalloc((void**)&db->batch_buf, (size_t)need * 8));
+        VQ_HIP(vq::malloc_trim((void**)&db->batch_buf, (size_t)need * 8));
         db->batch_cap = need;
     }
     double* d_t = db->batch_buf;
@@ -1780,7 +1780,7 @@ static int ensure_grid_buf(vq_db* db, int64_t bytes) {
     if (db->grid_buf) VQ_HIP(hipFree(db->grid_buf));
     db->grid_buf = nullptr;
     db->grid_cap = 0;
-    VQ_HIP(hipMalloc((void**)&db->grid_buf, bytes));
+    VQ_HIP(vq::malloc_trim((void**)&db->grid_buf, bytes));
     db->grid_cap = bytes;
     return VQ_OK;
 }

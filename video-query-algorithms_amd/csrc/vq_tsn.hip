@@ -1644,8 +1644,8 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
                     table.push_back(ConvSeg{net->slots[L.dst] + L.dst_coff, tensors[L.dst].c, L.relu});
             }
         }
-        e = hipMalloc((void**)&net->seg_table, std::max<size_t>(table.size(), 1) * sizeof(ConvSeg));
-        if (e != hipSuccess) return bail("hipMalloc(destination tables)", e);
+        e = vq::malloc_trim((void**)&net->seg_table, std::max<size_t>(table.size(), 1) * sizeof(ConvSeg));
+        if (e != hipSuccess) return bail("vq::malloc_trim(destination tables)", e);
         e = hipMemcpy(net->seg_table, table.data(), table.size() * sizeof(ConvSeg), hipMemcpyHostToDevice);
         if (e != hipSuccess) return bail("hipMemcpy(destination tables)", e);
     }
@@ -1688,14 +1688,14 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
         e = hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming);
         if (e != hipSuccess) return bail("hipEventCreate(fork)", e);
     }
-    e = hipMalloc((void**)&net->zeros, 256);
-    if (e != hipSuccess) return bail("hipMalloc(zero page)", e);
+    e = vq::malloc_trim((void**)&net->zeros, 256);
+    if (e != hipSuccess) return bail("vq::malloc_trim(zero page)", e);
     e = hipMemset(net->zeros, 0, 256);
     if (e != hipSuccess) return bail("hipMemset(zero page)", e);
-    e = hipMalloc((void**)&net->mean_dev, (size_t)in_channels * sizeof(float));
-    if (e != hipSuccess) return bail("hipMalloc(mean)", e);
-    e = hipMalloc((void**)&net->feat_dev, (size_t)max_crops * net->D * sizeof(double));
-    if (e != hipSuccess) return bail("hipMalloc(features)", e);
+    e = vq::malloc_trim((void**)&net->mean_dev, (size_t)in_channels * sizeof(float));
+    if (e != hipSuccess) return bail("vq::malloc_trim(mean)", e);
+    e = vq::malloc_trim((void**)&net->feat_dev, (size_t)max_crops * net->D * sizeof(double));
+    if (e != hipSuccess) return bail("vq::malloc_trim(features)", e);
     *out = net;
     return VQ_OK;
 }
@@ -1793,7 +1793,7 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
             if (net->crops_dev) VQ_HIP(hipFree(net->crops_dev));
             net->crops_dev = nullptr;
             net->crops_cap = 0;
-            VQ_HIP(hipMalloc((void**)&net->crops_dev, bytes));
+            VQ_HIP(vq::malloc_trim((void**)&net->crops_dev, bytes));
             net->crops_cap = bytes;
         }
         VQ_HIP(hipMemcpyAsync(net->crops_dev, crops, bytes, hipMemcpyHostToDevice, net->stream));

@@ -82,6 +82,7 @@ class FrameIngest:
         # a stream of its own (non-blocking): the call may run in a thread of its own for a LATER batch while the network works on the
         # current one on the default stream -- decoding a batch of flow files keeps a few CUs busy for tens of milliseconds
         if st["stream"] is None:
+            # (a high-priority stream was tried for the decode kernels: no gain, 385-391 against 394-412 clips/s end to end)
             st["stream"] = torch.cuda.Stream(device=dev)
         ingest = st["stream"]
         stream = ingest.cuda_stream
