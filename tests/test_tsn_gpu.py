@@ -427,6 +427,67 @@ def test_calcsig_command_line_end_to_end(tsn, tmp_path):
             cn.close()
 
 
+def test_one_pass_ensemble_on_the_gpu_writes_the_bytes_of_separate_runs(tsn, tmp_path):
+    """calcSig_wOF_ensemble.sh:13-37 as ONE command (``--ensemble``): three weight sets fed from one decode on the real extractors --
+    two videos (batches straddle them), T = 3 -- must write, per member, the bytes a run of its own writes.  Once with decoded frames
+    resized on the GPU (one resize feeding three networks) and, where Pillow can make JPEG files, with ``--device_jpeg`` (the
+    work goes batch by batch through both streams there)."""
+    bi, net = tsn
+    from video_query_algorithms_amd import calcSig_wOF
+    from video_query_algorithms_amd.tsn import caffe_net, frames
+    rng = np.random.default_rng(17)
+    try:
+        from PIL import Image
+    except ImportError:
+        Image = None
+    protos = _write_protos(bi, tmp_path)
+    members = []
+    for k in (1, 2, 3):
+        files = {}
+        for name, c in (("rgb", 3), ("flow", 10)):
+            files[name] = str(tmp_path / ("ucf101_split%d_tsn_%s_bn.npz" % (k, name)))
+            caffe_net.save_weights(files[name], net.synthetic_weights(bi.bn_inception(c), seed=10 * k + c))
+        members.append(("UCF101_split%d" % k, files["rgb"], files["flow"]))
+
+    def tree(name, ext, write):
+        root = tmp_path / name
+        for video, clips in (("va", {"clip_0001": 6, "clip_0002": 8, "clip_0004": 6}), ("vb", {"clip_0003": 7})):
+            for clip, n in clips.items():
+                d = root / video / clip
+                d.mkdir(parents=True)
+                for i in range(1, n + 1):
+                    write(str(d / ("img_%05d%s" % (i, ext))), rng.integers(0, 256, (64, 96, 3), dtype=np.uint8))
+                    write(str(d / ("flow_x_%05d%s" % (i, ext))), rng.integers(0, 256, (64, 96), dtype=np.uint8))
+                    write(str(d / ("flow_y_%05d%s" % (i, ext))), rng.integers(0, 256, (64, 96), dtype=np.uint8))
+        return str(root)
+
+    def csvs(out):
+        found = {}
+        for dirpath, _, names in os.walk(out):
+            for fn in names:
+                found[os.path.relpath(os.path.join(dirpath, fn), out)] = open(os.path.join(dirpath, fn), "rb").read()
+        return found
+
+    cases = [("ppm", ".ppm", frames.write_pnm, [])]
+    if Image is not None:
+        cases.append(("jpg", ".jpg", lambda path, a: Image.fromarray(a).save(path, "JPEG", quality=92), ["--device_jpeg"]))
+    for label, ext, write, extra in cases:
+        root = tree("frames_" + label, ext, write)
+        common = ["--num_frame_per_video", "3", "--frame_ext", ext, "--batch_clips", "3", "--num_worker", "4"] + extra
+        want = {}
+        for name, w_rgb, w_flow in members:
+            out = str(tmp_path / ("sep_%s_%s" % (label, name)))
+            assert calcSig_wOF.main([root, protos["rgb"], w_rgb, protos["flow"], w_flow, "--outFeatures_dir", out, "--modelname", name] + common) == 0
+            want.update(csvs(out))
+        assert len(want) == 12 and len(set(want.values())) == 12            # 2 videos x 3 members x 2 streams, all different
+        out = str(tmp_path / ("ens_" + label))
+        argv = [root, protos["rgb"], members[0][1], protos["flow"], members[0][2], "--outFeatures_dir", out, "--modelname", members[0][0]] + common
+        for name, w_rgb, w_flow in members[1:]:
+            argv += ["--ensemble", name, w_rgb, w_flow]
+        assert calcSig_wOF.main(argv) == 0
+        assert csvs(out) == want
+
+
 def test_grouped_winograd_launches_do_not_change_a_bit(tsn, monkeypatch):
     """The Winograd convolutions of one dependency level (the 3x3 and the first double-3x3 arm of an inception module)
     and the level's pooling layer share one kernel launch.  VQ_TSN_GROUP=0 gives every layer its own launch: same bits
