@@ -12,7 +12,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 cd "$ROOT"
-python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err          # also warms the tiling cache
+python3 bench.py --details gpurun_out/${TAG}_bench_full.json > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err   # also warms the tiling cache
 rm -rf gpurun_out/prof_${TAG}
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${TAG} --output-format csv -- python3 bench.py --skip-cpu --profile-only \
     > gpurun_out/${TAG}_bench_under_rocprof.json 2> gpurun_out/${TAG}_bench_under_rocprof.err
