@@ -16,7 +16,7 @@ const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18,
 
 bool build_huff(const uint8_t* counts, const uint8_t* symbols, int n_symbols, Huff& h) {
     int code = 0, k = 0;
-    memset(&h, 0, sizeof h);             // every byte defined: identical tables of different files compare equal
+    memset(static_cast<void*>(&h), 0, sizeof h);             // every byte defined: identical tables of different files compare equal
     for (int ln = 1; ln <= 16; ++ln) {
         h.valptr[ln] = k;
         h.mincode[ln] = code;
