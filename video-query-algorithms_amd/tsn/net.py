@@ -148,6 +148,20 @@ def packer_digest() -> str:
     return _PACKER_DIGEST
 
 
+def _blob_hash(blob: np.ndarray, algo: str | None = None) -> str:
+    """``<algo>:<digest>`` of the packed blob's bytes: xxh3 where the module is there (5 ms for the 42 MB of a network; the check runs on
+    every cached build of an extractor), SHA-1 otherwise (37 ms).  A reader verifies with the algorithm the writer named."""
+    raw = np.ascontiguousarray(blob).view(np.uint8)
+    if algo in (None, "xxh3"):
+        try:
+            import xxhash
+            return "xxh3:" + xxhash.xxh3_64_hexdigest(raw)
+        except ImportError:
+            if algo == "xxh3":
+                raise
+    return "sha1:" + hashlib.sha1(raw).hexdigest()
+
+
 def _load_packed(path: str, n_ops: int):
     """(blob, layers, segments, conv_kp) of a packed network from the weight cache, or None -- also when the blob's bytes do not
     have the checksum stored with them (a torn or edited file)."""
@@ -160,13 +174,13 @@ def _load_packed(path: str, n_ops: int):
         if blob.dtype != np.float32 or blob.ndim != 1 or blob.size != meta["blob_floats"]:
             return None
         blob = np.ascontiguousarray(blob)
-        if hashlib.sha1(blob.view(np.uint8)).hexdigest() != meta["blob_sha1"]:
+        if _blob_hash(blob, meta["blob_hash"].split(":", 1)[0]) != meta["blob_hash"]:
             return None
         layers = (LayerDesc * n_ops).from_buffer_copy(bytes.fromhex(meta["layers"]))
         n_seg = meta["n_segments"]
         segs = list((ConvSegment * n_seg).from_buffer_copy(bytes.fromhex(meta["segments"]))) if n_seg else []
         return np.ascontiguousarray(blob), layers, segs, {int(k): v for k, v in meta["conv_kp"].items()}
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError, ImportError):
         return None
 
 
@@ -180,7 +194,7 @@ def _store_packed(path: str, blob, layers, seg_list, conv_kp) -> None:
             np.save(f, blob, allow_pickle=False)
         os.replace(tmp + ".npy", path + ".npy")
         segs = (ConvSegment * max(len(seg_list), 1))(*seg_list)
-        meta = {"n_ops": len(layers), "blob_floats": int(blob.size), "blob_sha1": hashlib.sha1(np.ascontiguousarray(blob).view(np.uint8)).hexdigest(),
+        meta = {"n_ops": len(layers), "blob_floats": int(blob.size), "blob_hash": _blob_hash(blob),
                 "layers": bytes(layers).hex(), "n_segments": len(seg_list),
                 "segments": bytes(segs).hex() if seg_list else "", "conv_kp": {str(k): int(v) for k, v in conv_kp.items()}}
         with open(tmp + ".json", "w") as f:
