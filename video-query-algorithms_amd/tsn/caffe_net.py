@@ -38,15 +38,19 @@ def load_weights(graph, spec: str):
 
 
 def weights_digest(spec: str) -> str:
-    """Names the CONTENT of a weights specification: ``synthetic:<seed>`` as it is, a file by the SHA-1 of its bytes."""
+    """Names the CONTENT of a weights specification: ``synthetic:<seed>`` as it is, a file by a digest of its bytes."""
     if spec.startswith("synthetic:"):
         return spec
-    import hashlib
-    h = hashlib.sha1()
+    try:                                   # 8 ms for a 41 MB .caffemodel; SHA-1 (40 ms) where the module is missing
+        import xxhash
+        h, tag = xxhash.xxh3_128(), "file:xxh3:"
+    except ImportError:
+        import hashlib
+        h, tag = hashlib.sha1(), "file:"
     with open(spec, "rb") as f:
         for piece in iter(lambda: f.read(1 << 22), b""):
             h.update(piece)
-    return "file:" + h.hexdigest()
+    return tag + h.hexdigest()
 
 
 def save_weights(path: str, weights):
