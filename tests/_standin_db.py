@@ -44,7 +44,7 @@ class OracleFeatureDB:
     def scan(self, weights=None, keep_sims=False):
         if self.fail_on_scan:
             raise RuntimeError("stand-in: this rank's scan fails")
-        _, self._avg, self._ne = so.dense_similarities(self.x, self._t, self._effective())
+        self._sims, self._avg, self._ne = so.dense_similarities(self.x, self._t, self._effective())
         self._scores = None if weights is None else so.dense_scores(self._avg, weights)
 
     def scan_batch(self, targets, weights, want=True):
@@ -57,7 +57,7 @@ class OracleFeatureDB:
     def similarities(self, sims=False):
         if self._avg is None:
             raise RuntimeError("no similarities cached")
-        return self._avg.copy(), self._ne.copy()
+        return (self._avg.copy(), self._ne.copy(), self._sims.copy()) if sims else (self._avg.copy(), self._ne.copy())
 
     def rescore(self, weights):
         self._scores = so.dense_scores(self._avg, weights)

@@ -165,10 +165,11 @@ def _spmd_worker(rank, world, port, n_total, tmp):
     t = sdb.set_query_from_row(n_total - 2)                           # the last rank holds the row
     want_t = np.stack([[so.scale_feature(x[n_total - 2, si, ei].astype(np.float64)) for ei in range(e)] for si in range(s)])
     assert (t == want_t).all()
-    sdb.scan(weights=[1.0, 1.5])
-    avg, ne = sdb.similarities()
-    _, o_avg, o_ne = so.dense_similarities(x, want_t)
-    assert (avg == o_avg).all() and (ne == o_ne).all()                # every clip independent of the sharding: bit for bit
+    sdb.scan(weights=[1.0, 1.5], keep_sims=True)
+    avg, ne, sims = sdb.similarities(sims=True)
+    o_sims, o_avg, o_ne = so.dense_similarities(x, want_t)
+    assert (avg == o_avg).all() and (ne == o_ne).all() and (sims == o_sims).all()     # every clip independent of the sharding: bit for bit
+    assert all((a == b).all() for a, b in zip(sdb.similarities(), (o_avg, o_ne)))
     sc = sdb.scores()
     o_sc = so.dense_scores(o_avg, [1.0, 1.5])
     assert (sc == o_sc).all()

@@ -303,11 +303,14 @@ class ShardedFeatureDB:
 
     # ------------------------------------------------------------------ results
     def similarities(self, sims: bool = False):
-        if sims:
-            raise NotImplementedError("per-split similarities stay on their rank (ask the local FeatureDB)")
-        self._announce(OP_SIMS)
+        """(avg [N,S], n_e [N,S]) in global order; with ``sims`` also the per-split dots [N,S,E] (kept by ``scan(keep_sims=True)``)."""
+        self._announce(OP_SIMS, ints=[1 if sims else 0])
         avg, ne = self._gather(["avg", "ne"])
-        return avg, ne
+        if not sims:
+            return avg, ne
+        part = self._local_step(lambda: self._torch.from_numpy(np.ascontiguousarray(self.local.similarities(sims=True)[2])).to(self._cdev))
+        full = self._coll(lambda: all_gather_rows(part, self.n, self.group))
+        return avg, ne, full.cpu().numpy()
 
     def scores(self) -> np.ndarray:
         return self.scores_tensor().cpu().numpy()
@@ -486,7 +489,7 @@ class ShardedFeatureDB:
             q = int(ints[0])
             self.scan_batch(floats[:q * S * E * D].reshape(q, S, E, D), floats[q * S * E * D:].reshape(q, S), want=bool(ints[1]))
         elif op == OP_SIMS:
-            self.similarities()
+            self.similarities(sims=bool(ints[0]))
         elif op == OP_SCORES:
             self.scores()
         elif op == OP_GRID:
