@@ -170,6 +170,32 @@ def test_cfg5_full_size_ten_thousand_clips_hundred_rounds(tsn, tmp_path, capsys)
     print("cfg5 full size: %.1f s extraction, %.3f s for 100 rounds" % (out["extract_total_s"], out["rounds_total_s"]))
 
 
+def test_cfg5_sharded_rounds_equal_one_gpu(tsn, tmp_path):
+    """BASELINE configs[4] in its N > 1 form, rehearsed with 2 and 3 ranks on this one card (gloo): clips sharded for the extraction, the
+    feature blocks STAY where they were produced as the rows of a ShardedFeatureDB (no feature gather), the weight-update rounds run on
+    all ranks through the same Ticket / Hyperparameter code.  A clip's features do not depend on the batch it travelled in and its score
+    not on the shard it sits in, so fitted weights, threshold and review-set size equal the one-GPU run's exactly."""
+    import subprocess
+    argv = ["--clips", "150", "--segments", "3", "--batch-clips", "16", "--rounds", "6", "--labels", "20", "--csv-clips", "16"]
+    tool = os.path.join(ROOT, "tools", "e2e_cfg5.py")
+
+    def run(world):
+        env = dict(os.environ, VQ_DIST_BACKEND="gloo", VQ_CFG5_ONE_CARD="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        cmd = [sys.executable, tool] if world == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                                                         "--master-addr", "127.0.0.1", "--master-port", str(29600 + world), tool]
+        p = subprocess.run(cmd + argv + ["--out", str(tmp_path / ("w%d" % world))], env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    one = run(1)
+    for world in (2, 3):
+        got = run(world)
+        assert got["world"] == world and got["features_gathered"] is False
+        assert got["final_weights"] == one["final_weights"] and got["final_threshold"] == one["final_threshold"]
+        assert got["final_matches"] == one["final_matches"] and got["rounds"] == 6
+
+
 def test_a_1600_crop_batch_crosses_the_32_bit_offset_limit_correctly(tsn):
     """`--batch_clips 64 --num_frame_per_video 25` = 1 600 crops per forward: conv1's output slot is 5.1 GB, the
     kernels address a slot with signed 32-bit byte offsets, so the executor covers such a slot with several launches over

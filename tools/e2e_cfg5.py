@@ -8,8 +8,12 @@
        through the drop-in Ticket / Hyperparameter API.
 
     python tools/e2e_cfg5.py [--clips 10000] [--rounds 100] [--csv-clips 200] [--out DIR]
-    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/e2e_cfg5.py ...   (clips sharded,
-        feature blocks all-gathered over RCCL, rounds on rank 0)
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/e2e_cfg5.py ...
+        N > 1: the clips are sharded for the extraction and the feature blocks STAY where they were produced -- every rank adopts its own
+        block as its rows of a ShardedFeatureDB ("produced in place by A"), no feature ever crosses xGMI; the rounds run on
+        all ranks (query broadcast, local scans, score slices gathered: sharded_db.py), rank 0 prints.  --gather-features keeps the
+        round-3 form (blocks all-gathered over RCCL, rounds on rank 0's GPU).  VQ_DIST_BACKEND=gloo + VQ_CFG5_ONE_CARD=1: every rank on
+        cuda:0 (a rehearsal of the N > 1 control flow on a one-GPU box)
 
 Prints one JSON object with the wall time of every stage.
 """
@@ -82,26 +86,41 @@ def main(argv=None, observer=None):
     ap.add_argument("--labels", type=int, default=20)
     ap.add_argument("--csv-clips", type=int, default=200)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--gather-features", action="store_true", help="N > 1: all-gather the feature blocks and run the rounds on rank 0 only")
     args = ap.parse_args(argv)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if os.environ.get("VQ_CFG5_ONE_CARD") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("VQ_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    sharded = world > 1 and not args.gather_features
     timings = {"clips": args.clips, "segments": args.segments, "world": world}
     t_all = time.perf_counter()
     first, count, mine = extract(args, device, rank, world, timings)
     t0 = time.perf_counter()
-    feats = all_gather_rows(mine.reshape(count, -1), args.clips).reshape(args.clips, len(STREAMS), len(SPLITS), 1024) if world > 1 else mine
+    if sharded:
+        feats = mine                                      # this rank's rows; nothing is gathered
+    else:
+        feats = all_gather_rows(mine.reshape(count, -1), args.clips).reshape(args.clips, len(STREAMS), len(SPLITS), 1024) if world > 1 else mine
     torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
     timings["all_gather_s"] = time.perf_counter() - t0
     timings["extract_total_s"] = time.perf_counter() - t_all
     timings["extract_clips_per_s"] = args.clips * len(SPLITS) / timings["extract_total_s"]   # (clip, split) pairs, both streams
-    if rank != 0:
+    timings["features_gathered"] = bool(world > 1 and not sharded)
+    if rank != 0 and not sharded:
+        dist.destroy_process_group()
         return 0
     clip_ids = np.arange(1, args.clips + 1, dtype=np.int64)
+    if sharded:
+        args.csv_clips = min(args.csv_clips, count if rank == 0 else 0)      # the CSV sample comes from rank 0's own rows
 
     # ---- data/features layout for the first clips, and back through the load_db parser rules -----------------
     n_csv = min(args.csv_clips, args.clips)
@@ -130,14 +149,22 @@ def main(argv=None, observer=None):
 
     # ---- resident DB (the device block A produced, adopted without a copy) + query rounds ---------------------
     t0 = time.perf_counter()
-    db = vqa.FeatureDB(args.clips, len(STREAMS), len(SPLITS), 1024, np.float32, device.index, clip_ids)
     feats = feats.contiguous()
-    db.adopt_device(feats.data_ptr(), keepalive=feats)
-    db.stream_names = list(STREAMS)
-    db.slot_splits = [list(SPLITS)] * len(STREAMS)
+    if sharded:
+        from video_query_algorithms_amd.sharded_db import ShardedFeatureDB
+        mine_db = vqa.FeatureDB(count, len(STREAMS), len(SPLITS), 1024, np.float32, device.index, clip_ids[first:first + count])
+        mine_db.adopt_device(feats.data_ptr(), keepalive=feats)
+        mine_db.stream_names = list(STREAMS)
+        mine_db.slot_splits = [list(SPLITS)] * len(STREAMS)
+        db = ShardedFeatureDB(mine_db, args.clips, first, clip_ids)           # SPMD: every rank runs the rounds below
+    else:
+        db = vqa.FeatureDB(args.clips, len(STREAMS), len(SPLITS), 1024, np.float32, device.index, clip_ids)
+        db.adopt_device(feats.data_ptr(), keepalive=feats)
+        db.stream_names = list(STREAMS)
+        db.slot_splits = [list(SPLITS)] * len(STREAMS)
     timings["db_adopt_s"] = time.perf_counter() - t0
     ref_row = 7
-    ref = feats[ref_row].to(torch.float64).cpu().numpy()
+    ref = db.read_rows([ref_row])[0].astype(np.float64)
     ref_records = [{"dnn_stream_id": st, "dnn_stream_split": sp, "name": "global_pool", "video_clip_id": int(clip_ids[ref_row]),
                     "feature_vector": ref[si, ei].tolist()} for si, st in enumerate(STREAMS) for ei, sp in enumerate(SPLITS)]
     hp = vqa.Hyperparameter({"rgb": 1.0, "warped_optical_flow": 1.5}, 0.8, 0.0, 0.35, 0.0, STREAMS, "global_pool", 1, 0.7, "bagging", 3)
@@ -186,8 +213,11 @@ def main(argv=None, observer=None):
     timings["final_threshold"] = float(hp.threshold)
     timings["final_matches"] = len(tk.matches)
     timings["total_s"] = time.perf_counter() - t_all
-    print(json.dumps(timings))
+    if rank == 0:
+        print(json.dumps(timings))
     db.close()
+    if world > 1:
+        dist.destroy_process_group()
     return 0
 
 
