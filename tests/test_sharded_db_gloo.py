@@ -246,3 +246,31 @@ def test_fanout_counts_gpus_without_hip(monkeypatch):
         monkeypatch.delenv(var, raising=False)
     assert fanout.visible_gpus() >= 0                                   # KFD topology (0 in a container without /sys/class/kfd)
     assert "torch" not in fanout.visible_gpus.__code__.co_names
+
+
+def test_a_terminated_parent_takes_its_children_with_it(tmp_path):
+    """fanout.run_children: the per-GPU children hold GPUs and may sit in a collective; a parent that gets SIGTERM (or Ctrl-C, or an
+    exception) must end them, not orphan them."""
+    import signal
+    import subprocess
+    import time
+    child = tmp_path / "child.py"
+    child.write_text("import os, sys, time\nopen(sys.argv[1] + '.' + os.environ['RANK'], 'w').write(str(os.getpid()))\ntime.sleep(600)\n")
+    parent = tmp_path / "parent.py"
+    parent.write_text("import sys\nsys.path.insert(0, %r)\nfrom video_query_algorithms_amd import fanout\n"
+                      "sys.exit(fanout.run_children(%r, [%r], fanout.rank_envs(2)))\n" % (ROOT, str(child), str(tmp_path / "pid")))
+    p = subprocess.Popen([sys.executable, str(parent)])
+    deadline = time.time() + 120
+    while time.time() < deadline and not all((tmp_path / ("pid.%d" % r)).exists() for r in range(2)):
+        time.sleep(0.1)
+    pids = [int((tmp_path / ("pid.%d" % r)).read_text()) for r in range(2)]
+    p.send_signal(signal.SIGTERM)
+    p.wait(timeout=60)
+    time.sleep(0.5)
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except ProcessLookupError:
+            alive = False
+        assert not alive, "child %d outlived its parent" % pid
