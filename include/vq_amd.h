@@ -277,10 +277,10 @@ typedef struct vq_input_desc {
     int32_t h, w, c;
     int32_t s2d_pad;
     int32_t s2d_kernel;          /* with s2d_pad >= 0: the k of the original first convolution */
-    int32_t s2d_order;           /* 0: cell channels (p*2+q)*c + ch as above.  1 (c = 3, 7x7 stem): x-major cells, (q*2+p)*c + ch -- the
-                                  * seven x-taps of a kernel row are then 42 contiguous floats of slot 0, and the first convolution's
-                                  * weights are packed [Cout][11][4][4] = W[o][ch][2r+p][t] at [o][s][r][e] with 4s + e = 6t + 3p + ch
-                                  * (zero for 2r+p = 7 and for the two floats behind the run): K = 176 instead of 192 */
+    int32_t s2d_order;           /* 0: cell channels (p*2+q)*c + ch as above.  1 (7x7 stem): x-major cells, (q*2+p)*c + ch -- the seven
+                                  * x-taps of a kernel row are then 14c contiguous floats of slot 0, and the first convolution's weights
+                                  * are packed [Cout][ceil(14c/4)][4][4] = W[o][ch][2r+p][t] at [o][s][r][e] with 4s + e = 2ct + cp + ch
+                                  * (zero for 2r+p = 7 and behind the run): K = 176 instead of 192 (c = 3), 560 instead of 640 (c = 10) */
 } vq_input_desc;
 
 /* `feature_slot` names the 1x1xD tensor that is the feature blob ("global_pool",

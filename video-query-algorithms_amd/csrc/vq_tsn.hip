@@ -52,7 +52,7 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ src, float* __rest
 // mean[c], zeros outside the crop (the first convolution's own zero padding, applied after the mean like Caffe does).
 // One thread per 16-byte chunk of the 4*C output channels of a cell.
 __global__ void preprocess_s2d_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int64_t nchunk, int H, int W, int C,
-                                      int Hs, int Ws, int pad, const float* __restrict__ mean) {
+                                      int Hs, int Ws, int pad, const float* __restrict__ mean, int xmajor) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nchunk) return;
     const int64_t cell = i / C;                     // 4*C channels = C chunks of 4 per cell
@@ -63,7 +63,8 @@ __global__ void preprocess_s2d_kernel(const uint8_t* __restrict__ src, float* __
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int j = j0 + e, pq = j / C, c = j - pq * C;
-        const int y = 2 * Y + (pq >> 1) - pad, x = 2 * X + (pq & 1) - pad;
+        const int p = xmajor ? pq & 1 : pq >> 1, q = xmajor ? pq >> 1 : pq & 1;       // s2d_order 1: cell channels (q*2+p)*C + c
+        const int y = 2 * Y + p - pad, x = 2 * X + q - pad;
         const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
         v[e] = in ? (float)src[((n * H + y) * W + x) * C + c] - mean[c] : 0.0f;
     }
@@ -145,6 +146,9 @@ struct ConvArgs {
 };
 
 constexpr int KPAD = 32;       // weights are packed [Cout][Kp] with Kp a multiple of 32
+// ... except the x-major space-to-depth stem (7x7 / stride 2 over c channels): four kernel rows of 7 x-taps x 2 rows x c floats each,
+// every row padded to whole 16-byte chunks, walked side by side (launch_conv_layer)
+static inline int stem_rows_kp(int c) { return 4 * ((14 * c + 3) / 4 * 4); }
 
 template <int BM, int BN, int BK>
 struct ConvSmem {
@@ -1066,17 +1070,17 @@ static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
     // decoding in its K loop.
     const bool stem_rows = L.src == 0 && net->input.s2d_pad >= 0 && net->input.s2d_order == 1;
     if (stem_rows) {
-        // The x-major space-to-depth stem (vq_input_desc.s2d_order = 1): a kernel row is 7 x-taps x (2 rows x 3 channels) = 42 contiguous
-        // floats of the slot (+ 2 of the next pixel against zero weights = 44), and the weights are packed [Cout][11 steps][4 rows][4]:
-        // chunk column r of a staged row holds kernel row r, every K-step advances 4 floats along all four rows at once.  K = 176
-        // instead of the 192 of the (p,q,c) order (whose zero taps are scattered through every 16-float step): one K-step of twelve
-        // less, with the address arithmetic of the aligned path (a per-lane row offset fixed for the whole loop, a uniform scalar
-        // offset per step).
+        // The x-major space-to-depth stem (vq_input_desc.s2d_order = 1): a kernel row is 7 x-taps x (2 rows x c channels) = 14 c contiguous
+        // floats of the slot (RGB: 42, + 2 of the next pixel against zero weights = 44; flow stack: 140), and the weights are packed
+        // [Cout][steps][4 rows][4]: chunk column r of a staged row holds kernel row r, every K-step advances 4 floats along all four
+        // rows at once.  K = 176 (RGB) / 560 (flow) instead of the 192 / 640 of the (p,q,c) order, whose zero taps are scattered
+        // through every 16-float step -- with the address arithmetic of the aligned path (a per-lane row offset fixed for the whole
+        // loop, a uniform scalar offset per step).
         a.k = a.kw = 1;
         a.Cin = 4 * L.k * L.cin;                       // never reached: the walk stays inside its one "tap"
         a.col_off = net->tensors[L.src].w * net->tensors[L.src].c;
         a.c_step = 4;
-        a.Kp = 176;
+        a.Kp = stem_rows_kp(net->input.c);
         a.w_bytes = (unsigned)((size_t)L.cout * a.Kp * sizeof(float));
     } else if (L.pad == 0 && L.k > 1 && L.cin == net->tensors[L.src].c && L.src_coff == 0) {
         a.kw = 1;
@@ -1515,11 +1519,11 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
             VQ_REQUIRE(td.h == (ts.h + 2 * L.pad - L.k) / L.stride + 1 && td.w == (ts.w + 2 * L.pad - L.k) / L.stride + 1,
                        "layer %d: conv output size mismatch", i);
             int64_t kp = (int64_t)(L.k * L.k * L.cin + KPAD - 1) / KPAD * KPAD;
-            if (L.src == 0 && input->s2d_pad >= 0 && input->s2d_order == 1) {      // x-major stem: [Cout][11][4][4], see launch_conv_layer
-                VQ_REQUIRE(in_channels == 3 && L.k == 4 && L.cin == 12 && L.stride == 1 && L.pad == 0 && L.src_coff == 0 && L.pre_pool_k == 0 &&
+            if (L.src == 0 && input->s2d_pad >= 0 && input->s2d_order == 1) {      // x-major stem: [Cout][steps][4][4], see launch_conv_layer
+                VQ_REQUIRE(L.k == 4 && L.cin == 4 * in_channels && L.stride == 1 && L.pad == 0 && L.src_coff == 0 && L.pre_pool_k == 0 &&
                                L.seg_count == 0 && input->s2d_kernel == 7,
-                           "layer %d: the x-major space-to-depth stem is the 7x7 / stride-2 convolution of a 3-channel crop", i);
-                kp = 176;
+                           "layer %d: the x-major space-to-depth stem is a 7x7 / stride-2 convolution reading the whole input slot", i);
+                kp = stem_rows_kp(in_channels);
             }
             VQ_REQUIRE(L.w_off >= 0 && L.w_off % 4 == 0 && L.w_off + (int64_t)L.cout * kp <= blob_floats,
                        "layer %d: weights outside the blob", i);
@@ -1737,7 +1741,7 @@ static int forward_launches(vq_tsn* net, const uint8_t* src, int n_crops, int T,
                                                                                    net->input.s2d_pad, net->mean_dev, net->input.s2d_order);
         else
             preprocess_s2d_kernel<<<cdiv(nchunk, 256), 256, 0, net->stream>>>(src, net->slots[0], nchunk, net->input.h, net->input.w, in_c,
-                                                                            t0.h, t0.w, net->input.s2d_pad, net->mean_dev);
+                                                                            t0.h, t0.w, net->input.s2d_pad, net->mean_dev, net->input.s2d_order);
     }
     VQ_CHECK_LAUNCH();
     if (n_split > 1) {

@@ -110,22 +110,24 @@ def s2d_stem_weights(W: np.ndarray) -> np.ndarray:
 
 
 def s2d_stem_weights_xmajor(W: np.ndarray) -> np.ndarray:
-    """[Cout][3][7][7] of the stride-2 stem -> [Cout][176] for the x-major space-to-depth slot (vq_input_desc.s2d_order = 1:
-    slot0[Y][X][(q*2+p)*3 + ch] = crop[2Y+p-pad][2X+q-pad][ch]).  Kernel row r (cell rows r = 0..3) reads ONE run of the slot: x-tap
-    t = 0..6, then (p, ch) -- 42 floats, position 6t + 3p + ch -- plus two floats of the next pixel against zero weights.  The four
-    runs advance together, four floats per K-step: packed index 16 s + 4 r + e for run position 4 s + e.  Zero where 2r + p = 7."""
+    """[Cout][c][7][7] of the stride-2 stem -> [Cout][K] for the x-major space-to-depth slot (vq_input_desc.s2d_order = 1:
+    slot0[Y][X][(q*2+p)*c + ch] = crop[2Y+p-pad][2X+q-pad][ch]).  Kernel row r (cell rows r = 0..3) reads ONE run of the slot: x-tap
+    t = 0..6, then (p, ch) -- 14 c floats, position 2 c t + c p + ch -- padded to whole 16-byte chunks against zero weights (RGB: 42 -> 44,
+    flow stack: 140).  The four runs advance together, four floats per K-step: packed index 16 s + 4 r + e for run position 4 s + e;
+    K = 176 (RGB) / 560 (flow).  Zero where 2r + p = 7."""
     cout, c, k, _ = W.shape
-    if (c, k) != (3, 7):
-        raise ValueError("the x-major stem packing is for 3-channel 7x7 kernels")
-    out = np.zeros((cout, 11, 4, 4), dtype=W.dtype)
+    if k != 7:
+        raise ValueError("the x-major stem packing is for 7x7 kernels")
+    steps = (14 * c + 3) // 4
+    out = np.zeros((cout, steps, 4, 4), dtype=W.dtype)
     for r in range(4):
         for t in range(7):
             for p in range(2):
                 if 2 * r + p < k:
                     for ch in range(c):
-                        pos = 6 * t + 3 * p + ch
+                        pos = 2 * c * t + c * p + ch
                         out[:, pos // 4, r, pos % 4] = W[:, ch, 2 * r + p, t]
-    return out.reshape(cout, 176)
+    return out.reshape(cout, steps * 16)
 
 
 _PACKER_DIGEST = None
@@ -237,8 +239,13 @@ class TsnNet:
             if op.kind == "conv" and op.stride == 2 and not op.segments and op.k >= 3 and \
                     (mode == "2" or _round_up(k2 * k2 * 4 * self.in_channels, BK) <= 1.06 * _round_up(op.k * op.k * cin_pad, BK)):
                 self.stem_s2d = True
-        # x-major cells + row-interleaved packing (K = 176 instead of 192) for the RGB 7x7 stem; VQ_TSN_STEM_ORDER=0 keeps the (p,q,c) order
-        self.stem_xmajor = bool(self.stem_s2d and self.in_channels == 3 and stem[0].k == 7 and os.environ.get("VQ_TSN_STEM_ORDER", "1") != "0")
+        # x-major cells + row-interleaved packing for the RGB 7x7 stem (K = 176 instead of 192: conv1 0.250 -> 0.238 ms at 96 crops).
+        # The same form exists for any channel count (flow stack: K = 560 instead of 640) but LOSES there: 3.44 against 3.31 ms at 448
+        # crops -- the flow stem is bound by cache traffic (a 40-float cell is read by 16 (output pixel, kernel row) pairs), and four 16-byte
+        # chunks from four rows per lane group coalesce worse than 64 contiguous bytes.  VQ_TSN_STEM_ORDER: 0 = (p,q,c) everywhere,
+        # 1 (default) = x-major for <= 4 channels, 2 = x-major everywhere (the measurement above).
+        order = os.environ.get("VQ_TSN_STEM_ORDER", "1")
+        self.stem_xmajor = bool(self.stem_s2d and stem[0].k == 7 and (order == "2" or (order == "1" and self.in_channels <= 4)))
         in_slot_c = 4 * self.in_channels if self.stem_s2d else cin_pad
         tensors = (TensorDesc * len(plan.tensors))()
         for i, t in enumerate(plan.tensors):
