@@ -274,3 +274,19 @@ def test_a_terminated_parent_takes_its_children_with_it(tmp_path):
         except ProcessLookupError:
             alive = False
         assert not alive, "child %d outlived its parent" % pid
+
+
+def test_open_fails_fast_when_a_worker_cannot_start(tmp_path):
+    """ShardedFeatureDB.open watches its workers while it waits for them: a worker that dies at start (here: the store path does not
+    exist) is a ShardError in the broker within seconds, not a rendezvous that runs into its 600 s timeout."""
+    import subprocess
+    import time
+    code = ("import sys, time\nsys.path.insert(0, %r)\n"
+            "from video_query_algorithms_amd.sharded_db import ShardedFeatureDB, ShardError\n"
+            "t0 = time.time()\n"
+            "try:\n    ShardedFeatureDB.open(%r, gpus=[0, 1], backend='gloo')\n"
+            "except ShardError as e:\n    print('ShardError after %%.1f s: %%s' %% (time.time() - t0, e))\n" % (ROOT, str(tmp_path / "no_such_store")))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert "ShardError after" in r.stdout and "exited with code" in r.stdout, r.stdout[-2000:]
+    assert time.time() - t0 < 120

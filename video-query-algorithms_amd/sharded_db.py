@@ -122,25 +122,38 @@ class ShardedFeatureDB:
             raise RuntimeError("ShardedFeatureDB.open starts its own process group; this process already has one "
                                "(build the database with from_store(group=...) instead)")
         backend = backend or os.environ.get("VQ_DIST_BACKEND") or "nccl"
-        envs = fanout.rank_envs(len(gpus))
+        world = len(gpus)
+        envs = fanout.rank_envs(world)
+        port = int(envs[0]["MASTER_PORT"])
+        # the rendezvous store is this process's own: the workers report through it ("ready" once their arguments and the store
+        # files check out, "loaded" once their rows are on their GPU), and while it waits the broker watches that they are alive --
+        # a worker that dies on a typo or on a full GPU is an exception here within a second, not a collective that times out
+        store = dist.TCPStore("127.0.0.1", port, world, True, datetime.timedelta(seconds=timeout_s), wait_for_workers=False)
         procs = []
-        if len(gpus) > 1:
+        if world > 1:
             worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shard_worker.py")
-            argv = [os.path.abspath(store_path), "--backend", backend]
+            argv = [os.path.abspath(store_path), "--backend", backend, "--timeout", str(timeout_s)]
             for e, g in zip(envs[1:], gpus[1:]):
                 e["VQ_FANOUT_DEVICE"] = str(g)
             procs = fanout.start_children(worker, argv, envs[1:])
         try:
-            for k in ("MASTER_ADDR", "MASTER_PORT"):
-                os.environ[k] = envs[0][k]
-            kw = {"rank": 0, "world_size": len(gpus), "timeout": datetime.timedelta(seconds=timeout_s)}
+            _await_workers(store, ["ready/%d" % r for r in range(1, world)], procs, timeout_s, "start")
+            kw = {"rank": 0, "world_size": world, "store": store, "timeout": datetime.timedelta(seconds=timeout_s)}
             if backend == "nccl":
                 torch.cuda.set_device(gpus[0])
                 kw["device_id"] = torch.device("cuda", gpus[0])
             dist.init_process_group(backend, **kw)
-            db = cls.from_store(store_path, device=gpus[0], served=True)
+            from .feature_db import FeatureDB
+            from .feature_store import open_store
+            _meta, feats, ids, _present = open_store(store_path)
+            row0, rows = shard_range(feats.shape[0], world, 0)
+            local = FeatureDB.from_store(store_path, device=gpus[0], row0=row0, rows=rows)
+            _await_workers(store, ["loaded/%d" % r for r in range(1, world)], procs, timeout_s, "load their rows")
+            db = cls(local, feats.shape[0], row0, ids, served=True)
         except BaseException:
             fanout.stop_children(procs)
+            if dist.is_initialized():
+                dist.destroy_process_group()
             raise
         db._workers, db._owns_group = procs, True
         return db
@@ -531,6 +544,20 @@ class ShardedFeatureDB:
             pass
 
 
+def _await_workers(store, keys, procs, timeout_s: float, what: str):
+    """Wait until every key is in the rendezvous store, watching the worker processes meanwhile."""
+    import time
+    deadline = time.monotonic() + timeout_s
+    while keys and not store.check(list(keys)):
+        dead = [(i + 1, p.returncode) for i, p in enumerate(procs) if p.poll() is not None]
+        if dead:
+            raise ShardError("worker rank(s) %s exited with code(s) %s before they could %s (their messages are on stderr)"
+                             % ([r for r, _ in dead], [c for _, c in dead], what))
+        if time.monotonic() > deadline:
+            raise ShardError("the workers did not %s within %.0f s" % (what, timeout_s))
+        time.sleep(0.02)
+
+
 def worker_main(argv=None) -> int:
     """``shard_worker.py``: one non-root rank of a served database (started by ShardedFeatureDB.open)."""
     import argparse
@@ -542,13 +569,23 @@ def worker_main(argv=None) -> int:
     args = ap.parse_args(argv)
     import torch
     import torch.distributed as dist
+    from .feature_db import FeatureDB
+    from .feature_store import open_store
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     device = int(os.environ.get("VQ_FANOUT_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-    kw = {"timeout": datetime.timedelta(seconds=args.timeout)}
+    _meta, feats, ids, _present = open_store(args.store)                  # a bad path fails HERE, before anybody waits in a collective
+    row0, rows = shard_range(feats.shape[0], world, rank)
+    timeout = datetime.timedelta(seconds=args.timeout)
+    store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]), world, False, timeout)
+    store.set("ready/%d" % rank, "1")
+    kw = {"rank": rank, "world_size": world, "store": store, "timeout": timeout}
     if args.backend == "nccl":
         torch.cuda.set_device(device)
         kw["device_id"] = torch.device("cuda", device)
     dist.init_process_group(args.backend, **kw)
-    db = ShardedFeatureDB.from_store(args.store, device=device, served=True)
+    local = FeatureDB.from_store(args.store, device=device, row0=row0, rows=rows)
+    store.set("loaded/%d" % rank, "1")
+    db = ShardedFeatureDB(local, feats.shape[0], row0, ids, served=True)
     try:
         db.serve()
     finally:
