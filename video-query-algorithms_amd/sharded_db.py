@@ -174,6 +174,9 @@ class ShardedFeatureDB:
         int64 payload (the doubles travel as their bit patterns)."""
         if not self._driving:
             return
+        gone = [(i + 1, p.returncode) for i, p in enumerate(getattr(self, "_workers", ())) if p.poll() is not None]
+        if gone and op != OP_CLOSE:                      # a worker process that has died cannot answer: say so instead of waiting for it
+            raise ShardError("worker rank(s) %s are gone (exit code(s) %s)" % ([r for r, _ in gone], [c for _, c in gone]))
         torch, dist = self._torch, self._dist
         ints = np.asarray(ints, dtype=np.int64).reshape(-1)
         floats = np.ascontiguousarray(floats, dtype=np.float64).reshape(-1)
@@ -526,7 +529,8 @@ class ShardedFeatureDB:
             return
         self._closed = True
         try:
-            self._announce(OP_CLOSE)
+            if not any(p.poll() is not None for p in getattr(self, "_workers", ())):
+                self._announce(OP_CLOSE)                 # (with a dead worker the broadcast would never complete)
         finally:
             self.local.close()
             if getattr(self, "_owns_group", False):
