@@ -25,6 +25,8 @@
 extern "C" {
 #endif
 
+/* 6 (round 4): + vq_db_set_layout / vq_db_layout (block tiled in place; the mirrored copy of version 5 is gone), vq_db_read_rows,
+ * vq_db_read_scores_at, vq_db_ne_devptr, vq_format_feature_rows; vq_input_desc gained s2d_order. */
 #define VQ_ABI_VERSION 6
 
 enum {
