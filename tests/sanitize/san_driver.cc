@@ -141,9 +141,14 @@ static int run_batch(const char* dir) {
             std::vector<int> n_mcu, want;
             std::vector<size_t> region;
             stream_regions(fr.data(), sizes.data(), n, h, w, n_mcu, want, region);
-            std::vector<uint8_t> stream(region[(size_t)n]);
+            std::vector<uint8_t> stream(region[(size_t)n]), stream_device(region[(size_t)n]);
             std::vector<std::vector<uint32_t>> off, len;
-            (void)unstuff_batch(ptrs.data(), sizes.data(), n, fr.data(), stream.data(), region.data(), want.data(), off, len, workers);
+            size_t sent = 0;
+            (void)unstuff_batch(ptrs.data(), sizes.data(), n, fr.data(), stream.data(), region.data(), want.data(), off, len, workers, 4, [&](size_t b0, size_t b1) {
+                if (b0 == sent) sent = b1;                                                                // the pieces arrive in order, without gaps
+                memcpy(stream_device.data() + b0, stream.data() + b0, b1 - b0);                            // while other workers still write theirs
+            });
+            if (sent != region[(size_t)n]) return 8;
         }
     }
     printf("batch: %zu sizes, %d batches decoded, %d with a damaged scan\n", by_size.size(), ok, bad);

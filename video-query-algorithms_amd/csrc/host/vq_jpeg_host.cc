@@ -39,6 +39,8 @@ bool build_huff(const uint8_t* counts, const uint8_t* symbols, int n_symbols, Hu
         code <<= 1;
     }
     h.maxcode[17] = 0x7fffffff;
+    memcpy(h.counts, counts, sizeof h.counts);
+    h.n_vals = (uint16_t)k;
     h.present = true;
     return true;
 }
@@ -319,47 +321,62 @@ int parse_batch(const uint8_t* const* files, const int64_t* sizes, int n, int h,
     return first_failure(status, message);
 }
 
+namespace {
+// Items [0, n) on `workers` threads (item i on thread i % workers, so the items finish roughly in index order), handed to the caller in
+// `groups` runs of consecutive items as each run completes: ready(i0, i1) on the calling thread, in order.
+template <typename Item, typename Ready>
+void in_groups(int n, int workers, int groups, Item&& item, Ready&& ready) {
+    groups = std::max(1, std::min(groups, n));
+    std::vector<std::atomic<int>> group_done((size_t)groups);
+    for (auto& g : group_done) g.store(0);
+    auto group_of = [&](int i) { return (int)((long long)i * groups / n); };
+    std::vector<std::thread> pool;
+    for (int k = 0; k < workers; ++k)
+        pool.emplace_back([&, k] {
+            for (int i = k; i < n; i += workers) {
+                item(i);
+                group_done[(size_t)group_of(i)].fetch_add(1, std::memory_order_release);
+            }
+        });
+    for (int g = 0, i0 = 0; g < groups; ++g) {
+        int i1 = i0;
+        while (i1 < n && group_of(i1) == g) ++i1;
+        if (i1 == i0) continue;
+        while (group_done[(size_t)g].load(std::memory_order_acquire) < i1 - i0) std::this_thread::yield();
+        ready(i0, i1);
+        i0 = i1;
+    }
+    for (std::thread& th : pool) th.join();
+}
+}  // namespace
+
 int decode_batch(const uint8_t* const* files, const int64_t* sizes, int n, Frame* fr, int16_t* coef_host, const size_t* comp_off, size_t blocks,
                  int workers, int groups, const std::function<void(size_t, size_t)>& group_ready) {
     std::vector<int> status((size_t)n, VQ_OK);
     std::vector<std::string> message((size_t)n);
-    groups = std::max(1, groups);
-    std::vector<std::atomic<int>> group_done((size_t)groups);
-    for (auto& g : group_done) g.store(0);
-    auto group_of = [&](int i) { return (int)((long long)i * groups / n); };
-    auto work = [&](int first) {
-        for (int i = first; i < n; i += workers) {
+    in_groups(
+        n, workers, groups,
+        [&](int i) {
             // the frame's blocks start from zero (only non-zero coefficients are written): cleared here, by the frame's own thread
             const size_t b0 = comp_off[(size_t)i * 3], b1 = i + 1 < n ? comp_off[(size_t)(i + 1) * 3] : blocks;
             memset(coef_host + b0 * 64, 0, (b1 - b0) * 64 * sizeof(int16_t));
             status[i] = decode_scan(files[i], (size_t)sizes[i], fr[i], coef_host, &comp_off[(size_t)i * 3]);
             if (status[i] != VQ_OK) message[i] = last_error_ref();       // thread-local message of this worker
-            group_done[(size_t)group_of(i)].fetch_add(1, std::memory_order_release);
-        }
-    };
-    std::vector<std::thread> pool;
-    for (int k = 0; k < workers; ++k) pool.emplace_back(work, k);
-    for (int g = 0; g < groups; ++g) {
-        int i0 = 0, i1 = 0;                                           // the group's frames
-        while (i0 < n && group_of(i0) < g) ++i0;
-        i1 = i0;
-        while (i1 < n && group_of(i1) == g) ++i1;
-        if (i1 == i0) continue;
-        while (group_done[(size_t)g].load(std::memory_order_acquire) < i1 - i0) std::this_thread::yield();
-        group_ready(comp_off[(size_t)i0 * 3], i1 < n ? comp_off[(size_t)i1 * 3] : blocks);
-    }
-    for (std::thread& th : pool) th.join();
+        },
+        [&](int i0, int i1) { group_ready(comp_off[(size_t)i0 * 3], i1 < n ? comp_off[(size_t)i1 * 3] : blocks); });
     return first_failure(status, message);
 }
 
 int unstuff_batch(const uint8_t* const* files, const int64_t* sizes, int n, const Frame* fr, uint8_t* stream_host, const size_t* region,
-                  const int* want_segs, std::vector<std::vector<uint32_t>>& seg_off, std::vector<std::vector<uint32_t>>& seg_len, int workers) {
+                  const int* want_segs, std::vector<std::vector<uint32_t>>& seg_off, std::vector<std::vector<uint32_t>>& seg_len, int workers,
+                  int groups, const std::function<void(size_t, size_t)>& group_ready) {
     std::vector<int> status((size_t)n, VQ_OK);
     std::vector<std::string> message((size_t)n);
     seg_off.assign((size_t)n, {});
     seg_len.assign((size_t)n, {});
-    strided(workers, [&](int first) {
-        for (int i = first; i < n; i += workers) {
+    in_groups(
+        n, workers, groups,
+        [&](int i) {
             seg_off[i].assign((size_t)want_segs[i], 0);
             seg_len[i].assign((size_t)want_segs[i], 0);
             const int got = unstuff_scan(files[i], (size_t)sizes[i], fr[i].scan, stream_host + region[i], want_segs[i], seg_off[i].data(), seg_len[i].data());
@@ -367,8 +384,10 @@ int unstuff_batch(const uint8_t* const* files, const int64_t* sizes, int n, cons
                 status[i] = VQ_E_INVALID;
                 message[i] = "JPEG: restart marker missing";
             }
-        }
-    });
+        },
+        [&](int i0, int i1) {
+            if (group_ready) group_ready(region[i0], region[i1]);
+        });
     return first_failure(status, message);
 }
 

@@ -27,8 +27,14 @@ struct Huff {
     uint8_t look_sym[512], look_len[512];
     int maxcode[18], valptr[17], mincode[17];
     uint8_t vals[256];
+    uint8_t counts[16];        // codes per length and their number: with vals[0, n_vals) these determine everything above
+    uint16_t n_vals;
     bool present = false;
 };
+
+inline bool same_huff(const Huff& a, const Huff& b) {
+    return a.present == b.present && a.n_vals == b.n_vals && !memcmp(a.counts, b.counts, sizeof a.counts) && !memcmp(a.vals, b.vals, a.n_vals);
+}
 
 bool build_huff(const uint8_t* counts, const uint8_t* symbols, int n_symbols, Huff& h);
 
@@ -185,9 +191,11 @@ int parse_batch(const uint8_t* const* files, const int64_t* sizes, int n, int h,
 // group are decoded (in group order) -- the caller queues that piece's copy to the device while later pieces are still decoded.
 int decode_batch(const uint8_t* const* files, const int64_t* sizes, int n, Frame* fr, int16_t* coef_host, const size_t* comp_off, size_t blocks,
                  int workers, int groups, const std::function<void(size_t, size_t)>& group_ready);
-// the unstuffing pass of all files into stream_host + region[i]; seg_off / seg_len get want_segs[i] entries per file
+// the unstuffing pass of all files into stream_host + region[i] (region has n + 1 entries); seg_off / seg_len get want_segs[i] entries per
+// file.  With a callback the stream buffer is handed over in `groups` pieces like decode_batch's coefficients: group_ready(first byte, end byte).
 int unstuff_batch(const uint8_t* const* files, const int64_t* sizes, int n, const Frame* fr, uint8_t* stream_host, const size_t* region,
-                  const int* want_segs, std::vector<std::vector<uint32_t>>& seg_off, std::vector<std::vector<uint32_t>>& seg_len, int workers);
+                  const int* want_segs, std::vector<std::vector<uint32_t>>& seg_off, std::vector<std::vector<uint32_t>>& seg_len, int workers,
+                  int groups = 1, const std::function<void(size_t, size_t)>& group_ready = {});
 // whole files into memory; VQ_E_INVALID naming the first unreadable one
 int read_files(const char* const* paths, int n, std::vector<std::vector<uint8_t>>& data, int workers);
 
