@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 /* 6 (round 4): + vq_db_set_layout / vq_db_layout (block tiled in place; the mirrored copy of version 5 is gone), vq_db_read_rows,
- * vq_db_read_scores_at, vq_db_ne_devptr, vq_format_feature_rows; vq_input_desc gained s2d_order. */
+ * vq_db_read_scores_at, vq_db_ne_devptr, vq_format_feature_rows, vq_jpeg_decode_path_list; vq_input_desc gained s2d_order. */
 #define VQ_ABI_VERSION 6
 
 enum {
@@ -219,6 +219,10 @@ int vq_jpeg_decode(vq_jpeg* jpeg, const uint8_t* const* files, const int64_t* si
  * a file's frame header. */
 int vq_jpeg_decode_files(vq_jpeg* jpeg, const char* const* paths, int32_t n, int32_t color, int32_t h, int32_t w, uint8_t* out_host,
                          uint8_t** out_dev, void* hip_stream);
+/* ... and on a path LIST: n paths back to back in one buffer of paths_bytes bytes, each closed by its NUL (a caller under an
+ * interpreter builds one bytes object instead of an array of thousands of pointers). */
+int vq_jpeg_decode_path_list(vq_jpeg* jpeg, const char* paths, int64_t paths_bytes, int32_t n, int32_t color, int32_t h, int32_t w,
+                             uint8_t* out_host, uint8_t** out_dev, void* hip_stream);
 int vq_jpeg_info_file(const char* path, int32_t* h, int32_t* w, int32_t* components);
 
 enum {

@@ -94,6 +94,38 @@ def test_what_is_refused(jpeg):
 
 
 @needs_pil
+def test_files_by_path_and_the_path_list_entry(jpeg, tmp_path):
+    """Paths instead of contents: the library's threads read the files (vq_jpeg_decode_path_list: the paths in one buffer, each closed
+    by its NUL) -- the same pixels; a list that holds fewer paths than the call names, an unterminated list, an unreadable file and a
+    path with a NUL inside are refused."""
+    import ctypes as C
+    from video_query_algorithms_amd import VqError, _lib
+    blobs = [encode(picture(40, 56, k), quality=85, subsampling=2) for k in range(5)]
+    paths = []
+    for k, b in enumerate(blobs):
+        paths.append(str(tmp_path / ("f%d.jpg" % k)))
+        with open(paths[-1], "wb") as f:
+            f.write(b)
+    dec = jpeg.JpegDecoder(8, 40, 56)
+    assert (dec.decode(paths) == dec.decode(blobs)).all()
+    assert (dec.decode(paths, color=False) == dec.decode(blobs, color=False)).all()
+    with pytest.raises(VqError, match="nope.jpg"):
+        dec.decode(paths[:2] + [str(tmp_path / "nope.jpg")])
+    with pytest.raises(ValueError, match="NUL"):
+        dec.decode([paths[0], paths[1] + "\0x"])
+    out = np.empty((5, 40, 56, 3), np.uint8)
+    buf = b"".join(p.encode() + b"\0" for p in paths)
+    args = lambda b, n: (dec._h, b, len(b), n, 1, 40, 56, out.ctypes.data_as(C.c_void_p), None, None)
+    with pytest.raises(VqError, match="holds 5 paths"):
+        _lib.call("vq_jpeg_decode_path_list", *args(buf, 6))
+    with pytest.raises(VqError, match="NUL of its last path"):
+        _lib.call("vq_jpeg_decode_path_list", *args(buf[:-1] + b"x", 5))
+    _lib.call("vq_jpeg_decode_path_list", *args(buf, 5))
+    assert (out == dec.decode(blobs)).all()
+    dec.close()
+
+
+@needs_pil
 def test_cli_on_a_jpeg_frame_tree_device_decode_equals_host_decode(jpeg, tmp_path):
     """calcSig_wOF.py on img_/flow_x_/flow_y_ .jpg files as build_wof_clips.py leaves them: --device_jpeg (library decoder,
     frames never on the host) writes the same CSV bytes as the default path (host libjpeg through Pillow, resize on the GPU)

@@ -98,7 +98,8 @@ SIGNATURES = {
     "vq_jpeg_info": [_P, _I64, _pI32, _pI32, _pI32],
     "vq_jpeg_create": [_I32, _I32, _I32, _I32, _PP], "vq_jpeg_destroy": [_P],
     "vq_jpeg_decode": [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P],
-    "vq_jpeg_decode_files": [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P], "vq_jpeg_info_file": [C.c_char_p, _pI32, _pI32, _pI32],
+    "vq_jpeg_decode_files": [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P],
+    "vq_jpeg_decode_path_list": [_P, C.c_char_p, C.c_int64, _I32, _I32, _I32, _I32, _P, _P, _P], "vq_jpeg_info_file": [C.c_char_p, _pI32, _pI32, _pI32],
     "vq_flow_good_features": [_P, _P, _I32, _I32, _I32, C.c_float, C.c_float, _P, _P, _P],
     "vq_flow_ransac_homography": [_P, _P, _P, _P, _I32, _I32, C.c_float, _I32, C.c_uint32, _I32, _P, _P, _P, _P, _P],
     "vq_comm_unique_id": [_P], "vq_comm_init": [_I32, _I32, _P, _I32, _PP], "vq_comm_destroy": [_P],

@@ -922,6 +922,22 @@ int vq_jpeg_decode_files(vq_jpeg* j, const char* const* paths, int32_t n, int32_
     return vq_jpeg_decode(j, ptrs.data(), sizes.data(), n, color, h, w, out_host, out_dev, hip_stream);
 }
 
+// ... on a path LIST: the n paths back to back, each closed by its NUL (one bytes object on the caller's side instead of an array of
+// 8 000 pointers built under the interpreter's lock: 3-4 ms per flow batch of the command line).
+int vq_jpeg_decode_path_list(vq_jpeg* j, const char* paths, int64_t paths_bytes, int32_t n, int32_t color, int32_t h, int32_t w, uint8_t* out_host,
+                             uint8_t** out_dev, void* hip_stream) {
+    VQ_REQUIRE(j && paths && n > 0 && paths_bytes > 0, "bad argument");
+    VQ_REQUIRE(paths[paths_bytes - 1] == 0, "the path list must end with the NUL of its last path");
+    std::vector<const char*> each;
+    each.reserve((size_t)n);
+    for (int64_t at = 0; at < paths_bytes && (int)each.size() < n;) {
+        each.push_back(paths + at);
+        at += (int64_t)strlen(paths + at) + 1;
+    }
+    VQ_REQUIRE((int)each.size() == n, "the path list holds %d paths, the call names %d", (int)each.size(), n);
+    return vq_jpeg_decode_files(j, each.data(), n, color, h, w, out_host, out_dev, hip_stream);
+}
+
 int vq_jpeg_info_file(const char* path, int32_t* h, int32_t* w, int32_t* components) {
     VQ_REQUIRE(path, "NULL argument");
     FILE* f = fopen(path, "rb");

@@ -107,7 +107,7 @@ class FrameIngest:
             per = max(1, cap // ch)
             for i in range(0, n, per):
                 m = min(per, n - i)
-                group = [files[(i + q) * ch + k] for k in range(ch) for q in range(m)]
+                group = [f for k in range(ch) for f in files[i * ch + k:(i + m) * ch:ch]]
                 ptr, _ = dec.decode_to_device(group, color=False, stream=stream)
                 for k in range(ch):
                     call("vq_resize_crop", C.c_void_p(ptr + k * m * h * w), 1, m, h, w, 1, frame_size[0], frame_size[1], crop,

@@ -37,10 +37,13 @@ class JpegDecoder:
         if len(files) and all(isinstance(f, str) for f in files):      # paths only: the library's threads read the files
             n = len(files)
             h, w, _ = info(files[0])
-            paths = (C.c_char_p * n)(*[os.fsencode(f) for f in files])
+            joined = "\0".join(files)                                  # one object, not n pointers (3-4 ms per 8 000 under the interpreter lock)
+            if joined.count("\0") != n - 1:
+                raise ValueError("a path contains a NUL character")
+            paths = os.fsencode(joined + "\0")
             dev = C.c_void_p()
             host = np.empty((n, h, w, 3) if color else (n, h, w), dtype=np.uint8) if out_host else None
-            call("vq_jpeg_decode_files", self._h, paths, n, int(bool(color)), h, w, host.ctypes.data_as(C.c_void_p) if host is not None else None,
+            call("vq_jpeg_decode_path_list", self._h, paths, len(paths), n, int(bool(color)), h, w, host.ctypes.data_as(C.c_void_p) if host is not None else None,
                  C.byref(dev) if want_dev else None, C.c_void_p(stream) if stream else None)
             return host, dev.value, (n, h, w)
         blobs: List[bytes] = []
