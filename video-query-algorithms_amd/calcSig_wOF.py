@@ -358,11 +358,14 @@ def main(argv=None, net_factory=None, program=None):
                 csv_jobs.append(io_pool.submit(write_features, args.outFeatures_dir, video_path.split('/')[-2], video_path, m['modelname'],
                                                args.featureBlob, clip_list, {s['mode']: block},
                                                {'rgb': m['rgb'], 'warped_optical_flow': m['flow']}, args.number_format))
+    stamp("features gathered, feature files queued")
     for per_stream in nets:
         for n in per_stream or []:
             n.close()
+    stamp("networks closed")
     if crop_pipe:
         crop_pipe.close()
+    stamp("ingest closed")
     pool.shutdown()
     build_pool.shutdown()
     stamp("extractors closed")

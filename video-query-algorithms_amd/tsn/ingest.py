@@ -9,9 +9,50 @@ first batches while the current stream's last ones are in the network, and feeds
 """
 from __future__ import annotations
 
+import atexit
+import threading
+
 import numpy as np
 
 from . import frames
+
+
+# Decoders of closed FrameIngest objects, per device: a decoder's buffers (pinned host memory for the unstuffed streams / coefficients,
+# device planes and pixels: 1-2 GB at the command line's batch sizes) cost 40 ms to free and as much to allocate again, so a process that
+# runs the command line's main() again (the bench, a broker's worker) takes its decoders from here.  At most _POOL_KEEP idle ones per device.
+_POOL_KEEP = 4
+_idle_decoders = {}
+_idle_lock = threading.Lock()
+
+
+def _take_decoder(device, h, w):
+    with _idle_lock:
+        idle = _idle_decoders.get(device, [])
+        for k, dec in enumerate(idle):
+            if dec.max_h >= h and dec.max_w >= w:
+                return idle.pop(k)
+    return None
+
+
+def _give_decoder(device, dec):
+    with _idle_lock:
+        idle = _idle_decoders.setdefault(device, [])
+        if len(idle) < _POOL_KEEP:
+            idle.append(dec)
+            return
+    dec.close()
+
+
+def drain_decoder_pool():
+    """Close the idle decoders (also at interpreter exit)."""
+    with _idle_lock:
+        idle = [d for ds in _idle_decoders.values() for d in ds]
+        _idle_decoders.clear()
+    for dec in idle:
+        dec.close()
+
+
+atexit.register(drain_decoder_pool)
 
 
 class FrameIngest:
@@ -61,7 +102,6 @@ class FrameIngest:
         snippet (x0, y0, x1, y1, ...).  The pixels are libjpeg's (what cv2.imread returns), bit for bit.  ``lane``: calls of
         different lanes own different decoders and streams and may run at the same time in different threads (the command line
         keeps two batches in preparation: one's host half -- reading, unstuffing -- overlaps the other's device half)."""
-        import threading
         import torch
         ch = self._channels
         per_snip = 1 if ch == 3 else ch
@@ -93,7 +133,8 @@ class FrameIngest:
         if dec is None or dec.max_h < h or dec.max_w < w:
             if dec is not None:
                 dec.close()
-            dec = st["jpeg"] = jpeg.JpegDecoder(cap, h, w, self.device)
+            dec = st["jpeg"] = _take_decoder(self.device, h, w) or jpeg.JpegDecoder(cap, h, w, self.device)
+        cap = min(cap, dec.max_frames)
         if ch == 3:
             for i in range(0, n, cap):
                 ptr, (m, _, _) = dec.decode_to_device(files[i:i + cap], color=True, stream=stream)
@@ -118,5 +159,5 @@ class FrameIngest:
     def close(self):
         for st in self._lanes.values():
             if st["jpeg"] is not None:
-                st["jpeg"].close()
+                _give_decoder(self.device, st["jpeg"])             # idle, not freed: see _idle_decoders
                 st["jpeg"] = None
