@@ -103,6 +103,7 @@ static int run_batch(const char* dir) {
         if (!d.empty() && parse_headers(d.data(), d.size(), f) == VQ_OK && (long long)f.H * f.W <= 1024 * 1024) by_size[{f.H, f.W}].push_back(p);
     }
     int ok = 0, bad = 0;
+    std::vector<std::vector<uint8_t>> data;                 // kept over all batches, as the decoder handle keeps its own (read_files only grows it)
     for (auto& kv : by_size) {
         const int h = kv.first.first, w = kv.first.second;
         std::vector<std::string> paths;
@@ -111,13 +112,12 @@ static int run_batch(const char* dir) {
         std::vector<const char*> cpaths;
         for (const std::string& p : paths) cpaths.push_back(p.c_str());
         for (int round = 0; round < 3; ++round) {
-            std::vector<std::vector<uint8_t>> data;
             if (read_files(cpaths.data(), n, data, workers) != VQ_OK) return 4;
             std::vector<const uint8_t*> ptrs;
             std::vector<int64_t> sizes;
-            for (auto& v : data) {
-                ptrs.push_back(v.data());
-                sizes.push_back((int64_t)v.size());
+            for (int i = 0; i < n; ++i) {
+                ptrs.push_back(data[(size_t)i].data());
+                sizes.push_back((int64_t)data[(size_t)i].size());
             }
             std::vector<Frame> fr((size_t)n);
             if (parse_batch(ptrs.data(), sizes.data(), n, h, w, fr.data(), workers) != VQ_OK) return 5;      // they all parsed alone

@@ -20,6 +20,15 @@ for k in range(16):
     blobs.append(buf.getvalue())
 batch = [blobs[i % 16] for i in range(nb)]
 print("mean file %.1f KB" % (sum(map(len, batch)) / nb / 1024))
+if len(sys.argv) > 2 and sys.argv[2] == "paths":          # the files by PATH, as the command line hands them over: the library reads them
+    import tempfile
+    root = tempfile.mkdtemp(prefix="vq_flow_batch_")
+    paths = []
+    for i, b in enumerate(batch):
+        paths.append(os.path.join(root, "flow_%05d.jpg" % i))
+        with open(paths[-1], "wb") as f:
+            f.write(b)
+    batch = paths
 d = JpegDecoder(nb, h, w)
 d.decode_to_device(batch, color=False)
 for _ in range(3):

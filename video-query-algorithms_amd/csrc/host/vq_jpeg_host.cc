@@ -1,7 +1,12 @@
 // See vq_jpeg_host.h.  Host-only translation unit: no HIP.
 #include "vq_jpeg_host.h"
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <atomic>
+#include <cerrno>
 #include <cstdio>
 #include <thread>
 
@@ -392,27 +397,33 @@ int unstuff_batch(const uint8_t* const* files, const int64_t* sizes, int n, cons
 }
 
 int read_files(const char* const* paths, int n, std::vector<std::vector<uint8_t>>& data, int workers) {
-    data.assign((size_t)n, {});
+    // The caller's vectors are REUSED (only grown): fresh heap memory for 8 000 files is 100 MB of first-touch page faults per call --
+    // 28 ms on 16 threads, twice the decoding -- while a second call into the same vectors reads the page cache at memcpy speed.
+    if (data.size() < (size_t)n) data.resize((size_t)n);
     std::vector<int> bad((size_t)n, 0);
+    // open / fstat / read / close: four system calls per file (stdio made nine, and read every file through a buffer of its own)
     strided(workers, [&](int first) {
         for (int i = first; i < n; i += workers) {
-            FILE* f = paths[i] ? fopen(paths[i], "rb") : nullptr;
-            if (!f) {
+            const int fd = paths[i] ? open(paths[i], O_RDONLY | O_CLOEXEC) : -1;
+            if (fd < 0) {
                 bad[i] = 1;
                 continue;
             }
-            if (fseek(f, 0, SEEK_END) == 0) {
-                const long sz = ftell(f);
-                if (sz > 0 && fseek(f, 0, SEEK_SET) == 0) {
-                    data[i].resize((size_t)sz);
-                    if (fread(data[i].data(), 1, (size_t)sz, f) != (size_t)sz) bad[i] = 1;
-                } else {
-                    bad[i] = 1;
+            struct stat st;
+            if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+                data[i].resize((size_t)st.st_size);
+                size_t got = 0;
+                while (got < data[i].size()) {
+                    const ssize_t r = read(fd, data[i].data() + got, data[i].size() - got);
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) break;
+                    got += (size_t)r;
                 }
+                if (got != data[i].size()) bad[i] = 1;
             } else {
                 bad[i] = 1;
             }
-            fclose(f);
+            close(fd);
         }
     });
     for (int i = 0; i < n; ++i)

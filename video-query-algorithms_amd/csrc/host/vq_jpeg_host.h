@@ -196,7 +196,8 @@ int decode_batch(const uint8_t* const* files, const int64_t* sizes, int n, Frame
 int unstuff_batch(const uint8_t* const* files, const int64_t* sizes, int n, const Frame* fr, uint8_t* stream_host, const size_t* region,
                   const int* want_segs, std::vector<std::vector<uint32_t>>& seg_off, std::vector<std::vector<uint32_t>>& seg_len, int workers,
                   int groups = 1, const std::function<void(size_t, size_t)>& group_ready = {});
-// whole files into memory; VQ_E_INVALID naming the first unreadable one
+// whole files into memory: data[i] for i < n (data is grown to n entries, never shrunk -- keep it between calls, its memory is what the
+// call costs); VQ_E_INVALID naming the first unreadable one
 int read_files(const char* const* paths, int n, std::vector<std::vector<uint8_t>>& data, int workers);
 
 }  // namespace jpeg

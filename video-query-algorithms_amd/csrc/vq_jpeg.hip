@@ -511,6 +511,8 @@ struct vq_jpeg {
     int host_huffman = -1;             // VQ_JPEG_HOST_HUFFMAN at creation: 1 = always the host decoder of rounds 1-2, 0 = always the device
                                        // decoder, unset = by batch size
     long long dev_min_streams = 2048;  // VQ_JPEG_DEVICE_MIN_STREAMS: batches with at least this many streams decode on the device
+    std::mutex files_mu;               // vq_jpeg_decode_files: file_data from the read to the end of the decode
+    std::vector<std::vector<uint8_t>> file_data;   // the files of a call by path (kept: see read_files)
     std::vector<Frame> frames;         // the parsed headers of a call (12 KB each: kept, so that a call does not clear 100 MB first)
 };
 
@@ -908,10 +910,15 @@ int vq_jpeg_decode(vq_jpeg* j, const uint8_t* const* files, const int64_t* sizes
 int vq_jpeg_decode_files(vq_jpeg* j, const char* const* paths, int32_t n, int32_t color, int32_t h, int32_t w, uint8_t* out_host, uint8_t** out_dev,
                          void* hip_stream) {
     VQ_REQUIRE(j && paths && n > 0, "bad argument");
-    std::vector<std::vector<uint8_t>> data;
+    std::lock_guard<std::mutex> lk(j->files_mu);
+    std::vector<std::vector<uint8_t>>& data = j->file_data;
     {
+        const auto t0 = std::chrono::steady_clock::now();
         const int rc = read_files(paths, n, data, batch_workers(n));
         if (rc != VQ_OK) return rc;
+        if (getenv("VQ_JPEG_HOST_STAMPS"))
+            fprintf(stderr, "jpeg host phase %-28s %.2f ms\n", "files read (threads)",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
     std::vector<const uint8_t*> ptrs((size_t)n);
     std::vector<int64_t> sizes((size_t)n);
