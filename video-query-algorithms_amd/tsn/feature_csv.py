@@ -47,11 +47,11 @@ def format_rows(feat: np.ndarray, clip_numbers: np.ndarray, number_format: str =
     if feat.shape[0] == 0:
         return b""
     cap = feat.shape[0] * (feat.shape[1] * 26 + 22)
-    buf = C.create_string_buffer(cap)
+    buf = np.empty(cap, dtype=np.uint8)              # not cleared (a ctypes buffer is: 7 MB per 256 x 1024 file), copied once below
     n = C.c_int64()
     call("vq_format_feature_rows", feat.ctypes.data_as(C.c_void_p), feat.shape[0], feat.shape[1], nos.ctypes.data_as(C.c_void_p),
-         0 if number_format == "repr" else 1, buf, cap, C.byref(n))
-    return buf.raw[:n.value]
+         0 if number_format == "repr" else 1, buf.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+    return buf[:n.value].tobytes()
 
 
 def write_features(out_dir: str, video: str, video_path: str, modelname: str, blob: str, clip_names: Sequence[str],
