@@ -271,3 +271,37 @@ def test_two_batches_in_preparation_at_once_give_the_crops_of_one_at_a_time(jpeg
         for a, b in zip(one_by_one, together):
             assert a.shape == (6, 224, 224, ch) and (a == b).all()
         net.close()
+
+
+@needs_pil
+def test_closed_ingest_objects_leave_their_decoders_for_the_next(jpeg):
+    """tsn/ingest.py keeps the decoders of closed FrameIngest objects (their buffers cost tens of milliseconds to free and to allocate): a
+    second object takes them over -- for other frame sizes too, as long as they fit --, gives the same crops as a fresh decoder, the pool
+    never holds more than its limit, and drain_decoder_pool() closes what is idle."""
+    from video_query_algorithms_amd.tsn import ingest
+    ingest.drain_decoder_pool()
+    big = [encode(picture(256, 340, k), quality=90, subsampling=2) for k in range(4)]
+    small = [encode(picture(120, 160, k), quality=90, subsampling=2) for k in range(4)]
+    first = ingest.FrameIngest(3, 0)
+    want_big = first.crops_from_jpegs(big).cpu().numpy()
+    first.crops_from_jpegs(big, lane=1)
+    first.close()
+    assert len(ingest._idle_decoders[0]) == 2
+    kept = list(ingest._idle_decoders[0])
+    second = ingest.FrameIngest(3, 0)
+    got_small = second.crops_from_jpegs(small).cpu().numpy()              # smaller frames fit the kept decoder
+    assert second._lanes[0]["jpeg"] in kept and len(ingest._idle_decoders[0]) == 1
+    assert (second.crops_from_jpegs(big).cpu().numpy() == want_big).all()
+    second.close()
+    ingest.drain_decoder_pool()
+    fresh = ingest.FrameIngest(3, 0)
+    assert (fresh.crops_from_jpegs(small).cpu().numpy() == got_small).all()
+    fresh.close()
+    many = [ingest.FrameIngest(3, 0) for _ in range(ingest._POOL_KEEP + 2)]
+    for m in many:
+        m.crops_from_jpegs(small[:1])
+    for m in many:
+        m.close()
+    assert len(ingest._idle_decoders[0]) == ingest._POOL_KEEP
+    ingest.drain_decoder_pool()
+    assert not ingest._idle_decoders
