@@ -31,10 +31,7 @@ bool build_huff(const uint8_t* counts, const uint8_t* symbols, int n_symbols, Hu
             if (ln <= 9) {
                 const int first = code << (9 - ln), span = 1 << (9 - ln);
                 if (first + span > 512) return false;
-                for (int q = 0; q < span; ++q) {
-                    h.look_sym[first + q] = symbols[k];
-                    h.look_len[first + q] = (uint8_t)ln;
-                }
+                for (int q = 0; q < span; ++q) h.fast[first + q] = (uint16_t)((ln << 8) | symbols[k]);
             }
             ++code;
             ++k;
@@ -144,11 +141,77 @@ int decode_scan(const uint8_t* d, size_t n, Frame& f, int16_t* coef, const size_
     const bool single = f.nc == 1;
     const int mx = single ? cdiv(f.W, 8) : cdiv(f.W, 8 * f.hmax), my = single ? cdiv(f.H, 8) : cdiv(f.H, 8 * f.vmax);
     BitReader br{d, n, f.scan};
+    // The bit buffer lives in LOCALS (registers): the reader object escapes into fill() / restart(), so its members are memory to the
+    // compiler.  Every coefficient starts with a refill whose test is the same almost every time (eight bytes ahead without a 0xFF: OR them
+    // in, variant 4 of the classic left-aligned readers) instead of one taken when the DATA say so ("fewer than 32 bits left"), which the
+    // branch predictor cannot know: on noisy frames that test, the sign test of the value bits and the end-of-block test were half the time.
+    uint64_t acc = 0;
+    int bits = 0;
+    size_t p = br.p;
+    const size_t fast_end = n >= 8 ? n - 8 : 0;            // p <= fast_end: eight bytes can be loaded
+    bool plain = n >= 8;                                   // no marker met yet
+#define VQ_FILL()                                                                          \
+    {                                                                                      \
+        uint64_t wd_ = 0;                                                                  \
+        bool ok_ = plain && p <= fast_end;                                                 \
+        if (ok_) {                                                                         \
+            memcpy(&wd_, d + p, 8);                                                        \
+            const uint64_t x_ = ~wd_;                                                      \
+            ok_ = !((x_ - 0x0101010101010101ull) & ~x_ & 0x8080808080808080ull);           \
+        }                                                                                  \
+        if (__builtin_expect(ok_, 1)) {                                                    \
+            acc |= __builtin_bswap64(wd_) >> bits;                                         \
+            p += (size_t)((63 - bits) >> 3);                                               \
+            bits |= 56;                                                                    \
+        } else if (bits < 32) {                                                            \
+            br.acc = acc;                                                                  \
+            br.bits = bits;                                                                \
+            br.p = p;                                                                      \
+            br.fill();                                                                     \
+            acc = br.acc;                                                                  \
+            bits = br.bits;                                                                \
+            p = br.p;                                                                      \
+            plain = !br.hit_marker;                                                        \
+        }                                                                                  \
+    }
+#define VQ_PEEK(K) ((uint32_t)(acc >> (64 - (K))))
+#define VQ_SKIP(K)     \
+    {                  \
+        acc <<= (K);   \
+        bits -= (K);   \
+    }
+    // the next symbol of table H into SYM (-1: no such code); >= 16 valid bits on entry
+#define VQ_SYMBOL(H, SYM)                                                   \
+    {                                                                       \
+        const uint32_t e_ = (H).fast[VQ_PEEK(9)];                           \
+        if (e_) {                                                           \
+            VQ_SKIP((int)(e_ >> 8))                                         \
+            SYM = (int)(e_ & 255);                                          \
+        } else {                                                            \
+            int l_ = 10, code_ = (int)VQ_PEEK(10);                          \
+            while (l_ <= 16 && code_ > (H).maxcode[l_]) {                   \
+                ++l_;                                                       \
+                code_ = (int)VQ_PEEK(l_);                                   \
+            }                                                               \
+            if (l_ > 16) {                                                  \
+                SYM = -1;                                                   \
+            } else {                                                        \
+                VQ_SKIP(l_)                                                 \
+                const int idx_ = (H).valptr[l_] + code_ - (H).mincode[l_];  \
+                SYM = idx_ >= 0 && idx_ < 256 ? (H).vals[idx_] : -1;        \
+            }                                                               \
+        }                                                                   \
+    }
     int pred[3] = {0, 0, 0};
     int count = 0;
     for (int mcu = 0; mcu < mx * my; ++mcu) {
         if (f.ri && count == f.ri) {
+            br.p = p;
             if (!br.restart()) return fail(VQ_E_INVALID, "JPEG: restart marker missing");
+            acc = 0;
+            bits = 0;
+            p = br.p;
+            plain = n >= 8;
             pred[0] = pred[1] = pred[2] = 0;
             count = 0;
         }
@@ -161,12 +224,20 @@ int decode_scan(const uint8_t* d, size_t n, Frame& f, int16_t* coef, const size_
             for (int by = 0; by < vv; ++by)
                 for (int bx = 0; bx < hh; ++bx) {
                     int16_t* blk = coef + (comp_off[ci] + (size_t)(my_ * vv + by) * c.bw + (size_t)(mx_ * hh + bx)) * 64;
-                    int s = decode_symbol(br, hd);
+                    // one refill check per coefficient: a code (<= 16 bits) and its value bits (<= 15) fit what fill() leaves (>= 57)
+                    VQ_FILL()
+                    int s;
+                    VQ_SYMBOL(hd, s)
                     if (s < 0 || s > 11) return fail(VQ_E_INVALID, "JPEG: corrupt entropy-coded data (DC)");
-                    if (s) pred[ci] += extend((int)br.get(s), s);
+                    if (s) {
+                        pred[ci] += extend((int)VQ_PEEK(s), s);
+                        VQ_SKIP(s)
+                    }
                     blk[0] = (int16_t)pred[ci];
                     for (int k = 1; k < 64;) {
-                        const int rs = decode_symbol(br, ha);
+                        VQ_FILL()
+                        int rs;
+                        VQ_SYMBOL(ha, rs)
                         if (rs < 0) return fail(VQ_E_INVALID, "JPEG: corrupt entropy-coded data (AC)");
                         const int r = rs >> 4;
                         s = rs & 15;
@@ -179,12 +250,17 @@ int decode_scan(const uint8_t* d, size_t n, Frame& f, int16_t* coef, const size_
                         }
                         k += r;
                         if (k > 63) return fail(VQ_E_INVALID, "JPEG: corrupt entropy-coded data (run past the block)");
-                        blk[kZigzag[k]] = (int16_t)extend((int)br.get(s), s);
+                        blk[kZigzag[k]] = (int16_t)extend((int)VQ_PEEK(s), s);
+                        VQ_SKIP(s)
                         ++k;
                     }
                 }
         }
     }
+#undef VQ_FILL
+#undef VQ_PEEK
+#undef VQ_SKIP
+#undef VQ_SYMBOL
     return VQ_OK;
 }
 

@@ -23,8 +23,8 @@ namespace jpeg {
 extern const uint8_t kZigzag[64];
 
 struct Huff {
-    // lookup of the first 9 bits -> (symbol, code length), 0 length = longer code; canonical tables for the rest (T.81 F.2.2.3)
-    uint8_t look_sym[512], look_len[512];
+    // lookup of the first 9 bits -> (code length << 8) | symbol, 0 = longer code; canonical tables for the rest (T.81 F.2.2.3)
+    uint16_t fast[512];
     int maxcode[18], valptr[17], mincode[17];
     uint8_t vals[256];
     uint8_t counts[16];        // codes per length and their number: with vals[0, n_vals) these determine everything above
@@ -52,31 +52,31 @@ struct Frame {
     size_t scan = 0;
 };
 
+// The scan's bits, LEFT-aligned in a 64-bit buffer: the next bit of the stream is bit 63, `bits` of them are valid; what lies below the
+// valid ones is either zero or (after the fast refill) a prefix of the bytes that follow -- the very bits the next refill ORs in again.
 struct BitReader {
     const uint8_t* d;
     size_t n, p;
     uint64_t acc = 0;
     int bits = 0;
     bool hit_marker = false;
-    void fill() {                       // keep at least 25 bits; behind a marker the stream continues with zeros
+    // At least 57 valid bits afterwards; behind a marker (or the end of the file) the stream continues with zeros.
+    void fill() {
         if (!hit_marker && p + 8 <= n) {
-            // fast path: as many whole bytes as fit, in one go, unless one of them is 0xFF (stuffing or a marker: the byte loop below)
-            const int take = (64 - bits) >> 3;
             uint64_t wd;
             memcpy(&wd, d + p, 8);                                    // little-endian: the first stream byte is the lowest
             const uint64_t x = ~wd;                                    // a zero byte of x = a 0xFF byte of the stream
-            uint64_t ff = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
-            if (take < 8) ff &= (1ull << (8 * take)) - 1;
-            if (!ff && take > 0) {
-                const uint64_t be = __builtin_bswap64(wd);
-                acc = take == 8 ? be : (acc << (8 * take)) | (be >> (64 - 8 * take));
-                bits += 8 * take;
-                p += (size_t)take;
+            if (!((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull)) {
+                // no 0xFF among the next eight bytes (no stuffing, no marker): whole bytes in one go
+                acc |= __builtin_bswap64(wd) >> bits;
+                p += (size_t)((63 - bits) >> 3);
+                bits |= 56;
                 return;
             }
         }
+        acc = bits ? acc & (~0ull << (64 - bits)) : 0;               // only the valid bits: the byte loop appends behind them
         while (bits <= 56) {
-            uint32_t b = 0;
+            uint64_t b = 0;
             if (!hit_marker && p < n) {
                 b = d[p];
                 if (b == 0xFF) {
@@ -91,17 +91,20 @@ struct BitReader {
                     ++p;
                 }
             }
-            acc = (acc << 8) | b;
+            acc |= b << (56 - bits);
             bits += 8;
         }
     }
-    inline uint32_t peek(int k) { return (uint32_t)((acc >> (bits - k)) & ((1u << k) - 1)); }
-    inline void skip(int k) { bits -= k; }
+    inline uint32_t peek(int k) const { return (uint32_t)(acc >> (64 - k)); }      // 1 <= k <= 32
+    inline void skip(int k) {
+        acc <<= k;
+        bits -= k;
+    }
     inline uint32_t get(int k) {
         if (k == 0) return 0;
         if (bits < k) fill();
         const uint32_t v = peek(k);
-        bits -= k;
+        skip(k);
         return v;
     }
     bool restart() {                    // discard padding, consume the RSTn marker
@@ -115,16 +118,15 @@ struct BitReader {
     }
 };
 
-inline int decode_symbol(BitReader& br, const Huff& h) {
-    if (br.bits < 16) br.fill();
-    const uint32_t look = br.peek(9);
-    const int ln = h.look_len[look];
-    if (ln) {
-        br.skip(ln);
-        return h.look_sym[look];
+// The next symbol; the caller has made sure of >= 16 valid bits (fill()).
+inline int decode_symbol_filled(BitReader& br, const Huff& h) {
+    const uint32_t e = h.fast[br.peek(9)];
+    if (e) {
+        br.skip((int)(e >> 8));
+        return (int)(e & 255);
     }
-    int code = (int)br.peek(10);
     int l = 10;
+    int code = (int)br.peek(10);
     while (l <= 16 && code > h.maxcode[l]) {
         ++l;
         code = (int)br.peek(l);
@@ -134,8 +136,13 @@ inline int decode_symbol(BitReader& br, const Huff& h) {
     const int idx = h.valptr[l] + code - h.mincode[l];
     return idx >= 0 && idx < 256 ? h.vals[idx] : -1;
 }
+inline int decode_symbol(BitReader& br, const Huff& h) {
+    if (br.bits < 16) br.fill();
+    return decode_symbol_filled(br, h);
+}
 
-inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+// T.81 F.2.2.1 EXTEND, without a branch on the value's top bit (a coin toss on real data): 1 <= s <= 16, v < 2^s
+inline int extend(int v, int s) { return v + ((((v >> (s - 1)) & 1) - 1) & (1 - (1 << s))); }
 
 inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
 
