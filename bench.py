@@ -774,7 +774,9 @@ def bench_e2e_cli(device_index):
         for c in range(32):                                   # the first 32 clips once more as a tree of their own (links)
             os.symlink(os.path.join(root, "frames", "video", "clip_%04d" % (c + 1)), os.path.join(root, "frames32", "video", "clip_%04d" % (c + 1)))
         times = []
-        for rep, tree in enumerate(("frames", "frames", "frames32")):    # the first run also tunes the tilings of the 800-crop batch
+        # the first run also tunes the tilings of the 800-crop batch; the 256-clip job is then timed three times (the same binary moves by
+        # +-10 % from run to run on one box: thread scheduling around the first batch) and the MEDIAN is the value
+        for rep, tree in enumerate(("frames", "frames", "frames", "frames", "frames32")):
             out_dir = os.path.join(root, "features%d" % rep)
             argv = [os.path.join(root, tree), "rgb", "rgb_seed2.caffemodel", "flow", "flow_seed5.caffemodel", "--outFeatures_dir", out_dir,
                     "--modelname", "UCF101_split1", "--num_worker", "16", "--gpus", str(device_index), "--device_jpeg"]
@@ -801,9 +803,12 @@ def bench_e2e_cli(device_index):
         same = open(csv, "rb").read() == open(os.path.join(root, "ens1", "video", "UCF101_split1", "rgb_global_pool_features.csv"), "rb").read()
     finally:
         shutil.rmtree(root, ignore_errors=True)
+    runs = sorted(times[1:4])
+    times = [times[0], runs[1], times[4]]
     steady = (n_clips - 32) / max(times[1] - times[2], 1e-9)
     return {"metric": "clips/sec end to end through the drop-in command line (JPEG frame tree -> CSV tree), two-stream, T=25", "value": n_clips / times[1],
-            "unit": "clips/s", "clips": n_clips, "seconds": times[1], "first_run_seconds": times[0], "seconds_32_clips": times[2], "csv_rows": rows,
+            "unit": "clips/s", "clips": n_clips, "seconds": times[1], "seconds_of_the_three_runs": runs, "first_run_seconds": times[0],
+            "seconds_32_clips": times[2], "csv_rows": rows,
             "ensemble3": {"value": 3 * n_clips / ens_t[1], "unit": "(clip, member)/s", "seconds": ens_t[1], "first_run_seconds": ens_t[0],
                           "vs_three_runs": (3 * n_clips / ens_t[1]) / (n_clips / times[1]), "member_1_bytes_equal_single_run": bool(same)},
             "steady_state": {"value": steady, "unit": "clips/s",
