@@ -305,3 +305,35 @@ def test_closed_ingest_objects_leave_their_decoders_for_the_next(jpeg):
     assert len(ingest._idle_decoders[0]) == ingest._POOL_KEEP
     ingest.drain_decoder_pool()
     assert not ingest._idle_decoders
+
+
+@needs_pil
+def test_host_decoder_on_streams_full_of_stuffed_bytes(jpeg, monkeypatch):
+    """The host entropy decoder refills its bit buffer eight bytes at a time unless one of them is 0xFF (csrc/host/vq_jpeg_host.h): pure
+    noise at quality 100 stuffs an FF 00 every ~250 bytes and uses the longest codes and the largest coefficients there are; random
+    sizes, samplings, restart intervals and per-file tables on top.  Pixels of libjpeg-turbo, bit for bit -- and the same from the device
+    decoder."""
+    rng = np.random.default_rng(77)
+    for trial in range(12):
+        h, w = int(rng.integers(9, 120)), int(rng.integers(9, 150))
+        files = []
+        for k in range(6):
+            noise = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            kw = dict(quality=int(rng.choice([100, 98, 90, 50])), subsampling=int(rng.integers(0, 3)), optimize=bool(rng.integers(0, 2)))
+            if k % 3 == 2:
+                kw["restart_marker_blocks"] = int(rng.integers(1, 6))
+            try:
+                files.append(encode(noise if k % 2 else picture(h, w, trial * 10 + k), **kw))
+            except TypeError:                                         # an older Pillow without restart-marker options
+                kw.pop("restart_marker_blocks", None)
+                files.append(encode(noise, **kw))
+        assert any(b"\xff\x00" in f for f in files)
+        out = {}
+        for form in ("1", "0"):
+            monkeypatch.setenv("VQ_JPEG_HOST_HUFFMAN", form)
+            dec = jpeg.JpegDecoder(len(files), h, w)
+            out[form] = dec.decode(files)
+            dec.close()
+        for i, data in enumerate(files):
+            assert (out["1"][i] == pil_bgr(data)).all(), (trial, i)
+        assert (out["0"] == out["1"]).all()
