@@ -87,6 +87,33 @@ static int one_file(const std::vector<uint8_t>& d) {
     return rc == VQ_OK;
 }
 
+// coefficients of ONE file as two position-weighted sums per component (tests/test_sanitizers.py holds them against oracle/jpeg_oracle.py)
+static int run_coef(const char* path) {
+    const std::vector<uint8_t> d = slurp(path);
+    Frame f;
+    if (d.empty() || parse_headers(d.data(), d.size(), f) != VQ_OK) return 3;
+    size_t comp_off[3] = {0, 0, 0};
+    const size_t blocks = place_blocks(f, f.H, f.W);
+    size_t o = 0;
+    for (int c = 0; c < f.nc; ++c) {
+        comp_off[c] = o;
+        o += (size_t)f.comp[c].bw * f.comp[c].bh;
+    }
+    std::vector<int16_t> coef(blocks * 64, 0);
+    if (decode_scan(d.data(), d.size(), f, coef.data(), comp_off) != VQ_OK) return 4;
+    for (int c = 0; c < f.nc; ++c) {
+        const size_t n = (size_t)f.comp[c].bw * f.comp[c].bh * 64;
+        long long s1 = 0, s2 = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const long long v = coef[comp_off[c] * 64 + i];
+            s1 += v;
+            s2 += v * (long long)(i % 65521 + 1);
+        }
+        printf("component %d: %d x %d blocks, sums %lld %lld\n", c, f.comp[c].bh, f.comp[c].bw, s1, s2);
+    }
+    return 0;
+}
+
 static int run_single(const char* dir) {
     int decoded = 0, refused = 0;
     for (const std::string& p : list_dir(dir)) (one_file(slurp(p)) ? decoded : refused)++;
@@ -241,6 +268,7 @@ static int run_pool() {
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "";
     if (mode == "single" && argc > 2) return run_single(argv[2]);
+    if (mode == "coef" && argc > 2) return run_coef(argv[2]);
     if (mode == "batch" && argc > 2) return run_batch(argv[2]);
     if (mode == "csv") return run_csv();
     if (mode == "corners") return run_corners();

@@ -13,6 +13,7 @@ import glob
 import os
 import shutil
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -78,3 +79,44 @@ def test_threaded_batch_stages_under_asan_and_tsan(drivers, corpus):
 def test_formatter_corner_selection_and_block_pool(drivers, mode):
     for kind in ("asan", "tsan"):
         assert mode + ": ok" in _run(drivers[kind], mode)
+
+
+def test_host_entropy_decoder_gives_the_oracles_coefficients(drivers):
+    """No GPU needed for this half of the JPEG path: csrc/host/vq_jpeg_host.cc:decode_scan (the decoder of the command line's RGB batches)
+    against oracle/jpeg_oracle.py:decode_coefficients -- which is pinned against libjpeg-turbo -- on every committed fixture, as
+    position-weighted sums per component."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import jpeg_oracle as jo
+    files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "jpeg", "*.jpg")))
+    assert len(files) >= 5
+    try:                                                   # with Pillow here: noise at quality 100 (an FF 00 every ~250 bytes, the longest codes)
+        import io
+        from PIL import Image
+        rng = np.random.default_rng(5)
+        for k, (h, w, sub) in enumerate(((40, 56, 2), (33, 47, 1), (24, 24, 0), (64, 80, 2))):
+            buf = io.BytesIO()
+            kw = {"restart_marker_blocks": 3} if k == 3 else {}
+            try:
+                Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(buf, "JPEG", quality=100, subsampling=sub, **kw)
+            except TypeError:
+                continue
+            path = os.path.join(os.path.dirname(drivers["asan"]), "noise_%d.jpg" % k)
+            with open(path, "wb") as f:
+                f.write(buf.getvalue())
+            files.append(path)
+    except ImportError:
+        pass
+    for path in files:
+        data = open(path, "rb").read()
+        try:
+            _info, coef = jo.decode_coefficients(data)
+        except jo.JpegError:
+            continue                                       # a fixture the decoders refuse (progressive, ...)
+        out = _run(drivers["asan"], "coef", path)
+        lines = [ln for ln in out.splitlines() if ln.startswith("component")]
+        assert len(lines) == len(coef), out
+        for ln, c in zip(lines, coef):
+            flat = c.reshape(-1).astype(np.int64)
+            w = np.arange(flat.size, dtype=np.int64) % 65521 + 1
+            want = "%d x %d blocks, sums %d %d" % (c.shape[0], c.shape[1], int(flat.sum()), int((flat * w).sum()))
+            assert ln.endswith(want), (path, ln, want)
