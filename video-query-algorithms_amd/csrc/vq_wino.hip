@@ -97,7 +97,10 @@ __device__ __forceinline__ float relu1(float x) {
 #endif
 
 // (s_setprio 1 / 0 around every MFMA group -- cdna_hip_programming.md T5 -- was measured in round 4: 9 300 against 11 650 clips/s at cfg 2.
-// With four waves per SIMD the raised waves starve the ones that stage the next step; the order pinned by sched_barrier stays as it is.)
+// With four waves per SIMD the raised waves starve the ones that stage the next step; the order pinned by sched_barrier stays as it is.
+// Also measured there: the first K step peeled off so that the first MFMA of 3 of the 4 positions takes a literal 0 as C (`v_mfma ..., 0`)
+// and 48 x NB accumulator clears go: 11 437-11 534 against 11 487-11 582 clips/s in alternating builds on one box -- the clears sat in the
+// shadow of the prologue's first loads, the peeled step is a third more code.)
 constexpr int BP = 32;    // tiles per workgroup
 constexpr int KC = 8;     // channels per step
 constexpr int HS_STAGE = 4 * 4 * BP * KC;     // floats: h[r][j][tile][k]
