@@ -591,7 +591,7 @@ def bench_flow(device_index, with_cpu):
     # pixel-iterations / this run's device time of the inner loops; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction.
     peak_valu = 256 * 4 * 2.4e9 / 4 / 1e9
     per_pi = (prof or {}).get("valu_wave_insts_per_pixel_iteration")
-    flow_roof = {"kernel": "tvl1_block_kernel<64,1024> (4 inner iterations per launch on tiles resident in registers / LDS)",
+    flow_roof = {"kernel": "tvl1_tile_kernel<512> (4 inner iterations per launch on tiles fitted to the level, resident in registers / LDS)",
                  "avg_launch_ms": inner_ms / max(launches, 1), "pixel_iterations_per_second": pixel_iters / inner_ms * 1e3,
                  "traffic": prof.get("hbm_bytes_per_batch") if prof else None, "hbm_GBps_algorithmic": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
                  "bytes_per_batch": abytes,

@@ -114,3 +114,34 @@ def test_blocked_iterations_have_the_bits_of_the_two_launch_form(flow_mod, monke
         m.close()
     assert np.abs(out["0"]["iters"] - out["1"]["iters"]).max() <= 1
     assert np.abs(out["0"]["u1"] - out["1"]["u1"]).max() <= 2e-2 and np.abs(out["0"]["u2"] - out["1"]["u2"]).max() <= 2e-2
+
+
+def test_fitted_tiles_have_the_bits_of_the_square_ones(flow_mod, monkeypatch):
+    """tvl1_tile_kernel (a level cut into the tiles that cost it the least, cells dealt to the threads in row-major order) against
+    tvl1_block_kernel (64 x 64 tiles, VQ_FLOW_TILES=square when the handle is created): the same per-pixel operations in the same order,
+    so with a fixed iteration count the same bits -- sizes that give one tile, a single row or column of tiles, tiles wider than 64 cells,
+    batches of 1, 3 and 9 pairs (the cut depends on the number of pairs); with the convergence test active the two sum the squared update
+    over different tiles and may stop an iteration apart when the error grazes the threshold, as the blocked and the two-launch form."""
+    rng = np.random.default_rng(31)
+    for (h, w, iters, warps, scales, n) in ((64, 80, 7, 2, 3, 3), (100, 132, 12, 3, 2, 1), (256, 340, 6, 1, 5, 9), (48, 50, 9, 2, 2, 2), (40, 300, 5, 1, 1, 3),
+                                            (131, 174, 8, 1, 1, 4)):
+        pairs = [_shifted_pair(h, w, float(rng.uniform(-3, 3)), float(rng.uniform(-2, 2)), seed=300 + k, margin=12) for k in range(n)]
+        f0, f1 = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+        out = {}
+        for form in ("square", "fitted"):
+            monkeypatch.setenv("VQ_FLOW_TILES", form)
+            m = flow_mod.Tvl1Flow(n, h, w, epsilon=0.0, iterations=iters, warps=warps, nscales=scales)
+            out[form] = m.flow(f0, f1, iterations=True)
+            m.close()
+        assert (out["square"]["iters"] == iters).all() and (out["fitted"]["iters"] == iters).all()
+        assert (out["square"]["u1"] == out["fitted"]["u1"]).all() and (out["square"]["u2"] == out["fitted"]["u2"]).all(), (h, w)
+    pairs = [_shifted_pair(256, 340, dx, dy, seed=40 + k, margin=40) for k, (dx, dy) in enumerate([(2.0, 1.0), (-4.5, 0.5), (0.5, -3.0)])]
+    f0, f1 = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+    out = {}
+    for form in ("square", "fitted"):
+        monkeypatch.setenv("VQ_FLOW_TILES", form)
+        m = flow_mod.Tvl1Flow(3, 256, 340)
+        out[form] = m.flow(f0, f1, iterations=True)
+        m.close()
+    assert np.abs(out["square"]["iters"] - out["fitted"]["iters"]).max() <= 1
+    assert np.abs(out["square"]["u1"] - out["fitted"]["u1"]).max() <= 2e-2 and np.abs(out["square"]["u2"] - out["fitted"]["u2"]).max() <= 2e-2

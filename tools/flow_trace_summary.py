@@ -10,7 +10,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 d = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
     name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-    if "tvl1_block" in name or "tvl1_primal" in name or "tvl1_dual" in name:
+    if "tvl1_block" in name or "tvl1_tile" in name or "tvl1_primal" in name or "tvl1_dual" in name:
         name += " grid %sx%sx%s" % (r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])
     d[name][0] += 1
     d[name][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3

@@ -18,7 +18,7 @@ python3 - "$TAG" <<'PY'
 import csv, glob, json, sys
 tag = sys.argv[1]
 def total(pattern, counter):
-    rows = [r for r in csv.DictReader(open(glob.glob(pattern)[0])) if r["Counter_Name"] == counter and "tvl1_block_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(glob.glob(pattern)[0])) if r["Counter_Name"] == counter and ("tvl1_tile_kernel" in r["Kernel_Name"] or "tvl1_block_kernel" in r["Kernel_Name"])]
     return sum(float(r["Counter_Value"]) for r in rows), len(rows)
 f, nf = total("gpurun_out/pmc_flow_fetch/*/*counter_collection.csv", "FETCH_SIZE")
 w, nw = total("gpurun_out/pmc_flow_write/*/*counter_collection.csv", "WRITE_SIZE")
@@ -26,12 +26,12 @@ valu, _ = total("gpurun_out/pmc_flow_valu/*/*counter_collection.csv", "SQ_INSTS_
 gui, _ = total("gpurun_out/pmc_flow_valu/*/*counter_collection.csv", "GRBM_GUI_ACTIVE")
 batches = 2
 stats = {r["Name"]: r for r in csv.DictReader(open("gpurun_out/%s_flow_kernel_stats.csv" % tag))}
-blk = [v for k, v in stats.items() if "tvl1_block_kernel" in k][0]
+blk = [v for k, v in stats.items() if "tvl1_tile_kernel" in k or "tvl1_block_kernel" in k][0]
 line = [l for l in open("gpurun_out/flow_prof.log") if "pixel-iterations" in l][0]
 pix_it = float(line.split("pixel-iterations per batch")[1].split(";")[0])
 ms = float(blk["TotalDurationNs"]) / 1e6 / 3
 out = {"workload": "64 pairs of 340x256 frames, OpenCV default TV-L1 parameters, one batch (tools/flow_profile.py)",
-       "kernel": "tvl1_block_kernel<64,1024>", "launches_per_batch": int(blk["Calls"]) / 3, "kernel_ms_per_batch": ms,
+       "kernel": "tvl1_tile_kernel<512> (tiles fitted to the level, two workgroups per compute unit)", "launches_per_batch": int(blk["Calls"]) / 3, "kernel_ms_per_batch": ms,
        "avg_launch_us": float(blk["AverageNs"]) / 1e3, "pixel_iterations_per_batch": pix_it, "pixel_iterations_per_second": pix_it / ms * 1e3,
        "FETCH_SIZE_KB_per_batch": f / batches, "WRITE_SIZE_KB_per_batch": w / batches,
        "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section; calibrated there for 16-byte-per-lane streaming reads -- this kernel "

@@ -85,6 +85,35 @@ __device__ __forceinline__ float sample_bilinear(const float* __restrict__ a, in
 }
 
 constexpr int kBlkIters = 4;      // inner iterations per launch of the blocked form (= the halo of a tile)
+#ifndef VQ_FLOW_TILE_THREADS
+#define VQ_FLOW_TILE_THREADS 512
+#endif
+constexpr int kTileThreads = VQ_FLOW_TILE_THREADS;  // tvl1_tile_kernel: threads of a workgroup; two workgroups share a compute unit (128 VGPRs, 48 KB of LDS each)
+constexpr int kTileCells = 4 * kTileThreads;   // cells of a tile = floats of one of its six LDS planes
+// The cut of a w x h level into nx x ny tiles of ceil(w / nx) x ceil(h / ny) own pixels that costs `pairs` pairs the least on `slots`
+// workgroup slots (two per compute unit): a workgroup's time goes with its cells (halo included) in whole waves, a launch's with its rounds.
+struct TileCut {
+    int nx, ny, tw, th, ew, eh;
+};
+inline TileCut fit_tiles(int w, int h, int pairs, int slots) {
+    TileCut best{0, 0, 0, 0, 0, 0};
+    long long best_cost = -1;
+    for (int nx = 1; nx <= (w + 7) / 8; ++nx) {
+        const int tw = (w + nx - 1) / nx, ew = tw + 2 * kBlkIters;
+        for (int ny = 1; ny <= (h + 7) / 8; ++ny) {
+            const int th = (h + ny - 1) / ny, eh = th + 2 * kBlkIters;
+            if ((long long)ew * eh > kTileCells) continue;
+            const long long waves = ((long long)ew * eh + 63) / 64;
+            const long long rounds = ((long long)nx * ny * pairs + slots - 1) / slots;
+            const long long cost = rounds * waves;
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                best = TileCut{nx, ny, tw, th, ew, eh};
+            }
+        }
+    }
+    return best;
+}
 struct BlkSched {                 // what a pair does in one launch of the blocked form
     int mode;                     // kBlkRun: a block of n iterations; kBlkReplay: the exact n iterations of a block that ran past the stop; kBlkDone
     int src;                      // the set of planes the launch reads (it writes the other one)
@@ -407,6 +436,8 @@ struct BlockArgs {
     int h, w, L, max_iters;
     float l_t, theta, taut;
     double eps2;
+    int ew, eh, tw, th;               // tvl1_tile_kernel: a tile of ew x eh cells = tw x th own pixels + the halo; ew * eh <= 4 x its threads
+    float inv_ew;
 };
 
 template <bool FAST>
@@ -590,6 +621,151 @@ __global__ __launch_bounds__(NT) void tvl1_block_kernel(BlockArgs a) {
                 dst[5][g] = r22[j][i];
             }
         }
+}
+
+// The product form: tiles FITTED to the level, two workgroups per compute unit.  What round 4 measured about the kernel above: a
+// workgroup takes 11-12 us whether 41 or 64 of its waves' cells are live (a level cut into fewer, emptier or fuller 4 096-cell tiles
+// costs the same per round of workgroups) -- with ONE workgroup of 16 waves per unit (100 KB of LDS, 118 VGPRs) every barrier, every
+// LDS round trip and every division chain of its 4 iterations is exposed; the vector ALUs issue 45 % of the time.  So: 512 threads and
+// at most 2 048 cells per workgroup (48 KB of LDS, the same 4 cells and <= 128 VGPRs per thread), TWO workgroups per unit whose phases
+// overlap, and the level cut into nx x ny tiles of ceil(w / nx) x ceil(h / ny) own pixels chosen on the host for the fewest rounds x
+// waves (fit_tiles): inner loops 22.1 -> 20.0 ms per batch of 64 pairs (256 threads / 1 024 cells: 22.3, the halo eats it; 1 024 threads
+// with fitted tiles: 22.1).  The tile's cells are dealt to the threads in row-major order (cell tid + NT k of the ew x eh tile, which is
+// also its place in the LDS planes: no padding needed, neighbours in a row are neighbours in a wave), so the cells a tile does NOT have are
+// whole waves of its last quarter.  Per pixel the arithmetic and its order are those of the kernel above: same bits (tested).
+template <int NT, bool FAST>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void tvl1_tile_kernel(BlockArgs a) {
+    constexpr int K = kBlkIters, NC = 4;                 // a tile has at most NC x NT cells
+    extern __shared__ float lds[];                       // u1, u2, p11, p12, p21, p22: [eh][ew] each, a cell at its index tid + NT k
+    __shared__ double part[NT / 64];
+    const int ew = a.ew, plane = a.ew * a.eh;
+    float* __restrict__ U1 = lds;
+    float* __restrict__ U2 = lds + plane;
+    float* __restrict__ P11 = lds + 2 * plane;
+    float* __restrict__ P12 = lds + 3 * plane;
+    float* __restrict__ P21 = lds + 4 * plane;
+    float* __restrict__ P22 = lds + 5 * plane;
+    const int p = blockIdx.z;
+    PairState& st = a.st[p];
+    const int hw = a.h * a.w;
+    const BlkSched cur = next_schedule(st, a.L, hw, a.eps2, a.max_iters);
+    const bool scribe = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+    if (scribe) {
+        st.blk[a.L % 3] = cur;
+        for (int m = 0; m < K; ++m) st.err[(a.L + 1) % 3][m] = 0.0;
+        if (cur.mode == kBlkDone && (a.L == 0 || st.blk[(a.L - 1) % 3].mode != kBlkDone)) {      // the pair has just finished
+            st.final_set = cur.src;
+            st.iters = cur.base;
+            atomicSub(a.n_active, 1);
+        }
+    }
+    if (cur.mode == kBlkDone) return;
+    const float* const* src = a.set[cur.src];
+    float* const* dst = a.set[1 - cur.src];
+    const int xo = (int)blockIdx.x * a.tw - K, yo = (int)blockIdx.y * a.th - K;
+    const int64_t base = (int64_t)p * hw;
+    const int tid = (int)threadIdx.x;
+    float cgx[NC], cgy[NC], cgr[NC], crc[NC], ru1[NC], ru2[NC], r11[NC], r12[NC], r21[NC], r22[NC];
+    // what the iterations ask about a cell, decided once (lane masks): it exists; its left / upper neighbour is in the tile AND in the image
+    // (a tile-edge cell is outside the exact region, and subtracting the 0 the square kernel reads there gives the same bits as not
+    // subtracting); its right / lower one; it is one of the tile's own pixels
+    bool live[NC], hl[NC], hu[NC], rgt[NC], blw[NC], own[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int idx = tid + NT * k;
+        const int cy = (int)(((float)idx + 0.5f) * a.inv_ew), cx = idx - cy * ew, x = xo + cx, y = yo + cy;
+        const bool in_tile = idx < plane;
+        cgx[k] = cgy[k] = cgr[k] = crc[k] = 0.f;
+        ru1[k] = ru2[k] = r11[k] = r12[k] = r21[k] = r22[k] = 0.f;
+        live[k] = in_tile && x >= 0 && x < a.w && y >= 0 && y < a.h;
+        hl[k] = cx > 0 && x > 0;
+        hu[k] = cy > 0 && y > 0;
+        rgt[k] = x + 1 < a.w && cx + 1 < ew;
+        blw[k] = y + 1 < a.h && cy + 1 < a.eh;
+        own[k] = cx >= K && cx < ew - K && cy >= K && cy < a.eh - K;
+        if (live[k]) {
+            const int64_t g = base + (int64_t)y * a.w + x;
+            ru1[k] = src[0][g];
+            ru2[k] = src[1][g];
+            r11[k] = src[2][g];
+            r12[k] = src[3][g];
+            r21[k] = src[4][g];
+            r22[k] = src[5][g];
+            cgx[k] = a.i1wx[g];
+            cgy[k] = a.i1wy[g];
+            cgr[k] = a.grad[g];
+            crc[k] = a.rho_c[g];
+        }
+        if (in_tile) {
+            P11[idx] = r11[k];
+            P12[idx] = r12[k];
+            P21[idx] = r21[k];
+            P22[idx] = r22[k];
+        }
+    }
+    __syncthreads();
+    for (int m = 0; m < cur.n; ++m) {
+        double local = 0.0;
+        // primal step (a cell reads its own old u and p, the p11 / p21 of its left and the p12 / p22 of its upper neighbour)
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            if (live[k]) {
+                const int c = tid + NT * k;
+                const float q11 = r11[k], q12 = r12[k], q21 = r21[k], q22 = r22[k];
+                const float div1 = (hl[k] ? q11 - P11[c - 1] : q11) + (hu[k] ? q12 - P12[c - ew] : q12);
+                const float div2 = (hl[k] ? q21 - P21[c - 1] : q21) + (hu[k] ? q22 - P22[c - ew] : q22);
+                float n1, n2, err;
+                primal_pixel<FAST>(ru1[k], ru2[k], cgx[k], cgy[k], cgr[k], crc[k], div1, div2, a.l_t, a.theta, n1, n2, err);
+                ru1[k] = n1;
+                ru2[k] = n2;
+                U1[c] = n1;
+                U2[c] = n2;
+                if (own[k]) local += (double)err;
+            }
+        }
+        // the tile's squared update of this iteration: one atomic per workgroup
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
+        __syncthreads();                                 // also: every new primal value is in LDS, every old p has been read
+        if (threadIdx.x == 0) {
+            double sum = 0.0;
+#pragma unroll
+            for (int q = 0; q < NT / 64; ++q) sum += part[q];
+            if (sum != 0.0) atomicAdd(&st.err[a.L % 3][m], sum);
+        }
+        // dual step (a cell reads its own p and new u, the new u of its right and lower neighbour)
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            if (live[k]) {
+                const int c = tid + NT * k;
+                const float c1 = ru1[k], c2 = ru2[k];
+                const float u1x = rgt[k] ? U1[c + 1] - c1 : 0.0f, u1y = blw[k] ? U1[c + ew] - c1 : 0.0f;
+                const float u2x = rgt[k] ? U2[c + 1] - c2 : 0.0f, u2y = blw[k] ? U2[c + ew] - c2 : 0.0f;
+                dual_pair<FAST>(r11[k], r12[k], u1x, u1y, a.taut);
+                dual_pair<FAST>(r21[k], r22[k], u2x, u2y, a.taut);
+                P11[c] = r11[k];
+                P12[c] = r12[k];
+                P21[c] = r21[k];
+                P22[c] = r22[k];
+            }
+        }
+        __syncthreads();                                 // every new p is in LDS, every new u has been read
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        if (live[k] && own[k]) {
+            const int idx = tid + NT * k;
+            const int cy = (int)(((float)idx + 0.5f) * a.inv_ew), cx = idx - cy * ew;
+            const int64_t g = base + (int64_t)(yo + cy) * a.w + (xo + cx);
+            dst[0][g] = ru1[k];
+            dst[1][g] = ru2[k];
+            dst[2][g] = r11[k];
+            dst[3][g] = r12[k];
+            dst[4][g] = r21[k];
+            dst[5][g] = r22[k];
+        }
+    }
 }
 
 // After the inner loop of a warp: a pair whose fields ended in set 1 gets them copied back to set 0.
@@ -907,6 +1083,8 @@ struct vq_flow {
     double last_inner_ms = 0.0;            // device time of those loops in the last vq_flow_tvl1 call (sum of the pairs)
     int last_iter_launches = 0;            // iteration-kernel launches of the last call
     bool exact_math = true;                // VQ_FLOW_FAST=1 at creation switches to hardware reciprocals / roots in the inner iterations (see tv_rcp)
+    int n_cus = 256;                       // compute units of the device (tile fitting)
+    bool square_tiles = false;             // VQ_FLOW_TILES=square at creation: the 64 x 64 tiles of round 3 on every level (A/B tests)
     bool two_launch = false;               // VQ_FLOW_TWO_LAUNCH=1 at creation: the round-2 primal + dual launch pair per inner iteration (A/B tests)
 };
 
@@ -983,10 +1161,19 @@ int vq_flow_create(int32_t max_pairs, int32_t h, int32_t w, const vq_tvl1_params
         f->two_launch = e2 && *e2 == '1';
         const char* e3 = getenv("VQ_FLOW_FAST");
         f->exact_math = !(e3 && *e3 == '1');
+        hipDeviceProp_t prop;
+        VQ_HIP(hipGetDeviceProperties(&prop, device));
+        f->n_cus = std::max(1, prop.multiProcessorCount);
+        const char* e4 = getenv("VQ_FLOW_TILES");
+        f->square_tiles = e4 && !strcmp(e4, "square");
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tvl1_block_kernel<64, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    6 * 64 * 65 * (int)sizeof(float)));
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tvl1_block_kernel<64, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    6 * 64 * 65 * (int)sizeof(float)));
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tvl1_tile_kernel<kTileThreads, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   6 * kTileCells * (int)sizeof(float)));
+        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tvl1_tile_kernel<kTileThreads, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   6 * kTileCells * (int)sizeof(float)));
     }
     // level sizes, finest first: round(previous * scale_step), stop before 16 pixels (oracle.pyramid_sizes)
     size_t off = 0;
@@ -1153,7 +1340,15 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
         constexpr int E = 64, NT = 1024, T = E - 2 * kBlkIters;
         const dim3 bgrid((unsigned)cdiv(L.w, T), (unsigned)cdiv(L.h, T), (unsigned)n_pairs);
         const size_t blds = (size_t)6 * E * (E + 1) * sizeof(float);
+        const TileCut cut = fit_tiles(L.w, L.h, n_pairs, (1024 / kTileThreads) * f->n_cus);
+        const dim3 tgrid((unsigned)cut.nx, (unsigned)cut.ny, (unsigned)n_pairs);
+        const size_t tlds = (size_t)6 * cut.eh * cut.ew * sizeof(float);
         BlockArgs ba;
+        ba.ew = cut.ew;
+        ba.eh = cut.eh;
+        ba.tw = cut.tw;
+        ba.th = cut.th;
+        ba.inv_ew = 1.0f / (float)cut.ew;
         ba.i1wx = i1wx;
         ba.i1wy = i1wy;
         ba.grad = grad;
@@ -1188,8 +1383,13 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
                     const int chunk = std::min(max_launches - l0, l0 < 4 ? 2 : 4);
                     for (int k = 0; k < chunk; ++k) {
                         ba.L = l0 + k;
-                        if (f->exact_math) tvl1_block_kernel<E, NT, false><<<bgrid, NT, blds, st>>>(ba);
-                        else tvl1_block_kernel<E, NT, true><<<bgrid, NT, blds, st>>>(ba);
+                        if (f->square_tiles) {
+                            if (f->exact_math) tvl1_block_kernel<E, NT, false><<<bgrid, NT, blds, st>>>(ba);
+                            else tvl1_block_kernel<E, NT, true><<<bgrid, NT, blds, st>>>(ba);
+                        } else {
+                            if (f->exact_math) tvl1_tile_kernel<kTileThreads, false><<<tgrid, kTileThreads, tlds, st>>>(ba);
+                            else tvl1_tile_kernel<kTileThreads, true><<<tgrid, kTileThreads, tlds, st>>>(ba);
+                        }
                         ++iter_launches;
                     }
                     VQ_CHECK_LAUNCH();
