@@ -88,8 +88,15 @@ constexpr int kBlkIters = 4;      // inner iterations per launch of the blocked 
 #ifndef VQ_FLOW_TILE_THREADS
 #define VQ_FLOW_TILE_THREADS 512
 #endif
+#ifndef VQ_FLOW_TILE_NC
+#define VQ_FLOW_TILE_NC 4
+#endif
+#ifndef VQ_FLOW_TILE_WPE
+#define VQ_FLOW_TILE_WPE 4
+#endif
+constexpr int kTileNC = VQ_FLOW_TILE_NC;          // cells per thread
 constexpr int kTileThreads = VQ_FLOW_TILE_THREADS;  // tvl1_tile_kernel: threads of a workgroup; two workgroups share a compute unit (128 VGPRs, 48 KB of LDS each)
-constexpr int kTileCells = 4 * kTileThreads;   // cells of a tile = floats of one of its six LDS planes
+constexpr int kTileCells = kTileNC * kTileThreads;   // cells of a tile = floats of one of its six LDS planes
 // The cut of a w x h level into nx x ny tiles of ceil(w / nx) x ceil(h / ny) own pixels that costs `pairs` pairs the least on `slots`
 // workgroup slots (two per compute unit): a workgroup's time goes with its cells (halo included) in whole waves, a launch's with its rounds.
 struct TileCut {
@@ -634,8 +641,8 @@ __global__ __launch_bounds__(NT) void tvl1_block_kernel(BlockArgs a) {
 // also its place in the LDS planes: no padding needed, neighbours in a row are neighbours in a wave), so the cells a tile does NOT have are
 // whole waves of its last quarter.  Per pixel the arithmetic and its order are those of the kernel above: same bits (tested).
 template <int NT, bool FAST>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void tvl1_tile_kernel(BlockArgs a) {
-    constexpr int K = kBlkIters, NC = 4;                 // a tile has at most NC x NT cells
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(VQ_FLOW_TILE_WPE, VQ_FLOW_TILE_WPE))) void tvl1_tile_kernel(BlockArgs a) {
+    constexpr int K = kBlkIters, NC = kTileNC;                 // a tile has at most NC x NT cells
     extern __shared__ float lds[];                       // u1, u2, p11, p12, p21, p22: [eh][ew] each, a cell at its index tid + NT k
     __shared__ double part[NT / 64];
     const int ew = a.ew, plane = a.ew * a.eh;
@@ -1340,7 +1347,7 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
         constexpr int E = 64, NT = 1024, T = E - 2 * kBlkIters;
         const dim3 bgrid((unsigned)cdiv(L.w, T), (unsigned)cdiv(L.h, T), (unsigned)n_pairs);
         const size_t blds = (size_t)6 * E * (E + 1) * sizeof(float);
-        const TileCut cut = fit_tiles(L.w, L.h, n_pairs, (1024 / kTileThreads) * f->n_cus);
+        const TileCut cut = fit_tiles(L.w, L.h, n_pairs, std::max(1, VQ_FLOW_TILE_WPE * 256 / kTileThreads) * f->n_cus);
         const dim3 tgrid((unsigned)cut.nx, (unsigned)cut.ny, (unsigned)n_pairs);
         const size_t tlds = (size_t)6 * cut.eh * cut.ew * sizeof(float);
         BlockArgs ba;
