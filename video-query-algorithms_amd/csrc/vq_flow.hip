@@ -84,7 +84,10 @@ __device__ __forceinline__ float sample_bilinear(const float* __restrict__ a, in
     return top * (1.0f - wy) + bot * wy;
 }
 
-constexpr int kBlkIters = 4;      // inner iterations per launch of the blocked form (= the halo of a tile)
+#ifndef VQ_FLOW_BLOCK_ITERS
+#define VQ_FLOW_BLOCK_ITERS 4
+#endif
+constexpr int kBlkIters = VQ_FLOW_BLOCK_ITERS;      // inner iterations per launch of the blocked form (= the halo of a tile)
 #ifndef VQ_FLOW_TILE_THREADS
 #define VQ_FLOW_TILE_THREADS 512
 #endif
