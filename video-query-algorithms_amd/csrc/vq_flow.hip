@@ -144,10 +144,13 @@ constexpr int kNoStop = 0x7FFFFFFF;
 __global__ void tvl1_warp_kernel(const float* __restrict__ i0, const float* __restrict__ i1, const float* __restrict__ i1x,
                                  const float* __restrict__ i1y, const float* __restrict__ u1, const float* __restrict__ u2,
                                  float* __restrict__ i1wx, float* __restrict__ i1wy, float* __restrict__ grad, float* __restrict__ rho_c,
-                                 PairState* __restrict__ st, int* __restrict__ n_active, int n, int h, int w) {
+                                 PairState* __restrict__ st, int* __restrict__ n_active, int* __restrict__ live_flag, int n, int h, int w) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n * h * w) return;
-    if (i == 0) *n_active = n;       // every pair starts the warp's inner loop live
+    if (i == 0) {                    // every pair starts the warp's inner loop live
+        *n_active = n;
+        __hip_atomic_store(live_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const int x = (int)(i % w), y = (int)((i / w) % h);
     const int64_t p = i / ((int64_t)h * w), base = p * (int64_t)h * w;
     const float a = u1[i], b = u2[i];
@@ -443,6 +446,8 @@ struct BlockArgs {
     float* set[2][6];                 // u1, u2, p11, p12, p21, p22 of set 0 and set 1
     PairState* st;
     int* n_active;
+    int* live_flag;                   // in pinned host memory: 1 while a pair of the warp is live, 0 once the last one has stopped (the host reads
+                                      // it behind an event instead of copying n_active back: 141 copy kernels per batch of 64 pairs)
     int h, w, L, max_iters;
     float l_t, theta, taut;
     double eps2;
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(NT) void tvl1_block_kernel(BlockArgs a) {
         if (cur.mode == kBlkDone && (a.L == 0 || st.blk[(a.L - 1) % 3].mode != kBlkDone)) {      // the pair has just finished
             st.final_set = cur.src;
             st.iters = cur.base;
-            atomicSub(a.n_active, 1);
+            if (atomicSub(a.n_active, 1) == 1) __hip_atomic_store(a.live_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     if (cur.mode == kBlkDone) return;
@@ -666,7 +671,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(VQ_FLOW_TILE
         if (cur.mode == kBlkDone && (a.L == 0 || st.blk[(a.L - 1) % 3].mode != kBlkDone)) {      // the pair has just finished
             st.final_set = cur.src;
             st.iters = cur.base;
-            atomicSub(a.n_active, 1);
+            if (atomicSub(a.n_active, 1) == 1) __hip_atomic_store(a.live_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     if (cur.mode == kBlkDone) return;
@@ -1076,7 +1081,8 @@ struct vq_flow {
     PairState* st = nullptr;
     int* n_active = nullptr;
     int* iters_log = nullptr;              // [levels][warps][pairs]
-    int* live_host = nullptr;              // pinned: the two most recent polls of n_active
+    int* live_host = nullptr;              // pinned: [0], [1] the two most recent polls of n_active (two-launch form); [2] the blocked form's live flag
+    int* live_flag_dev = nullptr;          // live_host + 2 as the device sees it
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
     double* hinv_dev = nullptr;
     unsigned* frame_max = nullptr;         // [max_pairs] bit pattern of the largest corner strength of a frame
@@ -1222,7 +1228,8 @@ int vq_flow_create(int32_t max_pairs, int32_t h, int32_t w, const vq_tvl1_params
     if ((e = vq::malloc_trim((void**)&f->n_active, sizeof(int))) != hipSuccess) return bail("vq::malloc_trim(state)", e);
     if ((e = vq::malloc_trim((void**)&f->iters_log, (size_t)f->levels.size() * prm.warps * max_pairs * sizeof(int))) != hipSuccess)
         return bail("vq::malloc_trim(log)", e);
-    if ((e = hipHostMalloc((void**)&f->live_host, 2 * sizeof(int))) != hipSuccess) return bail("hipHostMalloc(poll)", e);
+    if ((e = hipHostMalloc((void**)&f->live_host, 4 * sizeof(int))) != hipSuccess) return bail("hipHostMalloc(poll)", e);
+    if ((e = hipHostGetDevicePointer((void**)&f->live_flag_dev, f->live_host + 2, 0)) != hipSuccess) return bail("hipHostGetDevicePointer(poll)", e);
     for (hipEvent_t& ev : f->poll_ev)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     f->loop_ev.assign((size_t)2 * f->levels.size() * prm.warps, nullptr);
@@ -1365,6 +1372,7 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
         ba.rho_c = rho_c;
         ba.st = f->st;
         ba.n_active = f->n_active;
+        ba.live_flag = f->live_flag_dev;
         ba.h = L.h;
         ba.w = L.w;
         ba.max_iters = P.iterations;
@@ -1379,7 +1387,7 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
             sa.set1[q] = ba.set[1][q] = set[1][q];
         }
         for (int wp = 0; wp < P.warps; ++wp) {
-            tvl1_warp_kernel<<<cdiv(tot, 256), 256, 0, st>>>(i0, i1, i1x, i1y, u1, u2, i1wx, i1wy, grad, rho_c, f->st, f->n_active, n_pairs, L.h, L.w);
+            tvl1_warp_kernel<<<cdiv(tot, 256), 256, 0, st>>>(i0, i1, i1x, i1y, u1, u2, i1wx, i1wy, grad, rho_c, f->st, f->n_active, f->live_flag_dev, n_pairs, L.h, L.w);
             // Converged pairs switch themselves off on the device (their workgroups exit at once).  The host polls the number
             // of live pairs once per chunk of iterations, one chunk BEHIND what it has queued: the stream never runs dry while
             // the host waits, at the price of at most one chunk of empty launches after the last pair has stopped.
@@ -1404,11 +1412,11 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
                     }
                     VQ_CHECK_LAUNCH();
                     l0 += chunk;
-                    VQ_HIP(hipMemcpyAsync(f->live_host + (chunk_no & 1), f->n_active, sizeof(int), hipMemcpyDeviceToHost, st));
                     VQ_HIP(hipEventRecord(f->poll_ev[chunk_no & 1], st));
                     if (chunk_no > 0) {
                         VQ_HIP(hipEventSynchronize(f->poll_ev[(chunk_no - 1) & 1]));
-                        if (f->live_host[(chunk_no - 1) & 1] == 0) break;
+                        // the kernels clear the flag in host memory when the last pair stops: no copy in the stream
+                        if (__atomic_load_n(const_cast<volatile int*>(f->live_host + 2), __ATOMIC_ACQUIRE) == 0) break;
                     }
                 }
             }
