@@ -359,7 +359,8 @@ int vq_tvl1_default_params(vq_tvl1_params* params);
 /* A batch workspace for up to max_pairs frame pairs of h x w grey pixels.  params NULL = defaults.
  * Environment, read here: VQ_FLOW_FAST=1 -- hardware reciprocal / square root (1 ulp) instead of IEEE division / sqrtf in the inner
  * iterations (faster; flow images differ from the default's on ~0.4 % of the pixels, without bound where the flow is not determined);
- * VQ_FLOW_TWO_LAUNCH=1 -- the un-blocked primal / dual launch pair per iteration (A/B tests; same bits as the default). */
+ * VQ_FLOW_TWO_LAUNCH=1 -- the un-blocked primal / dual launch pair per iteration (A/B tests; same bits as the default);
+ * VQ_FLOW_TILES=square -- the 64 x 64 tiles on 1 024 threads of round 3 instead of tiles fitted to the level on 512 (A/B tests; same bits). */
 int vq_flow_create(int32_t max_pairs, int32_t h, int32_t w, const vq_tvl1_params* params, int32_t device, vq_flow** out);
 int vq_flow_destroy(vq_flow* flow);
 /* Pyramid actually used: *n_levels and (h, w) of the first min(*n_levels, cap) levels, finest first. */
