@@ -33,8 +33,13 @@ class StandInNet:
         seed = int.from_bytes(hashlib.sha256(self.salt + np.ascontiguousarray(crops).tobytes()).digest()[:8], "little")
         return np.random.default_rng(seed).random(1024) * 10.0
 
+    calls = 0
+
     def extract_clips(self, crops, T, on_device=False):
         assert crops.shape[0] % T == 0 and crops.shape[0] <= self.max_crops
+        StandInNet.calls += 1
+        if os.environ.get("STANDIN_FAIL_AT_CALL") == str(StandInNet.calls):
+            raise RuntimeError("stand-in extractor told to fail at call %d" % StandInNet.calls)
         return np.stack([self._clip_feature(crops[i:i + T]) for i in range(0, crops.shape[0], T)])
 
     def close(self):

@@ -47,3 +47,18 @@ RAGGED_EXTRA = [
 
 def golden_target_array(g, splits=(1, 2, 3)):
     return np.array([[g["target"][st][str(sp)] for sp in splits] for st in STREAMS], dtype=np.float64)
+
+
+def mean_sum_bits(values, T):
+    """For positive float64 values a: the fewest significant bits B of a number s with fl(s / T) == a, s taken as T * a rounded to B
+    bits (53 when nothing shorter reproduces a).  When a = (fp64 sum of T fp32 numbers) / T -- calcSig_wOF.py:82,
+    ``np.array(frame_features).mean(axis=0)`` over T float32 blobs -- that sum is exact in fp64 and short: 24 bits + log2(T) +
+    the exponent spread of the T addends (about 31 bits in the median); for any other double, or another T, B is 53."""
+    a = np.asarray(values, dtype=np.float64).reshape(-1)
+    s = a * float(T)
+    m, e = np.frexp(s)
+    need = np.full(a.shape, 53, dtype=np.int64)
+    for bits in range(52, 9, -1):
+        r = np.ldexp(np.round(m * 2.0 ** bits), e - bits)
+        need[r / float(T) == a] = bits
+    return need

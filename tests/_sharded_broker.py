@@ -75,6 +75,11 @@ def main():
             wb = np.array([[1.0, 1.5], [1.0, 0.8], [1.0, 2.2]])
             assert (one.scan_batch(tb, wb) == sdb.scan_batch(tb, wb)).all()
             assert (sdb.set_query_from_row(41) == one.set_query_from_row(41)).all()
+            # several tickets (and threads) on the ONE served database: every round gets what it gets alone, and the workers never
+            # see one operation's header with another's payload (tests/_round_threads.py)
+            from _round_threads import check_shared_database
+            check_shared_database(vqa, sdb, recs, [int(c) for c in ids[[0, 7, 19, 33]]], g["labelled"], STREAMS, DEFAULT_WEIGHTS,
+                                  threads=2, repeats=3)
             one.close()
         finally:
             sdb.close()

@@ -59,6 +59,12 @@ class OracleFeatureDB:
             raise RuntimeError("no similarities cached")
         return (self._avg.copy(), self._ne.copy(), self._sims.copy()) if sims else (self._avg.copy(), self._ne.copy())
 
+    def write_avg(self, avg, n_e=None):
+        self._avg = np.array(avg, dtype=np.float64)
+        if n_e is not None:
+            self._ne = np.array(n_e, dtype=np.int32)
+        self._scores = None
+
     def rescore(self, weights):
         self._scores = so.dense_scores(self._avg, weights)
 

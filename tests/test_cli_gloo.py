@@ -203,3 +203,28 @@ def test_more_ranks_than_clips(tmp_path):
     r3 = _run_cli(_argv(root, str(tmp_path / "three"), gpus=("0", "1", "2"), workers="3"), {})
     assert r1.returncode == 0 and r3.returncode == 0, r1.stdout + r3.stdout
     assert _tree_bytes(str(tmp_path / "three")) == _tree_bytes(str(tmp_path / "one")) and len(_tree_bytes(str(tmp_path / "one"))) == 2
+
+
+def test_groups_of_videos_are_flushed_as_they_finish(tmp_path):
+    """the reference writes a video's files inside its per-video loop (calcSig_wOF.py:195-222).  The drop-in shares the
+    clips out over the ranks in GROUPS of whole videos (VQ_CLI_GROUP_CLIPS; default 16 batches per rank) and gathers and queues
+    a group's files before the next group starts: same bytes whatever the grouping, one rank or two -- and a failure in a later
+    group leaves the files of the finished groups behind (here: videoA = group 1 is on disk, videoB + videoC = group 2 failed)."""
+    frames_root = str(tmp_path / "frames")
+    _make_tree(frames_root)
+    one = str(tmp_path / "one")
+    r = _run_cli(_argv(frames_root, one, gpus=("0",)), {})
+    assert r.returncode == 0, r.stdout
+    want = _tree_bytes(one)
+    for gpus in (("0",), ("0", "1")):
+        out = str(tmp_path / ("grouped%d" % len(gpus)))
+        r = _run_cli(_argv(frames_root, out, gpus=gpus), {"VQ_CLI_GROUP_CLIPS": "4", "VQ_CLI_TRACE": "1"})
+        assert r.returncode == 0, r.stdout
+        assert "2 group(s)" in r.stdout
+        assert _tree_bytes(out) == want
+    out = str(tmp_path / "failed")
+    # one rank, batches of 2 clips: group 1 (videoA, 7 clips) is 4 rgb + 4 flow calls; the 10th call belongs to group 2
+    r = _run_cli(_argv(frames_root, out, gpus=("0",)), {"VQ_CLI_GROUP_CLIPS": "4", "STANDIN_FAIL_AT_CALL": "10"}, timeout=120)
+    assert r.returncode != 0 and "told to fail at call 10" in r.stdout
+    left = _tree_bytes(out)
+    assert sorted(left) == sorted(k for k in want if k.startswith("videoA/")) and all(left[k] == want[k] for k in left)

@@ -450,3 +450,39 @@ def test_native_row_formatter_prints_like_str_of_numpy_float64():
     assert format_rows(np.zeros((0, 4)), np.zeros(0, dtype=np.int64)) == b""
     with pytest.raises(KeyError):
         format_rows(vals, nos, "g7")
+
+
+def _reference_rgb_and_flow_values():
+    """Feature values of the reference's own shipped CSVs in their lossless (17-digit) number format: read from /root/reference
+    where it exists (the build container), and always the committed 24-clip extract of the same files (tests/golden/real_subset_x.npy,
+    exact fp64, written by oracle/gen_golden.py)."""
+    out = {"committed extract": np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real_subset_x.npy"), allow_pickle=False).reshape(-1)}
+    root = "/root/reference/data/features/stock-video-clips_features"
+    if os.path.isdir(root):
+        vals = []
+        for dirpath, _dirs, files in sorted(os.walk(root)):
+            for f in sorted(files):
+                if f.endswith("_global_pool_features.csv"):
+                    with open(os.path.join(dirpath, f)) as fh:
+                        fh.readline()
+                        vals += [float(t) for line in fh for t in line.strip().split(",")[1:]]
+        assert len(vals) == 6 * 87 * 1024
+        out["reference CSVs"] = np.array(vals)
+    return out
+
+
+def test_reference_feature_values_are_fp64_means_of_25_fp32_blobs():
+    """The ONE statement about half A's arithmetic that the reference's own fixtures can make: the
+    shipped feature files are outputs of calcSig_wOF.py:82 at the script's default of 25 snippets -- the fp64 mean of 25 fp32
+    global_pool blobs.  Then 25 x value is the EXACT fp64 sum of 25 float32 numbers, a short dyadic number (24 bits + log2 25 + the
+    exponent spread of the addends: 31 bits in the median, never the 53 of an arbitrary double), the values are post-ReLU averages
+    (>= 0), and they are NOT float32 numbers (the mean was not taken in fp32).  SURVEY's "<= 29 bits" is the equal-exponent case.
+    The GPU twin (tests/test_tsn_gpu.py::test_t25_features_have_the_arithmetic_of_the_reference_files) holds the product to the same."""
+    from _helpers import mean_sum_bits
+    for where, v in _reference_rgb_and_flow_values().items():
+        assert (v >= 0).all(), where
+        pos = v[v > 0]
+        need = mean_sum_bits(pos, 25)
+        assert np.median(need) <= 33 and (need <= 40).mean() >= 0.99 and need.max() <= 52, (where, np.median(need), (need <= 40).mean(), need.max())
+        assert (mean_sum_bits(pos[:20000], 24) >= 48).mean() >= 0.95, where         # ... of 25 addends: for another count nothing short fits
+        assert (pos.astype(np.float32).astype(np.float64) == pos).mean() <= 0.05, where    # consensus in fp64, not fp32

@@ -134,6 +134,22 @@ def _broker_round(name, sdb):
         assert all(_close(tk.scores[c], s) for c, s in zip(g["clip_order"], g["scores_opt"]))
 
 
+def _shared_rounds(name, sdb):
+    """Several tickets -- and threads -- on the ONE served database, and a badly shaped query before a normal
+    round (it must be refused BEFORE the announcement, or the workers wait for a partner that never comes)."""
+    import video_query_algorithms_amd as vqa
+    from _helpers import DEFAULT_WEIGHTS, STREAMS, records_from_dense
+    from _round_threads import check_shared_database
+    g, x, _present, ids = _golden_block(name)
+    with pytest.raises(ValueError):
+        sdb.set_query(np.zeros((sdb.S, sdb.E, sdb.D + 1)))
+    with pytest.raises(ValueError):
+        sdb.write_avg(np.zeros((sdb.n + 1, sdb.S)))
+    recs = records_from_dense(x, ids, [1, 2, 3])
+    check_shared_database(vqa, sdb, recs, [int(c) for c in np.asarray(ids)[[0, 7, 19, 33]]], g["labelled"], STREAMS, DEFAULT_WEIGHTS,
+                          threads=2, repeats=2)
+
+
 def _served_worker(rank, world, port, name):
     _setup(rank, world, port)
     _g, x, present, ids = _golden_block(name)
@@ -141,6 +157,8 @@ def _served_worker(rank, world, port, name):
     try:
         if rank == 0:
             _broker_round(name, sdb)
+            if name == "synth_small":
+                _shared_rounds(name, sdb)
             sdb.close()
         else:
             sdb.serve()                                   # returns when rank 0 closes the database

@@ -93,6 +93,61 @@ def test_conv_bn_relu_layer(tsn, monkeypatch, cin, h, cout, k, s, p, n, tile):
     m.close()
 
 
+def _pooled_mini(bi, c, h, k_mid, n_out):
+    """data -> 1x1 conv (k_mid channels) -> 3x3/2 max pool -> 1x1 conv (n_out) -> global average pool: the shape of
+    pool1 -> conv2/3x3_reduce and pool2 -> inception_3a's sibling 1x1 group (the pool disappears into the GEMM behind it)."""
+    g = bi.Graph("pooled", "data", (c, h, h))
+    g.layers.append(bi.Layer("c", "Convolution", ["data"], ["c"], k_mid, 1, 1, 0))
+    g.layers.append(bi.Layer("c_bn", "BN", ["c"], ["c_bn"]))
+    g.layers.append(bi.Layer("c_relu", "ReLU", ["c_bn"], ["c_bn"]))
+    g.layers.append(bi.Layer("p", "Pooling", ["c_bn"], ["p"], kernel=3, stride=2, pad=0, pool="MAX"))
+    g.layers.append(bi.Layer("d", "Convolution", ["p"], ["d"], n_out, 1, 1, 0))
+    g.layers.append(bi.Layer("d_bn", "BN", ["d"], ["d_bn"]))
+    g.layers.append(bi.Layer("d_relu", "ReLU", ["d_bn"], ["d_bn"]))
+    ho = to.pool_out(h, 3, 2, 0)
+    g.layers.append(bi.Layer("gp", "Pooling", ["d_bn"], ["gp"], kernel=ho, stride=1, pad=0, pool="AVE"))
+    return g
+
+
+@pytest.mark.parametrize("h,k_mid,n_out,n", [(28, 64, 64, 3),        # pool1 -> conv2/3x3_reduce in small
+                                             (17, 192, 224, 5),      # pool2 -> the 224-column group of inception_3a; odd size: clipped windows, ragged M
+                                             (12, 32, 96, 2)])
+def test_pooled_input_gemm_every_tiling(tsn, h, k_mid, n_out, n):
+    """A 3x3 max pool read by one 1x1 GEMM lives in that GEMM (bn_inception._fuse).  Every kernel that can run it -- the pooled
+    loader of conv_igemm_kernel under each of its tilings, and the two-phase pool_gemm_kernel -- gives the bits of the un-fused
+    pair of layers (max is exact, the k order of the GEMM is the same) and agrees with the fp64 oracle."""
+    bi, net = tsn
+    g = _pooled_mini(bi, 32, h, k_mid, n_out)
+    w = net.synthetic_weights(g, seed=h + n_out)
+    crops = np.random.default_rng(h).integers(0, 256, (n, h, h, 32), dtype=np.uint8)
+    mean = np.linspace(100.0, 130.0, 32).astype(np.float32)
+    want = to.forward(g.layers, "data", w, to.preprocess(crops, mean), keep=("d_bn",))["d_bn"]
+    plain = net.TsnNet(g, w, max_crops=n, feature_blob="gp", fuse=False)
+    plain.forward(crops, 1, mean)
+    base = plain.read_blob("d_bn", n)
+    plain.close()
+    assert np.abs(_nchw(base) - want).max() <= 2e-5 * np.abs(want).max()
+    m = net.TsnNet(g, w, max_crops=n, feature_blob="gp")
+    li = [i for i, o in enumerate(m.plan.ops) if o.pre_pool]
+    assert len(li) == 1 and "p" not in m.plan.blob_loc
+    ran = 0
+    for tile in [(128, 128, 16, 0), (128, 96, 16, 0), (128, 64, 16, 0), (64, 128, 32, 0), (64, 128, 16, 0), (64, 64, 32, 0), (64, 64, 16, 0),
+                 (128, 32, 16, 0), (64, 256, 16, 0), (64, 256, 8, 3), (64, 64, 8, 3), (128, 64, 8, 3)]:
+        if tile[3] == 3 and tile[0] * (k_mid + 4) * 4 > 64 * 1024:
+            continue                                                    # the pooled image of a tile must fit the LDS budget
+        m.forward(crops, 1, mean)                                       # tuned table for this batch size exists now
+        tiles = m.layer_tiles(n).copy()
+        tiles[li[0]] = tile
+        m.set_layer_tiles(n, tiles)
+        m.forward(crops, 1, mean)
+        assert (m.layer_tiles(n)[li[0]] == tile).all()
+        got = m.read_blob("d_bn", n)
+        assert (got == base).all(), tile
+        ran += 1
+    assert ran >= 11
+    m.close()
+
+
 def test_k_split_is_a_property_of_the_layer_not_of_the_batch(tsn, monkeypatch):
     """The 7x7-map layers with long K run as K slices + a combine pass (a different summation order than one chain, so
     it must apply to a layer at EVERY batch size).  Split and unsplit agree to rounding; with the split on, a crop's
@@ -239,7 +294,7 @@ def test_bn_inception_rgb_layerwise_and_features(tsn, rgb_case):
     plain = net.TsnNet(g, w, max_crops=4, fuse=False)      # materialises the blobs the fused plan folds away (the stem pools)
     plain.forward(crops, 2, net.RGB_MEAN)
     folded = [name for name in keep[:-1] if name not in m.plan.blob_loc]
-    assert folded == ["pool1/3x3_s2"]
+    assert folded == ["pool1/3x3_s2"] + (["pool2/3x3_s2"] if bi.FOLD_POOL_MAX_COUT >= 224 else [])
     for name in keep[:-1]:
         got = _nchw((plain if name in folded else m).read_blob(name, 4))
         d = np.abs(got - want[name]).max() / np.abs(want[name]).max()
@@ -319,6 +374,27 @@ def test_cfg2_shape_runs_and_is_deterministic(tsn):
     assert (p3 == p1[:6]).all() and (f3 == f1[:2]).all()
     m.close()
     m2.close()
+
+
+def test_t25_features_have_the_arithmetic_of_the_reference_files(tsn):
+    """The reference's shipped feature files are fp64 means of 25 fp32 global_pool blobs (calcSig_wOF.py:82 at the script's default
+    of 25 snippets; tests/test_feature_files.py::test_reference_feature_values_are_fp64_means_of_25_fp32_blobs measures it on the
+    files).  The product's T = 25 features have the same arithmetic: 25 x value is a short exact sum, values >= 0 and not fp32."""
+    from _helpers import mean_sum_bits
+    bi, net = tsn
+    g = bi.bn_inception(3)
+    w = net.synthetic_weights(g, seed=2)
+    crops = np.random.default_rng(25).integers(0, 256, (50, 224, 224, 3), dtype=np.uint8)
+    m = net.TsnNet(g, w, max_crops=50)
+    feat, ps = m.forward(crops, 25, net.RGB_MEAN)
+    m.close()
+    assert feat.shape == (2, 1024) and feat.dtype == np.float64 and (feat >= 0).all()
+    assert (feat == to.consensus(ps, 25)).all()
+    pos = feat[feat > 0]
+    need = mean_sum_bits(pos, 25)
+    assert np.median(need) <= 33 and (need <= 40).mean() >= 0.99 and need.max() <= 52, (np.median(need), (need <= 40).mean(), need.max())
+    assert (mean_sum_bits(pos, 24) >= 48).mean() >= 0.95
+    assert (pos.astype(np.float32).astype(np.float64) == pos).mean() <= 0.05
 
 
 def test_bad_shapes_are_rejected_before_launch(tsn):

@@ -222,18 +222,33 @@ def main(argv=None, net_factory=None, program=None):
     csv_jobs = []
     build_pool = ThreadPoolExecutor(max_workers=2)
 
-    # The clips of ALL videos of the tree form one list (video order, then clip number: calcSig_wOF.py:193-200) and THAT is what the
-    # ranks share out: contiguous ranges of it, whole batches of --batch_clips whatever the videos' sizes (the reference's fixtures
-    # are 87- and 114-clip videos: per-video sharding left 11-14 clips per rank on 8 GPUs and one collective per video and stream),
-    # one all-gather per stream (and ensemble member); the files are still one per video, stream and member.
+    # The clips of the videos form one list (video order, then clip number: calcSig_wOF.py:193-200) and THAT is what the ranks share
+    # out: contiguous ranges of it, whole batches of --batch_clips whatever the videos' sizes (the reference's fixtures are 87- and
+    # 114-clip videos: per-video sharding left 11-14 clips per rank on 8 GPUs and one collective per video and stream).  The list is
+    # cut into GROUPS of whole videos of at least 16 batches per rank: a group is shared out, extracted, all-gathered (one collective
+    # per stream and ensemble member) and its files are queued before the next group starts -- the reference writes a video's files
+    # inside its per-video loop (calcSig_wOF.py:195-222), so a bad frame or a kill near the end of a long tree leaves every finished
+    # video behind, and what a rank keeps in memory is bounded by a group, not by the tree.  The files are one per video, stream and
+    # member, with the bytes of the one-GPU run.
     videos = []
     for video_path in sorted(glob.glob(frame_path + '*/')):                            # calcSig_wOF.py:193-195
         f_info = frames.parse_directory(video_path, args.rgb_prefix, args.flow_x_prefix, args.flow_y_prefix)
         clip_list = sorted(list(f_info[0]), key=lambda clip: int(clip[-4:]))           # calcSig_wOF.py:199-200
         videos.append((video_path, f_info, clip_list))
-    units = [(vi, vid) for vi, (_p, _f, clip_list) in enumerate(videos) for vid in clip_list]
-    stamp("frame tree parsed: %d videos, %d clips" % (len(videos), len(units)))
-    first, count = shard_range(len(units), world, rank)
+    group_clips = int(os.environ.get("VQ_CLI_GROUP_CLIPS", "0")) or 16 * args.batch_clips * world
+    groups, acc, n_acc = [], [], 0                       # groups of video indices
+    for vi, (_p, _f, clip_list) in enumerate(videos):
+        acc.append(vi)
+        n_acc += len(clip_list)
+        if n_acc >= group_clips:
+            groups.append(acc)
+            acc, n_acc = [], 0
+    if acc:
+        groups.append(acc)
+    group_units = [[(vi, vid) for vi in g for vid in videos[vi][2]] for g in groups]
+    shards = [shard_range(len(u), world, rank) for u in group_units]
+    count = sum(c for _f, c in shards)                   # clips of this rank in the whole tree
+    stamp("frame tree parsed: %d videos, %d clips, %d group(s)" % (len(videos), sum(len(u) for u in group_units), len(groups)))
     on_gpu = world > 1                                   # blocks that will be all-gathered never visit the host
     host_rule = {'rule': rule} if args.host_resize else {}             # the host loaders resize; the others hand frames to the GPU
 
@@ -253,7 +268,10 @@ def main(argv=None, net_factory=None, program=None):
         load = frames.load_flow_jpegs if device_jpeg else frames.load_flow_snippets if args.host_resize else frames.load_flow_frames
         return load(f_info[0][vid], ticks, frame_cnt, s['stack_depth'], args.flow_x_prefix, args.flow_y_prefix, args.frame_ext, **host_rule)
 
-    batches = [units[b0:min(b0 + args.batch_clips, first + count)] for b0 in range(first, first + count, args.batch_clips)]
+    batches, group_batches = [], []                      # this rank's batches of all groups; per group: their indices
+    for units, (first, cnt) in zip(group_units, shards):
+        group_batches.append(list(range(len(batches), len(batches) + -(-cnt // args.batch_clips))))
+        batches += [units[b0:min(b0 + args.batch_clips, first + cnt)] for b0 in range(first, first + cnt, args.batch_clips)]
     n_streams = len(streamCNN)
     # The order of the work.  Host decoding: stream by stream, as the reference does (all RGB batches, then all flow batches).
     # --device_jpeg: batch by batch, the RGB and the flow half of a batch behind each other -- the preparation of a flow batch (8 000
@@ -263,14 +281,16 @@ def main(argv=None, net_factory=None, program=None):
     if device_jpeg and count:
         # (letting the flow stream trail the RGB stream by a batch or two, so that its extractor and first files are surely ready at its
         # first turn, was measured: 0.70-0.77 s against 0.63-0.65 for 256 clips -- the uneven ends cost more than the stall)
-        order = [(si, bi) for bi in range(len(batches)) for si in range(n_streams)]
+        group_order = [[(si, bi) for bi in gb for si in range(n_streams)] for gb in group_batches]
+        order = [x for go in group_order for x in go]
         crop_pipe = _CropPipeline([FrameIngest(3 if s['modality'] == 'rgb' else 2 * s['stack_depth'], device, rule) for s in streamCNN],
                                   batches, order, load_clip, pool)
         crop_pipe.start()                            # the first batches are read and decoded while the extractors are being built
     else:
-        order = [(si, bi) for si in range(n_streams) for bi in range(len(batches))]
+        group_order = [[(si, bi) for si in range(n_streams) for bi in gb] for gb in group_batches]
+        order = [x for go in group_order for x in go]
     nets = [None] * n_streams
-    mine = [[[] for _ in members] for _ in streamCNN]
+    mine = [[[] for _ in members] for _ in streamCNN]    # the feature blocks of the group in work
     waited = [{'files': 0.0, 'crops': 0.0, 'nets': 0.0} for _ in streamCNN]     # VQ_CLI_TRACE=1: where the loop waited, per stream
     pending = {}                                     # host decoding: (si, bi) -> futures of the batch's clips, one batch ahead
 
@@ -287,45 +307,79 @@ def main(argv=None, net_factory=None, program=None):
             mine[si][mi].append(make(net))
         waited[si]['nets'] += time.perf_counter() - t0
 
+    def flush(gi):
+        """Group gi is through the networks: gather its blocks (one collective per stream and member), queue its videos' files."""
+        n_units = len(group_units[gi])
+        for si, s in enumerate(streamCNN):
+            for mi, m in enumerate(members):
+                width = nets[si][mi].feature_dim if nets[si] else args.featureBlob_size
+                local_feat = _stack_rows(mine[si][mi], width)
+                mine[si][mi] = []
+                if world > 1:
+                    import torch
+                    if isinstance(local_feat, np.ndarray):       # host blocks, or a rank that owns no clip
+                        local_feat = torch.from_numpy(np.ascontiguousarray(local_feat, dtype=np.float64))
+                    if backend_device is not None and local_feat.device != backend_device:
+                        local_feat = local_feat.to(backend_device)
+                    local_feat = all_gather_rows(local_feat, n_units).cpu().numpy()
+                numFeatures = local_feat.shape[1] if n_units else args.featureBlob_size
+                assert numFeatures == args.featureBlob_size                                  # calcSig_wOF.py:219-220
+                if rank != 0:
+                    continue
+                row = 0
+                for video_path, _f, clip_list in (videos[vi] for vi in groups[gi]):
+                    block, row = local_feat[row:row + len(clip_list)], row + len(clip_list)
+                    if not clip_list:
+                        continue
+                    # a stream's file is formatted and written (half a million float reprs per 256 clips) by a thread of its own while the
+                    # next stream is on the GPU; the same files as writing both at the end (:116-134)
+                    csv_jobs.append(io_pool.submit(write_features, args.outFeatures_dir, video_path.split('/')[-2], video_path, m['modelname'],
+                                                   args.featureBlob, clip_list, {s['mode']: block},
+                                                   {'rgb': m['rgb'], 'warped_optical_flow': m['flow']}, args.number_format))
+
     t_loop = time.perf_counter()
     submit_files(0)
-    for k, (si, bi) in enumerate(order):
-        s, batch = streamCNN[si], batches[bi]
-        if nets[si] is None:
-            nets[si] = [net_jobs[(s['modality'], mi)].result() for mi in range(len(members))]
-            stamp("%s extractor(s) ready" % s['modality'])
-        crops = []
-        if not crop_pipe:
-            # --num_worker decoder threads (the reference runs that many worker PROCESSES, each with its own net,
-            # calcSig_wOF.py:204-210); the batch after the one on the GPU is decoded meanwhile
-            t0 = time.perf_counter()
-            crops = [f.result() for f in pending.pop((si, bi))]
-            waited[si]['files'] += time.perf_counter() - t0
-            submit_files(k + 1)
-        for _vi, vid in batch:
-            print('video {} for {} modality done'.format(vid, s['modality']))
-        if crop_pipe:
-            t0 = time.perf_counter()
-            dev_crops = crop_pipe.get(k)
-            waited[si]['crops'] += time.perf_counter() - t0
-            through_the_nets(si, lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu))
-        elif not crops:
-            continue
-        elif args.host_resize:
-            block = np.concatenate(crops, axis=0)
-            through_the_nets(si, lambda net: net.extract_clips(block, T, on_device=on_gpu))
-        else:
-            # resize + crop on the GPU, once per batch; clips of different frame sizes in one batch go one by one
-            groups = [np.concatenate(crops, axis=0)] if len({c.shape[1:] for c in crops}) == 1 else crops
-            for g in groups:
-                if len(nets[si]) == 1:
-                    through_the_nets(si, lambda net: net.extract_clips_from_frames(g, T, on_device=on_gpu))
-                else:
-                    per = args.batch_clips * T                      # = max_crops of the extractors
-                    for i in range(0, g.shape[0], per):
-                        dev_crops = nets[si][0].crops_from_frames(g[i:i + per])
-                        nets[si][0].sync_ingest()
-                        through_the_nets(si, lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu))
+    k = -1
+    for gi, go in enumerate(group_order):
+        for si, bi in go:
+            k += 1
+            s, batch = streamCNN[si], batches[bi]
+            if nets[si] is None:
+                nets[si] = [net_jobs[(s['modality'], mi)].result() for mi in range(len(members))]
+                stamp("%s extractor(s) ready" % s['modality'])
+            crops = []
+            if not crop_pipe:
+                # --num_worker decoder threads (the reference runs that many worker PROCESSES, each with its own net,
+                # calcSig_wOF.py:204-210); the batch after the one on the GPU is decoded meanwhile
+                t0 = time.perf_counter()
+                crops = [f.result() for f in pending.pop((si, bi))]
+                waited[si]['files'] += time.perf_counter() - t0
+                submit_files(k + 1)
+            for _vi, vid in batch:
+                print('video {} for {} modality done'.format(vid, s['modality']))
+            if crop_pipe:
+                t0 = time.perf_counter()
+                dev_crops = crop_pipe.get(k)
+                waited[si]['crops'] += time.perf_counter() - t0
+                through_the_nets(si, lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu))
+            elif not crops:
+                continue
+            elif args.host_resize:
+                block = np.concatenate(crops, axis=0)
+                through_the_nets(si, lambda net: net.extract_clips(block, T, on_device=on_gpu))
+            else:
+                # resize + crop on the GPU, once per batch; clips of different frame sizes in one batch go one by one
+                same_size = [np.concatenate(crops, axis=0)] if len({c.shape[1:] for c in crops}) == 1 else crops
+                for g in same_size:
+                    if len(nets[si]) == 1:
+                        through_the_nets(si, lambda net: net.extract_clips_from_frames(g, T, on_device=on_gpu))
+                    else:
+                        per = args.batch_clips * T                      # = max_crops of the extractors
+                        for i in range(0, g.shape[0], per):
+                            dev_crops = nets[si][0].crops_from_frames(g[i:i + per])
+                            nets[si][0].sync_ingest()
+                            through_the_nets(si, lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu))
+        flush(gi)
     stamp("last batch through the networks")
     if trace:
         for si, s in enumerate(streamCNN):
@@ -333,31 +387,6 @@ def main(argv=None, net_factory=None, program=None):
                   % (s['modality'], len(batches), time.perf_counter() - t_loop, waited[si]['files'], waited[si]['crops'], waited[si]['nets']),
                   file=sys.stderr, flush=True)
 
-    for si, s in enumerate(streamCNN):
-        for mi, m in enumerate(members):
-            width = nets[si][mi].feature_dim if nets[si] else args.featureBlob_size
-            local_feat = _stack_rows(mine[si][mi], width)
-            if world > 1:
-                import torch
-                if isinstance(local_feat, np.ndarray):       # host blocks, or a rank that owns no clip
-                    local_feat = torch.from_numpy(np.ascontiguousarray(local_feat, dtype=np.float64))
-                if backend_device is not None and local_feat.device != backend_device:
-                    local_feat = local_feat.to(backend_device)
-                local_feat = all_gather_rows(local_feat, len(units)).cpu().numpy()
-            numFeatures = local_feat.shape[1] if len(units) else args.featureBlob_size
-            assert numFeatures == args.featureBlob_size                                  # calcSig_wOF.py:219-220
-            if rank != 0:
-                continue
-            row = 0
-            for video_path, _f, clip_list in videos:
-                block, row = local_feat[row:row + len(clip_list)], row + len(clip_list)
-                if not clip_list:
-                    continue
-                # a stream's file is formatted and written (half a million float reprs per 256 clips) by a thread of its own while the
-                # next stream is on the GPU; the same files as writing both at the end (:116-134)
-                csv_jobs.append(io_pool.submit(write_features, args.outFeatures_dir, video_path.split('/')[-2], video_path, m['modelname'],
-                                               args.featureBlob, clip_list, {s['mode']: block},
-                                               {'rgb': m['rgb'], 'warped_optical_flow': m['flow']}, args.number_format))
     stamp("features gathered, feature files queued")
     for per_stream in nets:
         for n in per_stream or []:

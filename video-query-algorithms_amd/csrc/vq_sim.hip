@@ -1102,7 +1102,19 @@ static int convert_layout(vq_db* db, int to) {
         e = hipMalloc((void**)&scratch, (size_t)(per * tile_bytes));
     }
     if (e != hipSuccess) return fail(VQ_E_NOMEM, "no room for the %lld MB conversion block: %s", (long long)(per * tile_bytes >> 20), hipGetErrorString(e));
-    const size_t lds = 16 * (size_t)(db->D + 4) * sizeof(float);
+    const size_t lds = 16 * (size_t)(db->D + 4) * sizeof(float);         // 65 792 bytes at D = 1024: above the 64 KB default limit
+    {   // raised per (kernel, device) like every other large-LDS launch (vq_common.h); the caller holds a DeviceGuard
+        const auto raise = [&]() -> int {
+            VQ_DYN_LDS(mirror_build_kernel, lds);
+            VQ_DYN_LDS(untile_kernel, lds);
+            return VQ_OK;
+        };
+        const int rc0 = raise();
+        if (rc0 != VQ_OK) {
+            (void)hipFree(scratch);
+            return rc0;
+        }
+    }
     int rc = VQ_OK;
     for (int64_t t0 = 0; t0 < ntiles && rc == VQ_OK; t0 += per) {
         const int64_t k = std::min(per, ntiles - t0);

@@ -665,6 +665,153 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// max-pool + 1x1 convolution with the pooled activations of a workgroup resident in LDS (the stem pools: pool1 ->
+// conv2/3x3_reduce, pool2 -> the sibling 1x1 group of inception_3a).  The POOL instantiation of conv_igemm_kernel above stages
+// BOTH operands through a double-buffered LDS ring, K-step by K-step.  Here
+//   * the pooled image of the workgroup's BM pixels is written ONCE, slab by slab (32 channels of BM = 64 pixels), into a
+//     [BM][K] LDS image that is never overwritten -- so there is no ring and only one barrier per slab;
+//   * the 18 tap loads of slab s + 1 are in flight under the MFMAs of slab s (64 per wave on the 64 x 256 tile), their maxima
+//     (v_max3) and two ds_write_b128 follow those MFMAs;
+//   * the weight fragments go straight from L2 into registers one k-group ahead: every wave owns its own BN / WN output
+//     columns, nothing about the weights is shared inside a workgroup, so no LDS stage and no barrier exists for them.
+// Measured on pool2 -> inception_3a (75 264 x 224 x 192 at 96 crops): the pooling stream alone takes 0.061 ms, the GEMM alone
+// 0.069 ms; un-overlapped (all maxima first, then the GEMM; or the K-step ring of conv_igemm_kernel) 0.111 ms.
+// Same k order per output element as every other direct kernel (k-groups of 8 ascending, pairs {s, 4 + s} inside): same bits.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void pool_gemm_kernel(ConvArgs a) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(BM == 64 || BM == 128, "two staged chunks per thread and slab");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int SLAB = 2048 / BM;                              // channels per slab: 512 16-byte chunks = 2 per thread
+    constexpr int CPS = SLAB / 4;                                // chunks per row and slab
+    constexpr int GS = SLAB / 8;                                 // k-groups per slab (2 or 4)
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* As = reinterpret_cast<float*>(smem_raw);               // [BM][K + 4]: rows 16 bytes longer than K -> conflict-free b128 reads
+    const int K = a.Cin, pitch = K + 4;
+    const int tid = threadIdx.x;
+    const int tile = xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n);
+    const int m0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.w_bytes, 0x00020000);
+
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    floatx4 bias_v[TN];
+    ConvSeg seg_v[TN];
+    unsigned b_voff[TN];                                          // this lane's weight row, k = 4 half: + 32 bytes per k-group
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nb_ = n0 + wn * (BN / WN) + 32 * j;
+        const int n = nb_ + (lane & 7) * 4;
+        bias_v[j] = *reinterpret_cast<const floatx4*>(a.bias + (n < a.Cout ? n : 0));
+        seg_v[j] = a.segs[nb_ < a.Cout ? nb_ >> 5 : 0];
+        b_voff[j] = nb_ + l31 < a.Cout ? (unsigned)(((nb_ + l31) * a.Kp + half * 4) * 4) : 0xFFFFFFFFu;
+    }
+
+    // ---- staging role: chunk u of a slab = row (tid + 256 u) / CPS, 16-byte column (tid + 256 u) % CPS -- the same two rows for
+    // every slab, so the nine tap offsets of each are computed once (a tap outside the image re-reads the window's first pixel:
+    // the maximum is unchanged; a row past M reads zeros through the range check) and a slab adds its scalar channel offset
+    unsigned tap_off[2][9];
+    int a_dst[2];
+    {
+        const int px = a.Cs_in * 4, rowb = a.W * px;               // bytes to the next pixel / next image row
+        const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + 256 * u, row = idx / CPS, col = idx % CPS;
+            const int m = m0 + row;
+            const bool ok = m < a.M;
+            const int mm = ok ? m : 0;
+            const int n_img = mm / HoWo, rem = mm - n_img * HoWo;
+            const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+            const int ih0 = oh * a.pool_s, iw0 = ow * a.pool_s;
+            const unsigned base = (unsigned)((((n_img * a.H + ih0) * a.W + iw0) * a.Cs_in + a.coff_in + col * 4) * 4);
+            const int nvy = min(3, a.H - ih0), nvx = min(3, a.W - iw0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3, dx = t % 3;
+                tap_off[u][t] = ok ? base + ((dy < nvy && dx < nvx) ? (unsigned)(dy * rowb + dx * px) : 0u) : 0xFFFFFFFFu;
+            }
+            a_dst[u] = row * pitch + col * 4;
+        }
+    }
+    floatx4 v[2][9];
+#define VQ_PG_TAPS(S)                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                                   \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                               \
+            v[u][t] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, tap_off[u][t], (S) * (SLAB * 4), 0));
+#define VQ_PG_POOL(S)                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                 \
+        floatx4 r;                                                                                                  \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                             \
+            const float x = __builtin_fmaxf(__builtin_fmaxf(v[u][0][e], v[u][1][e]), v[u][2][e]);                  \
+            const float y = __builtin_fmaxf(__builtin_fmaxf(v[u][3][e], v[u][4][e]), v[u][5][e]);                  \
+            const float z = __builtin_fmaxf(__builtin_fmaxf(v[u][6][e], v[u][7][e]), v[u][8][e]);                  \
+            r[e] = __builtin_fmaxf(__builtin_fmaxf(x, y), z);                                                       \
+        }                                                                                                           \
+        *reinterpret_cast<floatx4*>(As + a_dst[u] + (S) * SLAB) = r;                                                \
+    }
+
+    // ---- compute role.  Lane (row r, half h) holds k = 8 g + 4 h + s for MFMA step s of k-group g, as in conv_igemm_kernel.
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const float* a_frag = As + (wm * (BM / WM) + l31) * pitch + half * 4;      // + 32 i rows, + 8 g floats
+    floatx4 fa[2][TM], fb[2][TN];
+#define VQ_PG_FETCH_B(SET, G)                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                  \
+        fb[SET][j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_voff[j], (G) * 32, 0));
+#define VQ_PG_FETCH_A(SET, G)                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                  \
+        fa[SET][i] = *reinterpret_cast<const floatx4*>(a_frag + 32 * i * pitch + (G) * 8);
+#define VQ_PG_MFMA(SET)                                                                                             \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                   \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                              \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                          \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][i][s], fb[SET][j][s], acc[i][j], 0, 0, 0);
+
+    const int ns = K / SLAB;
+    VQ_PG_TAPS(0)
+    VQ_PG_FETCH_B(0, 0)
+    VQ_PG_POOL(0)
+    __syncthreads();
+    for (int s = 0; s < ns; ++s) {
+        const bool more = s + 1 < ns;
+        if (more) VQ_PG_TAPS(s + 1)                                // in flight under this slab's MFMAs
+        VQ_PG_FETCH_A(0, s * GS)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < GS; ++q) {
+            // one k-group ahead: the weights always (they do not pass through LDS), the activations inside the slab only
+            if (q + 1 < GS) {
+                VQ_PG_FETCH_B((q + 1) & 1, s * GS + q + 1)
+                VQ_PG_FETCH_A((q + 1) & 1, s * GS + q + 1)
+            } else if (more) {
+                VQ_PG_FETCH_B(0, (s + 1) * GS)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            VQ_PG_MFMA(q & 1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) {
+            VQ_PG_POOL(s + 1)
+            __syncthreads();                                       // slab s + 1 is complete in LDS (nothing is ever overwritten)
+        }
+    }
+#undef VQ_PG_TAPS
+#undef VQ_PG_POOL
+#undef VQ_PG_FETCH_A
+#undef VQ_PG_FETCH_B
+#undef VQ_PG_MFMA
+    VQ_EPILOGUE()
+}
+
+// ------------------------------------------------------------------------------------------------
 // pooling (Caffe semantics: ceil-mode output size; MAX ignores padding; AVE divides by the window
 // clipped to the padded extent and accumulates h-major in fp32)
 // ------------------------------------------------------------------------------------------------
@@ -772,7 +919,8 @@ static inline bool is_conv(int op) { return op == VQ_OP_CONV || op == VQ_OP_CONV
 
 struct ConvTile {
     int bm, bn, bk;
-    int pipe;   // 1 = software-pipelined kernel (aligned Cin only)
+    int pipe;   // 1 = software-pipelined kernel (aligned Cin only); 3 = pool_gemm_kernel (pooled-input 1x1 layers only; bk is its
+                // k-group of 8).  2 is taken: vq_tsn_layer_tiles reports the Winograd form with it
 };
 
 // One kernel launch of a forward: a single layer, or the Winograd convolutions of one graph level together.
@@ -937,7 +1085,10 @@ static const ConvTile kTiles[] = {
     {32, 128, 32, 0},  {32, 128, 16, 0},
     {128, 128, 32, 1}, {128, 128, 16, 1}, {128, 96, 32, 1}, {128, 96, 16, 1}, {128, 64, 32, 1}, {128, 64, 16, 1},
     {64, 128, 32, 1},  {64, 128, 16, 1},  {64, 64, 32, 1},  {64, 64, 16, 1},  {128, 32, 32, 1}, {128, 32, 16, 1},
-    {32, 128, 32, 1},  {32, 128, 16, 1}};
+    {32, 128, 32, 1},  {32, 128, 16, 1},
+    // pooled-input 1x1 layers only: ONE column tile for up to 256 output columns (every pooling window is read once), and the
+    // two-phase kernel
+    {64, 256, 16, 0}, {64, 256, 8, 3}, {64, 64, 8, 3}, {128, 64, 8, 3}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 
 template <int BM, int BN, int WM, int WN, int BK, bool SMALL>
@@ -964,7 +1115,13 @@ static int launch_conv_pipe(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
 }
 
 // The pooled loader keeps 8 extra window taps per staged chunk in registers: tilings that stage at most two chunks per thread.
-static bool pool_tile_ok(const ConvTile& t) { return !t.pipe && t.bm >= 64 && (t.bk == 16 || t.bm == 64); }
+static bool pool_only_tile(const ConvTile& t) { return t.bn > 128 || t.pipe == 3; }      // instantiated for pooled-input layers only
+constexpr size_t kPoolGemmMaxLds = 64 * 1024;                  // pool_gemm_kernel: BM x (K + 4) floats, two or three workgroups per unit
+static size_t pool_gemm_lds(int bm, int K) { return std::max((size_t)bm * (K + 4) * sizeof(float), (size_t)4 * 32 * 36 * sizeof(float)); }
+static bool pool_tile_ok(const ConvTile& t, int K) {
+    if (t.pipe == 3) return pool_gemm_lds(t.bm, K) <= kPoolGemmMaxLds;
+    return !t.pipe && t.bm >= 64 && (t.bk == 16 || (t.bm == 64 && t.bn <= 128));
+}
 
 template <int BM, int BN, int WM, int WN, int BK>
 static int launch_conv_pool_t(vq_tsn* net, ConvArgs& a) {
@@ -978,11 +1135,29 @@ static int launch_conv_pool_t(vq_tsn* net, ConvArgs& a) {
     return VQ_OK;
 }
 
+template <int BM, int BN, int WM, int WN>
+static int launch_pool_gemm_t(vq_tsn* net, ConvArgs& a) {
+    a.tiles_m = cdiv(a.M, BM);
+    a.tiles_n = cdiv(a.Cout, BN);
+    auto kern = pool_gemm_kernel<BM, BN, WM, WN>;
+    VQ_DYN_LDS(kern, kPoolGemmMaxLds);            // per instantiation and device; a launch asks for what its K needs
+    VQ_LAUNCH(kern, a.tiles_m * a.tiles_n, 256, pool_gemm_lds(BM, a.Cin), net->ls, net->ev_start, net->ev_stop, a);
+    VQ_CHECK_LAUNCH();
+    return VQ_OK;
+}
+
 static int launch_conv_pool(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
+    if (t.pipe == 3) {
+        VQ_REQUIRE(a.pool_k == 3 && a.Cin % 32 == 0 && a.Kp == a.Cin && pool_tile_ok(t, a.Cin), "pool_gemm_kernel: a 3x3 window over a multiple of 32 channels");
+        if (t.bm == 64 && t.bn == 256) return launch_pool_gemm_t<64, 256, 1, 4>(net, a);
+        if (t.bm == 64 && t.bn == 64) return launch_pool_gemm_t<64, 64, 2, 2>(net, a);
+        if (t.bm == 128 && t.bn == 64) return launch_pool_gemm_t<128, 64, 2, 2>(net, a);
+        return fail(VQ_E_INVALID, "no pool_gemm kernel for tile %dx%d", t.bm, t.bn);
+    }
 #define T_(BM_, BN_, WM_, WN_, BK_) \
     if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_) return launch_conv_pool_t<BM_, BN_, WM_, WN_, BK_>(net, a);
     T_(128, 128, 2, 2, 16) T_(128, 96, 4, 1, 16) T_(128, 64, 2, 2, 16) T_(64, 128, 2, 2, 32) T_(64, 128, 2, 2, 16)
-    T_(64, 64, 2, 2, 32) T_(64, 64, 2, 2, 16) T_(128, 32, 4, 1, 16)
+    T_(64, 64, 2, 2, 32) T_(64, 64, 2, 2, 16) T_(128, 32, 4, 1, 16) T_(64, 256, 1, 4, 16)
 #undef T_
     return fail(VQ_E_INVALID, "no pooled-input kernel for tile %dx%dx%d", t.bm, t.bn, t.bk);
 }
@@ -1003,7 +1178,7 @@ static int heuristic_tile(int M, int N, int cus) {
     double bs = -1;
     for (int i = 0; i < kNumTiles; ++i) {
         const ConvTile& t = kTiles[i];
-        if (t.bk != 32 || t.pipe) continue;
+        if (t.bk != 32 || t.pipe || pool_only_tile(t)) continue;
         const long long tiles = (long long)cdiv(M, t.bm) * cdiv(N, t.bn);
         const double per_cu = (double)tiles / cus;
         const double balance = per_cu / std::ceil(per_cu);                      // tail quantisation
@@ -1090,7 +1265,7 @@ static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
         // max-pool folded into the loader: any tiling gives the same bits, so an unsupported choice (heuristic, VQ_TSN_TILE)
         // is replaced by the BK = 16 tiling of the same shape
         ConvTile t = kTiles[tile_idx];
-        if (!pool_tile_ok(t)) t = ConvTile{t.bm, t.bn, 16, 0};
+        if (!pool_tile_ok(t, a.Cin)) t = ConvTile{t.bm, std::min(t.bn, 128), 16, 0};
         return launch_conv_pool(net, a, t);
     }
     if (stem_rows) {                                   // four chunk columns = four kernel rows: BK = 16 tilings only (same bits for all)
@@ -1244,7 +1419,8 @@ static int autotune(vq_tsn* net, int n_crops) {
         int win = 0;
         const bool wino = net->layers[li].op == VQ_OP_CONV_WINOGRAD;
         for (int t = 0; t < (wino ? kWinoVariants : kNumTiles); ++t) {
-            if (!wino && net->layers[li].pre_pool_k > 0 && !pool_tile_ok(kTiles[t])) continue;
+            if (!wino && net->layers[li].pre_pool_k > 0 && !pool_tile_ok(kTiles[t], net->layers[li].cin)) continue;
+            if (!wino && net->layers[li].pre_pool_k == 0 && pool_only_tile(kTiles[t])) continue;
             for (int m : it.layers) choice[m] = t;             // a grouped launch runs one variant for all its members
             int rc = run_item(net, it, 0, n_crops, n_crops);   // warm
             if (rc != VQ_OK) return rc;

@@ -10,6 +10,7 @@ with it what ``random.sample`` draws in ``select_clips_to_review``).
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Iterable, Mapping, Sequence
 
 import numpy as np
@@ -42,6 +43,13 @@ class FeatureDB:
         self._row_of = None
         self.present = None
         self._keepalive = None
+        # One resident database may serve several tickets.  The query, the averaged similarities and the scores
+        # are state of the HANDLE, and a round is several calls (ticket.py:96-170): ``lock`` (re-entrant) makes a group of calls
+        # atomic, ``sims_owner`` / ``scores_owner`` say whose similarities / scores the device holds right now, so a ticket that finds
+        # another ticket's there puts its own back (TicketScoring._own_similarities) instead of scoring with a stranger's query.
+        self.lock = threading.RLock()
+        self.sims_owner = None
+        self.scores_owner = None
 
     # ------------------------------------------------------------------ construction
     @classmethod

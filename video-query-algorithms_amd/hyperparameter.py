@@ -11,6 +11,7 @@ is the separable three-point parabola below.
 """
 from __future__ import annotations
 
+import contextlib
 import logging
 import os
 
@@ -47,7 +48,10 @@ class Hyperparameter:
         first, second = (ticket._stream_names.index(st) for st in self.streams[:2])
         candidates = np.zeros((len(self.weight_grid), db.S))
         candidates[:, first], candidates[:, second] = 1.0, self.weight_grid
-        graded = db.scores_grid(candidates, rows)                                   # [40][L] in one launch
+        with getattr(db, "lock", None) or contextlib.nullcontext():
+            if hasattr(ticket, "_own_similarities"):
+                ticket._own_similarities()      # a resident database shared between tickets: this ticket's similarities (ticket.py)
+            graded = db.scores_grid(candidates, rows)                               # [40][L] in one launch
         th = self.threshold_grid[None, :]
         surface = np.tile(0.5 * th, (len(self.weight_grid), 1))
         for column, y in zip(graded.T, labels):                                     # dict order, one clip at a time

@@ -30,8 +30,10 @@ Nothing here computes on the host: the arithmetic is the local :class:`FeatureDB
 """
 from __future__ import annotations
 
+import functools
 import os
 import sys
+import threading
 from typing import Optional, Sequence
 
 import numpy as np
@@ -39,7 +41,18 @@ import numpy as np
 from .shard import all_gather_rows, merge_topk, shard_range
 
 OP_CLOSE, OP_RESTRICT, OP_SET_QUERY, OP_QUERY_FROM_ROW, OP_SCAN, OP_RESCORE, OP_SIMS, OP_SCORES, OP_GRID, OP_SELECT, OP_TOPK, \
-    OP_MIN, OP_FETCH, OP_SCAN_BATCH, OP_LAYOUT = range(15)
+    OP_MIN, OP_FETCH, OP_SCAN_BATCH, OP_LAYOUT, OP_WRITE_AVG = range(16)
+
+
+def _atomic(method):
+    """One operation of the sharded database = an announcement, this rank's step and its collectives: two threads of the broker's
+    process must not interleave them (the workers would pair one operation's header with the other's payload).  The lock is
+    re-entrant, so a caller that holds it across a whole round (TicketScoring) nests."""
+    @functools.wraps(method)
+    def locked(self, *args, **kw):
+        with self.lock:
+            return method(self, *args, **kw)
+    return locked
 
 
 class ShardError(RuntimeError):
@@ -69,6 +82,10 @@ class ShardedFeatureDB:
         self.stream_names = getattr(local, "stream_names", None)
         self.slot_splits = getattr(local, "slot_splits", None)
         self._row_of = None
+        # as FeatureDB: a re-entrant lock for groups of calls, and whose similarities / scores the ranks hold right now
+        self.lock = threading.RLock()
+        self.sims_owner = None
+        self.scores_owner = None
         backend = dist.get_backend(group)
         # collectives move tensors on the backend's device: RCCL = this rank's GPU (result arrays are viewed in place, never
         # staged through the host), gloo = host memory (CPU tests; rehearsals of N ranks on one card)
@@ -80,7 +97,7 @@ class ShardedFeatureDB:
         flag = torch.tensor([0 if getattr(local, "present", None) is None else 1], dtype=torch.int64, device=self._cdev)
         self._coll(lambda: dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group))
         # what TargetClip._resident_ok asks: None = every (clip, stream, split) is there, on every rank
-        self.present = None if int(flag.item()) == 0 else "sharded"
+        self.present = None if int(self._host(flag)[0]) == 0 else "sharded"
         self._closed = False
 
     # ------------------------------------------------------------------ construction
@@ -165,6 +182,13 @@ class ShardedFeatureDB:
         with self._torch.cuda.stream(self._stream):
             return fn()
 
+    def _host(self, t) -> np.ndarray:
+        """A collective's (or the library's) device tensor as a host array.  The copy is issued ON the database's stream: scans only
+        queue their launch there (vq_db_scan does not synchronise) and the stream is non-blocking, so a ``.cpu()`` / ``.item()`` on
+        torch's null stream would not wait for the scan or the collective that produced the values -- it would read what the
+        previous round left behind."""
+        return self._coll(lambda: t.cpu()).numpy()
+
     @property
     def _driving(self) -> bool:
         return self.served and self.rank == self.root
@@ -194,11 +218,12 @@ class ShardedFeatureDB:
                 raise err
             return
         torch, dist = self._torch, self._dist
-        bad = torch.zeros(self.world, dtype=torch.int64, device=self._cdev)
-        if err is not None:
-            bad[self.rank] = 1
+        flags = np.zeros(self.world, dtype=np.int64)            # built on the host: a fill kernel on torch's null stream would not
+        if err is not None:                                     # be ordered against the collective on the database's stream
+            flags[self.rank] = 1
+        bad = torch.from_numpy(flags).to(self._cdev)
         self._coll(lambda: dist.all_reduce(bad, op=dist.ReduceOp.SUM, group=self.group))
-        failed = [r for r, b in enumerate(bad.cpu().tolist()) if b]
+        failed = [r for r, b in enumerate(self._host(bad).tolist()) if b]
         if failed:
             raise ShardError("rank(s) %s of the sharded database failed%s" % (failed, ": %r" % (err,) if err is not None else "")) from err
 
@@ -225,13 +250,13 @@ class ShardedFeatureDB:
 
     def _gather(self, kinds):
         parts = self._local_step(lambda: self._result_tensors(kinds))
-        return [self._coll(lambda p=p: all_gather_rows(p, self.n, self.group)).cpu().numpy() for p in parts]
+        return [self._host(self._coll(lambda p=p: all_gather_rows(p, self.n, self.group))) for p in parts]
 
     def _sum(self, arr: np.ndarray) -> np.ndarray:
         """All-reduce SUM of an array in which every element is non-zero on at most one rank (x + 0 is exact)."""
         t = self._torch.from_numpy(np.ascontiguousarray(arr)).to(self._cdev)
         self._coll(lambda: self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group))
-        return t.cpu().numpy()
+        return self._host(t)
 
     def _mine(self, rows_global: np.ndarray):
         """(positions in the list, local row numbers) of the global rows this rank holds."""
@@ -242,11 +267,13 @@ class ShardedFeatureDB:
         return pos, rows_global[pos] - self.row0
 
     # ------------------------------------------------------------------ query
+    @_atomic
     def set_layout(self, layout: str):
         """Every rank re-tiles its own rows in place (FeatureDB.set_layout): once, after loading."""
         self._announce(OP_LAYOUT, ints=[1 if layout == "tiled" else 0])
         self._local_step(lambda: self.local.set_layout(layout))
 
+    @_atomic
     def restrict_slots(self, slot_used):
         used = None if slot_used is None else np.asarray(slot_used, dtype=bool)
         if used is not None and used.shape != (self.S, self.E):
@@ -254,11 +281,16 @@ class ShardedFeatureDB:
         self._announce(OP_RESTRICT, ints=[-1] if used is None else used.astype(np.int64).reshape(-1))
         self._local_step(lambda: self.local.restrict_slots(used))
 
+    @_atomic
     def set_query(self, t):
         """SPMD: the root's ``t`` is broadcast (the other ranks may pass None).  Served: it travels with the announcement."""
         torch, dist = self._torch, self._dist
         if self.served:
+            # validated BEFORE the announcement: a root that raised after it would leave the workers waiting in _agree for a
+            # partner that never comes, and every later operation out of step
             t = np.ascontiguousarray(t, dtype=np.float64)
+            if t.shape != (self.S, self.E, self.D):
+                raise ValueError("query must be [%d,%d,%d]" % (self.S, self.E, self.D))
             self._announce(OP_SET_QUERY, floats=t)
         else:
             buf = torch.zeros((self.S, self.E, self.D), dtype=torch.float64)
@@ -267,11 +299,12 @@ class ShardedFeatureDB:
             buf = buf.to(self._cdev)
             if self.world > 1:
                 self._coll(lambda: dist.broadcast(buf, self.root, group=self.group))
-            t = buf.cpu().numpy()
+            t = self._host(buf)
         if np.shape(t) != (self.S, self.E, self.D):
             raise ValueError("query must be [%d,%d,%d]" % (self.S, self.E, self.D))
         self._local_step(lambda: self.local.set_query(t))
 
+    @_atomic
     def set_query_from_row(self, row: int, want: bool = True):
         """t = r/(r.r) of a resident clip (target_clip.py:311-313), computed on the GPU of the rank that holds the row and
         handed to the others (80 KB)."""
@@ -288,6 +321,7 @@ class ShardedFeatureDB:
             self._agree(None)
         return t if want else None
 
+    @_atomic
     def scan(self, weights=None, keep_sims: bool = False):
         """Every rank scans its rows: one launch of scan_kernel each, no collective."""
         w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
@@ -296,6 +330,7 @@ class ShardedFeatureDB:
         self._announce(OP_SCAN, ints=[0 if w is None else 1, 1 if keep_sims else 0], floats=[] if w is None else w)
         self._local_step(lambda: self.local.scan(weights=w, keep_sims=keep_sims))
 
+    @_atomic
     def rescore(self, weights):
         w = np.ascontiguousarray(weights, dtype=np.float64)
         if w.shape != (self.S,):
@@ -303,6 +338,19 @@ class ShardedFeatureDB:
         self._announce(OP_RESCORE, floats=w)
         self._local_step(lambda: self.local.rescore(w))
 
+    @_atomic
+    def write_avg(self, avg, n_e=None):
+        """Put averaged similarities [N,S] (and split counts) back on the ranks -- every rank takes its own rows.  How a ticket whose
+        similarities were displaced by another ticket's round on the same database restores them before it scores (ticket.py)."""
+        a = np.ascontiguousarray(avg, dtype=np.float64)
+        ne = None if n_e is None else np.ascontiguousarray(n_e, dtype=np.int64)
+        if a.shape != (self.n, self.S) or (ne is not None and ne.shape != (self.n, self.S)):
+            raise ValueError("avg / n_e must be [%d,%d]" % (self.n, self.S))
+        self._announce(OP_WRITE_AVG, ints=[] if ne is None else ne.reshape(-1), floats=a.reshape(-1))
+        lo, hi = self.row0, self.row0 + self.local.n
+        self._local_step(lambda: self.local.write_avg(a[lo:hi], None if ne is None else ne[lo:hi].astype(np.int32)))
+
+    @_atomic
     def scan_batch(self, targets, weights, want: bool = True):
         """Q <= 16 queries in one pass of every rank over its rows -> scores [Q,N] (score slices gathered per query)."""
         t = np.ascontiguousarray(targets, dtype=np.float64)
@@ -315,9 +363,10 @@ class ShardedFeatureDB:
             return None
         loc = self._torch.from_numpy(np.ascontiguousarray(out.T)).to(self._cdev)              # [n_local, Q]
         full = self._coll(lambda: all_gather_rows(loc, self.n, self.group))
-        return np.ascontiguousarray(full.cpu().numpy().T)
+        return np.ascontiguousarray(self._host(full).T)
 
     # ------------------------------------------------------------------ results
+    @_atomic
     def similarities(self, sims: bool = False):
         """(avg [N,S], n_e [N,S]) in global order; with ``sims`` also the per-split dots [N,S,E] (kept by ``scan(keep_sims=True)``)."""
         self._announce(OP_SIMS, ints=[1 if sims else 0])
@@ -326,11 +375,13 @@ class ShardedFeatureDB:
             return avg, ne
         part = self._local_step(lambda: self._torch.from_numpy(np.ascontiguousarray(self.local.similarities(sims=True)[2])).to(self._cdev))
         full = self._coll(lambda: all_gather_rows(part, self.n, self.group))
-        return avg, ne, full.cpu().numpy()
+        return avg, ne, self._host(full)
 
+    @_atomic
     def scores(self) -> np.ndarray:
-        return self.scores_tensor().cpu().numpy()
+        return self._host(self.scores_tensor())
 
+    @_atomic
     def scores_tensor(self):
         """scores [N] in global order as a torch tensor on the collective's device (under RCCL: in HBM, no host copy -- what a
         caller that keeps working on the GPU, or a throughput measurement, wants)."""
@@ -343,6 +394,7 @@ class ShardedFeatureDB:
         """The torch stream scans and collectives are ordered on (None on a host-memory backend)."""
         return self._stream
 
+    @_atomic
     def scores_grid(self, w_grid, rows) -> np.ndarray:
         wg = np.ascontiguousarray(w_grid, dtype=np.float64)
         r = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1)
@@ -358,6 +410,7 @@ class ShardedFeatureDB:
             return out
         return self._sum(self._local_step(part))
 
+    @_atomic
     def select(self, threshold: float, lower: float):
         """(match rows, near rows, first arg-max of the near rows) in GLOBAL row numbers, order preserved: each rank partitions
         its own slice on its GPU, the lists are concatenated rank-major (ticket.py:325-340)."""
@@ -371,11 +424,11 @@ class ShardedFeatureDB:
         m, r, am, best = self._local_step(part)
         head = torch.from_numpy(np.concatenate([np.array([m.size, r.size, am], dtype=np.int64),
                                                 np.array([best], dtype=np.float64).view(np.int64)])).to(self._cdev)
-        heads = self._coll(lambda: all_gather_rows(head.reshape(1, 4), self.world, self.group)).cpu().numpy()
+        heads = self._host(self._coll(lambda: all_gather_rows(head.reshape(1, 4), self.world, self.group)))
         width = int((heads[:, 0] + heads[:, 1]).max())
         body = np.zeros(max(width, 1), dtype=np.int64)
         body[:m.size], body[m.size:m.size + r.size] = m, r
-        bodies = self._coll(lambda: all_gather_rows(torch.from_numpy(body).reshape(1, -1).to(self._cdev), self.world, self.group)).cpu().numpy()
+        bodies = self._host(self._coll(lambda: all_gather_rows(torch.from_numpy(body).reshape(1, -1).to(self._cdev), self.world, self.group)))
         match = np.concatenate([bodies[g, :heads[g, 0]] for g in range(self.world)])
         near = np.concatenate([bodies[g, heads[g, 0]:heads[g, 0] + heads[g, 1]] for g in range(self.world)])
         near_argmax, top = -1, None
@@ -386,6 +439,7 @@ class ShardedFeatureDB:
                     near_argmax, top = int(heads[g, 2]), v
         return match, near, near_argmax
 
+    @_atomic
     def topk(self, k: int):
         torch = self._torch
         k = int(min(k, self.n))
@@ -399,12 +453,13 @@ class ShardedFeatureDB:
             buf[0, 1 + k:1 + k + rows.size] = np.ascontiguousarray(vals, dtype=np.float64).view(np.int64)
             return buf
         buf = self._local_step(part)
-        allb = self._coll(lambda: all_gather_rows(torch.from_numpy(buf).to(self._cdev), self.world, self.group)).cpu().numpy()
+        allb = self._host(self._coll(lambda: all_gather_rows(torch.from_numpy(buf).to(self._cdev), self.world, self.group)))
         rows = [allb[g, 1:1 + allb[g, 0]] for g in range(self.world)]
         vals = [allb[g, 1 + k:1 + k + allb[g, 0]].view(np.float64) for g in range(self.world)]
         row0s = [shard_range(self.n, self.world, g)[0] for g in range(self.world)]
         return merge_topk(rows, vals, row0s, k)
 
+    @_atomic
     def min_score(self, rows) -> float:
         r = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1)
         self._announce(OP_MIN, ints=r)
@@ -415,8 +470,9 @@ class ShardedFeatureDB:
         m = self._local_step(part)
         t = self._torch.tensor([1.0 if m is None else m], dtype=self._torch.float64, device=self._cdev)
         self._coll(lambda: self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN, group=self.group))
-        return float(t.item())
+        return float(self._host(t)[0])
 
+    @_atomic
     def read_rows(self, rows) -> np.ndarray:
         """[L,S,E,D] feature rows by GLOBAL row number, from whichever ranks hold them (L x 40 KB; the only time features move)."""
         r = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1)
@@ -430,6 +486,7 @@ class ShardedFeatureDB:
             return out
         return self._sum(self._local_step(part))
 
+    @_atomic
     def bootstrap_target(self, valid_rows, invalid_rows=(), mu: float = 0.0, set_query: bool = True) -> np.ndarray:
         """New query vectors [S,E,D] from user-validated clips anywhere in the sharded database (target_clip.py:161-261): rows
         fetched from their owners, the closed forms on the root's GPU (same kernel as FeatureDB.bootstrap_target)."""
@@ -473,14 +530,14 @@ class ShardedFeatureDB:
         if not self.served or self.rank == self.root:
             raise RuntimeError("serve() is for the non-root ranks of a served database")
         while True:
-            hdr = torch.zeros(3, dtype=torch.int64, device=self._cdev)
+            hdr = self._coll(lambda: torch.zeros(3, dtype=torch.int64, device=self._cdev))      # filled on the collective's stream
             self._coll(lambda: dist.broadcast(hdr, self.root, group=self.group))
-            op, ni, nf = (int(v) for v in hdr.cpu().tolist())
+            op, ni, nf = (int(v) for v in self._host(hdr).tolist())
             ints, floats = np.zeros(0, np.int64), np.zeros(0)
             if ni + nf:
-                payload = torch.zeros(ni + nf, dtype=torch.int64, device=self._cdev)
+                payload = self._coll(lambda: torch.zeros(ni + nf, dtype=torch.int64, device=self._cdev))
                 self._coll(lambda: dist.broadcast(payload, self.root, group=self.group))
-                raw = payload.cpu().numpy()
+                raw = self._host(payload)
                 ints, floats = raw[:ni], raw[ni:].view(np.float64)
             if op == OP_CLOSE:
                 break
@@ -520,10 +577,13 @@ class ShardedFeatureDB:
             self.read_rows(ints)
         elif op == OP_LAYOUT:
             self.set_layout("tiled" if ints[0] else "rows")
+        elif op == OP_WRITE_AVG:
+            self.write_avg(floats.reshape(self.n, S), ints.reshape(self.n, S) if ints.size else None)
         else:
             raise RuntimeError("unknown operation %d announced" % op)
 
     # ------------------------------------------------------------------ teardown
+    @_atomic
     def close(self):
         if self._closed:
             return

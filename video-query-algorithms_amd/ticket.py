@@ -11,6 +11,7 @@ variant for offline use whose ``_request`` answers from in-memory records.
 """
 from __future__ import annotations
 
+import contextlib
 import random
 from collections.abc import Mapping
 
@@ -83,12 +84,19 @@ class SimilarityMap(Mapping):
         return ((int(c), self._entry(r)) for r, c in enumerate(self._ids.tolist()))
 
 
+def _db_lock(db):
+    """The database's re-entrant lock (FeatureDB / ShardedFeatureDB); a database object without one gets no locking."""
+    return getattr(db, "lock", None) or contextlib.nullcontext()
+
+
 class TicketScoring:
     """Hot-path methods of the reference's Ticket, on the GPU.  Attributes read: ``target``
     (``target_features``, ``splits``), ``search_set``, ``ref_clip_id``, ``user_matches``; attributes
     written: ``similarities``, ``scores``, ``matches`` -- as in the reference."""
 
     feature_db: FeatureDB | None = None      # a resident DB may be attached up front
+    _round = None                            # token of this ticket's latest compute_similarities (see _own_similarities)
+    _score_weights = None
     feature_db_dtype = np.float64            # dtype used when the DB is built from API records
     device = 0
 
@@ -111,10 +119,13 @@ class TicketScoring:
                 if st in target_features and sp in target_features[st]:
                     t[s, e] = np.asarray(target_features[st][sp], dtype=np.float64)
                     slot_used[s, e] = True
-        db.restrict_slots(slot_used)          # per query; the database's own mask is never modified
-        db.set_query(t)
-        db.scan(weights=None)
-        avg, n_e = db.similarities()
+        with _db_lock(db):                    # one resident database may serve several tickets: these four calls are one step
+            db.restrict_slots(slot_used)      # per query; the database's own mask is never modified
+            db.set_query(t)
+            db.scan(weights=None)
+            avg, n_e = db.similarities()
+            self._round = object()            # whose similarities the database holds now (see _own_similarities)
+            db.sims_owner, db.scores_owner = self._round, None
         self._stream_names = stream_names
         self._avg, self._n_e = avg, n_e
         self.similarities = SimilarityMap(db.clip_ids, stream_names, avg, n_e, db.row_of)
@@ -128,9 +139,35 @@ class TicketScoring:
             if s < 0 or (self._n_e[:, s] == 0).any():
                 raise KeyError(stream_type)          # vsim[stream_type] at ticket.py:177
             w[s] = ws
-        db.rescore(w)
-        self._score_values = db.scores()
+        with _db_lock(db):
+            self._own_similarities()
+            db.rescore(w)
+            self._score_values = db.scores()
+            self._score_weights = w
+            db.scores_owner = (self._round, w.tobytes())
         self.scores = ScoreMap(db.clip_ids, self._score_values, db.row_of)
+
+    # -- a resident database shared between tickets -------------------------------------------------
+    def _own_similarities(self):
+        """The query, the averaged similarities and the scores are state of the database HANDLE, and a round is several calls
+        (compute_similarities, optimize_weights, compute_scores, select_clips_to_review -- compute_matches.py:58-89).  When another
+        ticket used the same resident database in between, this ticket's averaged similarities (kept on the host since
+        compute_similarities) go back to the device before anything is computed from them: N x S x 12 bytes, only ever on a
+        collision.  Call with the database's lock held."""
+        db = self.feature_db
+        if getattr(db, "sims_owner", self._round) is not self._round:
+            db.write_avg(self._avg, self._n_e)
+            db.sims_owner, db.scores_owner = self._round, None
+
+    def _own_scores(self):
+        """As above for the scores the selection kernels read: recomputed from this ticket's similarities and its last weights
+        when the device holds somebody else's."""
+        db = self.feature_db
+        mine = (self._round, self._score_weights.tobytes())
+        if getattr(db, "scores_owner", mine) != mine:
+            self._own_similarities()
+            db.rescore(self._score_weights)
+            db.scores_owner = mine
 
     # -- ticket.py:301-309 ------------------------------------------------------------------
     def lowest_scoring_user_match(self):
@@ -148,7 +185,9 @@ class TicketScoring:
         db = self.feature_db
         vals, ids = self._score_values, db.clip_ids
         lower_limit = threshold - near_miss * (1 - threshold)
-        match_rows, near_rows, near_argmax = db.select(threshold, lower_limit)     # stable partition on the GPU
+        with _db_lock(db):
+            self._own_scores()
+            match_rows, near_rows, near_argmax = db.select(threshold, lower_limit)     # stable partition on the GPU
         mscores = int(min(max_number_matches / 2, len(match_rows)))
         m_near_scores = int(min(max_number_matches - mscores, len(near_rows)))
         # random.sample draws positions from (len(population), k) only, so sampling positions
@@ -284,9 +323,10 @@ def install(ticket_cls, hyperparameter_cls=None, target_clip_cls=None):
             construct(self, ticket, hyperparameters)
             self._ticket = ticket                          # lets the round use rows of a resident ticket.feature_db
         target_clip_cls.__init__ = remember_ticket
-    for name in ("compute_similarities", "compute_scores", "lowest_scoring_user_match", "select_clips_to_review"):
+    for name in ("compute_similarities", "compute_scores", "lowest_scoring_user_match", "select_clips_to_review",
+                 "_own_similarities", "_own_scores"):
         setattr(ticket_cls, name, getattr(TicketScoring, name))
-    for name in ("feature_db", "feature_db_dtype", "device"):
+    for name in ("feature_db", "feature_db_dtype", "device", "_round", "_score_weights"):
         if not hasattr(ticket_cls, name):
             setattr(ticket_cls, name, getattr(TicketScoring, name))
     if hyperparameter_cls is not None:

@@ -16,6 +16,7 @@ by the feature path (calcSig_wOF.py:95 reads ``global_pool``) -- is dropped.
 """
 from __future__ import annotations
 
+import os
 import re
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
@@ -232,7 +233,8 @@ def _lower(g: Graph, feature_blob: str) -> Plan:
     return Plan(tensors, keep, fs[0], fs[2], dict(loc))
 
 
-FOLD_POOL_MAX_COUT = 128     # one column tile of the widest tiling: the pooled loader then reads every window exactly once
+# one column tile of the widest tiling of the pooled loader (64 x 256): it then reads every window exactly once
+FOLD_POOL_MAX_COUT = int(os.environ.get("VQ_TSN_FOLD_POOL_COUT", "256"))
 
 
 def _fuse(plan: Plan) -> Plan:
