@@ -17,11 +17,16 @@ score slices all-gathered), HBM-bound.
 Both carry a `roofline` (HIP-event time of the dominant kernel inside the timed region vs the gfx950 peak) and a
 `cpu_baseline` (the oracle timed on the host cores, rank 0, N = 1 only, bounded sample).
 
-TSN roofline: `frac` = MFMA work the matrix pipe really EXECUTED (Winograd layers: 16 multiplies per 2x2 tile, K and
-tile padding of every kernel included) / conv kernel time / 157.3 TFLOP/s; `effective_frac` prices the same time
-against the ALGORITHMIC direct-convolution FLOPs of SURVEY.md 8(d) (2 x MACs of Appendix A) and exceeds `frac`
-because the Winograd form skips 20/36 of the multiplies.  Every PROFILE_EVERY-th step of the timed region carries
-per-launch start/stop events (the kernels' own timestamps); all steps issue the same launches on one stream.
+Timed region (configs[1]): K forwards as the PRODUCT runs them -- ``vq_tsn_forward`` with its default of two sub-batches on two HIP
+streams (VQ_TSN_SPLIT=2: one sub-batch's launch ramps and tails overlap the other's steady state; same bits as one stream).  Every
+PROFILE_EVERY-th step of the region runs on ONE stream with a start / stop event on every launch (the dispatch packets' own
+timestamps): there a launch's duration is the kernel alone on the chip, which is what the per-kernel figures need.
+TSN roofline: `achieved` / `frac` = ALGORITHMIC direct-convolution FLOPs of a step (2 x MACs of Appendix A x crops =
+390.06 GFLOP) / the whole timed step (`ms_per_step`) / 157.3 TFLOP/s.  Beside it, from the sampled steps' kernel timestamps:
+`kernel_frac` = the same FLOPs / the convolution launches' own time (exceeds the pipe's rate because the Winograd form skips 20/36 of
+the multiplies) and `matrix_pipe_frac` = MFMA work the matrix pipe really EXECUTED (Winograd layers: 16 multiplies per 2x2 tile, K
+and tile padding of every kernel included) / that time.  `single_stream` = the same K steps all on one stream (the timed mode of
+rounds 1-4), for comparison.
 """
 import argparse
 import ctypes as C
@@ -111,31 +116,31 @@ def tsn_roofline(model, n_crops, steps, every):
         ms = float(ms_layers[mask].sum())
         return {"kernel": kernel, "layers": int((mask & conv).sum()), "launches": len({int(item_of_layer[i]) for i in np.flatnonzero(mask)}),
                 "ms_per_step": ms, "executed_tflops": float(issued[mask].sum()) / ms / 1e9,
-                "frac": float(issued[mask].sum()) / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS,
-                "algorithmic_tflops": float(fl[mask].sum()) / ms / 1e9}
+                "matrix_pipe_frac": float(issued[mask].sum()) / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS,
+                "algorithmic_tflops": float(fl[mask].sum()) / ms / 1e9, "kernel_frac": float(fl[mask].sum()) / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS}
     fam = {"direct": family(direct, "conv_igemm_pipe_kernel / conv_igemm_kernel (implicit GEMM: 1x1, stride-2 and stem layers)"),
            "winograd": family(wino, "wino_f2x2_3x3_kernel (F(2x2,3x3): the 3x3 stride-1 layers; a launch carries the sibling arms "
                                     "of an inception module and its pooling layer)")}
     executed = float(issued.sum())
+    # `achieved` / `frac` (algorithmic FLOPs over the whole timed step) are filled in by the caller, who owns the clock
     roof = {"bound": "mfma",
             "kernel": "the %d convolution launches of a step (%d layers): %d direct implicit-GEMM launches + %d Winograd F(2x2,3x3) launches; "
                       "fp32 v_mfma_f32_32x32x2" % (conv_launches, int(conv.sum()), fam["direct"]["launches"], fam["winograd"]["launches"]),
-            "achieved": executed / conv_ms / 1e9, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": executed / conv_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-            "effective_tflops": conv_flops / conv_ms / 1e9, "effective_frac": conv_flops / conv_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS,
+            "achieved": None, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+            "kernel_tflops": conv_flops / conv_ms / 1e9, "kernel_frac": conv_flops / conv_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS,
+            "matrix_pipe_tflops": executed / conv_ms / 1e9, "matrix_pipe_frac": executed / conv_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS,
             "launches_per_step": conv_launches, "all_launches_per_step": int(n_items), "avg_launch_ms": conv_ms / conv_launches,
             "conv_ms_per_step": conv_ms, "other_kernels_ms_per_step": float(ms_layers[~in_conv_launch].sum()),
             # the pooling layers that ride in Winograd launches take part of those launches' time (their share by workgroup
-            # count); pool1 inside conv2/3x3_reduce's loader cannot be separated and stays in
+            # count); the stem pools inside the loaders of the 1x1 GEMMs behind them cannot be separated and stay in
             "pooling_share_of_conv_launches_ms": float(ms_layers[in_conv_launch & ~conv].sum()),
-            "frac_without_pooling_share": executed / float(ms_layers[conv].sum()) / 1e9 / PEAK_FP32_MFMA_TFLOPS,
             "flops_per_step": conv_flops, "executed_flops_per_step": executed, "profiled_steps": cdiv(steps, every),
             "families": fam,
-            "note": "achieved/frac = MFMA FLOPs the matrix pipe EXECUTED (K / tile padding included; Winograd layers issue 16 of the 36 "
-                    "direct-form multiplies) per second of convolution-kernel time; effective_* prices the same time against the "
-                    "ALGORITHMIC direct-convolution FLOPs of SURVEY 8(d) (2 x MACs of Appendix A).  Kernel times: the launches' own "
-                    "begin/end timestamps on every %d-th step of the timed region (a launch shared by sibling layers is split between "
-                    "them by matrix work)" % every}
+            "note": "achieved / frac = ALGORITHMIC direct-convolution FLOPs (SURVEY 8(d): 2 x MACs of Appendix A x crops) per second of the "
+                    "whole timed step.  kernel_* prices the same FLOPs against the convolution launches' own time, matrix_pipe_* the MFMA "
+                    "FLOPs the pipe EXECUTED (K / tile padding included; Winograd layers issue 16 of the 36 direct-form multiplies) against "
+                    "it.  Kernel times: the launches' own begin/end timestamps on every %d-th step of the timed region, which runs on one "
+                    "stream (a launch shared by sibling layers is split between them by matrix work)" % every}
     return roof
 
 
@@ -169,14 +174,19 @@ def bench_tsn(args, rank, world, device, stream):
                 e1.record(stream)
                 gather_events.append((e0, e1))
 
+    depth = min(cdiv(args.steps, PROFILE_EVERY), 1024)
     with torch.cuda.stream(stream):
-        model.set_profile(1)                         # warm up in the mode of the timed region (tunes this batch size)
-        for _ in range(max(args.warmup, 1)):
+        model.set_profile(1)                         # one sampled forward: tunes the tilings of the whole batch on one stream
+        step()
+        model.set_profile(0)
+        for _ in range(max(args.warmup, 2)):         # the product's mode: tunes the sub-batch size
             step()
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
-        model.set_profile(min(cdiv(args.steps, PROFILE_EVERY), 1024), every=PROFILE_EVERY)   # start/stop events per launch, no host sync
+        # The timed region: the product's own forward (two sub-batches on two HIP streams); every PROFILE_EVERY-th step runs on
+        # one stream with start/stop events on every launch (no host sync).  --profile-only: ALL steps on one stream.
+        model.set_profile(depth, every=PROFILE_EVERY, split_between=not args.profile_only)
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
@@ -211,14 +221,14 @@ def bench_tsn(args, rank, world, device, stream):
             roof["pmc_source"] = "profiles/%s: SQ_INSTS_MFMA x 64 / SIMD-cycles per kernel family (tools/pmc_mfma.sh), committed, not collected in this run" % name
             break
     feats = feat.clone()
-    model.set_profile(0)
-    # The same K steps once more in the configuration a user runs (no events at all, two sub-batches on two streams,
-    # VQ_TSN_SPLIT=2; the timed region above keeps one stream).  Reported beside `value`, never instead of it.
-    if args.profile_only:
-        roof["unprofiled_ms_per_step"] = float("nan")
+    # The same K steps once more, ALL on one stream with the same event sampling: the timed mode of rounds 1-4, reported beside
+    # `value` for comparison (never instead of it).
+    roof["single_stream_ms_per_step"] = float("nan")
     with torch.cuda.stream(stream):
-        for _ in range(0 if args.profile_only else max(args.warmup, 2)):
-            step()                                   # first un-profiled forward autotunes the sub-batch size
+        if not args.profile_only:
+            model.set_profile(depth, every=PROFILE_EVERY, split_between=False)
+            for _ in range(2):
+                step()
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
@@ -229,7 +239,8 @@ def bench_tsn(args, rank, world, device, stream):
         if world > 1:
             dist.barrier()
         if not args.profile_only:
-            roof["unprofiled_ms_per_step"] = (time.perf_counter() - t1) / args.steps * 1e3
+            roof["single_stream_ms_per_step"] = (time.perf_counter() - t1) / args.steps * 1e3
+    model.set_profile(0)
     if args.tiles and rank == 0 and not os.path.exists(args.tiles):
         os.makedirs(os.path.dirname(os.path.abspath(args.tiles)), exist_ok=True)
         with open(args.tiles, "w") as f:
@@ -245,7 +256,7 @@ def bench_two_stream(args, device, stream, with_cpu):
     B2, T2 = 64, 7
     n_crops = B2 * T2
     steps = max(4, args.steps // 5)
-    every = 2
+    every = steps                                     # the first step of the region is the sampled one
     out = {"metric": "clips/sec TSN two-stream feature-extract (RGB + 5-frame flow stack)", "unit": "clips/s", "steps": steps,
            "config": {"workload": "configs[2]: TSN two-stream RGB + warped-optical-flow (5-frame stack = 10 channels), T=7 segments, "
                                   "B=64 clips: 448 + 448 uint8 crops of 224x224 resident in HBM, random-init weights",
@@ -263,12 +274,16 @@ def bench_two_stream(args, device, stream, with_cpu):
         model.set_stream(stream.cuda_stream)
         gen = torch.Generator(device=device).manual_seed(40 + ch)
         crops = torch.randint(0, 256, (n_crops, 224, 224, ch), dtype=torch.uint8, device=device, generator=gen)
+        depth = cdiv(steps, every)
         with torch.cuda.stream(stream):
-            model.set_profile(1)
+            model.set_profile(1)                        # tunes the 448-crop tilings (one stream) ...
+            model.forward_device(crops.data_ptr(), n_crops, T2, mean)
+            model.set_profile(0)                        # ... and the sub-batches' (the product's mode)
             for _ in range(2):
                 model.forward_device(crops.data_ptr(), n_crops, T2, mean)
             torch.cuda.synchronize(device)
-            model.set_profile(min(cdiv(steps, every), 1024), every=every)
+            # timed like configs[1]: the product's forward, the first of every `every` steps sampled on one stream
+            model.set_profile(depth, every=every, split_between=not args.profile_only)
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
             for _ in range(steps):
@@ -277,22 +292,24 @@ def bench_two_stream(args, device, stream, with_cpu):
             ms = (time.perf_counter() - t0) / steps * 1e3
         roof = tsn_roofline(model, n_crops, steps, every)
         fl = model.flops_per_crop() * n_crops
+        roof["achieved"] = fl / ms / 1e9
+        roof["frac"] = roof["achieved"] / PEAK_FP32_MFMA_TFLOPS
         feat_ptr, _ = model.feat_devptr()
         keep[name] = (g, weights, crops[:T2].cpu().numpy(), dev_tensor(feat_ptr, (B2, model.feature_dim), "<f8", device)[:1].cpu().numpy(), mean)
-        model.set_profile(0)
-        prod_ms = float("nan")
-        if not args.profile_only:                       # production mode: no events, the batch split over two HIP streams
+        single_ms = float("nan")
+        if not args.profile_only:                       # all steps on one stream (the timed mode of rounds 1-4), for comparison
             with torch.cuda.stream(stream):
-                for _ in range(2):
-                    model.forward_device(crops.data_ptr(), n_crops, T2, mean)
+                model.set_profile(depth, every=every, split_between=False)
+                model.forward_device(crops.data_ptr(), n_crops, T2, mean)
                 torch.cuda.synchronize(device)
                 t0 = time.perf_counter()
                 for _ in range(steps):
                     model.forward_device(crops.data_ptr(), n_crops, T2, mean)
                 torch.cuda.synchronize(device)
-                prod_ms = (time.perf_counter() - t0) / steps * 1e3
+                single_ms = (time.perf_counter() - t0) / steps * 1e3
+        model.set_profile(0)
         out["streams"][name] = {"ms_per_step": ms, "clips_per_s": B2 / ms * 1e3, "algorithmic_gflop_per_clip": fl / B2 / 1e9,
-                                "whole_step_algorithmic_tflops": fl / ms / 1e9, "production_mode_ms_per_step": prod_ms, "roofline": roof}
+                                "single_stream_ms_per_step": single_ms, "roofline": roof}
         total_ms += ms
         flops += fl
         model.close()
@@ -300,18 +317,20 @@ def bench_two_stream(args, device, stream, with_cpu):
     out["value"] = B2 / total_ms * 1e3
     out["ms_per_step"] = total_ms
     out["algorithmic_gflop_per_clip"] = flops / B2 / 1e9
-    prod = sum(v["production_mode_ms_per_step"] for v in out["streams"].values())
-    if prod == prod:
-        out["production_mode"] = {"value": B2 / prod * 1e3, "unit": "clips/s", "ms_per_step": prod}
-    # one roofline for the pair: the two streams' convolution launches together
+    single = sum(v["single_stream_ms_per_step"] for v in out["streams"].values())
+    if single == single:
+        out["single_stream"] = {"value": B2 / single * 1e3, "unit": "clips/s", "ms_per_step": single}
+    # one roofline for the pair: SURVEY 8(d) -- the algorithmic FLOPs of both forwards over the whole timed step; beside it the two
+    # streams' convolution launches together (sampled steps, one stream)
     ex = sum(v["roofline"]["executed_flops_per_step"] for v in out["streams"].values())
     al = sum(v["roofline"]["flops_per_step"] for v in out["streams"].values())
     cm = sum(v["roofline"]["conv_ms_per_step"] for v in out["streams"].values())
     nl = sum(v["roofline"]["launches_per_step"] for v in out["streams"].values())
-    out["roofline"] = {"bound": "mfma", "achieved": ex / cm / 1e9, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                       "frac": ex / cm / 1e9 / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "effective_tflops": al / cm / 1e9,
-                       "effective_frac": al / cm / 1e9 / PEAK_FP32_MFMA_TFLOPS, "conv_ms_per_step": cm, "launches_per_step": nl,
-                       "avg_launch_ms": cm / nl, "kernel": "the convolution launches of both streams' forwards (per stream: streams.*.roofline)"}
+    out["roofline"] = {"bound": "mfma", "achieved": flops / total_ms / 1e9, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                       "frac": flops / total_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                       "kernel_frac": al / cm / 1e9 / PEAK_FP32_MFMA_TFLOPS, "matrix_pipe_frac": ex / cm / 1e9 / PEAK_FP32_MFMA_TFLOPS,
+                       "conv_ms_per_step": cm, "launches_per_step": nl, "avg_launch_ms": cm / nl,
+                       "kernel": "the convolution launches of both streams' forwards (per stream: streams.*.roofline)"}
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import tsn_oracle as to
@@ -801,13 +820,39 @@ def bench_e2e_cli(device_index):
             ens_t.append(time.perf_counter() - t0)
             assert rc == 0
         same = open(csv, "rb").read() == open(os.path.join(root, "ens1", "video", "UCF101_split1", "rgb_global_pool_features.csv"), "rb").read()
+        # ONE run as a fresh process -- `python calcSig_wOF.py ...` as a user types it (a child, never a re-exec): interpreter start, torch
+        # import, HIP context, first allocations, extractors built from the weight cache, default device-pool cap.  Same bytes.
+        fresh = None
+        try:
+            import subprocess
+            for name, ch in (("rgb", 3), ("flow", 10)):
+                with open(os.path.join(root, name + ".prototxt"), "w") as f:
+                    f.write(bn_inception.to_prototxt(bn_inception.bn_inception(ch)))
+            cli = os.path.join(ROOT, "video-query-algorithms_amd", "calcSig_wOF.py")
+            env = {k: v for k, v in os.environ.items() if k not in ("VQ_DEVICE_POOL_GB", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+            argv = [sys.executable, cli, os.path.join(root, "frames"), os.path.join(root, "rgb.prototxt"), "synthetic:2", os.path.join(root, "flow.prototxt"),
+                    "synthetic:5", "--outFeatures_dir", os.path.join(root, "fresh"), "--modelname", "UCF101_split1", "--num_worker", "16",
+                    "--gpus", str(device_index), "--device_jpeg"]
+            t0 = time.perf_counter()
+            r = subprocess.run(argv, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+            fresh_s = time.perf_counter() - t0
+            if r.returncode == 0:
+                fcsv = os.path.join(root, "fresh", "video", "UCF101_split1", "rgb_global_pool_features.csv")
+                body = lambda path: open(path, "rb").read().split(b"\n", 1)[1]          # the header names the weights file: rows only
+                fresh = {"seconds": fresh_s, "value": n_clips / fresh_s, "unit": "clips/s", "rows_equal_in_process_run": body(fcsv) == body(csv)}
+            else:
+                fresh = {"error": r.stderr.decode(errors="replace")[-300:]}
+        except Exception as e:          # noqa: BLE001 -- the in-process figures stand on their own
+            fresh = {"error": repr(e)[:300]}
     finally:
         shutil.rmtree(root, ignore_errors=True)
     runs = sorted(times[1:4])
     times = [times[0], runs[1], times[4]]
     steady = (n_clips - 32) / max(times[1] - times[2], 1e-9)
-    return {"metric": "clips/sec end to end through the drop-in command line (JPEG frame tree -> CSV tree), two-stream, T=25", "value": n_clips / times[1],
+    return {"metric": "clips/sec end to end through the drop-in command line (JPEG frame tree -> CSV tree), two-stream, T=25; warm: median of "
+                      "in-process repeats of main() (device block pool, decoder pool, weight and page caches warm)", "value": n_clips / times[1],
             "unit": "clips/s", "clips": n_clips, "seconds": times[1], "seconds_of_the_three_runs": runs, "first_run_seconds": times[0],
+            "fresh_process": fresh,
             "seconds_32_clips": times[2], "csv_rows": rows,
             "ensemble3": {"value": 3 * n_clips / ens_t[1], "unit": "(clip, member)/s", "seconds": ens_t[1], "first_run_seconds": ens_t[0],
                           "vs_three_runs": (3 * n_clips / ens_t[1]) / (n_clips / times[1]), "member_1_bytes_equal_single_run": bool(same)},
@@ -870,6 +915,138 @@ def bench_e2e_wof(device_index):
                     "GPU, 768 JPEG encodings on 16 host threads, the clip regrouping"}
 
 
+def bench_rounds(device_index, with_cpu):
+    """BASELINE configs[0] and configs[4] on the B seam, through the drop-in Ticket / Hyperparameter / TargetClip objects over a resident
+    FeatureDB (SURVEY.md 8(d) cfg 1 data: 10 000 clips x 2 streams x 3 splits x 1024 fp32, |N(0,1)| x 3.8 / x 1.2, reference clip = row 7,
+    broker defaults):
+      * one query = compute_similarities + compute_scores + select_clips_to_review (ticket.py:120-180,311-356) -- the three calls the
+        unmodified reference was timed on (oracle/time_reference_cfg1.py);
+      * 100 weight-update rounds = {compute_similarities, compute_scores, 20 labels off the top of the ranking, optimize_weights
+        (hyperparameter.py:29-76), compute_scores, select_clips_to_review} on the same resident database.
+    cpu_baseline: the oracle's FAITHFUL restatement of the same reference lines (dicts of Python lists, np.dot per (clip, stream, split),
+    one thread -- as the reference is) on a bounded sample of the clips, scaled; beside it the unmodified reference's own rate as timed in
+    the build container this round (it cannot travel to the GPU box)."""
+    import random
+    os.environ.setdefault("COMPUTE_EPS", "0.000003")
+    streams, splits, weights0 = ("rgb", "warped_optical_flow"), (1, 2, 3), {"rgb": 1.0, "warped_optical_flow": 1.5}
+    n, d = 10000, 1024
+    rng = np.random.default_rng(0)                       # SURVEY.md 8(d) cfg 1 (= oracle/sim_oracle.cfg1_features)
+    x = np.abs(rng.standard_normal((3, 2, n, d), dtype=np.float32))
+    x[:, 0] *= np.float32(3.8)
+    x[:, 1] *= np.float32(1.2)
+    x = np.ascontiguousarray(x.transpose(2, 1, 0, 3))    # [N, S, E, D]
+    clip_ids = np.arange(1, n + 1, dtype=np.int64)
+    db = vqa.FeatureDB.from_arrays(x, clip_ids=clip_ids, device=device_index)
+    db.stream_names, db.slot_splits = list(streams), [list(splits)] * 2
+    ref_row = 7
+    ref_records = [{"dnn_stream_id": st, "dnn_stream_split": sp, "name": "global_pool", "video_clip_id": int(clip_ids[ref_row]),
+                    "feature_vector": x[ref_row, si, ei].astype(np.float64).tolist()} for si, st in enumerate(streams) for ei, sp in enumerate(splits)]
+
+    def ticket():
+        hp = vqa.Hyperparameter(weights0, 0.8, 0.0, 0.35, 0.0, streams, "global_pool", 1, 0.7, "bagging", 3)      # broker.py:36-59
+        tk = vqa.Ticket({"query_id": 1, "video_id": 1, "ref_clip": 0, "ref_clip_id": int(clip_ids[ref_row]), "search_set": 1,
+                         "number_of_matches_to_review": 20, "dynamic_target_adjustment": False, "user_matches": {}},
+                        records=ref_records, feature_db=db, device=device_index)
+        tk.target = vqa.TargetClip(tk, hp)
+        tk.target.get_target_features()
+        return tk, hp
+    # ---- configs[0]: one query
+    tk, hp = ticket()
+    lat, parts = [], np.zeros(3)
+    for rep in range(60):
+        random.seed(a="73459912436")
+        t0 = time.perf_counter()
+        tk.compute_similarities(hp)
+        t1 = time.perf_counter()
+        tk.compute_scores(weights0)
+        t2 = time.perf_counter()
+        tk.select_clips_to_review(0.8, 20, 0.35)
+        t3 = time.perf_counter()
+        if rep >= 10:
+            lat.append(t3 - t0)
+            parts += (t1 - t0, t2 - t1, t3 - t2)
+    med = float(np.median(lat))
+    first_matches = dict(tk.matches)
+    avg0 = tk._avg.copy()
+    query = {"metric": "queries/sec weighted-cosine query on a resident 10k x 2 x 3 x 1024 database (similarities + scores + review set)",
+             "value": 1.0 / med, "unit": "queries/s", "ms_per_query": med * 1e3, "queries_timed": len(lat),
+             "ms": {"compute_similarities": parts[0] / len(lat) * 1e3, "compute_scores": parts[1] / len(lat) * 1e3,
+                    "select_clips_to_review": parts[2] / len(lat) * 1e3},
+             "config": {"workload": "configs[0]: compute_matches.py weighted cosine on 10k x 1024 fp32 features (2 streams x 3 splits), broker defaults"}}
+    # ---- configs[4]: 100 weight-update rounds on the resident database
+    tk, hp = ticket()
+    lab_rng = np.random.default_rng(5)
+    random.seed(a="73459912436")
+    R, L = 100, 20
+    stage = {"similarities": 0.0, "optimize_weights": 0.0, "scores": 0.0, "select": 0.0}
+    t_all = time.perf_counter()
+    for r in range(R):
+        t0 = time.perf_counter()
+        tk.compute_similarities(hp)
+        stage["similarities"] += time.perf_counter() - t0
+        if r == 0:
+            hp.weights, hp.threshold = dict(hp.default_weights), hp.default_threshold
+        t0 = time.perf_counter()
+        tk.compute_scores(hp.weights)                    # under the previous round's weights: what the user reviewed
+        stage["scores"] += time.perf_counter() - t0
+        rows, vals = db.topk(L)
+        tk.matches = [{"video_clip": int(clip_ids[row]), "user_match": bool(lab_rng.random() < 0.5 + 0.4 * (i < L // 2)), "is_match": bool(v >= hp.threshold)}
+                      for i, (row, v) in enumerate(zip(rows, vals))]
+        t0 = time.perf_counter()
+        hp.optimize_weights(tk)
+        stage["optimize_weights"] += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        tk.compute_scores(hp.weights)
+        stage["scores"] += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        tk.select_clips_to_review(hp.threshold, 20, hp.near_miss_default)
+        stage["select"] += time.perf_counter() - t0
+    total = time.perf_counter() - t_all
+    rounds = {"metric": "weight-update rounds/sec on a resident 10k-clip database (similarities, optimize_weights on 20 labels, scores, review set)",
+              "value": R / total, "unit": "rounds/s", "rounds": R, "ms_per_round": total / R * 1e3, "ms": {k: v / R * 1e3 for k, v in stage.items()},
+              "final_weight": float(hp.weights[streams[1]]), "final_threshold": float(hp.threshold),
+              "config": {"workload": "configs[4], the query half: 100 iterative compute_matches weight updates on 10k resident clips "
+                                     "(the extraction half: tools/e2e_cfg5.py, profiles/r0N_e2e_cfg5.json)"}}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import sim_oracle as so
+        ns = 2000                                         # bounded sample: the first 2 000 clips (the faithful walk is linear in the clips)
+        recs = [{"dnn_stream_id": st, "dnn_stream_split": sp, "name": "global_pool", "video_clip_id": int(c), "feature_vector": x[c - 1, si, ei].astype(np.float64).tolist()}
+                for ei, sp in enumerate(splits) for si, st in enumerate(streams) for c in clip_ids[:ns]]
+        target = so.faithful_scaled_ref_clip_features(so.faithful_clip_features(ref_records, streams, "global_pool")[0])
+        t0 = time.perf_counter()
+        cand = so.faithful_candidate_features(recs, list(splits), streams, "global_pool")
+        sims = so.faithful_similarities(target, cand)
+        t_sim = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        sc = so.faithful_scores(sims, weights0)
+        random.seed(a="73459912436")
+        so.faithful_select(sc, int(clip_ids[ref_row]), {}, 0.8, 20, 0.35)
+        t_sc = time.perf_counter() - t0
+        ranked = sorted(sc.items(), key=lambda kv: kv[1], reverse=True)[:L]
+        labelled = [{"video_clip": c, "user_match": bool(i % 3 != 2), "is_match": bool(v >= 0.8)} for i, (c, v) in enumerate(ranked)]
+        t0 = time.perf_counter()
+        so.faithful_optimize_weights(sims, labelled, streams, 0.0, float(os.environ["COMPUTE_EPS"]))
+        t_opt = time.perf_counter() - t0
+        scale = n / ns
+        # live parity of the timed path: the product's averaged similarities of the sample against the faithful walk
+        err = max(abs(avg0[c - 1, si] - sims[int(c)][st][0]) for c in clip_ids[:ns] for si, st in enumerate(streams))
+        ref_box = {}
+        rpath = os.path.join(ROOT, "profiles", "r05_reference_cfg1_container.json")
+        if os.path.exists(rpath):
+            with open(rpath) as f:
+                ref_box = json.load(f)
+        note = "faithful restatement (oracle/sim_oracle.py: dicts of lists, np.dot per (clip, stream, split)) of %d of the 10 000 clips, one thread, scaled x%d" % (ns, scale)
+        query["cpu_baseline"] = {"value": 1.0 / ((t_sim + t_sc) * scale), "unit": "queries/s", "cores": 1, "kind": "port", "sample": note,
+                                 "reference_unmodified_in_build_container": _pick(ref_box, ["queries_per_s", "date", "cpu_count"])}
+        rounds["cpu_baseline"] = {"value": 1.0 / ((t_sim + 2 * t_sc + t_opt) * scale), "unit": "rounds/s", "cores": 1, "kind": "port", "sample": note,
+                                  "reference_unmodified_in_build_container": _pick(ref_box, ["rounds_per_s", "date", "cpu_count"])}
+        query["parity_max_abs_err_vs_oracle"] = float(err)
+        query["review_set_size"] = len(first_matches)
+    db.close()
+    return {"query": query, "weight_updates": rounds}
+
+
 def _pick(d, keys):
     return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
 
@@ -896,17 +1073,18 @@ def compact(out):
     if cfg.get("distributed"):
         line["config"]["distributed"] = _pick(cfg["distributed"], ["backend", "world_size", "rccl_version", "rehearsal_on_one_gpu"])
     roof = out["roofline"]
-    line["roofline"] = _pick(roof, ["bound", "achieved", "peak", "unit", "frac", "traffic", "effective_frac", "avg_launch_ms", "launches_per_step",
-                                    "conv_ms_per_step", "other_kernels_ms_per_step", "all_gather_ms_per_step", "graph"])
+    line["roofline"] = _pick(roof, ["bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_frac", "matrix_pipe_frac", "avg_launch_ms",
+                                    "launches_per_step", "conv_ms_per_step", "other_kernels_ms_per_step", "all_gather_ms_per_step"])
     line["roofline"].setdefault("traffic", None)
-    line["roofline"]["kernel"] = "36 conv launches/step: conv_igemm(_pipe)_kernel + wino_f2x2_3x3_kernel, v_mfma_f32_32x32x2"
-    line["roofline"]["families"] = {k: _pick(v, ["frac", "ms_per_step", "launches"]) for k, v in roof.get("families", {}).items()}
+    line["roofline"]["kernel"] = "%d conv launches/step: conv_igemm(_pipe)_kernel / pool_gemm_kernel + wino_f2x2_3x3_kernel, v_mfma_f32_32x32x2" % roof["launches_per_step"]
+    line["roofline"]["families"] = {k: _pick(v, ["matrix_pipe_frac", "kernel_frac", "ms_per_step", "launches"]) for k, v in roof.get("families", {}).items()}
     if isinstance(roof.get("rank_ms_per_step"), dict):
-        line["roofline"]["rank_ms_per_step"] = _pick(roof["rank_ms_per_step"], ["min", "max"])
+        line["roofline"]["rank_ms_per_step"] = _pick(roof["rank_ms_per_step"], ["min", "max", "all"])
     if "pmc_matrix_pipe_utilisation" in roof:
         line["roofline"]["pmc_matrix_pipe"] = roof["pmc_matrix_pipe_utilisation"]
-    if "production_mode" in out:
-        line["production_mode"] = _pick(out["production_mode"], ["value", "ms_per_step"])
+    line["config"]["timed_mode"] = "product default: 2 sub-batches on 2 HIP streams; every %dth step sampled on one stream" % PROFILE_EVERY
+    if "single_stream" in out:
+        line["single_stream"] = _pick(out["single_stream"], ["value", "ms_per_step", "frac"])
     if "cpu_baseline" in out:
         cb = out["cpu_baseline"]
         line["cpu_baseline"] = _pick(cb, ["value", "unit", "cores", "kind"])
@@ -919,9 +1097,9 @@ def compact(out):
     if ts:
         line["two_stream"] = _pick(ts, ["value", "unit", "ms_per_step", "parity_vs_oracle_rel_err"])
         line["two_stream"]["config"] = {"workload": "configs[2]: two-stream RGB + 10-ch flow stack, T=7, B=64 (448+448 crops)"}
-        line["two_stream"]["roofline"] = _pick(ts["roofline"], ["bound", "frac", "effective_frac", "conv_ms_per_step"])
-        if "production_mode" in ts:
-            line["two_stream"]["production_mode"] = ts["production_mode"]["value"]
+        line["two_stream"]["roofline"] = _pick(ts["roofline"], ["bound", "frac", "kernel_frac", "matrix_pipe_frac", "conv_ms_per_step"])
+        if "single_stream" in ts:
+            line["two_stream"]["single_stream"] = ts["single_stream"]["value"]
         if "cpu_baseline" in ts:
             line["two_stream"]["cpu_baseline"] = _pick(ts["cpu_baseline"], ["value", "cores", "kind"])
     sim = out.get("similarity")
@@ -938,12 +1116,22 @@ def compact(out):
             c["cpu_baseline"] = _pick(sim["cpu_baseline"], ["value", "unit", "cores", "kind"])
             c["cpu_baseline"]["single_thread"] = sim["cpu_baseline"]["single_thread"]["value"]
         line["similarity"] = c
+    rd = out.get("rounds")
+    if rd:
+        c = {}
+        for key, cfgname in (("query", "configs[0]: one query on a resident 10k x 2 x 3 x 1024 DB"), ("weight_updates", "configs[4]: 100 weight-update rounds, 10k resident clips")):
+            q = rd[key]
+            c[key] = _pick(q, ["value", "unit", "ms_per_query", "ms_per_round", "ms", "parity_max_abs_err_vs_oracle"])
+            c[key]["config"] = {"workload": cfgname}
+            if "cpu_baseline" in q:
+                cb = q["cpu_baseline"]
+                c[key]["cpu_baseline"] = _pick(cb, ["value", "unit", "cores", "kind"])
+                c[key]["cpu_baseline"]["reference_unmodified"] = cb.get("reference_unmodified_in_build_container")
+        line["rounds"] = c
     fl = out.get("flow")
     if fl:
         c = _pick(fl, ["value", "unit", "ms_per_batch", "inner_loops_device_ms_per_batch", "iteration_launches_per_batch"])
         c["warped"] = fl["warped"]["value"]
-        if "fast_math" in fl:
-            c["fast_math"] = _pick(fl["fast_math"], ["value", "warped"])
         c["roofline"] = _pick(fl["roofline"], ["bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac"])
         if "cpu_baseline" in fl:
             c["cpu_baseline"] = _pick(fl["cpu_baseline"], ["value", "cores", "kind"])
@@ -952,12 +1140,13 @@ def compact(out):
     if jp:
         c = _pick(jp, ["value", "unit", "ms_per_batch", "bit_identical_to_libjpeg_turbo"])
         c["small_batch"] = jp["small_batch"]["value"]
-        c["large"] = {k: v["value"] for k, v in jp["large_batches"].items()}
         c["cpu_baseline"] = jp["cpu_baseline"]["value"]
         line["jpeg"] = c
     e2e = out.get("e2e_cli")
     if e2e:
-        line["e2e_cli"] = _pick(e2e, ["value", "unit", "seconds", "ensemble3"])
+        line["e2e_cli"] = _pick(e2e, ["value", "unit", "seconds", "first_run_seconds", "fresh_process"])
+        line["e2e_cli"]["mode"] = "warm, in-process repeats of main()"
+        line["e2e_cli"]["ensemble3"] = _pick(e2e["ensemble3"], ["value", "unit", "seconds", "vs_three_runs", "member_1_bytes_equal_single_run"])
         line["e2e_cli"]["steady"] = e2e["steady_state"]["value"]
     wof = out.get("e2e_wof_cli")
     if wof:
@@ -1018,6 +1207,8 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("VQ_BENCH_FAIL_INIT_RANK") == str(rank):      # tests: a rank that dies where RCCL would be initialised
+            raise SystemExit("rank %d told to fail before the process group exists" % rank)
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -1056,13 +1247,19 @@ def main():
                       "parallelism": "dp%d" % world, "collective": "all_gather feature blocks (RCCL)" if world > 1 else None,
                       "distributed": dist_info},
            "roofline": roof}
-    up = torch.tensor([roof.pop("unprofiled_ms_per_step")], dtype=torch.float64, device=device)
+    # algorithmic FLOPs of a step (per GPU) over the whole timed step
+    roof["achieved"] = roof["flops_per_step"] / out["ms_per_step"] / 1e9
+    roof["frac"] = roof["achieved"] / PEAK_FP32_MFMA_TFLOPS
+    out["config"]["timed_mode"] = ("all steps on one stream (--profile-only)" if args.profile_only else
+                                   "vq_tsn_forward's default: 2 sub-batches on 2 HIP streams; every %dth step on one stream with per-launch events" % PROFILE_EVERY)
+    up = torch.tensor([roof.pop("single_stream_ms_per_step")], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(up, op=dist.ReduceOp.MAX)
     if not args.profile_only:
-        out["production_mode"] = {"value": world * B_CLIPS / float(up.item()) * 1e3, "unit": "clips/s", "ms_per_step": float(up.item()),
-                                  "note": "same K steps, same bracketing, no profiling events, batch split over 2 HIP streams (the timed "
-                                          "region keeps everything on one stream so that every kernel duration is the launch alone)"}
+        out["single_stream"] = {"value": world * B_CLIPS / float(up.item()) * 1e3, "unit": "clips/s", "ms_per_step": float(up.item()),
+                                "frac": roof["flops_per_step"] / float(up.item()) / 1e9 / PEAK_FP32_MFMA_TFLOPS,
+                                "note": "same K steps, same bracketing, ALL on one stream (events on every %dth): the timed mode of rounds "
+                                        "1-4, for comparison" % PROFILE_EVERY}
     if rank == 0 and world == 1 and not args.skip_cpu:
         base, ps_cpu = cpu_baseline_tsn(crops.cpu().numpy(), (model.graph, tsn_net.synthetic_weights(model.graph, seed=2)))
         out["cpu_baseline"] = base
@@ -1100,6 +1297,8 @@ def main():
             sim["cpu_baseline"] = cpu_baseline_sim(db, row0)
         out["similarity"] = sim
         db.close()
+    if rank == 0 and world == 1 and not args.skip_sim and not args.profile_only:
+        out["rounds"] = bench_rounds(local_rank, not args.skip_cpu)
     if rank == 0 and world == 1 and not args.skip_flow and not args.profile_only:
         out["flow"] = bench_flow(local_rank, not args.skip_cpu)
         jp = bench_jpeg(local_rank)

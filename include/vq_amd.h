@@ -27,7 +27,7 @@ extern "C" {
 
 /* 6 (round 4): + vq_db_set_layout / vq_db_layout (block tiled in place; the mirrored copy of version 5 is gone), vq_db_read_rows,
  * vq_db_read_scores_at, vq_db_ne_devptr, vq_format_feature_rows, vq_jpeg_decode_path_list; vq_input_desc gained s2d_order. */
-#define VQ_ABI_VERSION 6
+#define VQ_ABI_VERSION 7
 
 enum {
     VQ_OK = 0,
@@ -321,6 +321,12 @@ int vq_tsn_set_profile(vq_tsn* net, int32_t depth);
 /* While profiling, only every `every`-th forward carries the events (the start/stop signals cost ~3 us per launch);
  * the forwards in between issue exactly the same launches on the same stream.  Default 1. */
 int vq_tsn_set_profile_every(vq_tsn* net, int32_t every);
+/* While profiling with every > 1: how the forwards BETWEEN two sampled ones run.  0 (default): like the sampled ones, on the
+ * handle's stream only (every forward of the region issues the same launches: what a rocprofv3 comparison wants).  1: as the
+ * product runs them when nobody profiles -- the batch split into VQ_TSN_SPLIT sub-batches on separate HIP streams; only the
+ * sampled forwards stay on one stream, so that their per-launch durations are each kernel alone on the chip (bench.py's timed
+ * region: the product's own mode with a clean kernel sample inside it).  Same bits either way. */
+int vq_tsn_set_profile_split(vq_tsn* net, int32_t unsampled_split);
 int vq_tsn_layer_times(vq_tsn* net, float* ms, double* flops, int32_t n_layers);
 /* The implicit-GEMM tiling (BM, BN, BK, pipelined?) each conv layer runs with at batch size n_crops: autotuned on the first
  * forward of that batch size (every candidate yields the same bits), else the occupancy heuristic.

@@ -793,35 +793,52 @@ def test_calcsig_two_ranks_write_the_same_bytes_as_one(tsn, tmp_path):
 
 
 def test_bench_two_rank_control_flow_rehearsal(tsn):
-    """bench.py under torch.distributed.run with 2 ranks, both on this one GPU through gloo (VQ_BENCH_REHEARSE=1): the
+    """bench.py under torch.distributed.run with 2 and 4 ranks, all on this one GPU through gloo (VQ_BENCH_REHEARSE=1): the
     weak-scaling control flow the driver runs on 2/4/8 GPUs -- per-rank batches, feature all-gather, barriers,
-    max-over-ranks timing, one JSON line from rank 0 -- must hold together.  The numbers of such a run mean nothing."""
+    max-over-ranks timing, one JSON line from rank 0 that says what torch.distributed saw -- must hold together.  The numbers
+    of such a run mean nothing; the line's arithmetic must still be SURVEY 8(d)'s (frac x peak x ms_per_step = 390.06 GFLOP)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, VQ_BENCH_REHEARSE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--skip-sim",
-           "--skip-cpu"]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
-    assert p.returncode == 0, p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["scaling"] == "weak" and out["value"] > 0
-    assert out["roofline"]["launches_per_step"] == 36 and out["config"]["distributed"]["world_size"] == 2
-    assert 0 < out["roofline"]["frac"] < 1 and out["roofline"]["frac"] < out["roofline"]["effective_frac"] < 2
-    assert len(lines[0]) < 4096                                     # the driver's record keeps the whole line
+    for world, port in ((2, "29533"), (4, "29535")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", port, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--skip-sim",
+               "--skip-cpu"]
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == world and out["config"]["global_batch"] == 32 * world and out["scaling"] == "weak" and out["value"] > 0
+        dist_cfg = out["config"]["distributed"]
+        assert dist_cfg["world_size"] == world and dist_cfg["backend"] == "gloo" and dist_cfg["rehearsal_on_one_gpu"] is True and dist_cfg["rccl_version"]
+        roof = out["roofline"]
+        assert roof["launches_per_step"] == 36
+        assert len(roof["rank_ms_per_step"]["all"]) == world and roof["rank_ms_per_step"]["min"] <= roof["rank_ms_per_step"]["max"]
+        assert roof["all_gather_ms_per_step"] > 0
+        assert 0 < roof["matrix_pipe_frac"] < 1 and roof["matrix_pipe_frac"] < roof["kernel_frac"] < 2
+        assert abs(roof["frac"] * roof["peak"] * out["ms_per_step"] - 390.06) < 0.5          # SURVEY 8(d): TFLOP/s x ms = GFLOP per step
+        assert out["single_stream"]["ms_per_step"] > 0
+        assert len(lines[0]) < 4096                                 # the driver's record keeps the whole line
     # ``python bench.py --gpus 2`` with NO launcher starts its own ranks (before any GPU call) and prints the same one line
+    plain = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--skip-cpu"]
-    p = subprocess.run(cmd, env={k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}, capture_output=True, text=True, timeout=600)
+    p = subprocess.run(cmd, env=plain, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and len(lines[0]) < 4096
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["similarity"]["config"]["rows_per_gpu"] == 500_000 and out["similarity"]["value"] > 0
     assert out["similarity"]["roofline"]["kernel"].startswith("scan_tiled_kernel") and out["similarity"]["batched"]["value"] > 0
+    # a rank that dies where the communicator would be built: the parent ends its peers (they would wait in the rendezvous for
+    # ever) and the command exits non-zero, well inside the timeout -- children are started fresh, nothing is re-executed
+    import time
+    t0 = time.perf_counter()
+    p = subprocess.run(cmd + ["--skip-sim"], env=dict(plain, VQ_BENCH_FAIL_INIT_RANK="1"), capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "told to fail" in p.stderr and time.perf_counter() - t0 < 120
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_tiling_tables_survive_the_process(tsn, monkeypatch, tmp_path):

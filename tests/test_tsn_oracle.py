@@ -202,3 +202,11 @@ def test_space_to_depth_stem_rewrite_is_exact():
         got = to.conv_direct(S.transpose(0, 3, 1, 2), W2.transpose(0, 3, 1, 2), np.zeros(cout), 1, 0)
         assert got.shape == want.shape
         assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+
+
+def test_to_prototxt_round_trips_through_the_reader():
+    from video_query_algorithms_amd.tsn import bn_inception as bi
+    for c in (3, 10):
+        g = bi.bn_inception(c)
+        back = bi.parse_prototxt(bi.to_prototxt(g))
+        assert back.layers == g.layers and back.input_shape == g.input_shape

@@ -6,6 +6,6 @@ for cfg in "$@"; do
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][0])
 r=d['roofline']
-print('$cfg', 'value %.0f  ms %.3f  conv_ms %.3f other %.3f  prod %.0f' % (d['value'], d['ms_per_step'], r['conv_ms_per_step'], r['other_kernels_ms_per_step'], d['production_mode']['value']))"
+print('$cfg', 'value %.0f  ms %.3f  frac %.4f  single-stream ms %.3f  (sampled: conv_ms %.3f other %.3f)' % (d['value'], d['ms_per_step'], r['frac'], d['single_stream']['ms_per_step'], r['conv_ms_per_step'], r['other_kernels_ms_per_step']))"
 done
 done

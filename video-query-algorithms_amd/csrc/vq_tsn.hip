@@ -977,6 +977,7 @@ struct vq_tsn {
     int profile_count = 0;                // profiled forwards so far (ring of profile_depth event sets)
     int profile_every = 1;                // while profiling: every n-th forward carries the events, all run on one stream
     int profile_tick = 0;                 // forwards since vq_tsn_set_profile
+    bool profile_split = false;           // while profiling: the un-sampled forwards run split over the sub-batch streams (vq_tsn_set_profile_split)
     std::vector<hipEvent_t> events;       // profile_depth x n_items x {start, stop}
     int crop_off = 0;                     // first crop the next launch works on (sub-batches, 32-bit offset chunks)
     int n_split = 1;                      // VQ_TSN_SPLIT: sub-batches of one forward run on separate streams
@@ -1995,11 +1996,12 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
     const bool profiling = net->profile_depth > 0;
     if (profiling && net->profile_tick++ % net->profile_every == 0)
         ev = net->events.data() + (size_t)(net->profile_count % net->profile_depth) * (2 * n_items);
-    // While profiling everything stays on the caller's stream (each duration is then the launch alone, and the forwards
-    // between two sampled ones issue exactly the same launches).
+    // A sampled forward stays on the caller's stream (each duration is then the launch alone); so do the forwards between two
+    // sampled ones (they issue exactly the same launches) unless vq_tsn_set_profile_split asked for the product's own mode there.
     int parts_sum = 0;
     for (int v : net->split_parts) parts_sum += v;
-    int n_split = (!profiling && net->n_split > 1 && n_crops % parts_sum == 0) ? net->n_split : 1;
+    const bool one_stream = profiling && (ev || !net->profile_split);
+    int n_split = (!one_stream && net->n_split > 1 && n_crops % parts_sum == 0) ? net->n_split : 1;
     std::vector<int> sub(n_split, n_crops), sub_off(n_split, 0);
     if (n_split > 1) {
         for (int sb = 0, o = 0; sb < n_split; ++sb) {
@@ -2134,6 +2136,13 @@ static double wino_weight(const vq_tsn* net, int li) {
         return ((double)ts.h * ts.w + (double)td.h * td.w) * L.cin * 4.0 / 4e12;
     }
     return 2.0 * 16.0 * ((td.h + 1) / 2) * ((td.w + 1) / 2) * (double)L.cin * L.cout / 100e12;
+}
+
+int vq_tsn_set_profile_split(vq_tsn* net, int32_t unsampled_split) {
+    VQ_REQUIRE(net, "net is NULL");
+    std::lock_guard<std::mutex> lk(net->mu);
+    net->profile_split = unsampled_split != 0;
+    return VQ_OK;
 }
 
 int vq_tsn_layer_times(vq_tsn* net, float* ms, double* flops, int32_t n_layers) {

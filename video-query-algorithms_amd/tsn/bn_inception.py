@@ -408,6 +408,25 @@ def parse_prototxt(text: str) -> Graph:
     return g
 
 
+def to_prototxt(g: Graph) -> str:
+    """The deploy prototxt of a graph in the layout of the reference's files (models/ucf101/tsn_bn_inception_*_deploy.prototxt):
+    what ``parse_prototxt`` reads back layer for layer.  For hosts that have the architecture but not the reference checkout
+    (bench.py's fresh-process run of the command line)."""
+    c, h, w = g.input_shape
+    lines = ['name: "%s"' % g.name, 'input: "%s"' % g.input_name, "input_dim: 1", "input_dim: %d" % c, "input_dim: %d" % h, "input_dim: %d" % w]
+    for l in g.layers:
+        body = 'layer { name: "%s" type: "%s" %s %s' % (l.name, l.type, " ".join('bottom: "%s"' % b for b in l.bottoms),
+                                                        " ".join('top: "%s"' % t for t in l.tops))
+        if l.type == "Convolution":
+            body += " convolution_param { num_output: %d pad: %d kernel_size: %d stride: %d }" % (l.num_output, l.pad, l.kernel, l.stride)
+        elif l.type == "Pooling":
+            body += " pooling_param { pool: %s kernel_size: %d stride: %d pad: %d }" % (l.pool, l.kernel, l.stride, l.pad)
+        elif l.type == "InnerProduct":
+            body += " inner_product_param { num_output: %d }" % l.num_output
+        lines.append(body + " }")
+    return "\n".join(lines) + "\n"
+
+
 def load_prototxt(path: str) -> Graph:
     with open(path) as f:
         return parse_prototxt(f.read())

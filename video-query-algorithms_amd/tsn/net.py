@@ -475,11 +475,14 @@ class TsnNet:
             return img[:, pad:pad + self.in_h, pad:pad + self.in_w]
         return buf[..., coff:coff + c]
 
-    def set_profile(self, depth: int, every: int = 1):
+    def set_profile(self, depth: int, every: int = 1, split_between: bool = False):
         """depth > 0: keep HIP-event timings of the last `depth` profiled forwards (averaged by layer_times); 0 = off.
-        every = n: only every n-th forward carries the events (all of them run the same launches on one stream)."""
+        every = n: only every n-th forward carries the events.  The forwards in between run the same launches on the same one
+        stream, or -- ``split_between`` -- as the product runs them (sub-batches on separate streams): only the sampled ones
+        then stay on one stream, where a launch's duration is the kernel alone."""
         call("vq_tsn_set_profile", self._h, int(depth))
         call("vq_tsn_set_profile_every", self._h, int(every))
+        call("vq_tsn_set_profile_split", self._h, 1 if split_between else 0)
 
     def layer_times(self):
         """(names, kinds, mean ms[n_layers] over the profiled forwards, flops[n_layers] of the last batch)."""
