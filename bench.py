@@ -240,6 +240,9 @@ def bench_tsn(args, rank, world, device, stream):
             dist.barrier()
         if not args.profile_only:
             roof["single_stream_ms_per_step"] = (time.perf_counter() - t1) / args.steps * 1e3
+            r1 = tsn_roofline(model, n_crops, args.steps, PROFILE_EVERY)        # this region's own sampled launches
+            roof["single_stream_kernels"] = {k: r1[k] for k in ("conv_ms_per_step", "other_kernels_ms_per_step", "kernel_frac", "matrix_pipe_frac")}
+            roof["single_stream_kernels"]["families"] = {k: {q: v[q] for q in ("matrix_pipe_frac", "kernel_frac", "ms_per_step", "launches")} for k, v in r1["families"].items()}
     model.set_profile(0)
     if args.tiles and rank == 0 and not os.path.exists(args.tiles):
         os.makedirs(os.path.dirname(os.path.abspath(args.tiles)), exist_ok=True)
@@ -1076,19 +1079,20 @@ def compact(out):
     line["roofline"] = _pick(roof, ["bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_frac", "matrix_pipe_frac", "avg_launch_ms",
                                     "launches_per_step", "conv_ms_per_step", "other_kernels_ms_per_step", "all_gather_ms_per_step"])
     line["roofline"].setdefault("traffic", None)
-    line["roofline"]["kernel"] = "%d conv launches/step: conv_igemm(_pipe)_kernel / pool_gemm_kernel + wino_f2x2_3x3_kernel, v_mfma_f32_32x32x2" % roof["launches_per_step"]
-    line["roofline"]["families"] = {k: _pick(v, ["matrix_pipe_frac", "kernel_frac", "ms_per_step", "launches"]) for k, v in roof.get("families", {}).items()}
+    line["roofline"]["kernel"] = "%d conv launches/step: conv_igemm(_pipe) / pool_gemm + wino_f2x2_3x3 kernels, v_mfma_f32_32x32x2" % roof["launches_per_step"]
+    line["roofline"]["families"] = {k: _pick(v, ["matrix_pipe_frac", "ms_per_step", "launches"]) for k, v in roof.get("families", {}).items()}
     if isinstance(roof.get("rank_ms_per_step"), dict):
         line["roofline"]["rank_ms_per_step"] = _pick(roof["rank_ms_per_step"], ["min", "max", "all"])
     if "pmc_matrix_pipe_utilisation" in roof:
         line["roofline"]["pmc_matrix_pipe"] = roof["pmc_matrix_pipe_utilisation"]
-    line["config"]["timed_mode"] = "product default: 2 sub-batches on 2 HIP streams; every %dth step sampled on one stream" % PROFILE_EVERY
+    line["config"]["timed_mode"] = "vq_tsn_forward default: 2 sub-batch streams; every %dth step sampled on 1 stream" % PROFILE_EVERY
     if "single_stream" in out:
         line["single_stream"] = _pick(out["single_stream"], ["value", "ms_per_step", "frac"])
+        line["single_stream"].update(_pick(out["single_stream"].get("kernels") or {}, ["conv_ms_per_step", "kernel_frac", "matrix_pipe_frac"]))
     if "cpu_baseline" in out:
         cb = out["cpu_baseline"]
         line["cpu_baseline"] = _pick(cb, ["value", "unit", "cores", "kind"])
-        line["cpu_baseline"]["sample"] = cb["sample"].split(",")[0]
+        line["cpu_baseline"]["sample"] = cb["sample"].split(" of the")[0]
         if "ten_crop_variant" in cb:
             line["cpu_baseline"]["ten_crop_value"] = cb["ten_crop_variant"]["value"]
     if "parity_vs_oracle_rel_err" in out:
@@ -1096,7 +1100,7 @@ def compact(out):
     ts = out.get("two_stream")
     if ts:
         line["two_stream"] = _pick(ts, ["value", "unit", "ms_per_step", "parity_vs_oracle_rel_err"])
-        line["two_stream"]["config"] = {"workload": "configs[2]: two-stream RGB + 10-ch flow stack, T=7, B=64 (448+448 crops)"}
+        line["two_stream"]["config"] = {"workload": "configs[2]: RGB + 10-ch flow stack, T=7, B=64 (448+448 crops)"}
         line["two_stream"]["roofline"] = _pick(ts["roofline"], ["bound", "frac", "kernel_frac", "matrix_pipe_frac", "conv_ms_per_step"])
         if "single_stream" in ts:
             line["two_stream"]["single_stream"] = ts["single_stream"]["value"]
@@ -1104,14 +1108,14 @@ def compact(out):
             line["two_stream"]["cpu_baseline"] = _pick(ts["cpu_baseline"], ["value", "cores", "kind"])
     sim = out.get("similarity")
     if sim:
-        c = _pick(sim, ["metric", "value", "unit", "ms_per_query", "steps", "scaling"])
-        c["config"] = {"workload": "configs[3]: 1 query x 1M clips x (2 x 5) x 1024 fp32 = 40.96 GB, row-sharded, tiled in place",
+        c = _pick(sim, ["value", "unit", "ms_per_query", "steps", "scaling"])
+        c["config"] = {"workload": "configs[3]: 1 query x 1M x (2 x 5) x 1024 fp32 = 40.96 GB, tiled in place",
                        "rows_per_gpu": sim["config"]["rows_per_gpu"]}
         c["roofline"] = _pick(sim["roofline"], ["bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms",
                                                 "score_all_gather_ms_per_query", "tile_in_place_ms"])
         c["roofline"]["row_major_frac"] = sim["roofline"]["row_major"]["frac"]
         if "batched" in sim:
-            c["batched"] = _pick(sim["batched"], ["value", "ms_per_pass", "pass_ms_by_hip_events", "hbm_frac", "traffic", "database_bytes_resident"])
+            c["batched"] = _pick(sim["batched"], ["value", "ms_per_pass", "hbm_frac", "traffic"])
         if "cpu_baseline" in sim:
             c["cpu_baseline"] = _pick(sim["cpu_baseline"], ["value", "unit", "cores", "kind"])
             c["cpu_baseline"]["single_thread"] = sim["cpu_baseline"]["single_thread"]["value"]
@@ -1119,20 +1123,21 @@ def compact(out):
     rd = out.get("rounds")
     if rd:
         c = {}
-        for key, cfgname in (("query", "configs[0]: one query on a resident 10k x 2 x 3 x 1024 DB"), ("weight_updates", "configs[4]: 100 weight-update rounds, 10k resident clips")):
+        for key, cfgname in (("query", "configs[0]: 1 query, resident 10k x 2 x 3 x 1024"), ("weight_updates", "configs[4]: 100 weight updates, 10k clips")):
             q = rd[key]
-            c[key] = _pick(q, ["value", "unit", "ms_per_query", "ms_per_round", "ms", "parity_max_abs_err_vs_oracle"])
+            c[key] = _pick(q, ["value", "unit", "ms_per_query", "ms_per_round", "parity_max_abs_err_vs_oracle"])
             c[key]["config"] = {"workload": cfgname}
             if "cpu_baseline" in q:
                 cb = q["cpu_baseline"]
-                c[key]["cpu_baseline"] = _pick(cb, ["value", "unit", "cores", "kind"])
-                c[key]["cpu_baseline"]["reference_unmodified"] = cb.get("reference_unmodified_in_build_container")
+                c[key]["cpu_baseline"] = _pick(cb, ["value", "cores", "kind"])
+                ref = cb.get("reference_unmodified_in_build_container") or {}
+                c[key]["cpu_baseline"]["reference_unmodified"] = [ref.get("queries_per_s", ref.get("rounds_per_s")), ref.get("date")]
         line["rounds"] = c
     fl = out.get("flow")
     if fl:
-        c = _pick(fl, ["value", "unit", "ms_per_batch", "inner_loops_device_ms_per_batch", "iteration_launches_per_batch"])
+        c = _pick(fl, ["value", "unit", "ms_per_batch", "iteration_launches_per_batch"])
         c["warped"] = fl["warped"]["value"]
-        c["roofline"] = _pick(fl["roofline"], ["bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac"])
+        c["roofline"] = _pick(fl["roofline"], ["bound", "achieved", "peak", "unit", "frac", "traffic"])
         if "cpu_baseline" in fl:
             c["cpu_baseline"] = _pick(fl["cpu_baseline"], ["value", "cores", "kind"])
         line["flow"] = c
@@ -1144,9 +1149,10 @@ def compact(out):
         line["jpeg"] = c
     e2e = out.get("e2e_cli")
     if e2e:
-        line["e2e_cli"] = _pick(e2e, ["value", "unit", "seconds", "first_run_seconds", "fresh_process"])
-        line["e2e_cli"]["mode"] = "warm, in-process repeats of main()"
-        line["e2e_cli"]["ensemble3"] = _pick(e2e["ensemble3"], ["value", "unit", "seconds", "vs_three_runs", "member_1_bytes_equal_single_run"])
+        line["e2e_cli"] = _pick(e2e, ["value", "unit", "seconds", "first_run_seconds"])
+        line["e2e_cli"]["mode"] = "warm in-process"
+        line["e2e_cli"]["fresh_process"] = _pick(e2e.get("fresh_process") or {}, ["seconds", "value", "error"])
+        line["e2e_cli"]["ensemble3"] = _pick(e2e["ensemble3"], ["value", "vs_three_runs", "member_1_bytes_equal_single_run"])
         line["e2e_cli"]["steady"] = e2e["steady_state"]["value"]
     wof = out.get("e2e_wof_cli")
     if wof:
@@ -1258,6 +1264,7 @@ def main():
     if not args.profile_only:
         out["single_stream"] = {"value": world * B_CLIPS / float(up.item()) * 1e3, "unit": "clips/s", "ms_per_step": float(up.item()),
                                 "frac": roof["flops_per_step"] / float(up.item()) / 1e9 / PEAK_FP32_MFMA_TFLOPS,
+                                "kernels": roof.pop("single_stream_kernels", None),
                                 "note": "same K steps, same bracketing, ALL on one stream (events on every %dth): the timed mode of rounds "
                                         "1-4, for comparison" % PROFILE_EVERY}
     if rank == 0 and world == 1 and not args.skip_cpu:

@@ -15,6 +15,31 @@
  *     device addresses on the handle's device.  No torch types anywhere.
  *   - all kernels are launched on the handle's stream (default: the null stream); set it with
  *     vq_*_set_stream(handle, hipStream_t) to interoperate with a framework's stream.
+ *
+ * Environment switches -- ALL of them (a handle reads its switches when it is created).  None changes a result bit except where
+ * it says so; the variants that rounds 1-4 kept compiled in beside the product kernels (the two-kernel batched scan, the
+ * two-launch and the square-tile TV-L1 forms, the (p,q,c)-ordered RGB stem, captured forwards) were removed in round 5.
+ *   the library
+ *     VQ_DEVICE_POOL_GB=<n>        device blocks of closed TSN extractors kept for the next one of the same shape (default 40, 0 = off)
+ *     VQ_TSN_SPLIT=<n> | a,b,..    sub-batches of a forward on separate HIP streams (default 2; 1 = one stream)
+ *     VQ_TSN_AUTOTUNE=0            tilings by the occupancy heuristic instead of by timing on the first forward of a batch size
+ *     VQ_TSN_TILE=BMxBN[xBK[xP]]   one tiling for every direct convolution (tests: every tiling gives the same bits)
+ *     VQ_TSN_GROUP=0, VQ_TSN_GROUP_POOL=0   a launch per layer instead of one per graph level / a launch per pooling layer (tests: same bits)
+ *     VQ_TSN_SPLITK=0              no split over K for the 7x7-map layers (another summation order: agrees to rounding, tested)
+ *     VQ_TSN_POISON=1              NaN-fill every activation slot before a forward (debugging: finds a kernel that leaves output unwritten)
+ *     VQ_FLOW_FAST=1               hardware reciprocal / square root in TV-L1's inner iterations: OUTSIDE the tested tolerances (see vq_flow_create)
+ *     VQ_JPEG_HOST_HUFFMAN=0|1, VQ_JPEG_DEVICE_MIN_STREAMS=<n>   force the device / host entropy decoder, or move the batch-size threshold (default 2 048 streams); same pixels
+ *     VQ_JPEG_STAMPS=1, VQ_JPEG_HOST_STAMPS=1   print the decoder waves' cycle stamps / the host phases of a call (diagnostics)
+ *     VQ_RCCL_LIB=<path>           the RCCL the Comm group loads with dlopen (default: the one already mapped, else librccl.so)
+ *   the Python package
+ *     VQ_AMD_LIB=<path>            libvqamd.so to load (default: next to the package)
+ *     VQ_TSN_WINOGRAD=0            every 3x3 layer in direct form (other rounding: both forms are tested against the fp64 oracle)
+ *     VQ_TUNE_CACHE=<dir>|0, VQ_WEIGHT_CACHE=<dir>|0   where the tiling tables / packed weights are kept between processes (0 = nowhere)
+ *     VQ_DIST_BACKEND=gloo|nccl    torch.distributed backend of the N > 1 entry points (default nccl = RCCL; gloo: CPU tests, one-card rehearsals)
+ *     VQ_CLI_TRACE=1               calcSig_wOF.py prints phase stamps; VQ_CLI_GROUP_CLIPS=<n>: clips per flush group (default 16 batches per rank)
+ *     VQ_FANOUT_*                  set BY fanout.py for the per-GPU children it starts (rank, world, device, workers): not for users
+ *   the build
+ *     VQ_EXTRA_HIPCC_FLAGS         extra hipcc flags for build.py (experiments; empty for the product)
  */
 #ifndef VQ_AMD_H
 #define VQ_AMD_H
@@ -26,7 +51,8 @@ extern "C" {
 #endif
 
 /* 6 (round 4): + vq_db_set_layout / vq_db_layout (block tiled in place; the mirrored copy of version 5 is gone), vq_db_read_rows,
- * vq_db_read_scores_at, vq_db_ne_devptr, vq_format_feature_rows, vq_jpeg_decode_path_list; vq_input_desc gained s2d_order. */
+ * vq_db_read_scores_at, vq_db_ne_devptr, vq_format_feature_rows, vq_jpeg_decode_path_list; vq_input_desc gained s2d_order.
+ * 7 (round 5): + vq_tsn_set_profile_split; the layer tiling tables know the pooled-input kernel (pipelined = 3). */
 #define VQ_ABI_VERSION 7
 
 enum {
@@ -364,9 +390,8 @@ typedef struct vq_tvl1_params {
 int vq_tvl1_default_params(vq_tvl1_params* params);
 /* A batch workspace for up to max_pairs frame pairs of h x w grey pixels.  params NULL = defaults.
  * Environment, read here: VQ_FLOW_FAST=1 -- hardware reciprocal / square root (1 ulp) instead of IEEE division / sqrtf in the inner
- * iterations (faster; flow images differ from the default's on ~0.4 % of the pixels, without bound where the flow is not determined);
- * VQ_FLOW_TWO_LAUNCH=1 -- the un-blocked primal / dual launch pair per iteration (A/B tests; same bits as the default);
- * VQ_FLOW_TILES=square -- the 64 x 64 tiles on 1 024 threads of round 3 instead of tiles fitted to the level on 512 (A/B tests; same bits). */
+ * iterations (faster; flow images differ from the default's on ~0.4 % of the pixels, without bound where the flow is not determined:
+ * outside the tolerances the kernels are tested to, never on by default, never in a reported headline). */
 int vq_flow_create(int32_t max_pairs, int32_t h, int32_t w, const vq_tvl1_params* params, int32_t device, vq_flow** out);
 int vq_flow_destroy(vq_flow* flow);
 /* Pyramid actually used: *n_levels and (h, w) of the first min(*n_levels, cap) levels, finest first. */

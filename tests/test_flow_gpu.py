@@ -81,67 +81,32 @@ def test_homography_warp_and_consecutive_frames(flow_mod):
     m.close()
 
 
-def test_blocked_iterations_have_the_bits_of_the_two_launch_form(flow_mod, monkeypatch):
-    """The blocked form of the inner loop (4 iterations per launch on tiles resident in LDS / registers with a 4-pixel halo, the
-    fields ping-ponging between two sets of planes, the stopping rule kept exact by replaying a block that ran past the stop)
-    against the round-2 form (a primal and a dual launch per iteration, VQ_FLOW_TWO_LAUNCH=1 when the handle is created).
-    With a fixed iteration count (epsilon = 0) the per-pixel operations are the same in the same order: the same bits --
-    iteration counts that are and are not multiples of the block (the tail block runs fewer), frames smaller than a tile and
-    larger than several, every level shape of the default pyramid.  With the convergence test active the two forms sum the
-    squared update in a different order (tiles vs strided pixels), so a pair may stop one iteration apart when its error
-    grazes the threshold: the tolerances of the oracle comparison above; identical frames stop after exactly one iteration
-    in both (the first block is replayed with one iteration)."""
-    rng = np.random.default_rng(12)
-    for (h, w, iters, warps, scales) in ((64, 80, 7, 2, 3), (100, 132, 12, 3, 2), (256, 340, 5, 1, 5), (48, 50, 9, 2, 2)):
-        pairs = [_shifted_pair(h, w, float(rng.uniform(-3, 3)), float(rng.uniform(-2, 2)), seed=100 + k, margin=16) for k in range(3)]
-        f0, f1 = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
-        out = {}
-        for form in ("1", "0"):
-            monkeypatch.setenv("VQ_FLOW_TWO_LAUNCH", form)
-            m = flow_mod.Tvl1Flow(4, h, w, epsilon=0.0, iterations=iters, warps=warps, nscales=scales)
-            out[form] = m.flow(f0, f1, iterations=True)
-            m.close()
-        assert (out["0"]["iters"] == iters).all() and (out["1"]["iters"] == iters).all()
-        assert (out["0"]["u1"] == out["1"]["u1"]).all() and (out["0"]["u2"] == out["1"]["u2"]).all()
-    # default parameters (convergence test active): same fields to the oracle tolerance, iteration counts at most one apart
-    pairs = [_shifted_pair(256, 340, dx, dy, seed=20 + k, margin=40) for k, (dx, dy) in enumerate([(2.0, 1.0), (-4.5, 0.5)])]
-    f0, f1 = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
-    out = {}
-    for form in ("1", "0"):
-        monkeypatch.setenv("VQ_FLOW_TWO_LAUNCH", form)
-        m = flow_mod.Tvl1Flow(2, 256, 340)
-        out[form] = m.flow(f0, f1, iterations=True)
-        m.close()
-    assert np.abs(out["0"]["iters"] - out["1"]["iters"]).max() <= 1
-    assert np.abs(out["0"]["u1"] - out["1"]["u1"]).max() <= 2e-2 and np.abs(out["0"]["u2"] - out["1"]["u2"]).max() <= 2e-2
-
-
-def test_fitted_tiles_have_the_bits_of_the_square_ones(flow_mod, monkeypatch):
-    """tvl1_tile_kernel (a level cut into the tiles that cost it the least, cells dealt to the threads in row-major order) against
-    tvl1_block_kernel (64 x 64 tiles, VQ_FLOW_TILES=square when the handle is created): the same per-pixel operations in the same order,
-    so with a fixed iteration count the same bits -- sizes that give one tile, a single row or column of tiles, tiles wider than 64 cells,
-    batches of 1, 3 and 9 pairs (the cut depends on the number of pairs); with the convergence test active the two sum the squared update
-    over different tiles and may stop an iteration apart when the error grazes the threshold, as the blocked and the two-launch form."""
+def test_blocked_tiles_against_the_oracle_on_every_cut(flow_mod):
+    """The inner loop runs in blocks of 4 iterations per launch on tiles FITTED to the level (the fields of a tile resident in
+    registers / LDS with a 4-pixel halo, the two sets of planes ping-ponging, the stopping rule kept exact by replaying a block that
+    ran past the stop).  With a fixed iteration count (epsilon = 0) the kernel follows the oracle operation for operation: 1e-4 px
+    (observed ~1e-6) on shapes that exercise the cut -- iteration counts that are and are not multiples of the block (the tail block
+    runs fewer), frames smaller than a tile and larger than several, a single row / column of tiles, tiles wider than 64 cells -- and
+    the cut itself (it depends on the level AND on the number of pairs in the batch) never changes a bit: a pair alone, in a batch
+    of 3 and in a batch of 9 gives the same fields.  (Rounds 2-4 also kept the un-blocked two-launch form and the square-tile form
+    in the library and compared them with this kernel bit for bit; they were removed in round 5.)"""
     rng = np.random.default_rng(31)
     for (h, w, iters, warps, scales, n) in ((64, 80, 7, 2, 3, 3), (100, 132, 12, 3, 2, 1), (256, 340, 6, 1, 5, 9), (48, 50, 9, 2, 2, 2), (40, 300, 5, 1, 1, 3),
                                             (131, 174, 8, 1, 1, 4)):
         pairs = [_shifted_pair(h, w, float(rng.uniform(-3, 3)), float(rng.uniform(-2, 2)), seed=300 + k, margin=12) for k in range(n)]
         f0, f1 = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
-        out = {}
-        for form in ("square", "fitted"):
-            monkeypatch.setenv("VQ_FLOW_TILES", form)
-            m = flow_mod.Tvl1Flow(n, h, w, epsilon=0.0, iterations=iters, warps=warps, nscales=scales)
-            out[form] = m.flow(f0, f1, iterations=True)
-            m.close()
-        assert (out["square"]["iters"] == iters).all() and (out["fitted"]["iters"] == iters).all()
-        assert (out["square"]["u1"] == out["fitted"]["u1"]).all() and (out["square"]["u2"] == out["fitted"]["u2"]).all(), (h, w)
-    pairs = [_shifted_pair(256, 340, dx, dy, seed=40 + k, margin=40) for k, (dx, dy) in enumerate([(2.0, 1.0), (-4.5, 0.5), (0.5, -3.0)])]
-    f0, f1 = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
-    out = {}
-    for form in ("square", "fitted"):
-        monkeypatch.setenv("VQ_FLOW_TILES", form)
-        m = flow_mod.Tvl1Flow(3, 256, 340)
-        out[form] = m.flow(f0, f1, iterations=True)
+        m = flow_mod.Tvl1Flow(n, h, w, epsilon=0.0, iterations=iters, warps=warps, nscales=scales)
+        r = m.flow(f0, f1, iterations=True)
+        assert (r["iters"] == iters).all()
+        for i in (0, n - 1):
+            u1, u2, _ = tv.tvl1_flow(f0[i], f1[i], nscales=scales, warps=warps, iterations=iters, epsilon=0.0)
+            assert np.abs(r["u1"][i] - u1).max() <= 1e-4 and np.abs(r["u2"][i] - u2).max() <= 1e-4, (h, w, i)
+        solo = m.flow(f0[n - 1:], f1[n - 1:])                       # another number of pairs = another cut of every level
+        assert (solo["u1"][0] == r["u1"][n - 1]).all() and (solo["u2"][0] == r["u2"][n - 1]).all(), (h, w)
         m.close()
-    assert np.abs(out["square"]["iters"] - out["fitted"]["iters"]).max() <= 1
-    assert np.abs(out["square"]["u1"] - out["fitted"]["u1"]).max() <= 2e-2 and np.abs(out["square"]["u2"] - out["fitted"]["u2"]).max() <= 2e-2
+    # identical frames stop after exactly one iteration (the first block is replayed with one iteration)
+    f = _shifted_pair(96, 128, 0.0, 0.0, seed=7)[0]
+    m = flow_mod.Tvl1Flow(2, 96, 128)
+    r = m.flow(f[None], f[None], iterations=True)
+    assert (r["iters"] == 1).all() and (r["u1"] == 0).all() and (r["u2"] == 0).all()
+    m.close()

@@ -41,14 +41,13 @@ if __name__ == "__main__" and len(sys.argv) == 1:
 
 
 def bench_batched(n=1_000_000, s=2, e=5, d=1024, q=16, reps=6):
-    """vq_db_scan_batch at cfg 4: the fused single launch, and (VQ_BATCH_TWO_KERNEL=1) the round-2 two-kernel form."""
+    """vq_db_scan_batch at cfg 4 (the fused single launch), three timed repeats."""
     import time
     db = vqa.FeatureDB.synthetic(n, s, e, d, seed=17, scales=(4.0, 1.0)[:s])
     rng = np.random.default_rng(0)
     t = rng.standard_normal((q, s, e, d)) / d
     w = 0.5 + rng.random((q, s))
-    for form in ("0", "1", "0"):
-        os.environ["VQ_BATCH_TWO_KERNEL"] = form
+    for form in ("fused", "fused", "fused"):
         db.scan_batch(t, w, want=False)
         db.scores_sync() if hasattr(db, "scores_sync") else db.scan_batch(t[:1], w[:1])     # drain
         tm = C.c_void_p()

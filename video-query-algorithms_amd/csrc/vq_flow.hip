@@ -12,14 +12,12 @@
 // warp_oracle.py) estimate it from corners moved by the first-pass flow.  The SURF matches the binary adds are not built.
 //
 // Shape of the work: a BATCH of independent frame pairs (one 340 x 256 pair is only 87 k pixels).  Per pyramid level and warp:
-// one warp kernel, then per inner iteration two stencil kernels over all pairs -- the primal step needs every neighbour's dual
-// variable, the dual step every neighbour's new primal value, so the two cannot share a launch without halo recomputation
-// (two launches per iteration; the dual launch also closes the iteration):
-//   tvl1_primal_kernel: thresholding step + u = v + theta div p, per-pair squared update summed in fp64 (one atomic per wave)
-//   tvl1_dual_kernel:   p = (p + tau/theta grad u) / (1 + tau/theta |grad u|)
+// one warp kernel, then the inner iterations in blocks of kBlkIters per launch on tiles whose fields stay in registers / LDS
+// (tvl1_tile_kernel below; rounds 1-2 streamed every plane through the caches twice per iteration with a primal and a dual launch,
+// ~90 bytes per pixel and iteration, round 3 ran square 64 x 64 tiles on 1 024 threads: both were checked bit for bit against the
+// present kernel until they were removed in round 5 -- git history).
 // A pair that has converged (mean squared update <= epsilon^2, or the iteration cap) is switched off on the device and its
-// workgroups exit at once; the host looks at the number of live pairs every few iterations only.  Everything is HBM / L2
-// streaming of fp32 planes (about 90 bytes per pixel and iteration): no LDS, no MFMA -- a bandwidth-bound stencil.
+// workgroups exit at once; the host looks at the number of live pairs every few launches only.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -179,29 +177,6 @@ __global__ void log_iters_kernel(const PairState* __restrict__ st, int* __restri
     if (p < n) log[p] = st[p].iters;
 }
 
-struct IterArgs {
-    const float *i1wx, *i1wy, *grad, *rho_c;
-    float *u1, *u2, *p11, *p12, *p21, *p22;
-    PairState* st;
-    int n, h, w;
-    int k;               // index of this inner iteration inside the warp
-    float l_t, theta, taut;
-};
-
-// Sum of `local` over the 256 threads of a block added to *dst with ONE atomic (the per-wave atomics of 64+ blocks on one
-// address used to cost more than the whole stencil: fp64 atomics on a line are served one after the other).
-__device__ __forceinline__ void block_add(double* dst, double local) {
-    __shared__ double part[4];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double sum = (part[0] + part[1]) + (part[2] + part[3]);
-        if (sum != 0.0) atomicAdd(dst, sum);
-    }
-}
-
 // The divisions and square roots of an inner iteration (one quotient in the primal step, four quotients over two denominators and two
 // roots in the dual step) are ~70 of its 273 vector instructions when IEEE-rounded, and the kernel is bound by vector-ALU issue
 // (0.42 of the rate).  FAST (VQ_FLOW_FAST=1 at creation; OFF by default) = the hardware's own v_rcp_f32 / v_sqrt_f32 (1 ulp) and one
@@ -231,194 +206,6 @@ __device__ __forceinline__ void dual_pair(float& pa, float& pb, float ux, float 
         pb = (pb + taut * uy) / ng;
     }
 }
-
-// Primal step of one pair per blockIdx.y; blockIdx.x strides over its pixels.
-template <bool FAST>
-__global__ __launch_bounds__(256) void tvl1_primal_kernel(IterArgs a) {
-    const int p = blockIdx.y;
-    if (a.st[p].stop_iter <= a.k) return;
-    const int hw = a.h * a.w;
-    const int64_t base = (int64_t)p * hw;
-    double local = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
-        const int x = i % a.w, y = i / a.w;
-        const int64_t g = base + i;
-        const float ux = a.u1[g], uy = a.u2[g], gx = a.i1wx[g], gy = a.i1wy[g], gr = a.grad[g];
-        const float rho = a.rho_c[g] + (gx * ux + gy * uy);
-        float d1, d2;
-        if (rho < -a.l_t * gr) {
-            d1 = a.l_t * gx;
-            d2 = a.l_t * gy;
-        } else if (rho > a.l_t * gr) {
-            d1 = -a.l_t * gx;
-            d2 = -a.l_t * gy;
-        } else if (gr > kGradIsZero) {
-            const float fi = FAST ? -rho * __builtin_amdgcn_rcpf(gr) : -rho / gr;
-            d1 = fi * gx;
-            d2 = fi * gy;
-        } else {
-            d1 = d2 = 0.0f;
-        }
-        // divergence of the dual variables: backward differences, p[-1] = 0
-        const float div1 = (x > 0 ? a.p11[g] - a.p11[g - 1] : a.p11[g]) + (y > 0 ? a.p12[g] - a.p12[g - a.w] : a.p12[g]);
-        const float div2 = (x > 0 ? a.p21[g] - a.p21[g - 1] : a.p21[g]) + (y > 0 ? a.p22[g] - a.p22[g - a.w] : a.p22[g]);
-        const float n1 = (ux + d1) + a.theta * div1, n2 = (uy + d2) + a.theta * div2;
-        const float e = (n1 - ux) * (n1 - ux) + (n2 - uy) * (n2 - uy);
-        local += (double)e;
-        a.u1[g] = n1;
-        a.u2[g] = n2;
-    }
-    block_add(&a.st[p].err[0][0], local);
-}
-
-// Dual step.  Its first thread also closes the iteration: the squared update of the primal step just finished (complete: it
-// ran in the previous launch) decides whether iteration k + 1 runs.  Every workgroup of this launch tests stop_iter > k,
-// which holds for the old value (no stop) and the new one (k + 1) alike, so the write cannot split the pair.
-template <bool FAST>
-__global__ __launch_bounds__(256) void tvl1_dual_kernel(IterArgs a, double eps2, int max_iters, int* n_active) {
-    const int p = blockIdx.y;
-    if (a.st[p].stop_iter <= a.k) return;
-    const int hw = a.h * a.w;
-    const int64_t base = (int64_t)p * hw;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
-        const int x = i % a.w, y = i / a.w;
-        const int64_t g = base + i;
-        const float c1 = a.u1[g], c2 = a.u2[g];
-        const float u1x = x + 1 < a.w ? a.u1[g + 1] - c1 : 0.0f, u1y = y + 1 < a.h ? a.u1[g + a.w] - c1 : 0.0f;
-        const float u2x = x + 1 < a.w ? a.u2[g + 1] - c2 : 0.0f, u2y = y + 1 < a.h ? a.u2[g + a.w] - c2 : 0.0f;
-        float q11 = a.p11[g], q12 = a.p12[g], q21 = a.p21[g], q22 = a.p22[g];
-        dual_pair<FAST>(q11, q12, u1x, u1y, a.taut);
-        dual_pair<FAST>(q21, q22, u2x, u2y, a.taut);
-        a.p11[g] = q11;
-        a.p12[g] = q12;
-        a.p21[g] = q21;
-        a.p22[g] = q22;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const double mean = a.st[p].err[0][0] / (double)hw;
-        a.st[p].err[0][0] = 0.0;
-        a.st[p].iters = a.k + 1;
-        if (!(mean > eps2) || a.k + 1 >= max_iters) {
-            a.st[p].stop_iter = a.k + 1;
-            atomicSub(n_active, 1);
-        }
-    }
-}
-
-// Row-vector forms of the two iteration kernels for levels whose width is a multiple of 4 (340 and 272 of the default
-// pyramid: 3/4 of all pixel-iterations): a thread owns 4 consecutive pixels of a row, every plane moves as 16-byte
-// accesses and the row / column decode happens once per 4 pixels.  Per pixel the operations and their order are those of
-// the scalar kernels above, so the fields are the same bits whichever form a level takes.
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
-template <bool FAST>
-__global__ __launch_bounds__(256) void tvl1_primal_kernel4(IterArgs a) {
-    const int p = blockIdx.y;
-    if (a.st[p].stop_iter <= a.k) return;
-    const int hw = a.h * a.w;
-    double local = 0.0;
-    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4; i < hw; i += gridDim.x * blockDim.x * 4) {
-        const int x0 = i % a.w, y = i / a.w;
-        const int64_t g = (int64_t)p * hw + i;
-        const floatx4 ux = *reinterpret_cast<const floatx4*>(a.u1 + g), uy = *reinterpret_cast<const floatx4*>(a.u2 + g);
-        const floatx4 gx = *reinterpret_cast<const floatx4*>(a.i1wx + g), gy = *reinterpret_cast<const floatx4*>(a.i1wy + g);
-        const floatx4 gr = *reinterpret_cast<const floatx4*>(a.grad + g), rc = *reinterpret_cast<const floatx4*>(a.rho_c + g);
-        const floatx4 q11 = *reinterpret_cast<const floatx4*>(a.p11 + g), q12 = *reinterpret_cast<const floatx4*>(a.p12 + g);
-        const floatx4 q21 = *reinterpret_cast<const floatx4*>(a.p21 + g), q22 = *reinterpret_cast<const floatx4*>(a.p22 + g);
-        floatx4 up12 = {0.f, 0.f, 0.f, 0.f}, up22 = {0.f, 0.f, 0.f, 0.f};
-        if (y > 0) {
-            up12 = *reinterpret_cast<const floatx4*>(a.p12 + g - a.w);
-            up22 = *reinterpret_cast<const floatx4*>(a.p22 + g - a.w);
-        }
-        float left11 = 0.f, left21 = 0.f;
-        if (x0 > 0) {
-            left11 = a.p11[g - 1];
-            left21 = a.p21[g - 1];
-        }
-        floatx4 n1v, n2v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float rho = rc[e] + (gx[e] * ux[e] + gy[e] * uy[e]);
-            float d1, d2;
-            if (rho < -a.l_t * gr[e]) {
-                d1 = a.l_t * gx[e];
-                d2 = a.l_t * gy[e];
-            } else if (rho > a.l_t * gr[e]) {
-                d1 = -a.l_t * gx[e];
-                d2 = -a.l_t * gy[e];
-            } else if (gr[e] > kGradIsZero) {
-                const float fi = FAST ? -rho * __builtin_amdgcn_rcpf(gr[e]) : -rho / gr[e];
-                d1 = fi * gx[e];
-                d2 = fi * gy[e];
-            } else {
-                d1 = d2 = 0.0f;
-            }
-            const float l11 = e == 0 ? left11 : q11[e > 0 ? e - 1 : 0], l21 = e == 0 ? left21 : q21[e > 0 ? e - 1 : 0];
-            const bool first = x0 + e == 0;
-            const float div1 = (first ? q11[e] : q11[e] - l11) + (y > 0 ? q12[e] - up12[e] : q12[e]);
-            const float div2 = (first ? q21[e] : q21[e] - l21) + (y > 0 ? q22[e] - up22[e] : q22[e]);
-            const float n1 = (ux[e] + d1) + a.theta * div1, n2 = (uy[e] + d2) + a.theta * div2;
-            const float err = (n1 - ux[e]) * (n1 - ux[e]) + (n2 - uy[e]) * (n2 - uy[e]);
-            local += (double)err;
-            n1v[e] = n1;
-            n2v[e] = n2;
-        }
-        *reinterpret_cast<floatx4*>(a.u1 + g) = n1v;
-        *reinterpret_cast<floatx4*>(a.u2 + g) = n2v;
-    }
-    block_add(&a.st[p].err[0][0], local);
-}
-
-template <bool FAST>
-__global__ __launch_bounds__(256) void tvl1_dual_kernel4(IterArgs a, double eps2, int max_iters, int* n_active) {
-    const int p = blockIdx.y;
-    if (a.st[p].stop_iter <= a.k) return;
-    const int hw = a.h * a.w;
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i < hw) {
-        const int x0 = i % a.w, y = i / a.w;
-        const int64_t g = (int64_t)p * hw + i;
-        const floatx4 c1 = *reinterpret_cast<const floatx4*>(a.u1 + g), c2 = *reinterpret_cast<const floatx4*>(a.u2 + g);
-        const bool right = x0 + 4 < a.w, below = y + 1 < a.h;
-        const float r1 = right ? a.u1[g + 4] : 0.f, r2 = right ? a.u2[g + 4] : 0.f;
-        floatx4 b1 = c1, b2 = c2;
-        if (below) {
-            b1 = *reinterpret_cast<const floatx4*>(a.u1 + g + a.w);
-            b2 = *reinterpret_cast<const floatx4*>(a.u2 + g + a.w);
-        }
-        floatx4 q11 = *reinterpret_cast<const floatx4*>(a.p11 + g), q12 = *reinterpret_cast<const floatx4*>(a.p12 + g);
-        floatx4 q21 = *reinterpret_cast<const floatx4*>(a.p21 + g), q22 = *reinterpret_cast<const floatx4*>(a.p22 + g);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bool has_right = e < 3 || right;
-            const float n1 = e < 3 ? c1[e < 3 ? e + 1 : 3] : r1, n2 = e < 3 ? c2[e < 3 ? e + 1 : 3] : r2;
-            const float u1x = has_right ? n1 - c1[e] : 0.0f, u1y = below ? b1[e] - c1[e] : 0.0f;
-            const float u2x = has_right ? n2 - c2[e] : 0.0f, u2y = below ? b2[e] - c2[e] : 0.0f;
-            float va = q11[e], vb = q12[e], vc = q21[e], vd = q22[e];       // (vector elements do not bind to references)
-            dual_pair<FAST>(va, vb, u1x, u1y, a.taut);
-            dual_pair<FAST>(vc, vd, u2x, u2y, a.taut);
-            q11[e] = va;
-            q12[e] = vb;
-            q21[e] = vc;
-            q22[e] = vd;
-        }
-        *reinterpret_cast<floatx4*>(a.p11 + g) = q11;
-        *reinterpret_cast<floatx4*>(a.p12 + g) = q12;
-        *reinterpret_cast<floatx4*>(a.p21 + g) = q21;
-        *reinterpret_cast<floatx4*>(a.p22 + g) = q22;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const double mean = a.st[p].err[0][0] / (double)hw;
-        a.st[p].err[0][0] = 0.0;
-        a.st[p].iters = a.k + 1;
-        if (!(mean > eps2) || a.k + 1 >= max_iters) {
-            a.st[p].stop_iter = a.k + 1;
-            atomicSub(n_active, 1);
-        }
-    }
-}
-
-
 
 // ---- the blocked form: kBlkIters inner iterations per launch, the fields of a tile resident in LDS ----------------------------
 // The two-launch form streams every plane through the caches twice per inner iteration (22 floats per pixel) and needs two
@@ -493,149 +280,6 @@ __device__ __forceinline__ BlkSched next_schedule(const PairState& st, int L, in
     }
     if (j == prev.n - 1) return BlkSched{kBlkDone, 1 - prev.src, prev.base + prev.n, 0};
     return BlkSched{kBlkReplay, prev.src, prev.base, j + 1};
-}
-
-template <int E, int NT, bool FAST>
-__global__ __launch_bounds__(NT) void tvl1_block_kernel(BlockArgs a) {
-    // NT threads as 32 x RY: a thread owns the cells (tx + 32 i, ty + RY j) of the E x E tile
-    constexpr int K = kBlkIters, T = E - 2 * K, RY = NT / 32, NI = (E + 31) / 32, NJ = (E + RY - 1) / RY, PITCH = E + 1;
-    extern __shared__ float lds[];                       // u1, u2, p11, p12, p21, p22: [E][PITCH] each
-    __shared__ double part[NT / 64];
-    constexpr int PLANE = E * PITCH;
-    float* __restrict__ U1 = lds;
-    float* __restrict__ U2 = lds + PLANE;
-    float* __restrict__ P11 = lds + 2 * PLANE;
-    float* __restrict__ P12 = lds + 3 * PLANE;
-    float* __restrict__ P21 = lds + 4 * PLANE;
-    float* __restrict__ P22 = lds + 5 * PLANE;
-    const int p = blockIdx.z;
-    PairState& st = a.st[p];
-    const int hw = a.h * a.w;
-    const BlkSched cur = next_schedule(st, a.L, hw, a.eps2, a.max_iters);
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const bool scribe = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
-    if (scribe) {
-        st.blk[a.L % 3] = cur;
-        for (int m = 0; m < K; ++m) st.err[(a.L + 1) % 3][m] = 0.0;
-        if (cur.mode == kBlkDone && (a.L == 0 || st.blk[(a.L - 1) % 3].mode != kBlkDone)) {      // the pair has just finished
-            st.final_set = cur.src;
-            st.iters = cur.base;
-            if (atomicSub(a.n_active, 1) == 1) __hip_atomic_store(a.live_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-    if (cur.mode == kBlkDone) return;
-    const float* const* src = a.set[cur.src];
-    float* const* dst = a.set[1 - cur.src];
-    const int xo = (int)blockIdx.x * T - K, yo = (int)blockIdx.y * T - K;
-    const int64_t base = (int64_t)p * hw;
-    // A thread's own cells live in registers (fields and constants); LDS carries what NEIGHBOURS read: p11 / p21 of the left cell
-    // and p12 / p22 of the upper one for the primal step, the new u1 / u2 of the right and lower cell for the dual step.
-    float cgx[NJ][NI], cgy[NJ][NI], cgr[NJ][NI], crc[NJ][NI];
-    float ru1[NJ][NI], ru2[NJ][NI], r11[NJ][NI], r12[NJ][NI], r21[NJ][NI], r22[NJ][NI];
-    bool live[NJ][NI];                                    // the cell exists in the tile and in the image
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int cx = tx + 32 * i, cy = ty + RY * j, x = xo + cx, y = yo + cy;
-            cgx[j][i] = cgy[j][i] = cgr[j][i] = crc[j][i] = 0.f;
-            ru1[j][i] = ru2[j][i] = r11[j][i] = r12[j][i] = r21[j][i] = r22[j][i] = 0.f;
-            live[j][i] = cx < E && cy < E && x >= 0 && x < a.w && y >= 0 && y < a.h;
-            if (live[j][i]) {
-                const int64_t g = base + (int64_t)y * a.w + x;
-                ru1[j][i] = src[0][g];
-                ru2[j][i] = src[1][g];
-                r11[j][i] = src[2][g];
-                r12[j][i] = src[3][g];
-                r21[j][i] = src[4][g];
-                r22[j][i] = src[5][g];
-                cgx[j][i] = a.i1wx[g];
-                cgy[j][i] = a.i1wy[g];
-                cgr[j][i] = a.grad[g];
-                crc[j][i] = a.rho_c[g];
-            }
-            if (cx < E && cy < E) {
-                const int c = cy * PITCH + cx;
-                P11[c] = r11[j][i];
-                P12[c] = r12[j][i];
-                P21[c] = r21[j][i];
-                P22[c] = r22[j][i];
-            }
-        }
-    __syncthreads();
-    for (int m = 0; m < cur.n; ++m) {
-        double local = 0.0;
-        // primal step (a cell reads its own old u and p, the p11 / p21 of its left and the p12 / p22 of its upper neighbour)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int cx = tx + 32 * i, cy = ty + RY * j, x = xo + cx, y = yo + cy;
-                if (live[j][i]) {
-                    const int c = cy * PITCH + cx;
-                    const float q11 = r11[j][i], q12 = r12[j][i], q21 = r21[j][i], q22 = r22[j][i];
-                    // divergence: backward differences, p[-1] = 0 at the image border (a tile-edge cell is outside the exact region)
-                    const float l11 = cx > 0 ? P11[c - 1] : 0.f, l21 = cx > 0 ? P21[c - 1] : 0.f;
-                    const float t12 = cy > 0 ? P12[c - PITCH] : 0.f, t22 = cy > 0 ? P22[c - PITCH] : 0.f;
-                    const float div1 = (x > 0 ? q11 - l11 : q11) + (y > 0 ? q12 - t12 : q12);
-                    const float div2 = (x > 0 ? q21 - l21 : q21) + (y > 0 ? q22 - t22 : q22);
-                    float n1, n2, err;
-                    primal_pixel<FAST>(ru1[j][i], ru2[j][i], cgx[j][i], cgy[j][i], cgr[j][i], crc[j][i], div1, div2, a.l_t, a.theta, n1, n2, err);
-                    ru1[j][i] = n1;
-                    ru2[j][i] = n2;
-                    U1[c] = n1;
-                    U2[c] = n2;
-                    if (cx >= K && cx < E - K && cy >= K && cy < E - K) local += (double)err;
-                }
-            }
-        // the tile's squared update of this iteration: one atomic per workgroup
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off, 64);
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
-        __syncthreads();                                 // also: every new primal value is in LDS, every old p has been read
-        if (threadIdx.x == 0) {
-            double sum = 0.0;
-#pragma unroll
-            for (int q = 0; q < NT / 64; ++q) sum += part[q];
-            if (sum != 0.0) atomicAdd(&st.err[a.L % 3][m], sum);
-        }
-        // dual step (a cell reads its own p and new u, the new u of its right and lower neighbour)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int cx = tx + 32 * i, cy = ty + RY * j, x = xo + cx, y = yo + cy;
-                if (live[j][i]) {
-                    const int c = cy * PITCH + cx;
-                    const bool has_right = x + 1 < a.w && cx + 1 < E, below = y + 1 < a.h && cy + 1 < E;
-                    const float c1 = ru1[j][i], c2 = ru2[j][i];
-                    const float u1x = has_right ? U1[c + 1] - c1 : 0.0f, u1y = below ? U1[c + PITCH] - c1 : 0.0f;
-                    const float u2x = has_right ? U2[c + 1] - c2 : 0.0f, u2y = below ? U2[c + PITCH] - c2 : 0.0f;
-                    dual_pair<FAST>(r11[j][i], r12[j][i], u1x, u1y, a.taut);
-                    dual_pair<FAST>(r21[j][i], r22[j][i], u2x, u2y, a.taut);
-                    P11[c] = r11[j][i];
-                    P12[c] = r12[j][i];
-                    P21[c] = r21[j][i];
-                    P22[c] = r22[j][i];
-                }
-            }
-        __syncthreads();                                 // every new p is in LDS, every new u has been read
-    }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int cx = tx + 32 * i, cy = ty + RY * j, x = xo + cx, y = yo + cy;
-            if (live[j][i] && cx >= K && cx < E - K && cy >= K && cy < E - K) {
-                const int64_t g = base + (int64_t)y * a.w + x;
-                dst[0][g] = ru1[j][i];
-                dst[1][g] = ru2[j][i];
-                dst[2][g] = r11[j][i];
-                dst[3][g] = r12[j][i];
-                dst[4][g] = r21[j][i];
-                dst[5][g] = r22[j][i];
-            }
-        }
 }
 
 // The product form: tiles FITTED to the level, two workgroups per compute unit.  What round 4 measured about the kernel above: a
@@ -1100,8 +744,6 @@ struct vq_flow {
     int last_iter_launches = 0;            // iteration-kernel launches of the last call
     bool exact_math = true;                // VQ_FLOW_FAST=1 at creation switches to hardware reciprocals / roots in the inner iterations (see tv_rcp)
     int n_cus = 256;                       // compute units of the device (tile fitting)
-    bool square_tiles = false;             // VQ_FLOW_TILES=square at creation: the 64 x 64 tiles of round 3 on every level (A/B tests)
-    bool two_launch = false;               // VQ_FLOW_TWO_LAUNCH=1 at creation: the round-2 primal + dual launch pair per inner iteration (A/B tests)
 };
 
 static void flow_free(vq_flow* f) {
@@ -1173,19 +815,11 @@ int vq_flow_create(int32_t max_pairs, int32_t h, int32_t w, const vq_tvl1_params
     f->w = w;
     f->prm = prm;
     {
-        const char* e2 = getenv("VQ_FLOW_TWO_LAUNCH");
-        f->two_launch = e2 && *e2 == '1';
         const char* e3 = getenv("VQ_FLOW_FAST");
         f->exact_math = !(e3 && *e3 == '1');
         hipDeviceProp_t prop;
         VQ_HIP(hipGetDeviceProperties(&prop, device));
         f->n_cus = std::max(1, prop.multiProcessorCount);
-        const char* e4 = getenv("VQ_FLOW_TILES");
-        f->square_tiles = e4 && !strcmp(e4, "square");
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tvl1_block_kernel<64, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   6 * 64 * 65 * (int)sizeof(float)));
-        VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tvl1_block_kernel<64, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   6 * 64 * 65 * (int)sizeof(float)));
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tvl1_tile_kernel<kTileThreads, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    6 * kTileCells * (int)sizeof(float)));
         VQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tvl1_tile_kernel<kTileThreads, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1330,33 +964,8 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
         const float *i0 = f->pyr0 + L.off, *i1 = f->pyr1 + L.off;
         gradient_kernel<<<cdiv(tot, 256), 256, 0, st>>>(i1, i1x, i1y, n_pairs, L.h, L.w);
         for (float* p : {p11, p12, p21, p22}) VQ_HIP(hipMemsetAsync(p, 0, (size_t)tot * sizeof(float), st));
-        IterArgs a;
-        a.i1wx = i1wx;
-        a.i1wy = i1wy;
-        a.grad = grad;
-        a.rho_c = rho_c;
-        a.u1 = u1;
-        a.u2 = u2;
-        a.p11 = p11;
-        a.p12 = p12;
-        a.p21 = p21;
-        a.p22 = p22;
-        a.st = f->st;
-        a.n = n_pairs;
-        a.h = L.h;
-        a.w = L.w;
-        a.l_t = (float)((double)P.lambda * (double)P.theta);      // oracle: float32(lam * theta) on the float32 parameters
-        a.theta = P.theta;
-        a.taut = (float)((double)P.tau / (double)P.theta);
-        const dim3 grid((unsigned)std::min(cdiv((int64_t)L.h * L.w, 256), 64), (unsigned)n_pairs);
-        // rows of a multiple of 4 pixels (and plane bases 16-byte aligned: hw is then a multiple of 4 too): the row-vector kernels
-        const bool vec = L.w % 4 == 0;
-        const dim3 grid4((unsigned)cdiv((int64_t)L.h * L.w / 4, 256), (unsigned)n_pairs);
-        const dim3 grid4p(std::min(grid4.x, 32u), (unsigned)n_pairs);      // primal: few blocks per pair = few atomics on its error sum
-        // the blocked form: tiles of T x T own pixels (+ a halo of kBlkIters) per 256-thread workgroup
-        constexpr int E = 64, NT = 1024, T = E - 2 * kBlkIters;
-        const dim3 bgrid((unsigned)cdiv(L.w, T), (unsigned)cdiv(L.h, T), (unsigned)n_pairs);
-        const size_t blds = (size_t)6 * E * (E + 1) * sizeof(float);
+        const float l_t = (float)((double)P.lambda * (double)P.theta);      // oracle: float32(lam * theta) on the float32 parameters
+        const float taut = (float)((double)P.tau / (double)P.theta);
         const TileCut cut = fit_tiles(L.w, L.h, n_pairs, std::max(1, VQ_FLOW_TILE_WPE * 256 / kTileThreads) * f->n_cus);
         const dim3 tgrid((unsigned)cut.nx, (unsigned)cut.ny, (unsigned)n_pairs);
         const size_t tlds = (size_t)6 * cut.eh * cut.ew * sizeof(float);
@@ -1376,9 +985,9 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
         ba.h = L.h;
         ba.w = L.w;
         ba.max_iters = P.iterations;
-        ba.l_t = a.l_t;
-        ba.theta = a.theta;
-        ba.taut = a.taut;
+        ba.l_t = l_t;
+        ba.theta = P.theta;
+        ba.taut = taut;
         ba.eps2 = eps2;
         float* set[2][6] = {{u1, u2, p11, p12, p21, p22}, {f->alt[0], f->alt[1], f->alt[2], f->alt[3], f->alt[4], f->alt[5]}};
         SettleArgs sa;
@@ -1394,20 +1003,15 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
             int chunk_no = 0;
             const size_t ev_i = 2 * ((size_t)(nl - 1 - s) * P.warps + wp);
             VQ_HIP(hipEventRecord(f->loop_ev[ev_i], st));
-            if (!f->two_launch) {
+            {
                 // blocks of kBlkIters iterations; a pair needs at most ceil(iterations / K) blocks, one replay and one closing launch
                 const int max_launches = cdiv(P.iterations, kBlkIters) + 2;
                 for (int l0 = 0; l0 < max_launches; ++chunk_no) {
                     const int chunk = std::min(max_launches - l0, l0 < 4 ? 2 : 4);
                     for (int k = 0; k < chunk; ++k) {
                         ba.L = l0 + k;
-                        if (f->square_tiles) {
-                            if (f->exact_math) tvl1_block_kernel<E, NT, false><<<bgrid, NT, blds, st>>>(ba);
-                            else tvl1_block_kernel<E, NT, true><<<bgrid, NT, blds, st>>>(ba);
-                        } else {
-                            if (f->exact_math) tvl1_tile_kernel<kTileThreads, false><<<tgrid, kTileThreads, tlds, st>>>(ba);
-                            else tvl1_tile_kernel<kTileThreads, true><<<tgrid, kTileThreads, tlds, st>>>(ba);
-                        }
+                        if (f->exact_math) tvl1_tile_kernel<kTileThreads, false><<<tgrid, kTileThreads, tlds, st>>>(ba);
+                        else tvl1_tile_kernel<kTileThreads, true><<<tgrid, kTileThreads, tlds, st>>>(ba);
                         ++iter_launches;
                     }
                     VQ_CHECK_LAUNCH();
@@ -1420,39 +1024,9 @@ int vq_flow_tvl1(vq_flow* f, const uint8_t* frames0, const uint8_t* frames1, int
                     }
                 }
             }
-            for (int it = 0; f->two_launch && it < P.iterations; ++chunk_no) {
-                const int chunk = std::min(P.iterations - it, it < 16 ? 8 : 16);
-                for (int k = 0; k < chunk; ++k) {
-                    a.k = it + k;
-                    if (vec && f->exact_math) {
-                        tvl1_primal_kernel4<false><<<grid4p, 256, 0, st>>>(a);
-                        tvl1_dual_kernel4<false><<<grid4, 256, 0, st>>>(a, eps2, P.iterations, f->n_active);
-                    } else if (vec) {
-                        tvl1_primal_kernel4<true><<<grid4p, 256, 0, st>>>(a);
-                        tvl1_dual_kernel4<true><<<grid4, 256, 0, st>>>(a, eps2, P.iterations, f->n_active);
-                    } else if (f->exact_math) {
-                        tvl1_primal_kernel<false><<<grid, 256, 0, st>>>(a);
-                        tvl1_dual_kernel<false><<<grid, 256, 0, st>>>(a, eps2, P.iterations, f->n_active);
-                    } else {
-                        tvl1_primal_kernel<true><<<grid, 256, 0, st>>>(a);
-                        tvl1_dual_kernel<true><<<grid, 256, 0, st>>>(a, eps2, P.iterations, f->n_active);
-                    }
-                    iter_launches += 2;
-                }
-                VQ_CHECK_LAUNCH();
-                it += chunk;
-                VQ_HIP(hipMemcpyAsync(f->live_host + (chunk_no & 1), f->n_active, sizeof(int), hipMemcpyDeviceToHost, st));
-                VQ_HIP(hipEventRecord(f->poll_ev[chunk_no & 1], st));
-                if (chunk_no > 0) {
-                    VQ_HIP(hipEventSynchronize(f->poll_ev[(chunk_no - 1) & 1]));
-                    if (f->live_host[(chunk_no - 1) & 1] == 0) break;
-                }
-            }
             VQ_HIP(hipEventRecord(f->loop_ev[ev_i + 1], st));
-            if (!f->two_launch) {
-                tvl1_settle_kernel<<<dim3((unsigned)std::min(cdiv((int64_t)L.h * L.w, 256), 32), (unsigned)n_pairs), 256, 0, st>>>(f->st, sa, L.h * L.w);
-                VQ_CHECK_LAUNCH();
-            }
+            tvl1_settle_kernel<<<dim3((unsigned)std::min(cdiv((int64_t)L.h * L.w, 256), 32), (unsigned)n_pairs), 256, 0, st>>>(f->st, sa, L.h * L.w);
+            VQ_CHECK_LAUNCH();
             if (iters_host)
                 log_iters_kernel<<<cdiv(n_pairs, 256), 256, 0, st>>>(f->st, f->iters_log + ((size_t)(nl - 1 - s) * P.warps + wp) * n_pairs, n_pairs);
         }

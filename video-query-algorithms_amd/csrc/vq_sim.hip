@@ -338,16 +338,10 @@ __global__ __launch_bounds__(256) void scan_tiled_kernel(ScanArgs a) {
 // values come from LDS with one ds_read_b64 per MFMA (rows swizzled: conflict-free).
 // The fp64 matrix rate (64 cycles per MFMA and SIMD = 78.6 TFLOP/s) puts 16 queries x 41 GB at 4.2 ms of matrix time,
 // under the 6.6 ms the HBM stream takes: the pass is HBM-bound, i.e. 16 queries cost what one does.
-// The dots go to sims[v][q][c] (16 consecutive clips of a query are 128 contiguous bytes); a second kernel applies the ensemble mean and the weighted score exactly like the
-// epilogue of scan_kernel.  The k order of a dot differs from scan_kernel's (matrix-core accumulation), so batched and
-// single-query scores agree to rounding (<= 1e-12, tested), not bit for bit.
-struct BatchArgs {
-    const void* feats;
-    const double* t;          // [Q][NV][D]
-    double* sims;             // [NV][Q][n]
-    int64_t n;
-    int32_t Q, NV, D, v;
-};
+// The k order of a dot differs from scan_kernel's (matrix-core accumulation), so batched and single-query scores agree to rounding
+// (<= 1e-12, tested), not bit for bit.  (Round 2 ran this as ten slice launches into a [slice][query][clip] matrix plus a finalising
+// launch -- 2.6 GB written and read back per pass at cfg 4; batch_fused_kernel below replaced it in round 3 and was checked against
+// it bit for bit until the two-kernel form was removed in round 5.)
 constexpr int kBatchSlots = 16;
 #ifndef VQ_TILED_GROUP
 #define VQ_TILED_GROUP 4
@@ -421,85 +415,6 @@ struct ChunkP<double, P> {
 // of 32, so slot = (q % 4) + 8 (q / 4) + 4 kk + const is a bijection onto 0..31.
 __device__ __forceinline__ int query_row(int q, int D) { return q * D + (q & 3) + 8 * (q >> 2); }
 
-template <typename T, int CH>
-__global__ __launch_bounds__(1024) void batch_mfma_kernel(BatchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double tq[];      // 16 swizzled rows of D doubles (+ 32 of slack)
-    constexpr int D = CH * 256, NCHUNK = D / 64;
-    for (int i = threadIdx.x; i < kBatchSlots * D; i += blockDim.x) {
-        const int q = i / D, k = i - q * D;
-        tq[query_row(q, D) + k] = q < a.Q ? a.t[((size_t)q * a.NV + a.v) * D + k] : 0.0;
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, col = lane & 15, kk = lane >> 4;
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int64_t ntiles = (a.n + 15) / 16;
-    const T* feats = static_cast<const T*>(a.feats) + (int64_t)a.v * D + 4 * kk;
-    const int64_t clip_elems = (int64_t)a.NV * D;
-    const double* tb = tq + query_row(col, D) + 4 * kk;               // this lane's query (B operand column), its k quarter
-    // NBUF chunks of a clip are in flight per lane (a ring of register buffers, refilled right after use): at 16 MFMAs x 64
-    // cycles x 4 waves per SIMD a chunk lasts ~4 k cycles, so three chunks ahead covers the loaded-HBM latency.
-    constexpr int NBUF = sizeof(T) == 4 ? 4 : 2;
-    static_assert(NCHUNK % NBUF == 0, "chunk ring must divide the vector");
-    for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
-        const int64_t c = min(tile * 16 + col, a.n - 1);              // rows past n recompute the last clip; never stored
-        const T* x = feats + c * clip_elems;
-        Chunk<T> buf[NBUF];
-#pragma unroll
-        for (int bq = 0; bq < NBUF; ++bq) buf[bq].load(x + 64 * bq);
-        doublex4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-        for (int ch0 = 0; ch0 < NCHUNK; ch0 += NBUF) {
-#pragma unroll
-            for (int bq = 0; bq < NBUF; ++bq) {
-                int off = 64 * (ch0 + bq);
-                // the query block never changes, so the compiler would hoist all 256 LDS reads of a tile out of the tile loop
-                // (512 registers: it spilled them to scratch); an opaque offset keeps every read next to its MFMA
-                asm volatile("" : "+v"(off));
-                const double* tbc = tb + off;
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[bq].at(m, e), tbc[16 * m + e], acc, 0, 0, 0);
-                if (ch0 + bq + NBUF < NCHUNK) buf[bq].load(x + 64 * (ch0 + bq + NBUF));
-            }
-        }
-        if (col < a.Q) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t cc = tile * 16 + kk + 4 * r;
-                if (cc < a.n) a.sims[((size_t)a.v * a.Q + col) * a.n + cc] = acc[r];   // [v][q][clip]: 16 consecutive clips = 128 B per query
-            }
-        }
-    }
-}
-
-// scores[q][c] from sims[q][c][.]: ticket.py:155-160 (mean over the splits present) + :172-180, the operations of
-// clip_add / clip_close_stream / score_from_avg in the same order.
-__global__ void batch_finalize_kernel(const double* sims, const uint8_t* present, const double* w, double* scores, int64_t n, int Q,
-                                      int S, int E) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)Q * n) return;
-    const int q = (int)(i / n);
-    const int64_t c = i - (int64_t)q * n;
-    double av[8], ww[8];
-    for (int s = 0; s < S; ++s) {
-        double acc = 0.0;
-        int cnt = 0;
-        for (int e = 0; e < E; ++e) {
-            const int64_t idx = (c * S + s) * E + e;
-            if (present ? present[idx] != 0 : true) {
-                acc = acc + sims[((int64_t)(s * E + e) * Q + q) * n + c];      // [v][q][clip]
-                ++cnt;
-            }
-        }
-        av[s] = acc / (double)cnt;
-        ww[s] = w[q * S + s];
-    }
-    scores[i] = score_from_avg(av, ww, S);
-}
-
 // The 16-query pass's view of an fp32 database: [tile of 16 clips][slice][k / 4][clip][4] -- every load instruction of a wave then
 // takes 1 KB of contiguous memory (whole 128-byte lines: the non-temporal hint pays), where the row-major layout gives it 64 bytes of
 // each of 16 clips 40 KB apart.  One workgroup per (tile, slice): the 16 rows come in whole (a wave reads 1 KB of one clip per
@@ -552,14 +467,14 @@ __global__ void scatter_rows_tiled_kernel(const float4* staged, float4* tiled, i
     tiled[((tile * NV + v) * d4 + g) * 16 + (clip & 15)] = staged[i];
 }
 
-// ---- the same pass as ONE launch: no dot matrix in memory ----------------------------------------------------------------
+// ---- the pass as ONE launch: no dot matrix in memory ----------------------------------------------------------------
 // A workgroup (16 waves, one per CU) owns TW tiles of 16 clips per wave and "round" and walks the (stream, split) slices
 // itself: barrier, the slice's sixteen query rows into LDS (128 KB; from L2 after the first workgroup), barrier, then every
 // wave multiplies its tiles against them.  What a tile carries from slice to slice lives in registers: the running sum
 // over the splits of the stream being walked (ticket.py:155-160) and the running sum of the weighted squared misses over the
-// streams already closed (ticket.py:172-180) -- 16 VGPRs per tile -- so the [slice][query][clip] matrix of the two-kernel
-// form (2.6 GB written and read back per pass at cfg 4) and its ten launch ramps never exist.  The operations per (clip,
-// query) are those of batch_mfma_kernel + batch_finalize_kernel in the same order: same bits.
+// streams already closed (ticket.py:172-180) -- 16 VGPRs per tile -- so no [slice][query][clip] matrix (2.6 GB per pass at cfg 4)
+// and no per-slice launch ramps exist.  Per (clip, query): the dots of the splits present, their mean per stream in split order, the
+// weighted squared misses in stream order (clip_add / clip_close_stream / score_from_avg, shared with scan_kernel's epilogue).
 // The feature stream never stops at a slice change: the ring of chunk buffers is refilled from the NEXT (slice, tile) of
 // the wave while the last chunks of the current one are multiplied, so the loads are in flight across the two barriers (a
 // plain __syncthreads() does not wait for vector memory) and HBM stays busy while the matrix pipe waits for the new rows.
@@ -669,7 +584,9 @@ __global__ __launch_bounds__(1024) void batch_fused_kernel(BatchFusedArgs a) {
 #pragma unroll
                         for (int bq = 0; bq < NBUF; ++bq) {
                             int off = CE * (ch0 + bq);
-                            asm volatile("" : "+v"(off));             // keeps every LDS read next to its MFMA (see batch_mfma_kernel)
+                            // the query rows of a slice do not change while a wave walks its tiles: the compiler would hoist all the LDS
+                            // reads of a tile out of the tile loop (512 registers: spilled); an opaque offset keeps every read next to its MFMA
+                            asm volatile("" : "+v"(off));
                             const double* tbc = tb + off;
 #pragma unroll
                             for (int m = 0; m < P; ++m)
@@ -1559,12 +1476,8 @@ int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const d
     std::lock_guard<std::mutex> lk(db->mu);
     DeviceGuard g(db->device);
     const int Q = n_queries, NV = db->S * db->E;
-    // VQ_BATCH_TWO_KERNEL=1 keeps the round-2 form (ten slice launches into a [slice][query][clip] matrix + a finalising
-    // launch) for A/B measurements; the product runs the single fused launch
-    const char* two_env = getenv("VQ_BATCH_TWO_KERNEL");
-    const bool two_kernel = two_env && *two_env == '1' && db->layout == VQ_LAYOUT_ROWS;
-    const int64_t n_t = (int64_t)Q * NV * db->D, n_w = (int64_t)Q * db->S, n_s = two_kernel ? (int64_t)Q * db->n * NV : 0, n_sc = (int64_t)Q * db->n;
-    const int64_t need = n_t + n_w + n_s + n_sc;
+    const int64_t n_t = (int64_t)Q * NV * db->D, n_w = (int64_t)Q * db->S, n_sc = (int64_t)Q * db->n;
+    const int64_t need = n_t + n_w + n_sc;
     if (db->batch_cap < need) {
         if (db->batch_buf) VQ_HIP(hipFree(db->batch_buf));
         db->batch_buf = nullptr;
@@ -1574,14 +1487,13 @@ int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const d
     }
     double* d_t = db->batch_buf;
     double* d_w = d_t + n_t;
-    double* d_sims = d_w + n_w;
-    double* d_scores = d_sims + n_s;
+    double* d_scores = d_w + n_w;
     db->batch_scores = d_scores;
     VQ_HIP(hipMemcpyAsync(d_t, t_host, (size_t)n_t * 8, hipMemcpyHostToDevice, db->stream));
     VQ_HIP(hipMemcpyAsync(d_w, w_host, (size_t)n_w * 8, hipMemcpyHostToDevice, db->stream));
     const size_t lds = ((size_t)kBatchSlots * db->D + 32) * 8;   // sixteen swizzled query rows
     const int ch = db->D / 256;
-    if (!two_kernel) {
+    {
         const bool tiled = db->layout == VQ_LAYOUT_TILED;      // whole 128-byte lines per load instruction, non-temporal: 0.75 of the HBM peak against 0.71
         BatchFusedArgs f;
         f.feats = db->feats;
@@ -1613,35 +1525,7 @@ int vq_db_scan_batch(vq_db* db, int32_t n_queries, const double* t_host, const d
         }
 #undef VQ_FUSED_LAUNCH
         VQ_CHECK_LAUNCH();
-    } else {
-    BatchArgs a;
-    a.feats = db->feats;
-    a.t = d_t;
-    a.sims = d_sims;
-    a.n = db->n;
-    a.Q = Q;
-    a.NV = NV;
-    a.D = db->D;
-    // one 16-wave workgroup per CU (the query block takes most of its LDS); a wave walks tiles of 16 clips
-    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(((db->n + 15) / 16 + 15) / 16, (int64_t)db->cus));
-    for (int v = 0; v < NV; ++v) {
-        a.v = v;
-#define VQ_BATCH_LAUNCH(T, CH)                                                                                             \
-    {                                                                                                                      \
-        auto kern = batch_mfma_kernel<T, CH>;                                                                              \
-        VQ_DYN_LDS(kern, (kBatchSlots * CH * 256 + 32) * 8);                                                                \
-        kern<<<blocks, 1024, lds, db->stream>>>(a);                                                                        \
-    }
-        if (db->dtype == VQ_F32) {
-            if (ch == 4) VQ_BATCH_LAUNCH(float, 4) else if (ch == 3) VQ_BATCH_LAUNCH(float, 3) else if (ch == 2) VQ_BATCH_LAUNCH(float, 2) else VQ_BATCH_LAUNCH(float, 1)
-        } else {
-            if (ch == 4) VQ_BATCH_LAUNCH(double, 4) else if (ch == 3) VQ_BATCH_LAUNCH(double, 3) else if (ch == 2) VQ_BATCH_LAUNCH(double, 2) else VQ_BATCH_LAUNCH(double, 1)
-        }
-#undef VQ_BATCH_LAUNCH
-        VQ_CHECK_LAUNCH();
-    }
-    batch_finalize_kernel<<<cdiv(n_sc, 256), 256, 0, db->stream>>>(d_sims, db->present, d_w, d_scores, db->n, Q, db->S, db->E);
-    VQ_CHECK_LAUNCH();
+
     }
     db->batch_q = Q;
     if (scores_host) {

@@ -985,24 +985,6 @@ struct vq_tsn {
     hipStream_t ls = nullptr;             // stream the next launch goes to
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // profiling: events of the next launch
     std::vector<hipStream_t> split_streams;       // [n_split]; entry 0 unused (caller's stream)
-    // Captured forwards (VQ_TSN_GRAPH=1; off by default): the whole launch list of a (crops address, batch, T, mode) as ONE hipGraph,
-    // replayed by later forwards of the same key.  Measured in round 4 (tools/graph_ab.py): same bits, and NO gain where the host keeps
-    // up -- 2.761 vs 2.768 ms per 96-crop step on one stream, 12 110 vs 12 050 clips/s with two sub-batch streams: the ~3 us between
-    // two dependent launches is the command processor's, not the host's, and a graph's kernel nodes pay it too.  It helps only a host
-    // that is late with its launches (3.21 -> 2.66 ms in a process whose other threads hold the interpreter).
-    struct GraphKey {
-        const void* src;
-        int n_crops, T, n_split;
-        bool operator<(const GraphKey& o) const { return std::tie(src, n_crops, T, n_split) < std::tie(o.src, o.n_crops, o.T, o.n_split); }
-    };
-    struct GraphEntry {
-        hipGraph_t graph;
-        hipGraphExec_t exec;
-        uint64_t used;
-    };
-    std::map<GraphKey, GraphEntry> graphs;
-    uint64_t graph_clock = 0;
-    bool use_graph = true;
     hipEvent_t fork_ev = nullptr;
     std::vector<hipEvent_t> join_ev;              // per extra stream
 };
@@ -1037,16 +1019,7 @@ static void pool_free(int device, void* p, size_t bytes) {
     if (!device_pool().give(device, p, bytes)) (void)hipFree(p);
 }
 
-static void drop_graphs(vq_tsn* net) {
-    for (auto& kv : net->graphs) {
-        (void)hipGraphExecDestroy(kv.second.exec);
-        (void)hipGraphDestroy(kv.second.graph);
-    }
-    net->graphs.clear();
-}
-
 static void tsn_free(vq_tsn* net) {
-    drop_graphs(net);
     for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
     net->events.clear();
     for (hipEvent_t e : net->join_ev)
@@ -1841,8 +1814,6 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
                 for (int i = 0; i < kNumTiles; ++i)
                     if (kTiles[i].bm == bm && kTiles[i].bn == bn && kTiles[i].bk == bk && kTiles[i].pipe == pipe) net->forced_tile = i;
         }
-        const char* gr = getenv("VQ_TSN_GRAPH");
-        net->use_graph = gr && *gr == '1';        // opt-in: measured, no gain (see the struct)
         const char* sp = getenv("VQ_TSN_SPLIT");
         if (sp && strchr(sp, ',')) {                   // "2,1": sub-batches of 2/3 and 1/3 of the crops
             for (const char* q = sp; *q;) {
@@ -2023,54 +1994,8 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
         const int rc = ensure_tuned(net, sub[sb]);
         if (rc != VQ_OK) return rc;
     }
-    // A forward that carries no events and moves nothing to or from the host is a fixed list of launches: the second time its key is
-    // seen it is captured into a hipGraph (forks to the sub-batch streams included), from then on it is replayed.
-    bool capturing = false;
-    vq_tsn::GraphKey key{src, n_crops, T, n_split};
-    if (net->use_graph && !ev && crops_on_device && !feat_host && !per_snippet_host && !net->poison && net->stream != nullptr) {
-        auto it = net->graphs.find(key);
-        if (it != net->graphs.end() && it->second.exec) {
-            it->second.used = ++net->graph_clock;
-            VQ_HIP(hipGraphLaunch(it->second.exec, net->stream));
-            net->last_crops = n_crops;
-            return VQ_OK;
-        }
-        if (it == net->graphs.end()) {
-            net->graphs[key] = vq_tsn::GraphEntry{nullptr, nullptr, ++net->graph_clock};      // seen once: the next one is captured
-            if (net->graphs.size() > 8) {                                                    // least recently used key goes
-                auto old = net->graphs.begin();
-                for (auto j = net->graphs.begin(); j != net->graphs.end(); ++j)
-                    if (j->second.used < old->second.used) old = j;
-                if (old->second.exec) (void)hipGraphExecDestroy(old->second.exec);
-                if (old->second.graph) (void)hipGraphDestroy(old->second.graph);
-                net->graphs.erase(old);
-            }
-        } else {
-            VQ_HIP(hipStreamBeginCapture(net->stream, hipStreamCaptureModeThreadLocal));
-            capturing = true;
-        }
-    }
     const int frc = forward_launches(net, src, n_crops, T, n_split, sub, sub_off, ev);
-    if (capturing) {
-        hipGraph_t graph = nullptr;
-        const hipError_t e = hipStreamEndCapture(net->stream, &graph);
-        if (frc != VQ_OK) {
-            if (graph) (void)hipGraphDestroy(graph);
-            return frc;
-        }
-        if (e != hipSuccess || !graph) return fail(VQ_E_HIP, "capturing the forward failed: %s", hipGetErrorString(e));
-        hipGraphExec_t exec = nullptr;
-        const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        if (e2 != hipSuccess) {
-            (void)hipGraphDestroy(graph);
-            return fail(VQ_E_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e2));
-        }
-        net->graphs[key] = vq_tsn::GraphEntry{graph, exec, ++net->graph_clock};
-        (void)hipGetLastError();                                 // whatever the capture left behind must not meet the next launch check
-        VQ_HIP(hipGraphLaunch(exec, net->stream));               // nothing ran while capturing
-    } else if (frc != VQ_OK) {
-        return frc;
-    }
+    if (frc != VQ_OK) return frc;
     net->last_crops = n_crops;
     const int B = n_crops / T;
     if (feat_host)
@@ -2250,7 +2175,6 @@ int vq_tsn_set_layer_tiles(vq_tsn* net, int32_t n_crops, const int32_t* tiles, i
     }
     std::lock_guard<std::mutex> lk(net->mu);
     net->tuned[n_crops] = choice;
-    drop_graphs(net);                             // captured forwards hold the old tilings' launches
     return VQ_OK;
 }
 

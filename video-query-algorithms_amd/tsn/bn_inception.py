@@ -16,7 +16,6 @@ by the feature path (calcSig_wOF.py:95 reads ``global_pool``) -- is dropped.
 """
 from __future__ import annotations
 
-import os
 import re
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
@@ -233,8 +232,8 @@ def _lower(g: Graph, feature_blob: str) -> Plan:
     return Plan(tensors, keep, fs[0], fs[2], dict(loc))
 
 
-# one column tile of the widest tiling of the pooled loader (64 x 256): it then reads every window exactly once
-FOLD_POOL_MAX_COUT = int(os.environ.get("VQ_TSN_FOLD_POOL_COUT", "256"))
+# one column tile of the widest tiling of the pooled-input kernels (64 x 256): every pooling window is then read exactly once
+FOLD_POOL_MAX_COUT = 256
 
 
 def _fuse(plan: Plan) -> Plan:
@@ -247,10 +246,11 @@ def _fuse(plan: Plan) -> Plan:
     * sibling 1x1/1 convolutions that read the same tensor (3-4 per inception block) become ONE implicit GEMM
       with concatenated output columns; each 32-column group is stored to its own destination;
     * a 3x3 max pool read by exactly one such GEMM of at most FOLD_POOL_MAX_COUT output columns (pool1 ->
-      conv2/3x3_reduce) disappears into it: the GEMM's loader takes the maximum over the window while it stages a
-      pixel, and the pooled tensor is never written or read back.  A wider GEMM walks its rows once per column tile and
-      would take every window maximum again each time (measured on pool2 -> the 224-column 1x1 group of inception_3a:
-      0.129 ms folded against 0.060 + 0.070 ms apart), so it keeps its pooling layer.
+      conv2/3x3_reduce; pool2 -> the 224-column sibling group of inception_3a) disappears into it: the GEMM takes the maximum
+      over the window while it stages a pixel, and the pooled tensor is never written or read back.  The limit is ONE column
+      tile of the widest pooled-input tiling (64 x 256): a wider GEMM would walk its rows once per column tile and take every
+      window maximum again each time (pool2 folded into two 128-column tiles: 0.129 ms against 0.060 + 0.070 ms apart; into one
+      256-column tile: 0.108-0.113 ms, round 5).
     """
     ops = list(plan.ops)
     tensors = list(plan.tensors)

@@ -232,7 +232,7 @@ class TsnNet:
         # faster because the per-chunk tap decoding disappears).
         stem = [op for op in plan.ops if op.src == 0]
         self.stem_s2d = False
-        mode = os.environ.get("VQ_TSN_STEM_S2D", "1") if stem_s2d is None else ("2" if stem_s2d else "0")   # 2 = whenever possible
+        mode = "1" if stem_s2d is None else ("2" if stem_s2d else "0")   # None: when K does not grow; True: whenever possible; False: never
         if mode != "0" and len(stem) == 1:
             op = stem[0]
             k2 = (op.k + 1) // 2
@@ -242,10 +242,8 @@ class TsnNet:
         # x-major cells + row-interleaved packing for the RGB 7x7 stem (K = 176 instead of 192: conv1 0.250 -> 0.238 ms at 96 crops).
         # The same form exists for any channel count (flow stack: K = 560 instead of 640) but LOSES there: 3.44 against 3.31 ms at 448
         # crops -- the flow stem is bound by cache traffic (a 40-float cell is read by 16 (output pixel, kernel row) pairs), and four 16-byte
-        # chunks from four rows per lane group coalesce worse than 64 contiguous bytes.  VQ_TSN_STEM_ORDER: 0 = (p,q,c) everywhere,
-        # 1 (default) = x-major for <= 4 channels, 2 = x-major everywhere (the measurement above).
-        order = os.environ.get("VQ_TSN_STEM_ORDER", "1")
-        self.stem_xmajor = bool(self.stem_s2d and stem[0].k == 7 and (order == "2" or (order == "1" and self.in_channels <= 4)))
+        # chunks from four rows per lane group coalesce worse than 64 contiguous bytes.  So: x-major for <= 4 channels, (p,q,c) otherwise.
+        self.stem_xmajor = bool(self.stem_s2d and stem[0].k == 7 and self.in_channels <= 4)
         in_slot_c = 4 * self.in_channels if self.stem_s2d else cin_pad
         tensors = (TensorDesc * len(plan.tensors))()
         for i, t in enumerate(plan.tensors):
