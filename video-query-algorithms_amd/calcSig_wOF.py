@@ -33,7 +33,7 @@ if __package__ in (None, ""):
     from video_query_algorithms_amd.tsn import frames
     from video_query_algorithms_amd.tsn.caffe_net import CaffeNet
     from video_query_algorithms_amd.tsn.ingest import FrameIngest
-    from video_query_algorithms_amd.tsn.feature_csv import write_features
+    from video_query_algorithms_amd.tsn.feature_csv import format_rows, write_feature_file, write_features
     from video_query_algorithms_amd.shard import all_gather_rows, shard_range
     from video_query_algorithms_amd import fanout
 else:
@@ -41,7 +41,7 @@ else:
     from .tsn import frames
     from .tsn.caffe_net import CaffeNet
     from .tsn.ingest import FrameIngest
-    from .tsn.feature_csv import write_features
+    from .tsn.feature_csv import format_rows, write_feature_file, write_features
     from .shard import all_gather_rows, shard_range
 
 
@@ -299,12 +299,32 @@ def main(argv=None, net_factory=None, program=None):
             si, bi = order[k]
             pending[(si, bi)] = [pool.submit(load_clip, si, u) for u in batches[bi]]
 
-    def through_the_nets(si, make):
-        """One batch through every member's network of stream si: ``make(net)`` hands a net the batch (decoded, resized and cropped
-        once, whatever the number of members)."""
+    # One rank: a batch's rows are on the host as soon as its forward returns, so they are FORMATTED (half a million float reprs per 256
+    # clips and stream) batch by batch on the writer threads while the next batch is on the GPU; what is left for the end of a group
+    # is a header and a write per file.  (Several ranks: the rows of a video come together in the all-gather; formatted then.)
+    early_rows = world == 1
+    row_jobs = [[{} for _ in members] for _ in streamCNN]        # [stream][member]{video index: [futures of formatted row blocks, in clip order]}
+    cursor = {}
+
+    def through_the_nets(si, make, batch_key):
+        """One batch (or a part of it: clips of another frame size, a chunk of the ensemble path) through every member's network of
+        stream si: ``make(net)`` hands a net the crops (decoded, resized and cropped once, whatever the number of members)."""
         t0 = time.perf_counter()
         for mi, net in enumerate(nets[si]):
-            mine[si][mi].append(make(net))
+            block = make(net)
+            mine[si][mi].append(block)
+            if early_rows and isinstance(block, np.ndarray):
+                units_here = batches[batch_key[1]][cursor.get(batch_key, 0):cursor.get(batch_key, 0) + block.shape[0]]
+                lo = 0
+                while lo < len(units_here):                        # a batch may straddle videos: one row block per (video, clip range)
+                    hi = lo
+                    while hi < len(units_here) and units_here[hi][0] == units_here[lo][0]:
+                        hi += 1
+                    nos = np.asarray([int(vid[-4:]) for _vi, vid in units_here[lo:hi]], dtype=np.int64)     # calcSig_wOF.py:131
+                    row_jobs[si][mi].setdefault(units_here[lo][0], []).append(io_pool.submit(format_rows, block[lo:hi], nos, args.number_format))
+                    lo = hi
+                if mi == len(nets[si]) - 1:
+                    cursor[batch_key] = cursor.get(batch_key, 0) + block.shape[0]
         waited[si]['nets'] += time.perf_counter() - t0
 
     def flush(gi):
@@ -325,6 +345,15 @@ def main(argv=None, net_factory=None, program=None):
                 numFeatures = local_feat.shape[1] if n_units else args.featureBlob_size
                 assert numFeatures == args.featureBlob_size                                  # calcSig_wOF.py:219-220
                 if rank != 0:
+                    continue
+                if early_rows and (row_jobs[si][mi] or not n_units):
+                    for vi in groups[gi]:
+                        video_path, _f, clip_list = videos[vi]
+                        blocks = row_jobs[si][mi].pop(vi, [])
+                        if clip_list:
+                            csv_jobs.append(io_pool.submit(lambda a_: write_feature_file(*a_[:-1], [f.result() for f in a_[-1]]),
+                                                           (args.outFeatures_dir, video_path.split('/')[-2], video_path, m['modelname'], args.featureBlob,
+                                                            s['mode'], {'rgb': m['rgb'], 'warped_optical_flow': m['flow']}[s['mode']], blocks)))
                     continue
                 row = 0
                 for video_path, _f, clip_list in (videos[vi] for vi in groups[gi]):
@@ -361,24 +390,24 @@ def main(argv=None, net_factory=None, program=None):
                 t0 = time.perf_counter()
                 dev_crops = crop_pipe.get(k)
                 waited[si]['crops'] += time.perf_counter() - t0
-                through_the_nets(si, lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu))
+                through_the_nets(si, lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu), (si, bi))
             elif not crops:
                 continue
             elif args.host_resize:
                 block = np.concatenate(crops, axis=0)
-                through_the_nets(si, lambda net: net.extract_clips(block, T, on_device=on_gpu))
+                through_the_nets(si, lambda net: net.extract_clips(block, T, on_device=on_gpu), (si, bi))
             else:
                 # resize + crop on the GPU, once per batch; clips of different frame sizes in one batch go one by one
                 same_size = [np.concatenate(crops, axis=0)] if len({c.shape[1:] for c in crops}) == 1 else crops
                 for g in same_size:
                     if len(nets[si]) == 1:
-                        through_the_nets(si, lambda net: net.extract_clips_from_frames(g, T, on_device=on_gpu))
+                        through_the_nets(si, lambda net: net.extract_clips_from_frames(g, T, on_device=on_gpu), (si, bi))
                     else:
                         per = args.batch_clips * T                      # = max_crops of the extractors
                         for i in range(0, g.shape[0], per):
                             dev_crops = nets[si][0].crops_from_frames(g[i:i + per])
                             nets[si][0].sync_ingest()
-                            through_the_nets(si, lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu))
+                            through_the_nets(si, lambda net: net.extract_clips_from_crops(dev_crops, T, on_device=on_gpu), (si, bi))
         flush(gi)
     stamp("last batch through the networks")
     if trace:

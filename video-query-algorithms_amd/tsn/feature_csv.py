@@ -75,6 +75,22 @@ def write_features(out_dir: str, video: str, video_path: str, modelname: str, bl
     return written
 
 
+def write_feature_file(out_dir: str, video: str, video_path: str, modelname: str, blob: str, mode: str, weights_file: str,
+                       row_blocks: Sequence[bytes]) -> str:
+    """One stream's file of one video from rows that are ALREADY formatted (``format_rows`` of consecutive clip ranges, in clip
+    order): the same bytes as ``write_features`` on the whole block.  The command line formats a batch's rows while the next batch
+    is on the GPU, so that a job's last feature files cost a header and a write."""
+    f_output_dir = os.path.join(out_dir, video, modelname)
+    os.makedirs(f_output_dir, exist_ok=True)
+    header_txt = 'video =' + video + ', video url =' + video_path + ', CNN stream =' + mode + ', feature blob =' + blob + ', caffe model =' + weights_file
+    outfile = os.path.join(f_output_dir, mode + "_" + blob + "_features.csv")
+    with open(outfile, mode='wb') as fout:
+        fout.write((header_txt + "\n").encode())
+        for rows in row_blocks:
+            fout.write(rows)
+    return outfile
+
+
 def read_features(csv_path: str) -> Tuple[dict, np.ndarray, np.ndarray]:
     """api_load_records.py:45-58: header fields via ``split('=')[-1]``; rows ``clip, f0, f1, ...``.
     Returns (header dict, clip numbers [n], features [n, D] float64)."""
