@@ -2,7 +2,7 @@
 # TV-L1 flow: kernel trace + HBM traffic of the iteration kernel (separate --pmc passes, kernel-trace only) for one batch of 64 pairs of
 # 340 x 256 frames (tools/flow_profile.py).  Writes gpurun_out/<tag>_flow_kernel_stats.csv, <tag>_flow_trace_summary.txt, <tag>_flow_summary.json.
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-.}"
 rm -rf gpurun_out/flow_prof gpurun_out/pmc_flow_fetch gpurun_out/pmc_flow_write

@@ -17,7 +17,7 @@ fam = collections.defaultdict(lambda: collections.defaultdict(float))
 n = collections.Counter()
 for r in rows:
     k = r["Kernel_Name"]
-    f = "wino_f2x2_3x3" if "wino_f2x2" in k else "conv_igemm_pipe" if "conv_igemm_pipe" in k else "conv_igemm" if "conv_igemm" in k else None
+    f = "wino_f2x2_3x3" if "wino_f2x2" in k else "conv_igemm_pipe" if "conv_igemm_pipe" in k else "conv_igemm" if "conv_igemm" in k else "pool_gemm" if "pool_gemm" in k else None
     if f is None:
         continue
     fam[f][r["Counter_Name"]] += float(r["Counter_Value"])

@@ -2,7 +2,7 @@
 # HBM traffic of the similarity scan and of the 16-query batched pass from the L2 memory-side counters (separate --pmc passes,
 # kernel-trace only).  Writes gpurun_out/<tag>_scan_traffic.json.
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-.}"
 cat > gpurun_out/sim_once.py <<'PY'

@@ -12,7 +12,7 @@ python3 - <<'PY'
 import csv, glob, json
 def total(pattern, counter):
     rows = [r for r in csv.DictReader(open(glob.glob(pattern)[0])) if r["Counter_Name"] == counter]
-    conv = [r for r in rows if "conv_igemm" in r["Kernel_Name"] or "wino_f2x2" in r["Kernel_Name"]]
+    conv = [r for r in rows if "conv_igemm" in r["Kernel_Name"] or "wino_f2x2" in r["Kernel_Name"] or "pool_gemm" in r["Kernel_Name"]]
     forwards = sum(1 for r in rows if "gavgpool" in r["Kernel_Name"])        # one global-pool launch per forward
     return sum(float(r["Counter_Value"]) for r in conv), len(conv), forwards
 f, nf, fw_f = total("gpurun_out/pmc_tsn_fetch/*/*counter_collection.csv", "FETCH_SIZE")

@@ -7,7 +7,7 @@
 #   <tag>_mfma_util.json, <tag>_tsn_traffic.json   separate --pmc passes (tools/pmc_mfma.sh, tools/pmc_tsn.sh)
 #   <tag>_flow_kernel_stats.csv, <tag>_flow_trace_summary.txt, <tag>_flow_summary.json   TV-L1: kernel trace + FETCH / WRITE passes (tools/pmc_flow.sh)
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"

@@ -7,7 +7,7 @@ stats, bench_json, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
 fam = {}
 for r in csv.DictReader(open(stats)):
     name = r["Name"]
-    key = ("conv direct (conv_igemm*)" if "conv_igemm" in name else "conv winograd (wino_f2x2_3x3, incl. the pooling that rides along)" if "wino_f2x2" in name
+    key = ("conv direct (conv_igemm*, pool_gemm)" if ("conv_igemm" in name or "pool_gemm" in name) else "conv winograd (wino_f2x2_3x3, incl. the pooling that rides along)" if "wino_f2x2" in name
            else "scan_tiled_kernel" if "scan_tiled_kernel" in name else "scan_kernel (row-major block, before the in-place tiling)" if "scan_kernel" in name
            else "batch_fused_kernel (16-query pass)" if "batch_fused" in name and "true>" in name
            else "batch_fused_kernel on the row-major block" if "batch_fused" in name
