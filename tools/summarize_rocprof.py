@@ -37,4 +37,4 @@ bk = [k for k in fam if k.startswith("batch_fused_kernel (16")]
 if bk and b.get("similarity", {}).get("batched"):
     c, t = fam[bk[0]]
     print("batched scan: rocprof avg launch %.4f ms over %d launches; bench.py HIP events around a pass (upload + launch) %.4f ms"
-          % (t / c / 1e6, c, b["similarity"]["batched"]["pass_ms_by_hip_events"]))
+          % (t / c / 1e6, c, b["similarity"]["batched"].get("pass_ms_by_hip_events", b["similarity"]["batched"]["ms_per_pass"])))
