@@ -1877,26 +1877,38 @@ static int forward_launches(vq_tsn* net, const uint8_t* src, int n_crops, int T,
                             const std::vector<int>& sub_off, hipEvent_t* ev) {
     const vq_tensor_desc& t0 = net->tensors[0];
     const int in_c = net->in_channels;
-    const int64_t npix = (int64_t)n_crops * net->input.h * net->input.w;
     const int n_items = (int)net->items.size();
-    if (net->input.s2d_pad < 0) {
-        const int64_t nchunk = npix * (t0.c / 4);
-        preprocess_kernel<<<cdiv(nchunk, 256), 256, 0, net->stream>>>(src, net->slots[0], nchunk, in_c, t0.c, net->mean_dev);
-    } else {
-        const int64_t nchunk = (int64_t)n_crops * t0.h * t0.w * in_c;
-        if (in_c == 3 && t0.c == 12)
-            preprocess_s2d3_kernel<<<cdiv(nchunk / 3, 256), 256, 0, net->stream>>>(src, net->slots[0], nchunk / 3, net->input.h, net->input.w, t0.h, t0.w,
-                                                                                   net->input.s2d_pad, net->mean_dev, net->input.s2d_order);
-        else
-            preprocess_s2d_kernel<<<cdiv(nchunk, 256), 256, 0, net->stream>>>(src, net->slots[0], nchunk, net->input.h, net->input.w, in_c,
-                                                                            t0.h, t0.w, net->input.s2d_pad, net->mean_dev, net->input.s2d_order);
-    }
-    VQ_CHECK_LAUNCH();
+    // uint8 crops [crop0, crop0 + n) -> the fp32 input slot, on stream st
+    auto preprocess = [&](int crop0, int n, hipStream_t st) -> int {
+        const uint8_t* from = src + (size_t)crop0 * net->input.h * net->input.w * in_c;
+        float* to = net->slots[0] + (size_t)crop0 * t0.h * t0.w * t0.c;
+        if (net->input.s2d_pad < 0) {
+            const int64_t nchunk = (int64_t)n * net->input.h * net->input.w * (t0.c / 4);
+            preprocess_kernel<<<cdiv(nchunk, 256), 256, 0, st>>>(from, to, nchunk, in_c, t0.c, net->mean_dev);
+        } else {
+            const int64_t nchunk = (int64_t)n * t0.h * t0.w * in_c;
+            if (in_c == 3 && t0.c == 12)
+                preprocess_s2d3_kernel<<<cdiv(nchunk / 3, 256), 256, 0, st>>>(from, to, nchunk / 3, net->input.h, net->input.w, t0.h, t0.w,
+                                                                               net->input.s2d_pad, net->mean_dev, net->input.s2d_order);
+            else
+                preprocess_s2d_kernel<<<cdiv(nchunk, 256), 256, 0, st>>>(from, to, nchunk, net->input.h, net->input.w, in_c, t0.h, t0.w,
+                                                                        net->input.s2d_pad, net->mean_dev, net->input.s2d_order);
+        }
+        VQ_CHECK_LAUNCH();
+        return VQ_OK;
+    };
     if (n_split > 1) {
-        // Batch split: the sub-batches are independent, so each runs the whole launch list on its own stream with no
-        // synchronisation in between; one sub-batch's launch ramp and tail overlap the other's steady state.
+        // Batch split: the sub-batches are independent, so each runs the whole launch list -- its share of the preprocessing included
+        // -- on its own stream with no synchronisation in between; one sub-batch's launch ramp and tail overlap the other's steady
+        // state.  (Measured in round 5, tools/trace_prod.sh: the two streams run in step, the GPU is idle 0.007 of 2.6 ms; letting
+        // sub-batch b start k launches behind sub-batch b-1, so that memory-bound and compute-bound launches meet, LOSES:
+        // 12 090 -> 11 950 / 11 870 / 11 670 clips/s for k = 1 / 2 / 3: the lone tail costs more than the mixing gains.)
         VQ_HIP(hipEventRecord(net->fork_ev, net->stream));
         for (int l = 1; l < n_split; ++l) VQ_HIP(hipStreamWaitEvent(net->split_streams[l], net->fork_ev, 0));
+        for (int sb = 0; sb < n_split; ++sb) {
+            const int rc = preprocess(sub_off[sb], sub[sb], sb > 0 ? net->split_streams[sb] : net->stream);
+            if (rc != VQ_OK) return rc;
+        }
         for (const LaunchItem& it : net->items)
             for (int sb = 0; sb < n_split; ++sb) {
                 net->ls = sb > 0 ? net->split_streams[sb] : net->stream;
@@ -1909,6 +1921,8 @@ static int forward_launches(vq_tsn* net, const uint8_t* src, int n_crops, int T,
             VQ_HIP(hipStreamWaitEvent(net->stream, net->join_ev[l], 0));
         }
     } else {
+        const int prc = preprocess(0, n_crops, net->stream);
+        if (prc != VQ_OK) return prc;
         net->ls = net->stream;
         for (int q = 0; q < n_items; ++q) {
             if (ev) {
