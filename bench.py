@@ -1152,6 +1152,8 @@ def compact(out):
         line["e2e_cli"] = _pick(e2e, ["value", "unit", "seconds", "first_run_seconds"])
         line["e2e_cli"]["mode"] = "warm in-process"
         line["e2e_cli"]["fresh_process"] = _pick(e2e.get("fresh_process") or {}, ["seconds", "value", "error"])
+        if "error" in line["e2e_cli"]["fresh_process"]:                     # the line must stay under 4 KB whatever went wrong
+            line["e2e_cli"]["fresh_process"]["error"] = str(line["e2e_cli"]["fresh_process"]["error"])[-80:]
         line["e2e_cli"]["ensemble3"] = _pick(e2e["ensemble3"], ["value", "vs_three_runs", "member_1_bytes_equal_single_run"])
         line["e2e_cli"]["steady"] = e2e["steady_state"]["value"]
     wof = out.get("e2e_wof_cli")
