@@ -712,10 +712,10 @@ __global__ __launch_bounds__(256) void pool_gemm_kernel(ConvArgs a) {
     // ---- staging role: chunk u of a slab = row (tid + 256 u) / CPS, 16-byte column (tid + 256 u) % CPS -- the same two rows for
     // every slab, so the nine tap offsets of each are computed once (a tap outside the image re-reads the window's first pixel:
     // the maximum is unchanged; a row past M reads zeros through the range check) and a slab adds its scalar channel offset
-    unsigned tap_off[2][9];
+    unsigned tap_base[2], tap_ok[2];                               // first window pixel (0xFFFFFFFF: row past M); bit t: tap t is inside the image
     int a_dst[2];
+    const int px = a.Cs_in * 4, rowb = a.W * px;                   // bytes to the next pixel / next image row (uniform)
     {
-        const int px = a.Cs_in * 4, rowb = a.W * px;               // bytes to the next pixel / next image row
         const int HoWo = a.Ho * a.Wo;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -726,21 +726,25 @@ __global__ __launch_bounds__(256) void pool_gemm_kernel(ConvArgs a) {
             const int n_img = mm / HoWo, rem = mm - n_img * HoWo;
             const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
             const int ih0 = oh * a.pool_s, iw0 = ow * a.pool_s;
-            const unsigned base = (unsigned)((((n_img * a.H + ih0) * a.W + iw0) * a.Cs_in + a.coff_in + col * 4) * 4);
+            tap_base[u] = ok ? (unsigned)((((n_img * a.H + ih0) * a.W + iw0) * a.Cs_in + a.coff_in + col * 4) * 4) : 0xFFFFFFFFu;
             const int nvy = min(3, a.H - ih0), nvx = min(3, a.W - iw0);
+            unsigned mask = 0;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int dy = t / 3, dx = t % 3;
-                tap_off[u][t] = ok ? base + ((dy < nvy && dx < nvx) ? (unsigned)(dy * rowb + dx * px) : 0u) : 0xFFFFFFFFu;
-            }
+            for (int t = 0; t < 9; ++t)
+                if (ok && t / 3 < nvy && t % 3 < nvx) mask |= 1u << t;
+            tap_ok[u] = mask;
             a_dst[u] = row * pitch + col * 4;
         }
     }
     floatx4 v[2][9];
 #define VQ_PG_TAPS(S)                                                                                               \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                                   \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                 \
+        unsigned inside = tap_ok[u];                                                                                \
+        asm volatile("" : "+v"(inside)); /* opaque: the 18 offsets must not be hoisted out of the slab loop into registers */ \
         _Pragma("unroll") for (int t = 0; t < 9; ++t)                                                               \
-            v[u][t] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, tap_off[u][t], (S) * (SLAB * 4), 0));
+            v[u][t] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(                            \
+                in_rsrc, tap_base[u] + (((inside >> t) & 1u) ? (unsigned)((t / 3) * rowb + (t % 3) * px) : 0u), (S) * (SLAB * 4), 0)); \
+    }
 #define VQ_PG_POOL(S)                                                                                               \
     _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                 \
         floatx4 r;                                                                                                  \
@@ -762,47 +766,58 @@ __global__ __launch_bounds__(256) void pool_gemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const float* a_frag = As + (wm * (BM / WM) + l31) * pitch + half * 4;      // + 32 i rows, + 8 g floats
-    floatx4 fa[2][TM], fb[2][TN];
-#define VQ_PG_FETCH_B(SET, G)                                                                                       \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                  \
-        fb[SET][j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_voff[j], (G) * 32, 0));
+    // A wave's vector-memory loads return IN ORDER as far as s_waitcnt vmcnt can tell: a weight fragment fetched behind the 18 tap
+    // loads of the next slab could not be consumed before every one of those (HBM) loads had landed -- the first form of this loop did
+    // that, and the memory stream and the matrix pipe took turns (0.108 ms for 0.061 + 0.069).  So ALL weight fragments of slab s + 1 are
+    // requested FIRST (8 loads, a second register set), the taps of slab s + 1 behind them; the MFMAs of slab s then touch only
+    // registers that arrived before the previous slab's closing wait and LDS (lgkmcnt): no vmcnt wait inside a slab.
+    floatx4 fa[2][TM], fbs[2][GS][TN];
+#define VQ_PG_FETCH_B(SET, S)                                                                                       \
+    _Pragma("unroll") for (int q = 0; q < GS; ++q)                                                                  \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                              \
+            fbs[SET][q][j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_voff[j], ((S) * GS + q) * 32, 0));
 #define VQ_PG_FETCH_A(SET, G)                                                                                       \
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                  \
         fa[SET][i] = *reinterpret_cast<const floatx4*>(a_frag + 32 * i * pitch + (G) * 8);
-#define VQ_PG_MFMA(SET)                                                                                             \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                   \
+#define VQ_PG_MFMA(SET, BSET, Q)                                                                                    \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                                                                \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                              \
             _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                          \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][i][s], fb[SET][j][s], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][i][s_], fbs[BSET][Q][j][s_], acc[i][j], 0, 0, 0);
+// one slab: BSET = the register set its weight fragments are in (slab parity)
+#define VQ_PG_SLAB(S, BSET)                                                                                         \
+    {                                                                                                               \
+        const bool more = (S) + 1 < ns;                                                                             \
+        if (more) {                                                                                                 \
+            VQ_PG_FETCH_B((BSET) ^ 1, (S) + 1)                                                                      \
+            VQ_PG_TAPS((S) + 1)                              /* in flight under this slab's MFMAs */                \
+        }                                                                                                           \
+        VQ_PG_FETCH_A(0, (S) * GS)                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        _Pragma("unroll") for (int q = 0; q < GS; ++q) {                                                            \
+            if (q + 1 < GS) VQ_PG_FETCH_A((q + 1) & 1, (S) * GS + q + 1)                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                      \
+            VQ_PG_MFMA(q & 1, BSET, q)                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                      \
+        }                                                                                                           \
+        if (more) {                                                                                                 \
+            VQ_PG_POOL((S) + 1)                                                                                     \
+            __syncthreads();                                 /* slab S + 1 is complete in LDS (nothing is ever overwritten) */ \
+        }                                                                                                           \
+    }
 
     const int ns = K / SLAB;
-    VQ_PG_TAPS(0)
     VQ_PG_FETCH_B(0, 0)
+    VQ_PG_TAPS(0)
     VQ_PG_POOL(0)
     __syncthreads();
-    for (int s = 0; s < ns; ++s) {
-        const bool more = s + 1 < ns;
-        if (more) VQ_PG_TAPS(s + 1)                                // in flight under this slab's MFMAs
-        VQ_PG_FETCH_A(0, s * GS)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < GS; ++q) {
-            // one k-group ahead: the weights always (they do not pass through LDS), the activations inside the slab only
-            if (q + 1 < GS) {
-                VQ_PG_FETCH_B((q + 1) & 1, s * GS + q + 1)
-                VQ_PG_FETCH_A((q + 1) & 1, s * GS + q + 1)
-            } else if (more) {
-                VQ_PG_FETCH_B(0, (s + 1) * GS)
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            VQ_PG_MFMA(q & 1)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (more) {
-            VQ_PG_POOL(s + 1)
-            __syncthreads();                                       // slab s + 1 is complete in LDS (nothing is ever overwritten)
-        }
+    int s = 0;
+    for (; s + 1 < ns; s += 2) {                                   // by two: the weight register sets have static names
+        VQ_PG_SLAB(s, 0)
+        VQ_PG_SLAB(s + 1, 1)
     }
+    if (s < ns) VQ_PG_SLAB(s, 0)
+#undef VQ_PG_SLAB
 #undef VQ_PG_TAPS
 #undef VQ_PG_POOL
 #undef VQ_PG_FETCH_A
