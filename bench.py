@@ -150,7 +150,8 @@ def bench_tsn(args, rank, world, device, stream):
     g = bn_inception.bn_inception(CH)
     weights = tsn_net.synthetic_weights(g, seed=2)
     n_crops = B_CLIPS * T_SEG
-    model = tsn_net.TsnNet(g, weights, max_crops=n_crops, device=device.index)
+    # the tilings are timed in THIS process (behind the autotuner's own warm-up), not taken from a table another process left behind
+    model = tsn_net.TsnNet(g, weights, max_crops=n_crops, device=device.index, tune_cache=args.tune_cache)
     model.set_stream(stream.cuda_stream)
     if args.tiles and os.path.exists(args.tiles):          # tiling table of an earlier run: skip the autotune launches
         with open(args.tiles) as f:
@@ -273,7 +274,7 @@ def bench_two_stream(args, device, stream, with_cpu):
             os.environ["VQ_TSN_SPLIT"] = "1"
         g = bn_inception.bn_inception(ch)
         weights = tsn_net.synthetic_weights(g, seed=seed)
-        model = tsn_net.TsnNet(g, weights, max_crops=n_crops, device=device.index)
+        model = tsn_net.TsnNet(g, weights, max_crops=n_crops, device=device.index, tune_cache=args.tune_cache)
         model.set_stream(stream.cuda_stream)
         gen = torch.Generator(device=device).manual_seed(40 + ch)
         crops = torch.randint(0, 256, (n_crops, 224, 224, ch), dtype=torch.uint8, device=device, generator=gen)
@@ -1191,6 +1192,9 @@ def main():
     ap.add_argument("--profile-only", action="store_true",
                     help="for rocprofv3 comparisons: every forward of the process runs like the timed region (one stream, "
                          "VQ_TSN_SPLIT=1) and the un-profiled production-mode pass is skipped")
+    ap.add_argument("--tune-cache", default="0", help="directory of conv tiling tables to read / extend (default 0: every run times the tilings "
+                                                        "itself; tools/profile_round.sh shares one directory between its runs so that the "
+                                                        "run under rocprofv3 traces no autotune launch)")
     ap.add_argument("--tiles", default=None, help="JSON file: load the conv tiling table if it exists, else write it")
     args = ap.parse_args()
     rc = self_launch(args)                                   # before ANY GPU call of this process

@@ -874,6 +874,22 @@ def test_tiling_tables_survive_the_process(tsn, monkeypatch, tmp_path):
     m = net.TsnNet(g, w, max_crops=6)
     assert m.tuned_sizes() == []
     m.close()
+    # a handle whose table was set by hand keeps its choices to itself: neither that table nor a size tuned (or borrowed) after it is saved
+    monkeypatch.setenv("VQ_TUNE_CACHE", str(tmp_path))
+    before = open(files[0]).read()
+    m = net.TsnNet(g, w, max_crops=12)
+    forced = tiles.copy()
+    conv = forced[:, 0] > 0
+    forced[conv & (forced[:, 3] != 2), :] = (64, 64, 32, 0)
+    m.set_layer_tiles(3, forced)
+    f3, _ = m.forward(crops, 3, net.RGB_MEAN)
+    m.forward(np.concatenate([crops, crops]), 3, net.RGB_MEAN)                # 12 crops: sub-batches of 6, a size without a table
+    assert sorted(m.tuned_sizes()) == [3, 6]
+    m.close()
+    assert (f3 == f1).all() and open(files[0]).read() == before
+    m = net.TsnNet(g, w, max_crops=6, tune_cache="0")                        # the keyword beats the environment
+    assert m.tuned_sizes() == []
+    m.close()
 
 
 def test_features_from_cached_packed_weights_equal_features_from_the_weights(tmp_path, monkeypatch):

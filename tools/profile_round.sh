@@ -12,9 +12,10 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 cd "$ROOT"
-python3 bench.py --details gpurun_out/${TAG}_bench_full.json > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err   # also warms the tiling cache
+rm -rf gpurun_out/tune_${TAG}              # the first run times the tilings itself and leaves its tables for the run under the profiler
+python3 bench.py --tune-cache gpurun_out/tune_${TAG} --details gpurun_out/${TAG}_bench_full.json > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 rm -rf gpurun_out/prof_${TAG}
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${TAG} --output-format csv -- python3 bench.py --skip-cpu --profile-only \
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${TAG} --output-format csv -- python3 bench.py --tune-cache gpurun_out/tune_${TAG} --skip-cpu --profile-only \
     > gpurun_out/${TAG}_bench_under_rocprof.json 2> gpurun_out/${TAG}_bench_under_rocprof.err
 STATS=$(ls gpurun_out/prof_${TAG}/*/*kernel_stats.csv | head -1)
 cp "$STATS" gpurun_out/${TAG}_bench_kernel_stats.csv

@@ -1394,6 +1394,11 @@ static int run_item(vq_tsn* net, const LaunchItem& it, int crop0, int n_crops, i
 
 // Time every candidate tiling of every conv launch at this batch size (activations hold whatever the slots
 // contain; only durations matter) and keep the fastest.
+// The chip's clock follows its load: a sweep that starts on an idle GPU times its first candidates at a lower clock than its last ones
+// (round 5: a 96-crop table tuned at the start of a test, behind seconds of host work, gave the first three launches of the forward -- conv1,
+// conv2/3x3_reduce, the inception_3a group -- the LAST candidates of the list, one of them 1.8x slower than the best: 2.91 ms per step
+// instead of 2.73, kept by the tiling cache).  So the sweep starts behind ~30 ms of the forward's own launches, and the three fastest
+// candidates of a launch are timed once more, back to back, before the winner is taken.
 static int autotune(vq_tsn* net, int n_crops) {
     std::vector<int>& choice = net->tuned[n_crops];
     choice.assign(net->layers.size(), 0);
@@ -1401,33 +1406,61 @@ static int autotune(vq_tsn* net, int n_crops) {
     hipEvent_t e0, e1;
     VQ_HIP(hipEventCreate(&e0));
     VQ_HIP(hipEventCreate(&e1));
+    auto timed = [&](const LaunchItem& it, int reps, float* ms) -> int {
+        int rc = run_item(net, it, 0, n_crops, n_crops);       // warm
+        if (rc != VQ_OK) return rc;
+        VQ_HIP(hipEventRecord(e0, net->stream));
+        for (int r = 0; r < reps; ++r) {
+            rc = run_item(net, it, 0, n_crops, n_crops);
+            if (rc != VQ_OK) return rc;
+        }
+        VQ_HIP(hipEventRecord(e1, net->stream));
+        VQ_HIP(hipEventSynchronize(e1));
+        VQ_HIP(hipEventElapsedTime(ms, e0, e1));
+        return VQ_OK;
+    };
+    {   // bring the clock up: the heuristic tilings (choice = 0 entries are replaced below) through the whole launch list
+        std::vector<int> saved = choice;
+        net->tuned.erase(n_crops);                            // run_layer falls back to the heuristic without a table
+        for (int r = 0; r < 10; ++r)
+            for (const LaunchItem& it : net->items) {
+                const int rc = run_item(net, it, 0, n_crops, n_crops);
+                if (rc != VQ_OK) return rc;
+            }
+        VQ_HIP(hipStreamSynchronize(net->stream));
+        net->tuned[n_crops] = saved;
+    }
+    std::vector<int>& pick = net->tuned[n_crops];
     for (const LaunchItem& it : net->items) {
         const int li = it.layers[0];
         if (!is_conv(net->layers[li].op)) continue;
-        float best = 1e30f;
-        int win = 0;
         const bool wino = net->layers[li].op == VQ_OP_CONV_WINOGRAD;
+        std::vector<std::pair<float, int>> seen;
         for (int t = 0; t < (wino ? kWinoVariants : kNumTiles); ++t) {
             if (!wino && net->layers[li].pre_pool_k > 0 && !pool_tile_ok(kTiles[t], net->layers[li].cin)) continue;
             if (!wino && net->layers[li].pre_pool_k == 0 && pool_only_tile(kTiles[t])) continue;
-            for (int m : it.layers) choice[m] = t;             // a grouped launch runs one variant for all its members
-            int rc = run_item(net, it, 0, n_crops, n_crops);   // warm
-            if (rc != VQ_OK) return rc;
-            VQ_HIP(hipEventRecord(e0, net->stream));
-            for (int r = 0; r < 3; ++r) {
-                rc = run_item(net, it, 0, n_crops, n_crops);
-                if (rc != VQ_OK) return rc;
-            }
-            VQ_HIP(hipEventRecord(e1, net->stream));
-            VQ_HIP(hipEventSynchronize(e1));
+            // a column tile that is mostly padding cannot win: do not let a timing fluke choose it
+            if (!wino && kTiles[t].bn >= 2 * ((net->layers[li].cout + 63) / 64 * 64)) continue;
+            for (int m : it.layers) pick[m] = t;               // a grouped launch runs one variant for all its members
             float ms = 0.f;
-            VQ_HIP(hipEventElapsedTime(&ms, e0, e1));
+            const int rc = timed(it, 3, &ms);
+            if (rc != VQ_OK) return rc;
+            seen.emplace_back(ms, t);
+        }
+        std::sort(seen.begin(), seen.end());
+        float best = 1e30f;
+        int win = seen.empty() ? 0 : seen[0].second;
+        for (size_t k = 0; k < std::min<size_t>(3, seen.size()) && seen.size() > 1; ++k) {      // the finalists, back to back
+            for (int m : it.layers) pick[m] = seen[k].second;
+            float ms = 0.f;
+            const int rc = timed(it, 5, &ms);
+            if (rc != VQ_OK) return rc;
             if (ms < best) {
                 best = ms;
-                win = t;
+                win = seen[k].second;
             }
         }
-        for (int m : it.layers) choice[m] = win;
+        for (int m : it.layers) pick[m] = win;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

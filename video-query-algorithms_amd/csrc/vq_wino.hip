@@ -113,11 +113,12 @@ struct TileAt {
     int img, ty, tx;
 };
 __device__ __forceinline__ TileAt tile_at(int t, int img0, int ty0, int tx0, int th, int tw, unsigned s_th, unsigned s_tw) {
+    // every factor is below 2^24 (launch_t checks the shapes): v_mul_u32_u24 runs at the full rate, v_mul_lo_u32 at a quarter of it
     const unsigned lin = (unsigned)(tx0 + t);
-    const unsigned q1 = (lin * s_tw) >> 16;
+    const unsigned q1 = __umul24(lin, s_tw) >> 16;
     const unsigned ly = (unsigned)ty0 + q1;
-    const unsigned q2 = (ly * s_th) >> 16;
-    return TileAt{img0 + (int)q2, (int)(ly - q2 * (unsigned)th), (int)(lin - q1 * (unsigned)tw)};
+    const unsigned q2 = __umul24(ly, s_th) >> 16;
+    return TileAt{img0 + (int)q2, (int)(ly - __umul24(q2, (unsigned)th)), (int)(lin - __umul24(q1, (unsigned)tw))};
 }
 
 template <int NB>
@@ -147,7 +148,7 @@ __device__ __forceinline__ void wino_unit(const WinoJob& a, int unit, float* hs)
         const TileAt ta = tile_at(t, img0, ty0, tx0, a.th, a.tw, a.s_th, a.s_tw);
         const int y = 2 * ta.ty - 1 + wave, x0 = 2 * ta.tx - 1;
         const bool row_ok = p0 + t < a.P && (unsigned)y < (unsigned)a.H;
-        const int base = (((ta.img * a.H + y) * a.W + x0) * a.Cs_in + a.coff_in + c4 * 4) * 4;
+        const int base = (__mul24(__mul24(ta.img * a.H + y, a.W) + x0, a.Cs_in) + a.coff_in + c4 * 4) * 4;
         const int px = a.Cs_in * 4;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -273,7 +274,7 @@ __device__ __forceinline__ void wino_unit(const WinoJob& a, int unit, float* hs)
     const TileAt te = tile_at(et, img0, ty0, tx0, a.th, a.tw, a.s_th, a.s_tw);
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
     const int oy = 2 * te.ty, ox = 2 * te.tx;
-    const int obase = (((te.img * a.H + oy) * a.W + ox) * a.Cs_out + a.coff_out + n0 + ec * 4) * 4;
+    const int obase = (__mul24(__mul24(te.img * a.H + oy, a.W) + ox, a.Cs_out) + a.coff_out + n0 + ec * 4) * 4;
     const bool tile_ok = p0 + et < a.P;
     unsigned ooff[4];                                      // (a_, b_) = (u >> 1, u & 1); 0xFFFFFFFF: the store is dropped
 #pragma unroll

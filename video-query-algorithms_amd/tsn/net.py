@@ -209,7 +209,8 @@ def _store_packed(path: str, blob, layers, seg_list, conv_kp) -> None:
 class TsnNet:
     def __init__(self, graph: Graph, weights, max_crops: int = 96, device: int = 0,
                  feature_blob: str = "global_pool", bn_eps: float = 1e-5, fuse: bool = True,
-                 winograd: bool | None = None, stem_s2d: bool | None = None, cache_key: str | None = None):
+                 winograd: bool | None = None, stem_s2d: bool | None = None, cache_key: str | None = None,
+                 tune_cache: str | None = None):
         """``weights``: {layer: {field: array}}, or a function without arguments that returns it (called only when the packed form
         is not in the cache).  ``cache_key``: names the weights' CONTENT (a digest of the file they come from, "synthetic:<seed>");
         with it the packed device blob -- BN folded, GEMM / Winograd layouts, biases -- is kept next to the library
@@ -359,14 +360,14 @@ class TsnNet:
         self._tensor_hw = [(tensors[i].h, tensors[i].w) for i in range(len(plan.tensors))]
         # Tiling tables survive the process: the first forward of a batch size times 24 tilings per layer (~2 s of
         # launches); the winners are kept per (layer table, library ABI) next to the library and installed at creation.
-        # Every tiling gives the same bits, so a stale or foreign table can only cost speed.  VQ_TUNE_CACHE=0 disables,
-        # VQ_TUNE_CACHE=<dir> moves the files.
+        # Every tiling gives the same bits, so a stale or foreign table can only cost speed.  VQ_TUNE_CACHE=0 (or tune_cache="0")
+        # disables, VQ_TUNE_CACHE=<dir> moves the files.
         desc = [(d.op, d.src, d.dst, d.src_coff, d.dst_coff, d.cin, d.cout, d.k, d.stride, d.pad, d.seg_count, d.pre_pool_k) for d in layers]
         shapes = [(tensors[i].h, tensors[i].w, tensors[i].c) for i in range(len(plan.tensors))]
         self._tune_file = None
         self._tune_saved = set()
         self._tune_checked = set()      # batch sizes whose first forward (the one that tunes) is behind us
-        where = os.environ.get("VQ_TUNE_CACHE", os.path.join(os.path.dirname(_lib.LIB_PATH), ".tune_cache"))
+        where = tune_cache if tune_cache is not None else os.environ.get("VQ_TUNE_CACHE", os.path.join(os.path.dirname(_lib.LIB_PATH), ".tune_cache"))
         if where != "0":
             key = hashlib.sha1(json.dumps([_lib.ABI_VERSION, desc, shapes]).encode()).hexdigest()[:20]
             self._tune_file = os.path.join(where, key + ".json")
@@ -374,7 +375,7 @@ class TsnNet:
                 with open(self._tune_file) as f:
                     for n_crops, tiles in json.load(f).items():
                         if int(n_crops) <= self.max_crops:
-                            self.set_layer_tiles(int(n_crops), np.array(tiles, dtype=np.int32))
+                            self._install_tiles(int(n_crops), np.array(tiles, dtype=np.int32))
                             self._tune_saved.add(int(n_crops))
             except (OSError, ValueError, _lib.VqError):
                 pass            # no file yet, or one written for another kernel set: tune afresh
@@ -516,7 +517,13 @@ class TsnNet:
         return out[:k.value].tolist()
 
     def set_layer_tiles(self, n_crops: int, tiles: np.ndarray):
-        """Install a tiling table (from layer_tiles, e.g. of an earlier process) instead of autotuning."""
+        """Install a tiling table (from layer_tiles, e.g. of an earlier process) instead of autotuning.  A handle whose tables were set by
+        hand no longer writes the tiling cache: what it would save is the caller's choice (a test forcing one kernel, an A/B), not a
+        measurement, and later sizes may borrow from it."""
+        self._tune_file = None
+        self._install_tiles(n_crops, tiles)
+
+    def _install_tiles(self, n_crops: int, tiles: np.ndarray):
         t = np.ascontiguousarray(tiles, dtype=np.int32)
         call("vq_tsn_set_layer_tiles", self._h, int(n_crops), t.ctypes.data_as(C.c_void_p), t.shape[0])
 
