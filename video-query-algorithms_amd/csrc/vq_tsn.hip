@@ -30,6 +30,7 @@ using namespace vq;
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned uintx4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
 
 // ------------------------------------------------------------------------------------------------
 // preprocess: uint8 NHWC crops -> fp32 NHWC (channels padded to a multiple of 4), minus mean
@@ -143,6 +144,10 @@ struct ConvArgs {
     int ksplit;          // > 1: the grid is ksplit x tiles; slice ks sums K floats [ks * k_per, (ks + 1) * k_per) only and stores
     int k_per;           // its raw partial sums (zero bias, no ReLU) through segs[ks * seg_stride ..] into a scratch plane;
     int seg_stride;      // splitk_combine_kernel adds the planes in slice order, then bias and ReLU.  Aligned Cin only.
+    // conv_igemm_pipe_kernel: the pixel decoding of a workgroup without a division (fill_pixel_walk)
+    unsigned m_tiles_n;            // magic_div constant for tiles_n
+    FullDiv d_howo, d_wo;          // first pixel of the tile -> (image, row, column) on the scalar unit
+    unsigned s_wo, s_ho;           // recip22 constants: the per-lane walk of at most BM pixels from there
 };
 
 constexpr int KPAD = 32;       // weights are packed [Cout][Kp] with Kp a multiple of 32
@@ -189,6 +194,46 @@ struct ConvSmem {
                         }                                                                                         \
                         if ((full_m || mb + row < a.M) && nb + pc4 * 4 < a.Cout)                                  \
                             *reinterpret_cast<floatx4*>(sg.out_base + (size_t)(a.out_row0 + mb + row) * sg.Cs + nb + pc4 * 4) = v; \
+                    }                                                                                             \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+
+// The same epilogue with 32-bit offsets into a buffer descriptor per destination segment (conv_igemm_pipe_kernel, whose wave index is a
+// scalar): the row / segment part of an address is uniform and rides in the store's scalar offset, the lane part (row in the 8-row group,
+// 16-byte column) is formed once per segment, a masked-off lane stores at 0xFFFFFFFF (dropped by the range check).  No 64-bit vector
+// arithmetic, no multiply per store.  A launch never spans 2^31 bytes of a destination slot (LaunchItem::max_crops).
+#define VQ_EPILOGUE_BUF()                                                                                         \
+    {                                                                                                             \
+        __syncthreads(); /* every wave is done with the K-loop image of the LDS */                               \
+        float* patch = reinterpret_cast<float*>(smem_raw) + wave * (32 * 36);                                     \
+        const int prow = lane >> 3, pc4 = lane & 7;                                                               \
+        const bool full_m = m0 + BM <= a.M;                                                                       \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                          \
+            const int nb = n0 + wn * (BN / WN) + 32 * j;                                                          \
+            if (nb < a.Cout) {                                                                                    \
+                const ConvSeg sg = seg_v[j];                                                                      \
+                const __amdgpu_buffer_rsrc_t o_rsrc =                                                             \
+                    __builtin_amdgcn_make_buffer_rsrc(sg.out_base + (size_t)a.out_row0 * sg.Cs, 0, 0x7FFFFFF0u, 0x00020000); \
+                const unsigned lane_off = nb + pc4 * 4 < a.Cout ? (unsigned)((imul24(prow, sg.Cs) + pc4 * 4) * 4) : 0xFFFFFFFFu; \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                  \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                \
+                        patch[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = acc[i][j][r];                     \
+                    const int mb = m0 + wm * (BM / WM) + 32 * i;                                                  \
+                    _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                            \
+                        const int row = prow + 8 * ps;                                                            \
+                        floatx4 v = *reinterpret_cast<const floatx4*>(&patch[row * 36 + pc4 * 4]);                \
+                        v += bias_v[j];                                                                           \
+                        if (sg.relu) {                                                                            \
+                            v[0] = fmaxf(v[0], 0.f);                                                              \
+                            v[1] = fmaxf(v[1], 0.f);                                                              \
+                            v[2] = fmaxf(v[2], 0.f);                                                              \
+                            v[3] = fmaxf(v[3], 0.f);                                                              \
+                        }                                                                                         \
+                        const unsigned off = (full_m || mb + row < a.M) ? lane_off : 0xFFFFFFFFu;                 \
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), o_rsrc, off,        \
+                                                               ((mb + 8 * ps) * sg.Cs + nb) * 4, 0);              \
                     }                                                                                             \
                 }                                                                                                 \
             }                                                                                                     \
@@ -413,8 +458,14 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     const int ks = a.ksplit > 1 ? (int)blockIdx.x / n_tiles : 0;            // K slice of this workgroup (uniform)
     const int kbeg = ks * a.k_per;
     const int tile = xcd_remap(blockIdx.x - ks * n_tiles, n_tiles);
-    const int m0 = (tile / a.tiles_n) * BM;
-    const int n0 = (tile % a.tiles_n) * BN;
+    // Which pixels, which channels: on the scalar unit, with reciprocals from the host (launch_conv_pipe_t).  An integer division costs
+    // ~30 vector instructions, a third of them at a quarter of the rate, and the vector unit's time is the matrix pipe's: the prologue
+    // of a K = 256 tile used to be 11 % of its issue slots.
+    const int tm = (int)magic_div((unsigned)tile, a.m_tiles_n);
+    const int m0 = tm * BM;
+    const int n0 = (tile - tm * a.tiles_n) * BN;
+    const unsigned img0 = full_div((unsigned)m0, a.d_howo), rem0 = (unsigned)m0 - img0 * (unsigned)(a.Ho * a.Wo);
+    const unsigned oh0 = full_div(rem0, a.d_wo), ow0 = rem0 - oh0 * (unsigned)a.Wo;
 
     // Staging addresses are 32-bit byte offsets into two buffer descriptors (activation slot, weights).  A lane
     // whose tap falls into the zero padding (or whose row is past M / Cout) uses offset 0xFFFFFFFF: the
@@ -426,20 +477,22 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     int a_off[NA];            // byte offset of (pixel, tap (0,0), channel chunk) -- may be "negative" in the padding
     unsigned long long a_mask[NA];   // bit kh*k+kw set: that tap reads inside the image (k*k <= 64)
     int a_row[NA], a_col[NA];
-    const int HoWo = a.Ho * a.Wo;
+    const unsigned HW = (unsigned)(a.H * a.W);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int c = tid + NT * i;
         a_row[i] = c / CPR;
         a_col[i] = c % CPR;
-        const int m = m0 + a_row[i];
-        const bool ok = m < a.M && a_row[i] < BM;
-        const int mm = ok ? m : 0;
-        const int n_img = mm / HoWo, rem = mm - n_img * HoWo;
-        const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-        const int ih0 = oh * a.stride - a.pad, iw0 = ow * a.stride - a.pad;
+        const bool ok = m0 + a_row[i] < a.M && a_row[i] < BM;
+        // the a_row-th pixel behind the tile's first one: a walk of < BM pixels (every factor below 2^24, launch_conv_pipe_t)
+        const unsigned lin = ow0 + (unsigned)a_row[i];
+        const unsigned q1 = umul24(lin, a.s_wo) >> kRecipShift;
+        const unsigned ly = oh0 + q1;
+        const unsigned q2 = umul24(ly, a.s_ho) >> kRecipShift;
+        const int ow = (int)(lin - umul24(q1, (unsigned)a.Wo)), oh = (int)(ly - umul24(q2, (unsigned)a.Ho));
+        const int ih0 = imul24(oh, a.stride) - a.pad, iw0 = imul24(ow, a.stride) - a.pad;
         // aligned mode: the chunk column is a channel offset inside the tap; small-Cin mode: it selects the tap itself
-        a_off[i] = (((n_img * a.H + ih0) * a.W + iw0) * a.Cs_in + a.coff_in + (SMALL_CIN ? 0 : a_col[i] * a.col_off)) * 4;
+        a_off[i] = (imul24((int)umul24(img0 + q2, HW) + imul24(ih0, a.W) + iw0, a.Cs_in) + a.coff_in + (SMALL_CIN ? 0 : imul24(a_col[i], a.col_off))) * 4;
         unsigned long long mask = 0;
         for (int th = 0; th < a.k; ++th)
             for (int tw = 0; tw < a.kw; ++tw)
@@ -454,7 +507,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         b_row[i] = c / CPR;
         b_col[i] = c % CPR;
         const int n = n0 + b_row[i];
-        b_off[i] = (n < a.Cout && b_row[i] < BN) ? (unsigned)((n * a.Kp + b_col[i] * 4 + kbeg) * 4) : 0xFFFFFFFFu;
+        b_off[i] = (n < a.Cout && b_row[i] < BN) ? (unsigned)((imul24(n, a.Kp) + b_col[i] * 4 + kbeg) * 4) : 0xFFFFFFFFu;
     }
 
     floatx4 ra[2][NA], rb[2][NB];   // two staging sets: tile kc+1 waits in one while tile kc+2 is fetched into the other
@@ -479,7 +532,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     const int c_step = a.c_step ? a.c_step : BK;
     const unsigned cpt = (unsigned)a.Cin >> 2, inv_cpt = 65536u / cpt + 1u, inv_k = 65536u / (unsigned)a.kw + 1u;   // small-Cin decode
 
-    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int arow0 = wm * (BM / WM) + l31, brow0 = wn * (BN / WN) + l31;
     floatx16 acc[TM][TN];
@@ -489,8 +542,8 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    floatx4 bias_v[TN];   // this lane's 4 output channels in the transposed store (see VQ_EPILOGUE)
-    ConvSeg seg_v[TN];    // where each 32-column group of this wave goes (wave-uniform)
+    floatx4 bias_v[TN];   // this lane's 4 output channels in the transposed store (see VQ_EPILOGUE_BUF)
+    ConvSeg seg_v[TN];    // where each 32-column group of this wave goes (wave-uniform: scalar loads)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int nb_ = n0 + wn * (BN / WN) + 32 * j;
@@ -656,7 +709,7 @@ __global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
     } else {
         VQ_PIPE_STEP(0, kc, false, false, 0, 0)
     }
-    VQ_EPILOGUE()
+    VQ_EPILOGUE_BUF()
 #undef VQ_G_LOAD
 #undef VQ_G_STORE
 #undef VQ_ADVANCE_TAP
@@ -1080,10 +1133,24 @@ static const ConvTile kTiles[] = {
     {64, 256, 16, 0}, {64, 256, 8, 3}, {64, 64, 8, 3}, {128, 64, 8, 3}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 
+// The pipelined kernel decodes pixels with host-made reciprocals on 24-bit multiplies: what the shapes must satisfy
+static bool pixel_walk_ok(const ConvArgs& a) {
+    const long long n_img = cdiv(a.M, a.Ho * a.Wo);
+    return n_img * a.H * a.W < (1 << 23) && a.Cs_in < (1 << 23) && a.Kp < (1 << 23) && a.Cout < (1 << 23) && a.stride < (1 << 23) &&
+           recip22_ok((unsigned)a.Wo, (unsigned)a.Wo + 128u) && recip22_ok((unsigned)a.Ho, (unsigned)a.Ho + 130u);
+}
+
 template <int BM, int BN, int WM, int WN, int BK, bool SMALL>
 static int launch_conv_pipe_t(vq_tsn* net, ConvArgs& a) {
     a.tiles_m = cdiv(a.M, BM);
     a.tiles_n = cdiv(a.Cout, BN);
+    VQ_REQUIRE(pixel_walk_ok(a) && (unsigned long long)a.tiles_m * a.tiles_n * a.tiles_n < 0x100000000ull,
+               "pipelined convolution: shape outside the range of its reciprocal divisions");
+    a.m_tiles_n = a.tiles_n == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)a.tiles_n) + 1u;
+    a.d_howo = full_div_for((unsigned)(a.Ho * a.Wo));
+    a.d_wo = full_div_for((unsigned)a.Wo);
+    a.s_wo = recip22((unsigned)a.Wo);
+    a.s_ho = recip22((unsigned)a.Ho);
     auto kern = conv_igemm_pipe_kernel<BM, BN, WM, WN, BK, SMALL>;
     const size_t lds = sizeof(ConvSmem<BM, BN, BK>);
     VQ_DYN_LDS(kern, lds);            // per instantiation and device
@@ -1260,7 +1327,7 @@ static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
     if (stem_rows) {                                   // four chunk columns = four kernel rows: BK = 16 tilings only (same bits for all)
         ConvTile t = kTiles[tile_idx];
         t.bk = 16;
-        return t.pipe ? launch_conv_pipe<false>(net, a, t) : launch_conv<false>(net, a, t);
+        return t.pipe && pixel_walk_ok(a) ? launch_conv_pipe<false>(net, a, t) : launch_conv<false>(net, a, t);
     }
     const bool small = (a.Cin % kTiles[tile_idx].bk) != 0;
     if (net->ksplit[li] > 1) {
@@ -1276,7 +1343,8 @@ static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
         // launch writes its [M][Cout] partial sums at the first whole row inside the stretch of its first crop.
         a.out_row0 = (int)cdiv((int64_t)net->crop_off * (int64_t)net->split_crop_floats, (int64_t)L.cout);
         net->ev_stop = nullptr;
-        int rc = kTiles[tile_idx].pipe == 1 ? launch_conv_pipe<false>(net, a, kTiles[tile_idx]) : launch_conv<false>(net, a, kTiles[tile_idx]);
+        int rc = kTiles[tile_idx].pipe == 1 && pixel_walk_ok(a) ? launch_conv_pipe<false>(net, a, kTiles[tile_idx])
+                                                                 : launch_conv<false>(net, a, kTiles[tile_idx]);
         net->ev_stop = e1;
         if (rc != VQ_OK) return rc;
         net->ev_start = nullptr;
@@ -1289,7 +1357,9 @@ static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
         VQ_CHECK_LAUNCH();
         return VQ_OK;
     }
-    if (kTiles[tile_idx].pipe == 1) return small ? launch_conv_pipe<true>(net, a, kTiles[tile_idx]) : launch_conv_pipe<false>(net, a, kTiles[tile_idx]);
+    // (shapes outside the pipelined kernel's reciprocal range run the plain kernel of the same tiling: same bits)
+    if (kTiles[tile_idx].pipe == 1 && pixel_walk_ok(a))
+        return small ? launch_conv_pipe<true>(net, a, kTiles[tile_idx]) : launch_conv_pipe<false>(net, a, kTiles[tile_idx]);
     return small ? launch_conv<true>(net, a, kTiles[tile_idx]) : launch_conv<false>(net, a, kTiles[tile_idx]);
 }
 

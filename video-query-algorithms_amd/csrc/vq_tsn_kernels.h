@@ -18,6 +18,45 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // which costs the matrix pipe nothing.
 __device__ __forceinline__ unsigned magic_div(unsigned x, unsigned m) { return m ? __umulhi(x, m) : x; }
 
+// x / d for EVERY 32-bit x (Granlund & Montgomery): l = ceil(log2 d), m = floor(2^32 (2^l - d) / d) + 1,
+// t = mulhi(m, x), q = (t + ((x - t) >> min(l, 1))) >> max(l - 1, 0).  Five scalar instructions on a uniform x.
+struct FullDiv {
+    unsigned m, sh1, sh2;
+};
+__device__ __forceinline__ unsigned full_div(unsigned x, const FullDiv& d) {
+    const unsigned t = __umulhi(d.m, x);
+    return (t + ((x - t) >> d.sh1)) >> d.sh2;
+}
+static inline FullDiv full_div_for(unsigned d) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    FullDiv f;
+    f.m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l > 1 ? l - 1 : 0;
+    return f;
+}
+// x / d = (x * s) >> 22 with s = 2^22 / d + 1 on 24-bit multiplies (v_mul_u32_u24: full rate; v_mul_lo / v_mul_hi_u32 run at a quarter
+// of it): exact while x (s d - 2^22) < 2^22, i.e. certainly for x d < 2^22, and x s < 2^32 (recip22_ok).
+constexpr int kRecipShift = 22;
+// 24-bit multiplies as inline asm: through __umul24 / __mul24 the compiler reasons about the operand masks, finds them dead where only the
+// low bits of a product are used further on, and is back at a plain 32-bit multiply (v_mul_lo_u32, v_mad_u64_u32).
+// The second factor is UNIFORM (a kernel argument or scalar arithmetic on some): it stays in a scalar register.
+__device__ __forceinline__ unsigned umul24(unsigned x, unsigned y_uniform) {
+    unsigned r;
+    asm("v_mul_u32_u24 %0, %2, %1" : "=v"(r) : "v"(x), "s"(y_uniform));
+    return r;
+}
+__device__ __forceinline__ int imul24(int x, int y_uniform) {
+    int r;
+    asm("v_mul_i32_i24 %0, %2, %1" : "=v"(r) : "v"(x), "s"(y_uniform));
+    return r;
+}
+static inline unsigned recip22(unsigned d) { return (1u << kRecipShift) / d + 1u; }
+static inline bool recip22_ok(unsigned d, unsigned xmax) {
+    return d >= 1 && (unsigned long long)xmax * d < (1ull << kRecipShift) && (unsigned long long)xmax * recip22(d) < (1ull << 32);
+}
+
 // ------------------------------------------------------------------------------------------------
 // pooling (Caffe semantics: ceil-mode output size; MAX ignores padding; AVE divides by the window
 // clipped to the padded extent and accumulates h-major in fp32)
@@ -107,7 +146,7 @@ struct WinoJob {
     int unit0, n_units;  // workgroups [unit0, unit0 + n_units) of the launch belong to this job (unit0 % 8 == 0)
     unsigned in_bytes, u_bytes, out_bytes;   // extents for the buffer descriptors (out-of-range offsets read as zero / are dropped)
     unsigned m_tiles_n, m_tpi, m_tw;         // magic_div constants for tiles_n, th * tw and tw
-    unsigned s_tw, s_th;                     // 16-bit reciprocals for the per-lane tile walk: x / tw = (x * s_tw) >> 16, x < 1024
+    unsigned s_tw, s_th;                     // recip22 constants for the per-lane tile walk (at most 31 tiles from the workgroup's first)
 #ifdef VQ_WINO_PHASES
     long long* phases;   // tools/ubench/wino_phases.hip: [workgroup][6] s_memtime stamps
 #endif

@@ -115,10 +115,10 @@ struct TileAt {
 __device__ __forceinline__ TileAt tile_at(int t, int img0, int ty0, int tx0, int th, int tw, unsigned s_th, unsigned s_tw) {
     // every factor is below 2^24 (launch_t checks the shapes): v_mul_u32_u24 runs at the full rate, v_mul_lo_u32 at a quarter of it
     const unsigned lin = (unsigned)(tx0 + t);
-    const unsigned q1 = __umul24(lin, s_tw) >> 16;
+    const unsigned q1 = umul24(lin, s_tw) >> kRecipShift;
     const unsigned ly = (unsigned)ty0 + q1;
-    const unsigned q2 = __umul24(ly, s_th) >> 16;
-    return TileAt{img0 + (int)q2, (int)(ly - __umul24(q2, (unsigned)th)), (int)(lin - __umul24(q1, (unsigned)tw))};
+    const unsigned q2 = umul24(ly, s_th) >> kRecipShift;
+    return TileAt{img0 + (int)q2, (int)(ly - umul24(q2, (unsigned)th)), (int)(lin - umul24(q1, (unsigned)tw))};
 }
 
 template <int NB>
@@ -148,7 +148,7 @@ __device__ __forceinline__ void wino_unit(const WinoJob& a, int unit, float* hs)
         const TileAt ta = tile_at(t, img0, ty0, tx0, a.th, a.tw, a.s_th, a.s_tw);
         const int y = 2 * ta.ty - 1 + wave, x0 = 2 * ta.tx - 1;
         const bool row_ok = p0 + t < a.P && (unsigned)y < (unsigned)a.H;
-        const int base = (__mul24(__mul24(ta.img * a.H + y, a.W) + x0, a.Cs_in) + a.coff_in + c4 * 4) * 4;
+        const int base = (imul24(imul24(ta.img * a.H + y, a.W) + x0, a.Cs_in) + a.coff_in + c4 * 4) * 4;
         const int px = a.Cs_in * 4;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -274,7 +274,7 @@ __device__ __forceinline__ void wino_unit(const WinoJob& a, int unit, float* hs)
     const TileAt te = tile_at(et, img0, ty0, tx0, a.th, a.tw, a.s_th, a.s_tw);
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
     const int oy = 2 * te.ty, ox = 2 * te.tx;
-    const int obase = (__mul24(__mul24(te.img * a.H + oy, a.W) + ox, a.Cs_out) + a.coff_out + n0 + ec * 4) * 4;
+    const int obase = (imul24(imul24(te.img * a.H + oy, a.W) + ox, a.Cs_out) + a.coff_out + n0 + ec * 4) * 4;
     const bool tile_ok = p0 + et < a.P;
     unsigned ooff[4];                                      // (a_, b_) = (u >> 1, u & 1); 0xFFFFFFFF: the store is dropped
 #pragma unroll
@@ -379,13 +379,16 @@ int launch_t(WinoGroup& g, hipStream_t stream, hipEvent_t ev_start, hipEvent_t e
         const unsigned tpi = (unsigned)(a.th * a.tw);
         // exactness of the multiply-high divisions (vq_tsn_kernels.h): dividend < 2^32 / divisor
         VQ_REQUIRE((unsigned long long)n * a.tiles_n < 0x100000000ull && (unsigned long long)(a.P + BP) * tpi < 0x100000000ull &&
-                       a.tw <= 1024 && a.th <= 1024,
+                       recip22_ok((unsigned)a.tw, (unsigned)a.tw + BP) && recip22_ok((unsigned)a.th, (unsigned)a.th + BP + 2),
                    "Winograd job %d: shape outside the reciprocal-division range", q);
+        // 24-bit multiplies in the address arithmetic (tile_at, the pixel index times the slot's channel count)
+        VQ_REQUIRE((unsigned long long)cdiv(a.P, (int)tpi) * a.H * a.W < (1ull << 23) && a.Cs_in < (1 << 23) && a.Cs_out < (1 << 23),
+                   "Winograd job %d: more than 2^23 pixels in a slot (split the batch)", q);
         a.m_tiles_n = magic_u32((unsigned)a.tiles_n);
         a.m_tpi = magic_u32(tpi);
         a.m_tw = magic_u32((unsigned)a.tw);
-        a.s_tw = 65536u / (unsigned)a.tw + 1u;
-        a.s_th = 65536u / (unsigned)a.th + 1u;
+        a.s_tw = recip22((unsigned)a.tw);
+        a.s_th = recip22((unsigned)a.th);
     }
     g.pool_unit0 = units;
     for (int q = 0; q < g.n_pools; ++q) {
