@@ -93,6 +93,33 @@ def test_conv_bn_relu_layer(tsn, monkeypatch, cin, h, cout, k, s, p, n, tile):
     m.close()
 
 
+def test_maps_wider_than_the_reciprocal_range_run_the_plain_kernel(tsn, monkeypatch):
+    """The pipelined kernel decodes a workgroup's pixels with 22-bit reciprocals (exact for output maps up to ~1 980 pixels wide, a sufficient
+    condition checked on the host: csrc/vq_tsn.hip:pixel_walk_ok); a 2 048-pixel-wide map asked for on a pipelined tiling runs the plain
+    kernel of the same tiling instead.  A 1x1 convolution + BN + ReLU is a per-pixel function: the oracle is run on the first and the last
+    two rows of the map; all tilings give the same bits."""
+    bi, net = tsn
+    h = 2048
+    g = _mini(bi, 8, h, h, 32, 1, 1, 0)
+    w = net.synthetic_weights(g, seed=5)
+    crops = np.random.default_rng(9).integers(0, 256, (1, h, h, 8), dtype=np.uint8)
+    mean = np.linspace(100.0, 130.0, 8).astype(np.float32)
+    ref = None
+    for tile in ("64x64x16", "64x64x16x1", "128x64x32x1"):
+        monkeypatch.setenv("VQ_TSN_TILE", tile)
+        m = net.TsnNet(g, w, max_crops=1, feature_blob="gp")
+        m.forward(crops, 1, mean)
+        got = _nchw(m.read_blob("c_bn", 1))
+        m.close()
+        if ref is None:
+            ref = got
+            for rows in (slice(0, 2), slice(h - 2, h)):
+                want = to.forward(g.layers[:3], "data", w, to.preprocess(crops[:, rows], mean), keep=("c_bn",))["c_bn"]
+                assert np.abs(got[:, :, rows] - want).max() <= 2e-5 * np.abs(want).max()
+        else:
+            assert (got == ref).all()
+
+
 def _pooled_mini(bi, c, h, k_mid, n_out):
     """data -> 1x1 conv (k_mid channels) -> 3x3/2 max pool -> 1x1 conv (n_out) -> global average pool: the shape of
     pool1 -> conv2/3x3_reduce and pool2 -> inception_3a's sibling 1x1 group (the pool disappears into the GEMM behind it)."""
