@@ -110,3 +110,21 @@ def test_blocked_tiles_against_the_oracle_on_every_cut(flow_mod):
     r = m.flow(f[None], f[None], iterations=True)
     assert (r["iters"] == 1).all() and (r["u1"] == 0).all() and (r["u2"] == 0).all()
     m.close()
+
+
+def test_packed_division_and_square_root_are_the_compilers_bit_for_bit(tmp_path):
+    """csrc/vq_flow_math.h writes the correctly rounded division and square root out (so that their refinement runs as packed instructions on
+    two cells at a time); tools/ubench/flow_math_check.hip compares them with `a / b` and sqrtf() on 2^24 x 2 operand pairs per case --
+    raw bit patterns (denormals, zeros, infinities, NaNs), the dual step's ranges, numerators that are exact zeros, sums of squares down
+    to the library's scaled path.  Compiled here with the flags of the library."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "flow_math_check")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-I" + os.path.join(root, "video-query-algorithms_amd", "csrc"),
+                    os.path.join(root, "tools", "ubench", "flow_math_check.hip"), "-o", exe], check=True, capture_output=True, timeout=300)
+    p = subprocess.run([exe, "24"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stdout[-2000:] + p.stderr[-2000:]
+    assert p.stdout.count(" 0 mismatches") == 5

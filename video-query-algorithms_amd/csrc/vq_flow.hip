@@ -207,6 +207,52 @@ __device__ __forceinline__ void dual_pair(float& pa, float& pb, float ux, float 
     }
 }
 
+// ---- two cells per instruction ---------------------------------------------------------------------------------------------------
+// gfx950 executes v_pk_{add,mul,fma}_f32 -- two fp32 operations per lane -- at the rate of the one-operation forms, and the iteration is
+// bound by the vector ALU's issue rate.  A thread's cells therefore go through the iteration in PAIRS: every addition / multiplication of the
+// primal and the dual step on a float2, no branch around a dead cell or around the three cases of the thresholding step (selects instead),
+// and the correctly rounded division written out -- v_div_scale, v_rcp, the six-operation refinement, v_div_fmas, v_div_fixup: exactly the
+// sequence the compiler emits for `a / b` (AMDGPUTargetLowering::LowerFDIV32) -- so that its refinement runs packed as well: 16 instructions
+// per two quotients instead of 22.  Per cell the operations, their operands and their order are unchanged: same bits as the cell-by-cell
+// form (tools/flow_bits_ab.py compares the two libraries).  The square root is the library's expansion without its scaling and class steps where they cannot act
+// (vq_flow_math.h).
+#include "vq_flow_math.h"
+
+// primal_pixel on two cells (same operations per cell)
+__device__ __forceinline__ void primal_pair(f2 ux, f2 uy, f2 gx, f2 gy, f2 gr, f2 rc, f2 div1, f2 div2, float l_t, float theta, f2& n1, f2& n2,
+                                            f2& err) {
+    const f2 rho = rc + (gx * ux + gy * uy);
+    const f2 lg = l_t * gr;                                   // -l_t * gr = -(l_t * gr), bit for bit
+    const f2 fi = div_ieee(-rho, gr);                         // used where |rho| <= l_t * gr and gr > kGradIsZero only (0 / 0 elsewhere: dropped)
+    f2 s;
+    bool any[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const bool below = rho[e] < -lg[e], above = rho[e] > lg[e];
+        s[e] = below ? l_t : (above ? -l_t : fi[e]);
+        any[e] = below || above || gr[e] > kGradIsZero;
+    }
+    f2 d1 = s * gx, d2 = s * gy;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        d1[e] = any[e] ? d1[e] : 0.0f;
+        d2[e] = any[e] ? d2[e] : 0.0f;
+    }
+    n1 = (ux + d1) + theta * div1;
+    n2 = (uy + d2) + theta * div2;
+    const f2 a1 = n1 - ux, a2 = n2 - uy;
+    err = a1 * a1 + a2 * a2;
+}
+
+// dual_pair (exact form) on two cells
+__device__ __forceinline__ void dual_pair2(f2& pa, f2& pb, f2 ux, f2 uy, float taut) {
+    const f2 sq = ux * ux + uy * uy;
+    const f2 rt = sqrt_ieee(sq);
+    const f2 ng = 1.0f + taut * rt;
+    pa = div_ieee(pa + taut * ux, ng);
+    pb = div_ieee(pb + taut * uy, ng);
+}
+
 // ---- the blocked form: kBlkIters inner iterations per launch, the fields of a tile resident in LDS ----------------------------
 // The two-launch form streams every plane through the caches twice per inner iteration (22 floats per pixel) and needs two
 // dependent launches for it; on the coarse levels a launch is a few microseconds of work.  Here a workgroup loads a tile of
@@ -363,23 +409,66 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(VQ_FLOW_TILE
         }
     }
     __syncthreads();
+    // the neighbour masks of a cell that does not exist are off: the pair form below has no branch around a dead cell (its fields are
+    // zeros and stay zeros: rho = 0, no case of the thresholding applies, |grad u| = 0; nothing of it is stored)
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        hl[k] = hl[k] && live[k];
+        hu[k] = hu[k] && live[k];
+        rgt[k] = rgt[k] && live[k];
+        blw[k] = blw[k] && live[k];
+    }
     for (int m = 0; m < cur.n; ++m) {
         double local = 0.0;
-        // primal step (a cell reads its own old u and p, the p11 / p21 of its left and the p12 / p22 of its upper neighbour)
+        if constexpr (!FAST) {
+            static_assert(NC % 2 == 0, "cells go through the iteration in pairs");
+            // primal step (a cell reads its own old u and p, the p11 / p21 of its left and the p12 / p22 of its upper neighbour)
 #pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            if (live[k]) {
-                const int c = tid + NT * k;
-                const float q11 = r11[k], q12 = r12[k], q21 = r21[k], q22 = r22[k];
-                const float div1 = (hl[k] ? q11 - P11[c - 1] : q11) + (hu[k] ? q12 - P12[c - ew] : q12);
-                const float div2 = (hl[k] ? q21 - P21[c - 1] : q21) + (hu[k] ? q22 - P22[c - ew] : q22);
-                float n1, n2, err;
-                primal_pixel<FAST>(ru1[k], ru2[k], cgx[k], cgy[k], cgr[k], crc[k], div1, div2, a.l_t, a.theta, n1, n2, err);
-                ru1[k] = n1;
-                ru2[k] = n2;
-                U1[c] = n1;
-                U2[c] = n2;
-                if (own[k]) local += (double)err;
+            for (int j = 0; j < NC; j += 2) {
+                if (live[j] || live[j + 1]) {
+                    const int ca = tid + NT * j, cb = ca + NT;
+                    const f2 q11 = {r11[j], r11[j + 1]}, q12 = {r12[j], r12[j + 1]}, q21 = {r21[j], r21[j + 1]}, q22 = {r22[j], r22[j + 1]};
+                    // (subtracting the 0 a masked neighbour stands for gives the bits of not subtracting)
+                    const f2 l11 = {hl[j] ? P11[ca - 1] : 0.0f, hl[j + 1] ? P11[cb - 1] : 0.0f};
+                    const f2 l21 = {hl[j] ? P21[ca - 1] : 0.0f, hl[j + 1] ? P21[cb - 1] : 0.0f};
+                    const f2 t12 = {hu[j] ? P12[ca - ew] : 0.0f, hu[j + 1] ? P12[cb - ew] : 0.0f};
+                    const f2 t22 = {hu[j] ? P22[ca - ew] : 0.0f, hu[j + 1] ? P22[cb - ew] : 0.0f};
+                    const f2 div1 = (q11 - l11) + (q12 - t12), div2 = (q21 - l21) + (q22 - t22);
+                    f2 n1, n2, err;
+                    primal_pair(f2{ru1[j], ru1[j + 1]}, f2{ru2[j], ru2[j + 1]}, f2{cgx[j], cgx[j + 1]}, f2{cgy[j], cgy[j + 1]}, f2{cgr[j], cgr[j + 1]},
+                                f2{crc[j], crc[j + 1]}, div1, div2, a.l_t, a.theta, n1, n2, err);
+                    ru1[j] = n1.x;
+                    ru1[j + 1] = n1.y;
+                    ru2[j] = n2.x;
+                    ru2[j + 1] = n2.y;
+                    if (live[j]) {
+                        U1[ca] = n1.x;
+                        U2[ca] = n2.x;
+                        if (own[j]) local += (double)err.x;
+                    }
+                    if (live[j + 1]) {
+                        U1[cb] = n1.y;
+                        U2[cb] = n2.y;
+                        if (own[j + 1]) local += (double)err.y;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                if (live[k]) {
+                    const int c = tid + NT * k;
+                    const float q11 = r11[k], q12 = r12[k], q21 = r21[k], q22 = r22[k];
+                    const float div1 = (hl[k] ? q11 - P11[c - 1] : q11) + (hu[k] ? q12 - P12[c - ew] : q12);
+                    const float div2 = (hl[k] ? q21 - P21[c - 1] : q21) + (hu[k] ? q22 - P22[c - ew] : q22);
+                    float n1, n2, err;
+                    primal_pixel<FAST>(ru1[k], ru2[k], cgx[k], cgy[k], cgr[k], crc[k], div1, div2, a.l_t, a.theta, n1, n2, err);
+                    ru1[k] = n1;
+                    ru2[k] = n2;
+                    U1[c] = n1;
+                    U2[c] = n2;
+                    if (own[k]) local += (double)err;
+                }
             }
         }
         // the tile's squared update of this iteration: one atomic per workgroup
@@ -394,19 +483,57 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(VQ_FLOW_TILE
             if (sum != 0.0) atomicAdd(&st.err[a.L % 3][m], sum);
         }
         // dual step (a cell reads its own p and new u, the new u of its right and lower neighbour)
+        if constexpr (!FAST) {
 #pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            if (live[k]) {
-                const int c = tid + NT * k;
-                const float c1 = ru1[k], c2 = ru2[k];
-                const float u1x = rgt[k] ? U1[c + 1] - c1 : 0.0f, u1y = blw[k] ? U1[c + ew] - c1 : 0.0f;
-                const float u2x = rgt[k] ? U2[c + 1] - c2 : 0.0f, u2y = blw[k] ? U2[c + ew] - c2 : 0.0f;
-                dual_pair<FAST>(r11[k], r12[k], u1x, u1y, a.taut);
-                dual_pair<FAST>(r21[k], r22[k], u2x, u2y, a.taut);
-                P11[c] = r11[k];
-                P12[c] = r12[k];
-                P21[c] = r21[k];
-                P22[c] = r22[k];
+            for (int j = 0; j < NC; j += 2) {
+                if (live[j] || live[j + 1]) {
+                    const int ca = tid + NT * j, cb = ca + NT;
+                    const f2 c1 = {ru1[j], ru1[j + 1]}, c2 = {ru2[j], ru2[j + 1]};
+                    // (a masked neighbour: the cell's own value, whose difference is the 0 of the cell-by-cell form)
+                    const f2 e1 = {rgt[j] ? U1[ca + 1] : c1.x, rgt[j + 1] ? U1[cb + 1] : c1.y};
+                    const f2 s1 = {blw[j] ? U1[ca + ew] : c1.x, blw[j + 1] ? U1[cb + ew] : c1.y};
+                    const f2 e2 = {rgt[j] ? U2[ca + 1] : c2.x, rgt[j + 1] ? U2[cb + 1] : c2.y};
+                    const f2 s2 = {blw[j] ? U2[ca + ew] : c2.x, blw[j + 1] ? U2[cb + ew] : c2.y};
+                    f2 pa1 = {r11[j], r11[j + 1]}, pb1 = {r12[j], r12[j + 1]}, pa2 = {r21[j], r21[j + 1]}, pb2 = {r22[j], r22[j + 1]};
+                    dual_pair2(pa1, pb1, e1 - c1, s1 - c1, a.taut);
+                    dual_pair2(pa2, pb2, e2 - c2, s2 - c2, a.taut);
+                    r11[j] = pa1.x;
+                    r11[j + 1] = pa1.y;
+                    r12[j] = pb1.x;
+                    r12[j + 1] = pb1.y;
+                    r21[j] = pa2.x;
+                    r21[j + 1] = pa2.y;
+                    r22[j] = pb2.x;
+                    r22[j + 1] = pb2.y;
+                    if (live[j]) {
+                        P11[ca] = pa1.x;
+                        P12[ca] = pb1.x;
+                        P21[ca] = pa2.x;
+                        P22[ca] = pb2.x;
+                    }
+                    if (live[j + 1]) {
+                        P11[cb] = pa1.y;
+                        P12[cb] = pb1.y;
+                        P21[cb] = pa2.y;
+                        P22[cb] = pb2.y;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                if (live[k]) {
+                    const int c = tid + NT * k;
+                    const float c1 = ru1[k], c2 = ru2[k];
+                    const float u1x = rgt[k] ? U1[c + 1] - c1 : 0.0f, u1y = blw[k] ? U1[c + ew] - c1 : 0.0f;
+                    const float u2x = rgt[k] ? U2[c + 1] - c2 : 0.0f, u2y = blw[k] ? U2[c + ew] - c2 : 0.0f;
+                    dual_pair<FAST>(r11[k], r12[k], u1x, u1y, a.taut);
+                    dual_pair<FAST>(r21[k], r22[k], u2x, u2y, a.taut);
+                    P11[c] = r11[k];
+                    P12[c] = r12[k];
+                    P21[c] = r21[k];
+                    P22[c] = r22[k];
+                }
             }
         }
         __syncthreads();                                 // every new p is in LDS, every new u has been read
