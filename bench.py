@@ -872,7 +872,7 @@ def bench_e2e_cli(device_index):
                     "through the two networks (which also loads / folds / uploads the weights), CSV writing"}
 
 
-def bench_e2e_wof(device_index):
+def bench_e2e_wof(device_index, max_pairs=64):
     """The drop-in build_wof_clips.py command line end to end on ONE GPU: a "video" (a directory of its 257 frames of 340 x 256, the form
     the command line takes where cv2.VideoCapture is missing) -> grey conversion -> warped TV-L1 flow in windows of 64 pairs -> 768
     img_ / flow_x_ / flow_y_ JPEG files (encoded by --num_worker host threads) -> clip directories.  Needs Pillow; absent -> skipped."""
@@ -904,8 +904,8 @@ def bench_e2e_wof(device_index):
             out = os.path.join(root, "out%d" % rep)
             t0 = time.perf_counter()
             with contextlib.redirect_stdout(io.StringIO()):
-                rc = build_wof_clips.main([os.path.join(root, "src"), out, "--fps", "15", "--clip_time", "10", "--max_pairs", "64", "--num_worker", "16",
-                                           "--starting_gpu", str(device_index)])
+                rc = build_wof_clips.main([os.path.join(root, "src"), out, "--fps", "15", "--clip_time", "10", "--num_worker", "16",
+                                           "--starting_gpu", str(device_index)] + (["--max_pairs", str(max_pairs)] if max_pairs else []))
             times.append(time.perf_counter() - t0)
             assert rc == 0
         clips = sorted(os.listdir(os.path.join(root, "out1", "pan")))
@@ -914,7 +914,8 @@ def bench_e2e_wof(device_index):
     return {"metric": "frames/sec end to end through the drop-in build_wof_clips.py (frames -> warped TV-L1 flow -> img / flow_x / flow_y JPEG files -> clips)",
             "value": (n_frames - 1) / times[1], "unit": "frames/s", "frames": n_frames - 1, "seconds": times[1], "first_run_seconds": times[0],
             "clip_directories": clips,
-            "config": {"workload": "one 257-frame video of 340x256 given as a directory of frames, --max_pairs 64 --num_worker 16, one GPU"},
+            "config": {"workload": "one 257-frame video of 340x256 given as a directory of frames, --num_worker 16 (--max_pairs: %s), one GPU"
+                                   % (max_pairs or "the command line's default")},
             "note": "whole process time of main(): reading and decoding the frames (host image library), grey conversion, 256 warped flows on the "
                     "GPU, 768 JPEG encodings on 16 host threads, the clip regrouping"}
 
