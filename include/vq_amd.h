@@ -53,7 +53,7 @@ extern "C" {
 /* 6 (round 4): + vq_db_set_layout / vq_db_layout (block tiled in place; the mirrored copy of version 5 is gone), vq_db_read_rows,
  * vq_db_read_scores_at, vq_db_ne_devptr, vq_format_feature_rows, vq_jpeg_decode_path_list; vq_input_desc gained s2d_order.
  * 7 (round 5): + vq_tsn_set_profile_split; the layer tiling tables know the pooled-input kernel (pipelined = 3). */
-#define VQ_ABI_VERSION 7
+#define VQ_ABI_VERSION 8
 
 enum {
     VQ_OK = 0,
@@ -225,6 +225,13 @@ typedef struct vq_tsn vq_tsn;
 int vq_resize_crop(const uint8_t* frames, int32_t frames_on_device, int32_t n, int32_t h, int32_t w, int32_t c,
                    int32_t resize_w, int32_t resize_h, int32_t crop, int32_t rule, uint8_t* crops_dev, int32_t dst_channels,
                    int32_t dst_channel0, int32_t device, void* hip_stream);
+
+/* The same for the ten grey planes of a batch of flow stacks in ONE launch: plane p of frame i at planes_dev + p * plane_stride + i * h * w
+ * (what vq_jpeg_decode leaves on the device when the files are handed over plane-major), written as the interleaved crops
+ * [n][crop][crop][c].  c must be 10 (predict_single_flow_stack's stack of 5 x/y pairs, calcSig_wOF.py:98-111); crop even.  Same bytes as c
+ * calls of vq_resize_crop (tested); a thread computes the taps of its two pixels once for all planes and stores whole words. */
+int vq_resize_crop_planes(const uint8_t* planes_dev, int32_t n, int32_t h, int32_t w, int32_t c, int64_t plane_stride, int32_t resize_w,
+                          int32_t resize_h, int32_t crop, int32_t rule, uint8_t* crops_dev, int32_t device, void* hip_stream);
 
 /* JPEG decode, the step in front of vq_resize_crop: replaces cv2.imread(img_NNNNN.jpg, IMREAD_COLOR) and
  * cv2.imread(flow_{x,y}_NNNNN.jpg, IMREAD_GRAYSCALE) at calcSig_wOF.py:92,105-106 for the baseline JPEG files

@@ -777,6 +777,21 @@ def test_device_resize_crop_against_the_pixel_loop_oracle(tsn, h, w):
     dev_feats = cf.extract_clips_from_frames(planes, 2, on_device=True)           # the block a rank all-gathers
     assert dev_feats.is_cuda and (dev_feats.cpu().numpy() == feats).all()
     cf.close()
+    # the ten planes in ONE launch (vq_resize_crop_planes: what the device JPEG path calls on the decoder's plane-major buffer), both rules
+    import ctypes as C
+    import torch
+    from video_query_algorithms_amd import _lib
+    from video_query_algorithms_amd.tsn import frames as fr
+    major = torch.from_numpy(np.ascontiguousarray(planes.transpose(1, 0, 2, 3))).cuda()          # [10][n][h][w]
+    for rule in ("cv2", "exact"):
+        out = torch.full((2, 224, 224, 10), 7, dtype=torch.uint8, device="cuda")
+        _lib.call("vq_resize_crop_planes", C.c_void_p(major.data_ptr()), 2, h, w, 10, 2 * h * w, 340, 256, 224, fr.RESIZE_RULES[rule],
+                  C.c_void_p(out.data_ptr()), 0, None)
+        torch.cuda.synchronize()
+        want = np.stack([fo.flow_stack_crop0(snip, rule=rule) for snip in planes])
+        assert (out.cpu().numpy() == want).all(), rule
+    with pytest.raises(_lib.VqError):
+        _lib.call("vq_resize_crop_planes", C.c_void_p(major.data_ptr()), 2, h, w, 3, 2 * h * w, 340, 256, 224, 0, C.c_void_p(out.data_ptr()), 0, None)
 
 
 def test_calcsig_two_ranks_write_the_same_bytes_as_one(tsn, tmp_path):

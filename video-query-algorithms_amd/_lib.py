@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvqamd.so")
 
-ABI_VERSION = 7                 # include/vq_amd.h: VQ_ABI_VERSION
+ABI_VERSION = 8                 # include/vq_amd.h: VQ_ABI_VERSION
 VQ_F32, VQ_F64 = 0, 1
 VQ_LAYOUT_ROWS, VQ_LAYOUT_TILED = 0, 1
 VQ_OP_CONV, VQ_OP_MAXPOOL, VQ_OP_AVGPOOL, VQ_OP_GLOBAL_AVGPOOL, VQ_OP_CONV_WINOGRAD = 1, 2, 3, 4, 5
@@ -81,6 +81,7 @@ SIGNATURES = {
     "vq_db_select_rows": [_P, _F64, _F64, _P, _I64, _P, _I64, _pI64, _pI64, _pI64],
     "vq_db_topk": [_P, _I64, _P, _P, _pI64], "vq_db_min_score": [_P, _P, _I32, _pF64],
     "vq_resize_crop": [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _P],
+    "vq_resize_crop_planes": [_P, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P],
     "vq_tsn_create": [C.POINTER(TensorDesc), _I32, C.POINTER(LayerDesc), _I32, C.POINTER(ConvSegment), _I32, _P, _I64,
                       C.POINTER(InputDesc), _I32, _I32, _I32, _PP],
     "vq_tsn_destroy": [_P], "vq_tsn_set_stream": [_P, _P],

@@ -147,11 +147,11 @@ class CaffeNet:
             crops = self.crops_from_jpegs(files[i * per_snip:(i + per) * per_snip], frame_size)
             torch.cuda.current_stream(dev).synchronize()
             nb = crops.shape[0]
-            self._model.forward_device(crops.data_ptr(), nb, T, self._mean)
             if on_device:
+                self._model.forward_device(crops.data_ptr(), nb, T, self._mean)
                 out.append(self._model.features_tensor(nb // T).clone())
             else:
-                out.append(self._model.read_features(np.empty((nb // T, self._model.feature_dim), dtype=np.float64)))
+                out.append(self._model.forward_device(crops.data_ptr(), nb, T, self._mean, np.empty((nb // T, self._model.feature_dim), dtype=np.float64)))
         return torch.cat(out, dim=0) if on_device else np.concatenate(out, axis=0)
 
     def extract_clips_from_crops(self, crops, T: int, on_device: bool = False):
@@ -161,10 +161,12 @@ class CaffeNet:
         nb = crops.shape[0]
         if nb > self._model.max_crops or nb % T:
             raise ValueError("%d crops: at most max_crops (%d), a multiple of T (%d)" % (nb, self._model.max_crops, T))
-        self._model.forward_device(crops.data_ptr(), nb, T, self._mean)
         if on_device:
+            self._model.forward_device(crops.data_ptr(), nb, T, self._mean)
             return self._model.features_tensor(nb // T).clone()
-        return self._model.read_features(np.empty((nb // T, self._model.feature_dim), dtype=np.float64))
+        # the features come back behind the forward on the extractor's own stream: the call does not wait for the decode kernels of the
+        # batches ahead, which other threads have in flight on the ingest streams
+        return self._model.forward_device(crops.data_ptr(), nb, T, self._mean, np.empty((nb // T, self._model.feature_dim), dtype=np.float64))
 
     def extract_clips_from_frames(self, frames_: np.ndarray, T: int, frame_size=(340, 256), on_device: bool = False):
         """Decoded frames of B*T snippets -> consensus features [B, D]: resize + crop 0 on the device, then the
@@ -179,11 +181,11 @@ class CaffeNet:
             crops = self.crops_from_frames(frames_[i:i + per], frame_size)
             torch.cuda.current_stream(dev).synchronize()
             nb = crops.shape[0]
-            self._model.forward_device(crops.data_ptr(), nb, T, self._mean)
             if on_device:
+                self._model.forward_device(crops.data_ptr(), nb, T, self._mean)
                 out.append(self._model.features_tensor(nb // T).clone())
             else:
-                out.append(self._model.read_features(np.empty((nb // T, self._model.feature_dim), dtype=np.float64)))
+                out.append(self._model.forward_device(crops.data_ptr(), nb, T, self._mean, np.empty((nb // T, self._model.feature_dim), dtype=np.float64)))
         return torch.cat(out, dim=0) if on_device else np.concatenate(out, axis=0)
 
     @property

@@ -150,9 +150,15 @@ class FrameIngest:
                 m = min(per, n - i)
                 group = [f for k in range(ch) for f in files[i * ch + k:(i + m) * ch:ch]]
                 ptr, _ = dec.decode_to_device(group, color=False, stream=stream)
-                for k in range(ch):
-                    call("vq_resize_crop", C.c_void_p(ptr + k * m * h * w), 1, m, h, w, 1, frame_size[0], frame_size[1], crop,
-                         frames.RESIZE_RULES[self._resize_rule], C.c_void_p(out[i:i + m].data_ptr()), ch, k, self.device, C.c_void_p(stream))
+                if ch == 10 and crop % 2 == 0:
+                    # the ten planes of the stacks in ONE launch (taps once per pixel, whole-word stores; frames that have the size already
+                    # are copied): 10 launches of 0.53 ms per 800 crops took 5.3 ms of the GPU per batch beside the networks
+                    call("vq_resize_crop_planes", C.c_void_p(ptr), m, h, w, ch, m * h * w, frame_size[0], frame_size[1], crop,
+                         frames.RESIZE_RULES[self._resize_rule], C.c_void_p(out[i:i + m].data_ptr()), self.device, C.c_void_p(stream))
+                else:
+                    for k in range(ch):
+                        call("vq_resize_crop", C.c_void_p(ptr + k * m * h * w), 1, m, h, w, 1, frame_size[0], frame_size[1], crop,
+                             frames.RESIZE_RULES[self._resize_rule], C.c_void_p(out[i:i + m].data_ptr()), ch, k, self.device, C.c_void_p(stream))
                 ingest.synchronize()
         return out
 

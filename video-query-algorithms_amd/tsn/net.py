@@ -428,11 +428,20 @@ class TsnNet:
         self._persist_tuning(n)
         return feat, ps
 
-    def forward_device(self, crops_dev_ptr: int, n: int, T: int, mean: Sequence[float]):
-        """Crops already in HBM (uint8 NHWC); results stay on the device (see feat_devptr)."""
+    def forward_device(self, crops_dev_ptr: int, n: int, T: int, mean: Sequence[float], feat_out: np.ndarray | None = None):
+        """Crops already in HBM (uint8 NHWC); results stay on the device (see feat_devptr).  With ``feat_out`` (float64 [n / T, D],
+        C-contiguous) the consensus features are also copied to the host behind the forward and the call returns when they are there:
+        it waits for the handle's OWN stream only -- not, as a device-wide synchronisation would, for the decode kernels of later batches
+        that other threads have in flight on other streams."""
         m = np.ascontiguousarray(mean, dtype=np.float32)
-        call("vq_tsn_forward", self._h, C.c_void_p(crops_dev_ptr), 1, n, T, m.ctypes.data_as(C.POINTER(C.c_float)), None, None)
+        host = None
+        if feat_out is not None:
+            if feat_out.dtype != np.float64 or not feat_out.flags.c_contiguous or feat_out.shape != (n // T, self.feature_dim):
+                raise ValueError("feat_out must be a C-contiguous float64 array of shape (%d, %d)" % (n // T, self.feature_dim))
+            host = feat_out.ctypes.data_as(C.c_void_p)
+        call("vq_tsn_forward", self._h, C.c_void_p(crops_dev_ptr), 1, n, T, m.ctypes.data_as(C.POINTER(C.c_float)), host, None)
         self._persist_tuning(n)
+        return feat_out
 
     def features_tensor(self, n_clips: int):
         """Zero-copy torch view [n_clips, D] fp64 of the consensus features of the last forward (device memory owned
