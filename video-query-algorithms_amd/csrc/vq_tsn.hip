@@ -1469,24 +1469,43 @@ static int run_item(vq_tsn* net, const LaunchItem& it, int crop0, int n_crops, i
 // conv2/3x3_reduce, the inception_3a group -- the LAST candidates of the list, one of them 1.8x slower than the best: 2.91 ms per step
 // instead of 2.73, kept by the tiling cache).  So the sweep starts behind ~30 ms of the forward's own launches, and the three fastest
 // candidates of a launch are timed once more, back to back, before the winner is taken.
-static int autotune(vq_tsn* net, int n_crops) {
+// ``paired``: the size is that of a SUB-BATCH of the default forward (two sub-batches on two streams, side by side): a candidate is timed
+// the way it will run -- the same launch on both streams at once, on the crop ranges of sub-batch 0 and 1 -- because the best tiling of a
+// launch that has the chip to itself (few, large workgroups fill it badly) is not the best one beside its twin.
+static int autotune(vq_tsn* net, int n_crops, bool paired) {
     std::vector<int>& choice = net->tuned[n_crops];
     choice.assign(net->layers.size(), 0);
     net->ls = net->stream;
-    hipEvent_t e0, e1;
+    paired = paired && net->n_split > 1 && 2 * n_crops <= net->max_crops;
+    hipEvent_t e0, e1, f1;
     VQ_HIP(hipEventCreate(&e0));
     VQ_HIP(hipEventCreate(&e1));
+    VQ_HIP(hipEventCreate(&f1));
     auto timed = [&](const LaunchItem& it, int reps, float* ms) -> int {
         int rc = run_item(net, it, 0, n_crops, n_crops);       // warm
         if (rc != VQ_OK) return rc;
         VQ_HIP(hipEventRecord(e0, net->stream));
+        if (paired) VQ_HIP(hipStreamWaitEvent(net->split_streams[1], e0, 0));
         for (int r = 0; r < reps; ++r) {
+            net->ls = net->stream;
             rc = run_item(net, it, 0, n_crops, n_crops);
+            if (rc == VQ_OK && paired) {
+                net->ls = net->split_streams[1];
+                rc = run_item(net, it, n_crops, n_crops, n_crops);
+                net->ls = net->stream;
+            }
             if (rc != VQ_OK) return rc;
         }
         VQ_HIP(hipEventRecord(e1, net->stream));
+        if (paired) VQ_HIP(hipEventRecord(f1, net->split_streams[1]));
         VQ_HIP(hipEventSynchronize(e1));
         VQ_HIP(hipEventElapsedTime(ms, e0, e1));
+        if (paired) {
+            float other = 0.f;
+            VQ_HIP(hipEventSynchronize(f1));
+            VQ_HIP(hipEventElapsedTime(&other, e0, f1));
+            *ms = std::max(*ms, other);
+        }
         return VQ_OK;
     };
     {   // bring the clock up: the heuristic tilings (choice = 0 entries are replaced below) through the whole launch list
@@ -1534,13 +1553,14 @@ static int autotune(vq_tsn* net, int n_crops) {
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(f1);
     return VQ_OK;
 }
 
 // Make sure a tiling table exists for this batch size.  The first size seen is autotuned; a later size within 1.5x of
 // a tuned one borrows that table (the ragged last batch of a video must not cost 2 s of tuning launches -- every
 // tiling gives the same bits, only the speed differs); anything further away is tuned itself.
-static int ensure_tuned(vq_tsn* net, int n_crops) {
+static int ensure_tuned(vq_tsn* net, int n_crops, bool paired) {
     if (!net->autotune || net->forced_tile >= 0 || net->tuned.find(n_crops) != net->tuned.end()) return VQ_OK;
     int nearest = 0;
     for (const auto& kv : net->tuned)
@@ -1549,7 +1569,7 @@ static int ensure_tuned(vq_tsn* net, int n_crops) {
         net->tuned[n_crops] = net->tuned[nearest];
         return VQ_OK;
     }
-    return autotune(net, n_crops);
+    return autotune(net, n_crops, paired);
 }
 
 static int run_layer(vq_tsn* net, int li, int n_crops, int tune_key) {
@@ -2123,7 +2143,7 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
         net->fused_consensus = whole;
     }
     for (int sb = 0; sb < n_split; ++sb) {      // n_split == 1: sub[0] is the whole batch
-        const int rc = ensure_tuned(net, sub[sb]);
+        const int rc = ensure_tuned(net, sub[sb], n_split > 1);
         if (rc != VQ_OK) return rc;
     }
     const int frc = forward_launches(net, src, n_crops, T, n_split, sub, sub_off, ev);
