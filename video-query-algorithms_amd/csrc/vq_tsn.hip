@@ -1467,43 +1467,41 @@ static int run_item(vq_tsn* net, const LaunchItem& it, int crop0, int n_crops, i
 // The chip's clock follows its load: a sweep that starts on an idle GPU times its first candidates at a lower clock than its last ones
 // (round 5: a 96-crop table tuned at the start of a test, behind seconds of host work, gave the first three launches of the forward -- conv1,
 // conv2/3x3_reduce, the inception_3a group -- the LAST candidates of the list, one of them 1.8x slower than the best: 2.91 ms per step
-// instead of 2.73, kept by the tiling cache).  So the sweep starts behind ~30 ms of the forward's own launches, and the three fastest
-// candidates of a launch are timed once more, back to back, before the winner is taken.
+// instead of 2.73, kept by the tiling cache).  So the sweep starts behind ~30 ms of the forward's own launches, and the fastest
+// candidates of a launch are timed again, back to back, before the winner is taken.
 // ``paired``: the size is that of a SUB-BATCH of the default forward (two sub-batches on two streams, side by side): a candidate is timed
-// the way it will run -- the same launch on both streams at once, on the crop ranges of sub-batch 0 and 1 -- because the best tiling of a
+// the way it will run -- the same launch on all sub-batch streams at once, on the crop ranges of the sub-batches -- because the best tiling of a
 // launch that has the chip to itself (few, large workgroups fill it badly) is not the best one beside its twin.
 static int autotune(vq_tsn* net, int n_crops, bool paired) {
     std::vector<int>& choice = net->tuned[n_crops];
     choice.assign(net->layers.size(), 0);
     net->ls = net->stream;
-    paired = paired && net->n_split > 1 && 2 * n_crops <= net->max_crops;
-    hipEvent_t e0, e1, f1;
+    const int ways = paired ? std::max(1, std::min(net->n_split, net->max_crops / n_crops)) : 1;     // streams that run the launch side by side
+    hipEvent_t e0, e1;
+    std::vector<hipEvent_t> f(ways, nullptr);
     VQ_HIP(hipEventCreate(&e0));
     VQ_HIP(hipEventCreate(&e1));
-    VQ_HIP(hipEventCreate(&f1));
+    for (int l = 1; l < ways; ++l) VQ_HIP(hipEventCreate(&f[l]));
     auto timed = [&](const LaunchItem& it, int reps, float* ms) -> int {
         int rc = run_item(net, it, 0, n_crops, n_crops);       // warm
         if (rc != VQ_OK) return rc;
         VQ_HIP(hipEventRecord(e0, net->stream));
-        if (paired) VQ_HIP(hipStreamWaitEvent(net->split_streams[1], e0, 0));
-        for (int r = 0; r < reps; ++r) {
-            net->ls = net->stream;
-            rc = run_item(net, it, 0, n_crops, n_crops);
-            if (rc == VQ_OK && paired) {
-                net->ls = net->split_streams[1];
-                rc = run_item(net, it, n_crops, n_crops, n_crops);
+        for (int l = 1; l < ways; ++l) VQ_HIP(hipStreamWaitEvent(net->split_streams[l], e0, 0));
+        for (int r = 0; r < reps; ++r)
+            for (int l = 0; l < ways; ++l) {
+                net->ls = l > 0 ? net->split_streams[l] : net->stream;
+                rc = run_item(net, it, l * n_crops, n_crops, n_crops);
                 net->ls = net->stream;
+                if (rc != VQ_OK) return rc;
             }
-            if (rc != VQ_OK) return rc;
-        }
         VQ_HIP(hipEventRecord(e1, net->stream));
-        if (paired) VQ_HIP(hipEventRecord(f1, net->split_streams[1]));
+        for (int l = 1; l < ways; ++l) VQ_HIP(hipEventRecord(f[l], net->split_streams[l]));
         VQ_HIP(hipEventSynchronize(e1));
         VQ_HIP(hipEventElapsedTime(ms, e0, e1));
-        if (paired) {
+        for (int l = 1; l < ways; ++l) {
             float other = 0.f;
-            VQ_HIP(hipEventSynchronize(f1));
-            VQ_HIP(hipEventElapsedTime(&other, e0, f1));
+            VQ_HIP(hipEventSynchronize(f[l]));
+            VQ_HIP(hipEventElapsedTime(&other, e0, f[l]));
             *ms = std::max(*ms, other);
         }
         return VQ_OK;
@@ -1553,7 +1551,7 @@ static int autotune(vq_tsn* net, int n_crops, bool paired) {
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    (void)hipEventDestroy(f1);
+    for (int l = 1; l < ways; ++l) (void)hipEventDestroy(f[l]);
     return VQ_OK;
 }
 
