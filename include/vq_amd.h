@@ -53,8 +53,9 @@ extern "C" {
 /* 6 (round 4): + vq_db_set_layout / vq_db_layout (block tiled in place; the mirrored copy of version 5 is gone), vq_db_read_rows,
  * vq_db_read_scores_at, vq_db_ne_devptr, vq_format_feature_rows, vq_jpeg_decode_path_list; vq_input_desc gained s2d_order.
  * 7 (round 5): + vq_tsn_set_profile_split; the layer tiling tables know the pooled-input kernel (pipelined = 3).
- * 8 (round 5): + vq_resize_crop_planes (the ten grey planes of a batch of flow stacks resized / cropped in one launch). */
-#define VQ_ABI_VERSION 8
+ * 8 (round 5): + vq_resize_crop_planes (the ten grey planes of a batch of flow stacks resized / cropped in one launch).
+ * 9 (round 5): + vq_jpeg_crops; vq_jpeg_decode*(color | 2) stops at the component planes. */
+#define VQ_ABI_VERSION 9
 
 enum {
     VQ_OK = 0,
@@ -258,6 +259,13 @@ int vq_jpeg_decode_files(vq_jpeg* jpeg, const char* const* paths, int32_t n, int
 int vq_jpeg_decode_path_list(vq_jpeg* jpeg, const char* paths, int64_t paths_bytes, int32_t n, int32_t color, int32_t h, int32_t w,
                              uint8_t* out_host, uint8_t** out_dev, void* hip_stream);
 int vq_jpeg_info_file(const char* path, int32_t* h, int32_t* w, int32_t* components);
+/* Decode + crop 0 without the whole-frame pixel pass, for frames that already have the resize size (what build_wof_clips.py writes: 340 x 256;
+ * cv2.resize to the same size is the identity, so the over-sample crop 0 of calcSig_wOF.py:94,111 is the top-left crop x crop pixels).
+ * A decode call with (color | 2) stops at the component planes (no out_host, *out_dev = NULL); vq_jpeg_crops then writes
+ *   c == 3:  [n][crop][crop][3] B,G,R of the n colour frames of that call,
+ *   c == 10: [n / 10][crop][crop][10] of n grey frames handed over plane-major (frame p * (n / 10) + i = plane p of stack i)
+ * into crops_dev -- the bytes of vq_jpeg_decode + vq_resize_crop(_planes) (tested). */
+int vq_jpeg_crops(vq_jpeg* jpeg, int32_t c, int32_t crop, uint8_t* crops_dev, void* hip_stream);
 
 enum {
     VQ_OP_CONV = 1,

@@ -337,3 +337,49 @@ def test_host_decoder_on_streams_full_of_stuffed_bytes(jpeg, monkeypatch):
         for i, data in enumerate(files):
             assert (out["1"][i] == pil_bgr(data)).all(), (trial, i)
         assert (out["0"] == out["1"]).all()
+
+
+@needs_pil
+def test_frames_that_have_the_size_are_decoded_straight_into_crops(jpeg):
+    """build_wof_clips.py writes 340 x 256 frames, so cv2.resize(frame, (340, 256)) is the identity and crop 0 is the top-left 224 x 224:
+    ``crops_from_jpegs`` then decodes to the component planes only and crops from there (vq_jpeg_decode(color | 2) + vq_jpeg_crops) -- the
+    same bytes as libjpeg's whole frames cropped on the host, colour (4:2:0, 4:2:2, 4:4:4 and grey files in one batch) and flow stacks
+    (files in stack order x0, y0, x1, ...); frames of another size keep the resize path (same bytes as decode + resize on the host)."""
+    import ctypes as C
+
+    import torch
+    from video_query_algorithms_amd import _lib
+    from video_query_algorithms_amd.tsn import frames
+    from video_query_algorithms_amd.tsn.ingest import FrameIngest
+    rng = np.random.default_rng(5)
+    base = picture(256, 340, 21).astype(np.int16)
+
+    def noisy(img):
+        return np.clip(img + rng.integers(-30, 30, img.shape), 0, 255).astype(np.uint8)
+    rgb_files = [encode(noisy(base), quality=int(q), subsampling=int(s)) for q, s in ((95, 2), (80, 1), (90, 0), (60, 2), (95, 2))]
+    rgb_files.append(encode(noisy(base[:, :, 0]), quality=90))                       # a grey file read as colour: B = G = R = Y
+    ing = FrameIngest(3, 0, "cv2")
+    got = ing.crops_from_jpegs(rgb_files).cpu().numpy()
+    want = np.stack([pil_bgr(f)[:224, :224] for f in rgb_files])
+    assert got.shape == (6, 224, 224, 3) and (got == want).all()
+    ing.close()
+    flow_files = [encode(noisy(base[:, :, k % 3]), quality=95) for k in range(3 * 10)]           # three stacks, stack order
+    ing = FrameIngest(10, 0, "cv2")
+    got = ing.crops_from_jpegs(flow_files).cpu().numpy()
+    planes = np.stack([np.asarray(Image.open(io.BytesIO(f)).convert("L")) for f in flow_files]).reshape(3, 10, 256, 340)
+    assert got.shape == (3, 224, 224, 10) and (got == planes[:, :, :224, :224].transpose(0, 2, 3, 1)).all()
+    # another frame size: the resize path, as before
+    small = [encode(noisy(picture(120, 160, 3 + k)[:, :, 0]), quality=90) for k in range(10)]
+    got = ing.crops_from_jpegs(small).cpu().numpy()
+    grey = np.stack([np.asarray(Image.open(io.BytesIO(f)).convert("L")) for f in small])
+    assert (got[0] == np.stack([frames.crop0(g, (340, 256)) for g in grey], axis=-1)).all()
+    ing.close()
+    # the entry refuses what it cannot do
+    dec = jpeg.JpegDecoder(8, 256, 340, 0)
+    out = torch.empty((1, 224, 224, 10), dtype=torch.uint8, device="cuda")
+    with pytest.raises(_lib.VqError):
+        _lib.call("vq_jpeg_crops", dec._h, 10, 224, C.c_void_p(out.data_ptr()), None)            # nothing decoded yet
+    dec.decode_to_device(rgb_files[:2], color=True)
+    with pytest.raises(_lib.VqError):
+        _lib.call("vq_jpeg_crops", dec._h, 10, 224, C.c_void_p(out.data_ptr()), None)            # colour frames are not grey planes
+    dec.close()

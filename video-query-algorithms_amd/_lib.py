@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvqamd.so")
 
-ABI_VERSION = 8                 # include/vq_amd.h: VQ_ABI_VERSION
+ABI_VERSION = 9                 # include/vq_amd.h: VQ_ABI_VERSION
 VQ_F32, VQ_F64 = 0, 1
 VQ_LAYOUT_ROWS, VQ_LAYOUT_TILED = 0, 1
 VQ_OP_CONV, VQ_OP_MAXPOOL, VQ_OP_AVGPOOL, VQ_OP_GLOBAL_AVGPOOL, VQ_OP_CONV_WINOGRAD = 1, 2, 3, 4, 5
@@ -101,6 +101,7 @@ SIGNATURES = {
     "vq_jpeg_decode": [_P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P],
     "vq_jpeg_decode_files": [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P],
     "vq_jpeg_decode_path_list": [_P, C.c_char_p, C.c_int64, _I32, _I32, _I32, _I32, _P, _P, _P], "vq_jpeg_info_file": [C.c_char_p, _pI32, _pI32, _pI32],
+    "vq_jpeg_crops": [_P, _I32, _I32, _P, _P],
     "vq_flow_good_features": [_P, _P, _I32, _I32, _I32, C.c_float, C.c_float, _P, _P, _P],
     "vq_flow_ransac_homography": [_P, _P, _P, _P, _I32, _I32, C.c_float, _I32, C.c_uint32, _I32, _P, _P, _P, _P, _P],
     "vq_comm_unique_id": [_P], "vq_comm_init": [_I32, _I32, _P, _I32, _PP], "vq_comm_destroy": [_P],

@@ -10,6 +10,7 @@ first batches while the current stream's last ones are in the network, and feeds
 from __future__ import annotations
 
 import atexit
+import os
 import threading
 
 import numpy as np
@@ -135,6 +136,16 @@ class FrameIngest:
                 dec.close()
             dec = st["jpeg"] = _take_decoder(self.device, h, w) or jpeg.JpegDecoder(cap, h, w, self.device)
         cap = min(cap, dec.max_frames)
+        same_size = (w, h) == tuple(frame_size) and crop % 2 == 0 and crop <= min(h, w)
+        if same_size and ch in (3, 10):
+            # frames as build_wof_clips.py writes them: resize is the identity, crop 0 the top-left pixels -- decoded and cropped without the
+            # whole-frame pixel pass in between (8 000 grey frames per flow batch: 0.7 GB written and read again for the 57 % that survive)
+            per = cap if ch == 3 else max(1, cap // ch)
+            for i in range(0, n, per):
+                m = min(per, n - i)
+                group = files[i:i + m] if ch == 3 else [f for k in range(ch) for f in files[i * ch + k:(i + m) * ch:ch]]
+                dec.decode_to_crops(group, ch == 3, crop, out[i:i + m].data_ptr(), planes=ch, stream=stream)
+            return out
         if ch == 3:
             for i in range(0, n, cap):
                 ptr, (m, _, _) = dec.decode_to_device(files[i:i + cap], color=True, stream=stream)

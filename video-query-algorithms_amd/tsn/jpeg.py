@@ -33,7 +33,7 @@ class JpegDecoder:
         self._h = C.c_void_p()
         call("vq_jpeg_create", self.max_frames, self.max_h, self.max_w, self.device, C.byref(self._h))
 
-    def _submit(self, files: Sequence[Union[bytes, str]], color: bool, out_host, want_dev: bool, stream: int = 0):
+    def _submit(self, files: Sequence[Union[bytes, str]], color: bool, out_host, want_dev: bool, stream: int = 0, planes_only: bool = False):
         if len(files) and all(isinstance(f, str) for f in files):      # paths only: the library's threads read the files
             n = len(files)
             h, w, _ = info(files[0])
@@ -43,7 +43,7 @@ class JpegDecoder:
             paths = os.fsencode(joined + "\0")
             dev = C.c_void_p()
             host = np.empty((n, h, w, 3) if color else (n, h, w), dtype=np.uint8) if out_host else None
-            call("vq_jpeg_decode_path_list", self._h, paths, len(paths), n, int(bool(color)), h, w, host.ctypes.data_as(C.c_void_p) if host is not None else None,
+            call("vq_jpeg_decode_path_list", self._h, paths, len(paths), n, int(bool(color)) | (2 if planes_only else 0), h, w, host.ctypes.data_as(C.c_void_p) if host is not None else None,
                  C.byref(dev) if want_dev else None, C.c_void_p(stream) if stream else None)
             return host, dev.value, (n, h, w)
         blobs: List[bytes] = []
@@ -63,7 +63,7 @@ class JpegDecoder:
         host = None
         if out_host:
             host = np.empty((n, h, w, 3) if color else (n, h, w), dtype=np.uint8)
-        call("vq_jpeg_decode", self._h, ptrs, sizes, n, int(bool(color)), h, w, host.ctypes.data_as(C.c_void_p) if host is not None else None,
+        call("vq_jpeg_decode", self._h, ptrs, sizes, n, int(bool(color)) | (2 if planes_only else 0), h, w, host.ctypes.data_as(C.c_void_p) if host is not None else None,
              C.byref(dev) if want_dev else None, C.c_void_p(stream) if stream else None)
         return host, dev.value, (n, h, w)
 
@@ -77,6 +77,14 @@ class JpegDecoder:
         on (the call returns when they are done)."""
         _, dev, shape = self._submit(files, color, False, True, stream)
         return dev, shape
+
+    def decode_to_crops(self, files: Sequence[Union[bytes, str]], color: bool, crop: int, crops_dev_ptr: int, planes: int = 10, stream: int = 0):
+        """Frames that already have the resize size: decode and write the top-left ``crop`` x ``crop`` pixels -- what resize + crop 0 leaves
+        of them -- into device memory without the whole-frame pixel pass (vq_jpeg_crops).  Colour: [n, crop, crop, 3] B, G, R; grey:
+        the files plane-major (all frames of plane 0, then plane 1, ...), [n / planes, crop, crop, planes].  Returns (n, h, w)."""
+        _, _, shape = self._submit(files, color, False, False, stream, planes_only=True)
+        call("vq_jpeg_crops", self._h, 3 if color else int(planes), int(crop), C.c_void_p(crops_dev_ptr), C.c_void_p(stream) if stream else None)
+        return shape
 
     def close(self):
         if self._h:
