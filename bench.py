@@ -49,7 +49,8 @@ from video_query_algorithms_amd.tsn import bn_inception, net as tsn_net
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.29 TB/s measured achievable per the same guide)
 B_CLIPS, T_SEG, CH = 32, 3, 3     # configs[1]
-PROFILE_EVERY = 10                # every 10th timed step carries per-launch events (~3 us per launch of signal handling: 0.11 ms on such a step)
+PROFILE_EVERY = 25                # every 25th timed step runs on one stream with per-launch events (2.85 against 2.58 ms: two such steps in the default 50
+                                  # cost the region 0.4 %; rounds 4-5 sampled every 10th: 1 %)
 SIM_N, SIM_S, SIM_E, SIM_D = 1_000_000, 2, 5, 1024   # configs[3]
 TILED_GROUP = 4                   # csrc/vq_sim.hip: kTiledGroup
 
