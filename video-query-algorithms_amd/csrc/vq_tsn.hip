@@ -1483,8 +1483,15 @@ static int autotune(vq_tsn* net, int n_crops, bool paired) {
     VQ_HIP(hipEventCreate(&e1));
     for (int l = 1; l < ways; ++l) VQ_HIP(hipEventCreate(&f[l]));
     auto timed = [&](const LaunchItem& it, int reps, float* ms) -> int {
+        VQ_HIP(hipEventRecord(e0, net->stream));
         int rc = run_item(net, it, 0, n_crops, n_crops);       // warm
         if (rc != VQ_OK) return rc;
+        VQ_HIP(hipEventRecord(e1, net->stream));
+        VQ_HIP(hipEventSynchronize(e1));
+        float warm = 0.f;
+        VQ_HIP(hipEventElapsedTime(&warm, e0, e1));
+        if (warm > 0.25f) reps = std::max(1, reps / 3);        // a long launch (the command line's 400-crop sub-batches) needs no averaging: the
+                                                               // first run on a machine tunes two networks at that size
         VQ_HIP(hipEventRecord(e0, net->stream));
         for (int l = 1; l < ways; ++l) VQ_HIP(hipStreamWaitEvent(net->split_streams[l], e0, 0));
         for (int r = 0; r < reps; ++r)
