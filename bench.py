@@ -841,6 +841,8 @@ def bench_e2e_cli(device_index):
             t0 = time.perf_counter()
             r = subprocess.run(argv, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
             fresh_s = time.perf_counter() - t0
+            if os.environ.get("VQ_CLI_TRACE") == "1":                       # tools/e2e_trace.py: the child's own stamps
+                sys.stderr.write("fresh process (%.3f s):\n%s" % (fresh_s, r.stderr.decode(errors="replace")[-3000:]))
             if r.returncode == 0:
                 fcsv = os.path.join(root, "fresh", "video", "UCF101_split1", "rgb_global_pool_features.csv")
                 body = lambda path: open(path, "rb").read().split(b"\n", 1)[1]          # the header names the weights file: rows only
