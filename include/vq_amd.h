@@ -54,8 +54,9 @@ extern "C" {
  * vq_db_read_scores_at, vq_db_ne_devptr, vq_format_feature_rows, vq_jpeg_decode_path_list; vq_input_desc gained s2d_order.
  * 7 (round 5): + vq_tsn_set_profile_split; the layer tiling tables know the pooled-input kernel (pipelined = 3).
  * 8 (round 5): + vq_resize_crop_planes (the ten grey planes of a batch of flow stacks resized / cropped in one launch).
- * 9 (round 5): + vq_jpeg_crops; vq_jpeg_decode*(color | 2) stops at the component planes. */
-#define VQ_ABI_VERSION 9
+ * 9 (round 5): + vq_jpeg_crops; vq_jpeg_decode*(color | 2) stops at the component planes.
+ * 10 (round 5): + vq_dev_malloc / vq_dev_free / vq_stream_create / vq_stream_destroy / vq_stream_synchronize / vq_dev_read. */
+#define VQ_ABI_VERSION 10
 
 enum {
     VQ_OK = 0,
@@ -234,6 +235,15 @@ int vq_resize_crop(const uint8_t* frames, int32_t frames_on_device, int32_t n, i
  * calls of vq_resize_crop (tested); a thread computes the taps of its two pixels once for all planes and stores whole words. */
 int vq_resize_crop_planes(const uint8_t* planes_dev, int32_t n, int32_t h, int32_t w, int32_t c, int64_t plane_stride, int32_t resize_w,
                           int32_t resize_h, int32_t crop, int32_t rule, uint8_t* crops_dev, int32_t device, void* hip_stream);
+
+/* Device plumbing for a host that has no tensor library loaded (the single-GPU command line runs without importing torch: tsn/devmem.py):
+ * a device buffer, a non-blocking stream, a wait (stream NULL: the default stream), a blocking read-back. */
+int vq_dev_malloc(void** ptr, int64_t bytes, int32_t device);
+int vq_dev_free(void* ptr, int32_t device);
+int vq_stream_create(void** hip_stream, int32_t device);
+int vq_stream_destroy(void* hip_stream, int32_t device);
+int vq_stream_synchronize(void* hip_stream, int32_t device);
+int vq_dev_read(void* host, const void* dev, int64_t bytes, int32_t device);
 
 /* JPEG decode, the step in front of vq_resize_crop: replaces cv2.imread(img_NNNNN.jpg, IMREAD_COLOR) and
  * cv2.imread(flow_{x,y}_NNNNN.jpg, IMREAD_GRAYSCALE) at calcSig_wOF.py:92,105-106 for the baseline JPEG files

@@ -794,6 +794,46 @@ def test_device_resize_crop_against_the_pixel_loop_oracle(tsn, h, w):
         _lib.call("vq_resize_crop_planes", C.c_void_p(major.data_ptr()), 2, h, w, 3, 2 * h * w, 340, 256, 224, 0, C.c_void_p(out.data_ptr()), 0, None)
 
 
+def test_calcsig_as_a_fresh_process_runs_without_torch(tsn, tmp_path):
+    """``python calcSig_wOF.py ...`` on one GPU never imports torch (tsn/devmem.py: the crops' device buffers, the preparation lanes' streams
+    and the waits come from the library; VQ_NO_TORCH is set by main() before the library is loaded) -- 0.8 s of a 2.3 s process -- and writes
+    the bytes of the in-process run of this (torch-holding) test process, host decode + device resize and --device_jpeg alike."""
+    import subprocess
+    import sys
+    from video_query_algorithms_amd import calcSig_wOF
+    bi, net = tsn
+    pytest.importorskip("PIL")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_jpeg_oracle import encode, picture
+    root = tmp_path / "frames"
+    rng = np.random.default_rng(3)
+    for clip, n in (("clip_0001", 7), ("clip_0002", 9), ("clip_0003", 6)):
+        d = root / "vid" / clip
+        d.mkdir(parents=True)
+        for i in range(1, n + 1):
+            (d / ("img_%05d.jpg" % i)).write_bytes(encode(picture(256, 340, int(rng.integers(1 << 30))), quality=90, subsampling=2))
+            for p in ("flow_x", "flow_y"):
+                (d / ("%s_%05d.jpg" % (p, i))).write_bytes(encode(picture(256, 340, int(rng.integers(1 << 30)))[:, :, 0], quality=90))
+    protos = _write_protos(bi, tmp_path)
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-query-algorithms_amd", "calcSig_wOF.py")
+    files = ("rgb_global_pool_features.csv", "warped_optical_flow_global_pool_features.csv")
+    for tag, extra in (("host", []), ("device", ["--device_jpeg"])):
+        args = [str(root), protos["rgb"], "synthetic:2", protos["flow"], "synthetic:5", "--num_frame_per_video", "3", "--modelname", "UCF101_split1",
+                "--batch_clips", "2"] + extra
+        assert calcSig_wOF.main(args + ["--outFeatures_dir", str(tmp_path / ("in_" + tag))]) == 0
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "VQ_NO_TORCH")}
+        env["VQ_CLI_TRACE"] = "1"
+        p = subprocess.run([sys.executable, cli] + args + ["--outFeatures_dir", str(tmp_path / ("out_" + tag))], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert "torch imported: False" in p.stderr, p.stderr[-1000:]
+        for f in files:
+            assert (tmp_path / ("out_" + tag) / "vid" / "UCF101_split1" / f).read_bytes() == (tmp_path / ("in_" + tag) / "vid" / "UCF101_split1" / f).read_bytes(), (tag, f)
+    # VQ_NO_TORCH=0 keeps torch in the process
+    p = subprocess.run([sys.executable, cli] + args + ["--outFeatures_dir", str(tmp_path / "out_torch")], env=dict(env, VQ_NO_TORCH="0"), capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0 and "torch imported: True" in p.stderr, p.stderr[-1000:]
+
+
 def test_calcsig_two_ranks_write_the_same_bytes_as_one(tsn, tmp_path):
     """The N > 1 path of the drop-in command line with the REAL extractor: two ranks under torch.distributed.run, both
     on this one GPU with the gloo backend (VQ_DIST_BACKEND=gloo; RCCL refuses two ranks on one device), clips sharded

@@ -7,12 +7,13 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvqamd.so")
 
-ABI_VERSION = 9                 # include/vq_amd.h: VQ_ABI_VERSION
+ABI_VERSION = 10                 # include/vq_amd.h: VQ_ABI_VERSION
 VQ_F32, VQ_F64 = 0, 1
 VQ_LAYOUT_ROWS, VQ_LAYOUT_TILED = 0, 1
 VQ_OP_CONV, VQ_OP_MAXPOOL, VQ_OP_AVGPOOL, VQ_OP_GLOBAL_AVGPOOL, VQ_OP_CONV_WINOGRAD = 1, 2, 3, 4, 5
@@ -102,6 +103,8 @@ SIGNATURES = {
     "vq_jpeg_decode_files": [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P],
     "vq_jpeg_decode_path_list": [_P, C.c_char_p, C.c_int64, _I32, _I32, _I32, _I32, _P, _P, _P], "vq_jpeg_info_file": [C.c_char_p, _pI32, _pI32, _pI32],
     "vq_jpeg_crops": [_P, _I32, _I32, _P, _P],
+    "vq_dev_malloc": [_PP, _I64, _I32], "vq_dev_free": [_P, _I32], "vq_stream_create": [_PP, _I32], "vq_stream_destroy": [_P, _I32],
+    "vq_stream_synchronize": [_P, _I32], "vq_dev_read": [_P, _P, _I64, _I32],
     "vq_flow_good_features": [_P, _P, _I32, _I32, _I32, C.c_float, C.c_float, _P, _P, _P],
     "vq_flow_ransac_homography": [_P, _P, _P, _P, _I32, _I32, C.c_float, _I32, C.c_uint32, _I32, _P, _P, _P, _P, _P],
     "vq_comm_unique_id": [_P], "vq_comm_init": [_I32, _I32, _P, _I32, _PP], "vq_comm_destroy": [_P],
@@ -117,7 +120,11 @@ _lock = threading.Lock()
 
 def _preload_torch_hip():
     """If torch is importable, import it first so that ONE HIP runtime (torch's bundled
-    libamdhip64.so.7) serves both torch and libvqamd; device pointers are then interchangeable."""
+    libamdhip64.so.7) serves both torch and libvqamd; device pointers are then interchangeable.
+    VQ_NO_TORCH=1 (set by the single-GPU command line before anything touches the library): the process will not use torch at all
+    (tsn/devmem.py), the library runs on the system's HIP runtime and the 0.8 s import is saved."""
+    if os.environ.get("VQ_NO_TORCH") == "1" and "torch" not in sys.modules:
+        return
     try:
         import torch  # noqa: F401
     except Exception:

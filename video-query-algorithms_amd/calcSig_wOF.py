@@ -198,6 +198,11 @@ def main(argv=None, net_factory=None, program=None):
     if fanout.is_child() and "VQ_FANOUT_DEVICE" in os.environ:                         # the GPU the parent mapped this rank to
         device = int(os.environ["VQ_FANOUT_DEVICE"])
     rank, world = _join_world(device)
+    if world == 1 and "torch" not in sys.modules:
+        # one rank: nothing here needs torch (device buffers and streams come from the library, tsn/devmem.py) -- 0.8 s of import for a
+        # process that takes 2.3 s for 256 clips.  Decided before the library is loaded: it must share ONE HIP runtime with torch if torch
+        # is in the process (VQ_NO_TORCH=0 keeps torch).
+        os.environ.setdefault("VQ_NO_TORCH", "1")
     backend_device = None                                # where a rank's blocks must live for the collective (RCCL: its GPU)
     if world > 1:
         import torch.distributed as dist
@@ -432,7 +437,7 @@ def main(argv=None, net_factory=None, program=None):
     for job in csv_jobs:
         job.result()                                                     # a writer's exception is the command's
     io_pool.shutdown()
-    stamp("feature files written")
+    stamp("feature files written (torch imported: %s)" % ("torch" in sys.modules))
     return 0
 
 

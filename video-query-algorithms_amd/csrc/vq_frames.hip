@@ -270,3 +270,50 @@ extern "C" int vq_resize_crop(const uint8_t* frames, int32_t frames_on_device, i
     if (le != hipSuccess) return fail(VQ_E_HIP, "kernel launch failed: %s", hipGetErrorString(le));
     return VQ_OK;
 }
+
+// ---- device plumbing for a host that has no tensor library loaded ----------------------------------------------------------------
+// The single-GPU command line needs four things of a device runtime: a buffer for the crops of a batch, a stream per preparation lane,
+// a wait, a read-back.  With these the drop-in `python calcSig_wOF.py ...` runs without importing torch (0.8 s of a 2.3 s process); ranks
+// of a multi-GPU run, and anything that holds torch tensors already, keep using torch (tsn/devmem.py decides once per process).
+extern "C" int vq_dev_malloc(void** ptr, int64_t bytes, int32_t device) {
+    VQ_REQUIRE(ptr && bytes > 0, "bad argument");
+    DeviceGuard g(device);
+    VQ_HIP(vq::malloc_trim(ptr, (size_t)bytes));
+    return VQ_OK;
+}
+
+extern "C" int vq_dev_free(void* ptr, int32_t device) {
+    if (!ptr) return VQ_OK;
+    DeviceGuard g(device);
+    VQ_HIP(hipFree(ptr));
+    return VQ_OK;
+}
+
+extern "C" int vq_stream_create(void** stream, int32_t device) {
+    VQ_REQUIRE(stream, "NULL argument");
+    DeviceGuard g(device);
+    hipStream_t st;
+    VQ_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *stream = (void*)st;
+    return VQ_OK;
+}
+
+extern "C" int vq_stream_destroy(void* stream, int32_t device) {
+    if (!stream) return VQ_OK;
+    DeviceGuard g(device);
+    VQ_HIP(hipStreamDestroy((hipStream_t)stream));
+    return VQ_OK;
+}
+
+extern "C" int vq_stream_synchronize(void* stream, int32_t device) {
+    DeviceGuard g(device);
+    VQ_HIP(hipStreamSynchronize((hipStream_t)stream));          // NULL: the default stream
+    return VQ_OK;
+}
+
+extern "C" int vq_dev_read(void* host, const void* dev, int64_t bytes, int32_t device) {
+    VQ_REQUIRE(host && dev && bytes > 0, "bad argument");
+    DeviceGuard g(device);
+    VQ_HIP(hipMemcpy(host, dev, (size_t)bytes, hipMemcpyDeviceToHost));
+    return VQ_OK;
+}

@@ -136,28 +136,29 @@ class CaffeNet:
 
     def extract_clips_from_jpegs(self, files, T: int, frame_size=(340, 256), on_device: bool = False):
         """JPEG file contents of B*T snippets (flow: * C planes) -> consensus features [B, D]; see crops_from_jpegs."""
-        import torch
+        from . import devmem
         per_snip = 1 if self._channels == 3 else self._channels
         per = (self._model.max_crops // T) * T
         if per == 0:
             raise ValueError("max_crops (%d) is smaller than T (%d)" % (self._model.max_crops, T))
-        dev = torch.device("cuda", self._model.device)
         out = []
         for i in range(0, len(files) // per_snip, per):
             crops = self.crops_from_jpegs(files[i * per_snip:(i + per) * per_snip], frame_size)
-            torch.cuda.current_stream(dev).synchronize()
+            devmem.synchronize_current(self._model.device)
             nb = crops.shape[0]
             if on_device:
                 self._model.forward_device(crops.data_ptr(), nb, T, self._mean)
                 out.append(self._model.features_tensor(nb // T).clone())
             else:
                 out.append(self._model.forward_device(crops.data_ptr(), nb, T, self._mean, np.empty((nb // T, self._model.feature_dim), dtype=np.float64)))
-        return torch.cat(out, dim=0) if on_device else np.concatenate(out, axis=0)
+        if on_device:
+            import torch
+            return torch.cat(out, dim=0)
+        return np.concatenate(out, axis=0)
 
     def extract_clips_from_crops(self, crops, T: int, on_device: bool = False):
         """Device crops (torch uint8 [B*T, crop, crop, C], e.g. from ``crops_from_jpegs`` run by another thread for the NEXT batch while
         this one is in the network) -> consensus features [B, D]."""
-        import torch
         nb = crops.shape[0]
         if nb > self._model.max_crops or nb % T:
             raise ValueError("%d crops: at most max_crops (%d), a multiple of T (%d)" % (nb, self._model.max_crops, T))
@@ -171,22 +172,24 @@ class CaffeNet:
     def extract_clips_from_frames(self, frames_: np.ndarray, T: int, frame_size=(340, 256), on_device: bool = False):
         """Decoded frames of B*T snippets -> consensus features [B, D]: resize + crop 0 on the device, then the
         batched forward on the resident crops (no host-side image processing at all).  ``on_device``: see extract_clips."""
-        import torch
+        from . import devmem
         per = (self._model.max_crops // T) * T
         if per == 0:
             raise ValueError("max_crops (%d) is smaller than T (%d)" % (self._model.max_crops, T))
-        dev = torch.device("cuda", self._model.device)
         out = []
         for i in range(0, frames_.shape[0], per):
             crops = self.crops_from_frames(frames_[i:i + per], frame_size)
-            torch.cuda.current_stream(dev).synchronize()
+            devmem.synchronize_current(self._model.device)
             nb = crops.shape[0]
             if on_device:
                 self._model.forward_device(crops.data_ptr(), nb, T, self._mean)
                 out.append(self._model.features_tensor(nb // T).clone())
             else:
                 out.append(self._model.forward_device(crops.data_ptr(), nb, T, self._mean, np.empty((nb // T, self._model.feature_dim), dtype=np.float64)))
-        return torch.cat(out, dim=0) if on_device else np.concatenate(out, axis=0)
+        if on_device:
+            import torch
+            return torch.cat(out, dim=0)
+        return np.concatenate(out, axis=0)
 
     @property
     def feature_dim(self):

@@ -67,15 +67,14 @@ class FrameIngest:
         """Decoded frames -> device crops (torch uint8 [n, crop, crop, C]) through vq_resize_crop: RGB frames
         [n, H, W, 3], or flow planes [n, C, H, W] (grey x/y frames in stack order).  Same bytes as frames.crop0."""
         import ctypes as C
-        import torch
         from .._lib import call
+        from . import devmem
         f = np.ascontiguousarray(frames_, dtype=np.uint8)
         if f.ndim != 4:
             raise ValueError("frames must be [n,H,W,3] (RGB) or [n,C,H,W] (flow planes)")
-        dev = torch.device("cuda", self.device)
         n = f.shape[0]
-        out = torch.empty((n, crop, crop, self._channels), dtype=torch.uint8, device=dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        out = devmem.empty_u8((n, crop, crop, self._channels), self.device)
+        stream = devmem.current_stream_handle(self.device)
         if self._channels == 3:
             if f.shape[3] != 3:
                 raise ValueError("RGB frames must be [n,H,W,3]")
@@ -93,8 +92,8 @@ class FrameIngest:
     def sync(self):
         """Wait for the resize / crop work of ``crops_from_frames`` (queued on torch's current stream) before an extractor's own
         stream reads the crops."""
-        import torch
-        torch.cuda.current_stream(torch.device("cuda", self.device)).synchronize()
+        from . import devmem
+        devmem.synchronize_current(self.device)
 
     def crops_from_jpegs(self, files, frame_size=(340, 256), crop=224, lane=0):
         """JPEG file contents -> device crops (torch uint8 [n, crop, crop, C]) without the frames ever visiting the host:
@@ -103,28 +102,26 @@ class FrameIngest:
         snippet (x0, y0, x1, y1, ...).  The pixels are libjpeg's (what cv2.imread returns), bit for bit.  ``lane``: calls of
         different lanes own different decoders and streams and may run at the same time in different threads (the command line
         keeps two batches in preparation: one's host half -- reading, unstuffing -- overlaps the other's device half)."""
-        import torch
+        from . import devmem
         ch = self._channels
         per_snip = 1 if ch == 3 else ch
         if len(files) % per_snip:
             raise ValueError("flow net: %d files is not a multiple of the %d planes of a snippet" % (len(files), ch))
         n = len(files) // per_snip
-        dev = torch.device("cuda", self.device)
-        out = torch.empty((n, crop, crop, ch), dtype=torch.uint8, device=dev)
+        out = devmem.empty_u8((n, crop, crop, ch), self.device)
         st = self._lanes.setdefault(lane, {"stream": None, "jpeg": None, "lock": threading.Lock()})
         with st["lock"]:                                 # a lane's decoder buffer and stream serve one call at a time
-            return self._crops_from_jpegs_on(st, files, n, ch, frame_size, crop, out, dev)
+            return self._crops_from_jpegs_on(st, files, n, ch, frame_size, crop, out)
 
-    def _crops_from_jpegs_on(self, st, files, n, ch, frame_size, crop, out, dev):
+    def _crops_from_jpegs_on(self, st, files, n, ch, frame_size, crop, out):
         import ctypes as C
-        import torch
         from .._lib import call
-        from . import jpeg
+        from . import devmem, jpeg
         # a stream of its own (non-blocking): the call may run in a thread of its own for a LATER batch while the network works on the
         # current one on the default stream -- decoding a batch of flow files keeps a few CUs busy for tens of milliseconds
         if st["stream"] is None:
             # (a high-priority stream was tried for the decode kernels: no gain, 385-391 against 394-412 clips/s end to end)
-            st["stream"] = torch.cuda.Stream(device=dev)
+            st["stream"] = devmem.new_stream(self.device)
         ingest = st["stream"]
         stream = ingest.cuda_stream
         h, w, _ = jpeg.info(files[0])
