@@ -37,6 +37,8 @@
  *     VQ_TUNE_CACHE=<dir>|0, VQ_WEIGHT_CACHE=<dir>|0   where the tiling tables / packed weights are kept between processes (0 = nowhere)
  *     VQ_DIST_BACKEND=gloo|nccl    torch.distributed backend of the N > 1 entry points (default nccl = RCCL; gloo: CPU tests, one-card rehearsals)
  *     VQ_CLI_TRACE=1               calcSig_wOF.py prints phase stamps; VQ_CLI_GROUP_CLIPS=<n>: clips per flush group (default 16 batches per rank)
+ *     VQ_NO_TORCH=0|1              one-rank calcSig_wOF.py runs WITHOUT importing torch (set to 1 by main() before the library is loaded: device buffers
+ *                                  and streams from vq_dev_malloc / vq_stream_*, tsn/devmem.py); 0 keeps torch; same bytes either way
  *     VQ_FANOUT_*                  set BY fanout.py for the per-GPU children it starts (rank, world, device, workers): not for users
  *   the build
  *     VQ_EXTRA_HIPCC_FLAGS         extra hipcc flags for build.py (experiments; empty for the product)
