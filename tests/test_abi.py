@@ -129,3 +129,22 @@ def test_comm_group_without_rccl_reports_unsupported(tmp_path):
     env = dict(os.environ, VQ_RCCL_LIB=str(tmp_path / "no_such_rccl.so"))
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout
+
+
+def test_every_environment_switch_is_listed_in_the_header():
+    """include/vq_amd.h documents ALL switches: every VQ_* variable the library (getenv) or the package (os.environ) reads appears there."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "vq_amd.h")).read()
+    names = set()
+    pkg = os.path.join(root, "video-query-algorithms_amd")
+    for path in glob.glob(os.path.join(pkg, "**", "*"), recursive=True):
+        if not path.endswith((".py", ".hip", ".cc", ".h")):
+            continue
+        text = open(path, errors="replace").read()
+        for m in re.finditer(r'getenv\("(VQ_[A-Z0-9_]+)"\)|environ(?:\.get|\.setdefault)?\(?\[?"(VQ_[A-Z0-9_]+)"', text):
+            names.add(m.group(1) or m.group(2))
+    assert len(names) > 20
+    missing = sorted(n for n in names if n not in header and not n.startswith("VQ_FANOUT_"))
+    assert "VQ_FANOUT_*" in header and not missing, missing
