@@ -77,6 +77,15 @@ def test_command_line_on_a_frame_directory(gpu, tmp_path):
     img = frames.imread(str(out / "pan" / "clip_0001" / ("img_00001" + ext)), True)
     want = frames.imread(str(src / "frame_00001.ppm"), True)                   # the initial frame is skipped: img 1 = frame 1
     assert img.shape == (96, 128, 3) and np.abs(img.astype(int) - want.astype(int)).max() <= (12 if ext == ".jpg" else 0)
+    # the same command as a fresh process: it never imports torch (nothing here holds a tensor; VQ_NO_TORCH is set before the library is
+    # loaded) and writes the same files
+    import subprocess
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-query-algorithms_amd", "build_wof_clips.py")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("VQ_FANOUT") and k != "VQ_NO_TORCH"}
+    p = subprocess.run([sys.executable, cli, str(tmp_path / "src"), str(tmp_path / "out2"), "--fps", "5", "--clip_time", "3", "--max_pairs", "16"],
+                       env=dict(env, VQ_CLI_TRACE="1"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "torch imported: False" in p.stderr, p.stderr[-1500:]
+    assert _tree(str(out)) == _tree(str(tmp_path / "out2"))
 
 
 def _run_wof(argv, env_extra=None, timeout=300):

@@ -240,6 +240,10 @@ def create_clip(vid_path: str, out_path: str, frames_per_clip: int = 150, frames
 
 
 def main(argv=None, program=None) -> int:
+    if "torch" not in sys.modules:
+        # nothing here holds a tensor: the library runs on the system's HIP runtime and the 0.8 s import is saved (VQ_NO_TORCH=0 keeps torch;
+        # decided before the library is loaded, _lib._preload_torch_hip)
+        os.environ.setdefault("VQ_NO_TORCH", "1")
     parser = argparse.ArgumentParser(description="Extract rgb and warped optical flow frames")
     parser.add_argument("src_dir", help="directory with video files")
     parser.add_argument("out_dir")
@@ -293,6 +297,8 @@ def main(argv=None, program=None) -> int:
         writers.shutdown()
     for f in flows.values():
         f.close()
+    if os.environ.get("VQ_CLI_TRACE") == "1":
+        print("trace: done (torch imported: %s)" % ("torch" in sys.modules), file=sys.stderr, flush=True)
     return 0
 
 
