@@ -1490,8 +1490,10 @@ static int autotune(vq_tsn* net, int n_crops, bool paired) {
         VQ_HIP(hipEventSynchronize(e1));
         float warm = 0.f;
         VQ_HIP(hipEventElapsedTime(&warm, e0, e1));
-        if (warm > 0.25f) reps = std::max(1, reps / 3);        // a long launch (the command line's 400-crop sub-batches) needs no averaging: the
-                                                               // first run on a machine tunes two networks at that size
+        // long launches need fewer repetitions (the command line's first run on a machine tunes two networks at 2 x 400 crops) -- but not
+        // one look at a 0.3 ms launch: with that, the 224-crop tables of cfg 3 came out 9 % slower (2 345 against 2 580 clips/s)
+        // (and with two looks at launches above 0.5 ms still 2 480: only launches of more than 2 ms are timed once)
+        if (warm > 2.0f) reps = 1;
         VQ_HIP(hipEventRecord(e0, net->stream));
         for (int l = 1; l < ways; ++l) VQ_HIP(hipStreamWaitEvent(net->split_streams[l], e0, 0));
         for (int r = 0; r < reps; ++r)
