@@ -9,7 +9,7 @@ import csv, glob
 rows = list(csv.DictReader(open(glob.glob("gpurun_out/trace_prod/*/*kernel_trace.csv")[0])))
 ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:40], r.get("Queue_Id", "0")) for r in rows))
 starts = [i for i, k in enumerate(ks) if "preprocess" in k[2]]
-a, b = starts[-2], starts[-1]
+a, b = starts[-4], starts[-2]        # two preprocess launches per forward (one per sub-batch)
 seg = ks[a:b]
 t0 = seg[0][0]
 for s, e, n, q in seg:
