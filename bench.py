@@ -18,15 +18,18 @@ Both carry a `roofline` (HIP-event time of the dominant kernel inside the timed 
 `cpu_baseline` (the oracle timed on the host cores, rank 0, N = 1 only, bounded sample).
 
 Timed region (configs[1]): K forwards as the PRODUCT runs them -- ``vq_tsn_forward`` with its default of two sub-batches on two HIP
-streams (VQ_TSN_SPLIT=2: one sub-batch's launch ramps and tails overlap the other's steady state; same bits as one stream).  Every
-PROFILE_EVERY-th step of the region runs on ONE stream with a start / stop event on every launch (the dispatch packets' own
-timestamps): there a launch's duration is the kernel alone on the chip, which is what the per-kernel figures need.
+streams (VQ_TSN_SPLIT=2: one sub-batch's launch ramps and tails overlap the other's steady state; same bits as one stream); no launch
+of that region carries an event.  `single_stream` = the same K steps, same bracketing, all on ONE stream (the timed mode of rounds
+1-4; first-class, never shed from the line): there a launch's duration is the kernel alone on the chip, so every per-kernel figure of
+the line comes from THAT region -- sample_every(K) of its steps (>= 3 at the driver's K = 20) run with a start / stop event on every
+launch (the dispatch packets' own timestamps), `roofline.kernel_fields_from` says so and `roofline.profiled_steps` counts them.
 TSN roofline: `achieved` / `frac` = ALGORITHMIC direct-convolution FLOPs of a step (2 x MACs of Appendix A x crops =
-390.06 GFLOP) / the whole timed step (`ms_per_step`) / 157.3 TFLOP/s.  Beside it, from the sampled steps' kernel timestamps:
-`kernel_frac` = the same FLOPs / the convolution launches' own time (exceeds the pipe's rate because the Winograd form skips 20/36 of
-the multiplies) and `matrix_pipe_frac` = MFMA work the matrix pipe really EXECUTED (Winograd layers: 16 multiplies per 2x2 tile, K
-and tile padding of every kernel included) / that time.  `single_stream` = the same K steps all on one stream (the timed mode of
-rounds 1-4), for comparison.
+390.06 GFLOP) / the whole timed step (`ms_per_step`, product mode) / 157.3 TFLOP/s.  Beside it, from the one-stream region's sampled
+steps: `kernel_frac` = the same FLOPs / the convolution launches' own time (exceeds the pipe's rate because the Winograd form skips
+20/36 of the multiplies) and `matrix_pipe_frac` = MFMA work the matrix pipe really EXECUTED (Winograd layers: 16 multiplies per 2x2
+tile, K and tile padding of every kernel included) / that time.  Two streams overlap, so the product-mode step can be SHORTER than the
+sum of its kernels' one-stream durations (`conv_ms_per_step`): profiles/r06_two_queue_trace.txt is the kernel trace that shows it.
+`roofline.traffic` is HBM bytes PER LAUNCH (like `avg_launch_ms`); `traffic_per_step` = x launches_per_step.
 """
 import argparse
 import ctypes as C
@@ -49,8 +52,14 @@ from video_query_algorithms_amd.tsn import bn_inception, net as tsn_net
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0             # HBM3E spec (6.29 TB/s measured achievable per the same guide)
 B_CLIPS, T_SEG, CH = 32, 3, 3     # configs[1]
-PROFILE_EVERY = 25                # every 25th timed step runs on one stream with per-launch events (2.85 against 2.58 ms: two such steps in the default 50
-                                  # cost the region 0.4 %; rounds 4-5 sampled every 10th: 1 %)
+MIN_SAMPLED = 4                   # steps of the one-stream region that carry per-launch events (~0.1 ms each: 37 launches x ~3 us of signals)
+
+
+def sample_every(steps):
+    """Every n-th step of the one-stream region is sampled: at least min(steps, MIN_SAMPLED) of them (K = 20 -> 4, K = 50 -> 5)."""
+    return max(1, steps // MIN_SAMPLED)
+
+
 SIM_N, SIM_S, SIM_E, SIM_D = 1_000_000, 2, 5, 1024   # configs[3]
 TILED_GROUP = 4                   # csrc/vq_sim.hip: kTiledGroup
 
@@ -176,7 +185,8 @@ def bench_tsn(args, rank, world, device, stream):
                 e1.record(stream)
                 gather_events.append((e0, e1))
 
-    depth = min(cdiv(args.steps, PROFILE_EVERY), 1024)
+    every = sample_every(args.steps)
+    depth = min(cdiv(args.steps, every), 1024)
     with torch.cuda.stream(stream):
         model.set_profile(1)                         # one sampled forward: tunes the tilings of the whole batch on one stream
         step()
@@ -186,9 +196,10 @@ def bench_tsn(args, rank, world, device, stream):
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
-        # The timed region: the product's own forward (two sub-batches on two HIP streams); every PROFILE_EVERY-th step runs on
-        # one stream with start/stop events on every launch (no host sync).  --profile-only: ALL steps on one stream.
-        model.set_profile(depth, every=PROFILE_EVERY, split_between=not args.profile_only)
+        # The timed region: the product's own forward (two sub-batches on two HIP streams), no events on any launch.
+        # --profile-only: ALL steps on one stream, every `every`-th with start/stop events on every launch (no host sync).
+        if args.profile_only:
+            model.set_profile(depth, every=every, split_between=False)
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
@@ -200,37 +211,18 @@ def bench_tsn(args, rank, world, device, stream):
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
-    roof = tsn_roofline(model, n_crops, args.steps, PROFILE_EVERY)
-    roof["rank_ms_per_step"] = dt_rank / args.steps * 1e3
-    if gather_events:
-        roof["all_gather_ms_per_step"] = float(np.mean([a.elapsed_time(b) for a, b in gather_events]))
-    # Off-line PMC evidence for the same command, committed under profiles/ (NOT measured in this run): HBM bytes per conv
-    # launch (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as the microarchitecture guide
-    # prescribes for gfx950) and the SQ matrix-pipe utilisation per kernel family.
-    for name in ("r05_tsn_traffic.json", "r04_tsn_traffic.json", "r03_tsn_traffic.json", "r02_tsn_traffic.json", "r01_tsn_traffic.json"):
-        tpath = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                roof["traffic"] = json.load(f)["hbm_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/%s: committed PMC passes of this command (tools/pmc_tsn.sh), not collected in this run" % name
-            break
-    for name in ("r05_mfma_util.json", "r04_mfma_util.json", "r03_mfma_util.json", "r02_mfma_util.json", "r01_mfma_util.json"):
-        upath = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(upath):
-            with open(upath) as f:
-                u = json.load(f)
-            roof["pmc_matrix_pipe_utilisation"] = {k: v["matrix_pipe_utilisation"] for k, v in u.items() if isinstance(v, dict)}
-            roof["pmc_source"] = "profiles/%s: SQ_INSTS_MFMA x 64 / SIMD-cycles per kernel family (tools/pmc_mfma.sh), committed, not collected in this run" % name
-            break
+    rank_ms = dt_rank / args.steps * 1e3
+    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_events])) if gather_events else None
     feats = feat.clone()
-    # The same K steps once more, ALL on one stream with the same event sampling: the timed mode of rounds 1-4, reported beside
-    # `value` for comparison (never instead of it).
-    roof["single_stream_ms_per_step"] = float("nan")
+    # The same K steps once more, ALL on one stream, `every`-th step with events on every launch: the timed mode of rounds 1-4,
+    # reported beside `value` (never instead of it) -- and the region every per-kernel figure of the line comes from.
+    single_ms = float("nan")
     with torch.cuda.stream(stream):
         if not args.profile_only:
-            model.set_profile(depth, every=PROFILE_EVERY, split_between=False)
+            model.set_profile(depth, every=every, split_between=False)
             for _ in range(2):
                 step()
+            model.set_profile(depth, every=every, split_between=False)      # counters back to zero: the region's own samples only
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
@@ -241,10 +233,34 @@ def bench_tsn(args, rank, world, device, stream):
         if world > 1:
             dist.barrier()
         if not args.profile_only:
-            roof["single_stream_ms_per_step"] = (time.perf_counter() - t1) / args.steps * 1e3
-            r1 = tsn_roofline(model, n_crops, args.steps, PROFILE_EVERY)        # this region's own sampled launches
-            roof["single_stream_kernels"] = {k: r1[k] for k in ("conv_ms_per_step", "other_kernels_ms_per_step", "kernel_frac", "matrix_pipe_frac")}
-            roof["single_stream_kernels"]["families"] = {k: {q: v[q] for q in ("matrix_pipe_frac", "kernel_frac", "ms_per_step", "launches")} for k, v in r1["families"].items()}
+            single_ms = (time.perf_counter() - t1) / args.steps * 1e3
+    roof = tsn_roofline(model, n_crops, args.steps, every)
+    roof["kernel_fields_from"] = ("the timed region (--profile-only: every step on one stream)" if args.profile_only else
+                                  "single_stream region") + ": %d sampled steps (every %d%s of %d)" % (
+                                      roof["profiled_steps"], every, "th" if every > 3 else ("st", "nd", "rd")[every - 1], args.steps)
+    roof["single_stream_ms_per_step"] = single_ms
+    roof["rank_ms_per_step"] = rank_ms
+    if gather_ms is not None:
+        roof["all_gather_ms_per_step"] = gather_ms
+    # Off-line PMC evidence for the same command, committed under profiles/ (NOT measured in this run): HBM bytes per conv
+    # launch (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as the microarchitecture guide
+    # prescribes for gfx950) and the SQ matrix-pipe utilisation per kernel family.
+    for name in ("r06_tsn_traffic.json", "r05_tsn_traffic.json", "r04_tsn_traffic.json", "r03_tsn_traffic.json", "r02_tsn_traffic.json", "r01_tsn_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                roof["traffic"] = json.load(f)["hbm_bytes_per_launch"]
+            roof["traffic_per_step"] = roof["traffic"] * roof["launches_per_step"]
+            roof["traffic_source"] = "profiles/%s: committed PMC passes of this command (tools/pmc_tsn.sh), not collected in this run" % name
+            break
+    for name in ("r06_mfma_util.json", "r05_mfma_util.json", "r04_mfma_util.json", "r03_mfma_util.json", "r02_mfma_util.json", "r01_mfma_util.json"):
+        upath = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(upath):
+            with open(upath) as f:
+                u = json.load(f)
+            roof["pmc_matrix_pipe_utilisation"] = {k: v["matrix_pipe_utilisation"] for k, v in u.items() if isinstance(v, dict)}
+            roof["pmc_source"] = "profiles/%s: SQ_INSTS_MFMA x 64 / SIMD-cycles per kernel family (tools/pmc_mfma.sh), committed, not collected in this run" % name
+            break
     model.set_profile(0)
     if args.tiles and rank == 0 and not os.path.exists(args.tiles):
         os.makedirs(os.path.dirname(os.path.abspath(args.tiles)), exist_ok=True)
@@ -960,7 +976,7 @@ def bench_rounds(device_index, with_cpu):
         return tk, hp
     # ---- configs[0]: one query
     tk, hp = ticket()
-    lat, parts = [], np.zeros(3)
+    lat, parts = [], []
     for rep in range(60):
         random.seed(a="73459912436")
         t0 = time.perf_counter()
@@ -972,14 +988,13 @@ def bench_rounds(device_index, with_cpu):
         t3 = time.perf_counter()
         if rep >= 10:
             lat.append(t3 - t0)
-            parts += (t1 - t0, t2 - t1, t3 - t2)
+            parts.append((t1 - t0, t2 - t1, t3 - t2))
     med = float(np.median(lat))
     first_matches = dict(tk.matches)
     avg0 = tk._avg.copy()
     query = {"metric": "queries/sec weighted-cosine query on a resident 10k x 2 x 3 x 1024 database (similarities + scores + review set)",
              "value": 1.0 / med, "unit": "queries/s", "ms_per_query": med * 1e3, "queries_timed": len(lat),
-             "ms": {"compute_similarities": parts[0] / len(lat) * 1e3, "compute_scores": parts[1] / len(lat) * 1e3,
-                    "select_clips_to_review": parts[2] / len(lat) * 1e3},
+             "ms": dict(zip(("compute_similarities", "compute_scores", "select_clips_to_review"), (np.median(np.array(parts), axis=0) * 1e3).tolist())),
              "config": {"workload": "configs[0]: compute_matches.py weighted cosine on 10k x 1024 fp32 features (2 streams x 3 splits), broker defaults"}}
     # ---- configs[4]: 100 weight-update rounds on the resident database
     tk, hp = ticket()
@@ -1085,7 +1100,8 @@ def compact(out):
         line["config"]["distributed"] = _pick(cfg["distributed"], ["backend", "world_size", "rccl_version", "rehearsal_on_one_gpu"])
     roof = out["roofline"]
     line["roofline"] = _pick(roof, ["bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_frac", "matrix_pipe_frac", "avg_launch_ms",
-                                    "launches_per_step", "conv_ms_per_step", "other_kernels_ms_per_step", "all_gather_ms_per_step"])
+                                    "launches_per_step", "conv_ms_per_step", "other_kernels_ms_per_step", "all_gather_ms_per_step", "profiled_steps",
+                                    "traffic_per_step"])
     line["roofline"].setdefault("traffic", None)
     line["roofline"]["kernel"] = "%d conv launches/step: conv_igemm(_pipe) / pool_gemm + wino_f2x2_3x3 kernels, v_mfma_f32_32x32x2" % roof["launches_per_step"]
     line["roofline"]["families"] = {k: _pick(v, ["matrix_pipe_frac", "ms_per_step", "launches"]) for k, v in roof.get("families", {}).items()}
@@ -1093,9 +1109,9 @@ def compact(out):
         line["roofline"]["rank_ms_per_step"] = _pick(roof["rank_ms_per_step"], ["min", "max", "all"])
     if "pmc_matrix_pipe_utilisation" in roof:
         line["roofline"]["pmc_matrix_pipe"] = roof["pmc_matrix_pipe_utilisation"]
-    line["config"]["timed_mode"] = "vq_tsn_forward default: 2 sub-batch streams; every %dth step sampled on 1 stream" % PROFILE_EVERY
+    line["config"]["timed_mode"] = "vq_tsn_forward default: 2 sub-batch streams, no events; per-kernel fields: " + str(roof.get("kernel_fields_from"))
     if "single_stream" in out:
-        line["single_stream"] = _pick(out["single_stream"], ["value", "ms_per_step", "frac"])
+        line["single_stream"] = _pick(out["single_stream"], ["value", "ms_per_step", "frac", "profiled_steps"])
         line["single_stream"].update(_pick(out["single_stream"].get("kernels") or {}, ["conv_ms_per_step", "kernel_frac", "matrix_pipe_frac"]))
     if "cpu_baseline" in out:
         cb = out["cpu_baseline"]
@@ -1282,16 +1298,17 @@ def main():
     roof["achieved"] = roof["flops_per_step"] / out["ms_per_step"] / 1e9
     roof["frac"] = roof["achieved"] / PEAK_FP32_MFMA_TFLOPS
     out["config"]["timed_mode"] = ("all steps on one stream (--profile-only)" if args.profile_only else
-                                   "vq_tsn_forward's default: 2 sub-batches on 2 HIP streams; every %dth step on one stream with per-launch events" % PROFILE_EVERY)
+                                   "vq_tsn_forward's default: 2 sub-batches on 2 HIP streams, no launch carries an event; per-kernel fields from the " + roof["kernel_fields_from"])
     up = torch.tensor([roof.pop("single_stream_ms_per_step")], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(up, op=dist.ReduceOp.MAX)
     if not args.profile_only:
         out["single_stream"] = {"value": world * B_CLIPS / float(up.item()) * 1e3, "unit": "clips/s", "ms_per_step": float(up.item()),
                                 "frac": roof["flops_per_step"] / float(up.item()) / 1e9 / PEAK_FP32_MFMA_TFLOPS,
-                                "kernels": roof.pop("single_stream_kernels", None),
+                                "kernels": {k: roof[k] for k in ("conv_ms_per_step", "other_kernels_ms_per_step", "kernel_frac", "matrix_pipe_frac")},
+                                "profiled_steps": roof["profiled_steps"],
                                 "note": "same K steps, same bracketing, ALL on one stream (events on every %dth): the timed mode of rounds "
-                                        "1-4, for comparison" % PROFILE_EVERY}
+                                        "1-4, like for like with BENCH_r01..r04's value" % sample_every(args.steps)}
     if rank == 0 and world == 1 and not args.skip_cpu:
         base, ps_cpu = cpu_baseline_tsn(crops.cpu().numpy(), (model.graph, tsn_net.synthetic_weights(model.graph, seed=2)))
         out["cpu_baseline"] = base

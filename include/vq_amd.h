@@ -22,7 +22,10 @@
  *   the library
  *     VQ_DEVICE_POOL_GB=<n>        device blocks of closed TSN extractors kept for the next one of the same shape (default 40, 0 = off)
  *     VQ_TSN_SPLIT=<n> | a,b,..    sub-batches of a forward on separate HIP streams (default 2; 1 = one stream)
- *     VQ_TSN_AUTOTUNE=0            tilings by the occupancy heuristic instead of by timing on the first forward of a batch size
+ *     VQ_TSN_AUTOTUNE=0|1          0: batch sizes without a tiling table run the occupancy heuristic (nothing is ever timed); 1: the tables
+ *                                  shipped beside the library are left out and every size is timed in its first forward; unset: shipped
+ *                                  tables, and a timing sweep only for sizes further than 1.6x from every table
+ *     VQ_TSN_DEFAULT_TILES=0       leave the shipped tables (tsn/default_tiles.json) out without forcing a sweep elsewhere
  *     VQ_TSN_TILE=BMxBN[xBK[xP]]   one tiling for every direct convolution (tests: every tiling gives the same bits)
  *     VQ_TSN_GROUP=0, VQ_TSN_GROUP_POOL=0   a launch per layer instead of one per graph level / a launch per pooling layer (tests: same bits)
  *     VQ_TSN_SPLITK=0              no split over K for the 7x7-map layers (another summation order: agrees to rounding, tested)
@@ -57,8 +60,10 @@ extern "C" {
  * 7 (round 5): + vq_tsn_set_profile_split; the layer tiling tables know the pooled-input kernel (pipelined = 3).
  * 8 (round 5): + vq_resize_crop_planes (the ten grey planes of a batch of flow stacks resized / cropped in one launch).
  * 9 (round 5): + vq_jpeg_crops; vq_jpeg_decode*(color | 2) stops at the component planes.
- * 10 (round 5): + vq_dev_malloc / vq_dev_free / vq_stream_create / vq_stream_destroy / vq_stream_synchronize / vq_dev_read. */
-#define VQ_ABI_VERSION 10
+ * 10 (round 5): + vq_dev_malloc / vq_dev_free / vq_stream_create / vq_stream_destroy / vq_stream_synchronize / vq_dev_read.
+ * 11 (round 6): + vq_tsn_tile_tables / vq_tsn_get_tiles / vq_tsn_set_tiles / vq_tsn_tune / vq_tsn_set_split (a tiling table is keyed by (batch size, timed side by side on
+ *      the sub-batch streams | alone)); vq_db_query_round / vq_db_round_layout / vq_host_alloc / vq_host_free (a query round in one call). */
+#define VQ_ABI_VERSION 11
 
 enum {
     VQ_OK = 0,
@@ -204,6 +209,27 @@ int vq_db_select_fetch(vq_db* db, int64_t* match_rows_host, int64_t cap_match, i
  * (N each is always enough); VQ_E_INVALID with the counts filled in if one is too small. */
 int vq_db_select_rows(vq_db* db, double threshold, double lower, int64_t* match_rows_host, int64_t cap_match,
                       int64_t* near_rows_host, int64_t cap_near, int64_t* n_match, int64_t* n_near, int64_t* near_argmax);
+/* One query round on a resident database as ONE locked call with ONE synchronisation and one copy back: what
+ * Ticket.compute_similarities + compute_scores + select_clips_to_review (ticket.py:120-180,311-356; called in that order by
+ * compute_matches.py:58-89) are per query.  ``block`` is page-locked host memory (vq_host_alloc) laid out as vq_db_round_layout says
+ * (byte offsets, every piece 64-byte aligned):
+ *     off[0] query t [S][E][D] f64 (in)      off[1] weights [8] f64 (in)
+ *     off[2] avg [N][S] f64                  off[3] n_e [N][S] i32              off[4] scores [N] f64
+ *     off[5] result i64 [4] = n_match, n_near, near_argmax (-1: none), 0
+ *     off[6] the first off[9] match rows     off[7] the first off[9] near rows   (both in database order)
+ *     off[8] bytes of the block              off[9] rows in each prefix list (1 024)
+ * flags: 1 = take the query from the block and scan (ticket.py:120-163; else the similarities the handle holds are used),
+ *        2 = scores under the block's weights (ticket.py:165-180; fused into the scan when both are asked for),
+ *        4 = the order-preserving partition of vq_db_select under (threshold, lower).
+ * What was computed is copied back (from avg on after a scan, from scores on otherwise).  A list longer than its prefix is fetched in
+ * full with vq_db_select_fetch.  The handle's state afterwards is that of the separate calls (vq_db_set_query, vq_db_scan, vq_db_rescore,
+ * vq_db_select), whose results this call equals bit for bit (tests/test_ticket_gpu.py); per-query slot restrictions stay with
+ * vq_db_set_present. */
+int vq_db_round_layout(vq_db* db, int64_t off[10]);
+int vq_db_query_round(vq_db* db, void* block, int64_t block_bytes, int32_t flags, double threshold, double lower);
+/* Page-locked host memory for such blocks (device copies to and from it are asynchronous and need no staging). */
+int vq_host_alloc(void** ptr, int64_t bytes);
+int vq_host_free(void* ptr);
 /* Rows of the k largest scores, descending, ties by ascending row (the stable sort of the final
  * report, ticket.py:266).  *k_out = min(k, number of non-NaN scores). */
 int vq_db_topk(vq_db* db, int64_t k, int64_t* rows_host, double* vals_host, int64_t* k_out);
@@ -395,6 +421,25 @@ int vq_tsn_set_layer_tiles(vq_tsn* net, int32_t n_crops, const int32_t* tiles, i
 int vq_tsn_launch_items(vq_tsn* net, int32_t* item_of_layer, int32_t n_layers, int32_t* n_items);
 /* Batch sizes that hold a tiling table (autotuned or installed): *n of them, the first min(*n, cap) in sizes[]. */
 int vq_tsn_tuned_sizes(vq_tsn* net, int32_t* sizes, int32_t cap, int32_t* n);
+/* A handle holds one tiling table per (batch size, paired): ``paired`` tables belong to the SUB-BATCH sizes of the default forward
+ * (calcSig_wOF.py:88-113 runs one net.forward per snippet; here a batch is split into VQ_TSN_SPLIT sub-batches that run side by side on
+ * separate HIP streams, and a launch beside its twin prefers other tilings than one that has the chip to itself); un-paired tables
+ * belong to forwards that run on one stream.  vq_tsn_tile_tables lists them: *n tables, the first min(*n, cap) in sizes[] / flags[]
+ * (bit 0: paired; bit 1: borrowed from a neighbouring size within 1.6x instead of measured or installed -- such a table is never worth
+ * persisting).  vq_tsn_get_tiles / vq_tsn_set_tiles read / install one table (layout as vq_tsn_layer_tiles); the older
+ * vq_tsn_layer_tiles / vq_tsn_set_layer_tiles address the un-paired table of a size (reading falls back to the paired one).
+ * Tables come from three places, in this order: the machine's own tuning cache, the default tables shipped beside the library for the
+ * BASELINE shapes on gfx950 (tsn/default_tiles.json), a timing sweep inside the first forward of an unseen size (VQ_TSN_AUTOTUNE=0: the
+ * occupancy heuristic instead; =1: sweep even where a shipped table exists).  No table changes a result bit. */
+int vq_tsn_tile_tables(vq_tsn* net, int32_t* sizes, int32_t* flags, int32_t cap, int32_t* n);
+/* Whether a forward of (about) n_crops is cut into sub-batches on separate streams: split = 0: one stream (measured faster at that size:
+ * the flow network at 448 crops, tools/make_default_tiles.py), 1: sub-batches, -1: forget the entry.  A forward takes the entry of the
+ * nearest size within 1.6x; without one it splits (VQ_TSN_SPLIT).  Same bits either way. */
+int vq_tsn_set_split(vq_tsn* net, int32_t n_crops, int32_t split);
+/* Run the timing sweep for one table now (what the first forward of an unseen size does by itself; tools/make_default_tiles.py). */
+int vq_tsn_tune(vq_tsn* net, int32_t n_crops, int32_t paired);
+int vq_tsn_get_tiles(vq_tsn* net, int32_t n_crops, int32_t paired, int32_t* tiles, int32_t n_layers);
+int vq_tsn_set_tiles(vq_tsn* net, int32_t n_crops, int32_t paired, const int32_t* tiles, int32_t n_layers);
 /* Algorithmic FLOPs (2*MACs of the conv layers) of one crop, for roofline accounting. */
 int vq_tsn_flops_per_crop(vq_tsn* net, double* flops);
 

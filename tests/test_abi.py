@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(vqa._lib.LIB_PATH)
     for name in _declared():
         assert hasattr(raw, name), "libvqamd.so does not export %s" % name
-    assert lib.vq_abi_version() == vqa._lib.ABI_VERSION == 10
+    assert lib.vq_abi_version() == vqa._lib.ABI_VERSION == 11
 
 
 def test_ctypes_table_covers_the_header():

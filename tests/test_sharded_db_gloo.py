@@ -99,7 +99,23 @@ def _broker_round(name, sdb):
     tk.target = vqa.TargetClip(tk, hp)
     tk.target.get_target_features()
     assert sorted(tk.target.splits) == g["target_splits"]
-    tk.compute_similarities(hp)
+    announced = []
+    real_announce = type(sdb)._announce
+
+    def counting(self, op, ints=(), floats=()):
+        announced.append(op)
+        return real_announce(self, op, ints, floats)
+    type(sdb)._announce = counting
+    try:
+        tk.compute_similarities(hp)
+        tk.compute_scores(DEFAULT_WEIGHTS)
+        random.seed(a=SEED)
+        tk.select_clips_to_review(0.8, 20, 0.35)
+    finally:
+        type(sdb)._announce = real_announce
+    from video_query_algorithms_amd.sharded_db import OP_RESTRICT, OP_ROUND
+    assert [op for op in announced if op != OP_RESTRICT] == [OP_ROUND], announced      # the whole round: ONE announcement to the ranks
+    _same_matches(tk.matches, g["select_default"])
     assert list(tk.similarities.keys()) == g["clip_order"]
     for c, avg_row, n_row in zip(g["clip_order"], g["sim_avg"], g["sim_n"]):
         entry = tk.similarities[c]
@@ -211,6 +227,17 @@ def _spmd_worker(rank, world, port, n_total, tmp):
     wb = np.array([[1.0, 1.5], [1.0, 2.0]])
     got = sdb.scan_batch(tb, wb)
     assert got.shape == (2, n_total) and (got[0] == o_sc).all()
+    # the round as ONE operation: the arrays of the separate calls above, bit for bit -- with the scan ...
+    r1 = sdb.query_round(want_t, weights=[1.0, 1.5], select=(th, th - 0.2))
+    assert (r1.avg == o_avg).all() and (r1.n_e == o_ne).all() and r1.n_e.dtype == np.int32 and (r1.scores == o_sc).all()
+    assert (r1.match_rows == m).all() and (r1.near_rows == r).all() and r1.near_argmax == am
+    # ... and as a re-weighting of the similarities the ranks hold (no scan, no similarities back)
+    r2 = sdb.query_round(None, weights=[1.0, 0.7], select=(th, th - 0.2))
+    sc2 = so.dense_scores(o_avg, [1.0, 0.7])
+    assert r2.avg is None and (r2.scores == sc2).all() and (r2.match_rows == np.flatnonzero(sc2 >= th)).all()
+    assert (r2.near_rows == np.flatnonzero((th - 0.2 <= sc2) & (sc2 < th))).all() and (sdb.scores() == sc2).all()
+    with pytest.raises(ValueError):
+        sdb.query_round(None, weights=None, select=(th, th - 0.2))      # refused before anything is announced
     sdb.set_query(want_t * 2.0 if rank == 0 else None)                # SPMD: the root's vectors win
     sdb.scan(weights=None)
     assert (sdb.similarities()[0] == so.dense_similarities(x, want_t * 2.0)[1]).all()

@@ -151,7 +151,7 @@ def _check_select(vqa, scores, th, lower):
     return db, sc
 
 
-@pytest.mark.parametrize("n", [1, 7, 2048, 2049, 100003])
+@pytest.mark.parametrize("n", [1, 7, 2048, 2049, 16383, 16384, 16385, 100003])
 def test_select_partition_is_stable_and_complete(vqa, n):
     rng = np.random.default_rng(n)
     scores = rng.random(n)
@@ -165,8 +165,9 @@ def test_select_partition_is_stable_and_complete(vqa, n):
     _check_select(vqa, scores, -1.0, -2.0)                   # everything matches
 
 
-@pytest.mark.parametrize("n,k", [(1, 1), (50, 50), (5000, 20), (100003, 1000), (100003, 100003)])
+@pytest.mark.parametrize("n,k", [(1, 1), (50, 50), (5000, 20), (16384, 1024), (9001, 1000), (16385, 20), (5000, 1025), (100003, 1000), (100003, 100003)])
 def test_topk_sorted_stable(vqa, n, k):
+    """n <= 16 384 and k <= 1 024: the one-workgroup kernel (keys in LDS); everything else: the radix-select launch sequence."""
     rng = np.random.default_rng(k)
     scores = np.round(rng.random(n), 3)                       # many exact ties
     if n > 10:
@@ -549,10 +550,24 @@ def test_a_topk_between_select_and_fetch_is_detected(vqa):
     import ctypes as C
     from video_query_algorithms_amd._lib import call
     rng = np.random.default_rng(4)
-    db = vqa.FeatureDB(5000, 2, 1, 1024)
+    # a small database's top-k (one workgroup, own scratch) leaves the selection lists alone: the fetch then returns them, correct
+    small = vqa.FeatureDB(5000, 2, 1, 1024)
     sc = rng.random(5000)
+    small.write_avg(np.stack([sc, sc], axis=1), np.ones((5000, 2), dtype=np.int32))
+    small.rescore([1.0, 1.0])
+    got = small.scores()
+    nm, nn, am = C.c_int64(), C.c_int64(), C.c_int64()
+    call("vq_db_select", small._h, 0.7, 0.6, C.byref(nm), C.byref(nn), C.byref(am))
+    small.topk(10)
+    m = np.empty(nm.value, dtype=np.int64)
+    r = np.empty(nn.value, dtype=np.int64)
+    call("vq_db_select_fetch", small._h, m.ctypes.data_as(C.c_void_p), m.size, r.ctypes.data_as(C.c_void_p), r.size)
+    assert np.array_equal(m, np.flatnonzero(got >= 0.7)) and np.array_equal(r, np.flatnonzero((0.6 <= got) & (got < 0.7)))
+    small.close()
+    db = vqa.FeatureDB(20000, 2, 1, 1024)
+    sc = rng.random(20000)
     avg = np.stack([sc, sc], axis=1)
-    db.write_avg(avg, np.ones((5000, 2), dtype=np.int32))
+    db.write_avg(avg, np.ones((20000, 2), dtype=np.int32))
     db.rescore([1.0, 1.0])
     got = db.scores()
     nm, nn, am = C.c_int64(), C.c_int64(), C.c_int64()

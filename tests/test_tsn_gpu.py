@@ -69,7 +69,8 @@ CONV_CASES = [
                                   "128x128x16", "128x96x16", "128x64x16", "128x32x16", "64x64x16", "64x128x16",
                                   "128x128x32x1", "128x96x32x1", "128x64x32x1", "128x32x32x1", "64x64x32x1", "64x128x32x1",
                                   "128x128x16x1", "128x96x16x1", "128x64x16x1", "128x32x16x1", "64x64x16x1", "64x128x16x1",
-                                  "32x128", "32x128x16", "32x128x32x1", "32x128x16x1"])
+                                  "32x128", "32x128x16", "32x128x32x1", "32x128x16x1",
+                                  "256x64", "256x64x16", "256x64x32x1", "256x64x16x1"])
 def test_conv_bn_relu_layer(tsn, monkeypatch, cin, h, cout, k, s, p, n, tile):
     bi, net = tsn
     if tile:
@@ -645,10 +646,10 @@ def test_every_winograd_variant_writes_all_it_owns(tsn, monkeypatch, channels, s
     m.forward(crops, 3, mean)
     got = {}
     for variant in (0, 1):
-        for n in m.tuned_sizes():
-            t = m.layer_tiles(n)
+        for n, paired, _ in m.tile_tables():
+            t = m.layer_tiles(n, paired=paired)
             t[t[:, 3] == 2, 1] = 32 * (variant + 1)
-            m.set_layer_tiles(n, t)
+            m.set_layer_tiles(n, t, paired=paired)
         f, p = m.forward(crops, 3, mean)
         assert np.isfinite(p).all() and np.isfinite(f).all()
         for name in m.plan.blob_loc:
@@ -942,7 +943,7 @@ def test_tiling_tables_survive_the_process(tsn, monkeypatch, tmp_path):
     tiles = m.layer_tiles(3)
     m.close()
     files = glob.glob(str(tmp_path / "*.json"))
-    assert len(files) == 1 and list(json.load(open(files[0]))) == ["3"]
+    assert len(files) == 1 and list(json.load(open(files[0]))) == ["3p"]          # timed side by side on the two sub-batch streams
     m = net.TsnNet(g, w, max_crops=6)
     assert m.tuned_sizes() == [3] and (m.layer_tiles(3) == tiles).all()      # installed before any forward
     f2, p2 = m.forward(crops, 3, net.RGB_MEAN)
@@ -963,7 +964,7 @@ def test_tiling_tables_survive_the_process(tsn, monkeypatch, tmp_path):
     forced = tiles.copy()
     conv = forced[:, 0] > 0
     forced[conv & (forced[:, 3] != 2), :] = (64, 64, 32, 0)
-    m.set_layer_tiles(3, forced)
+    m.set_layer_tiles(3, forced, paired=True)
     f3, _ = m.forward(crops, 3, net.RGB_MEAN)
     m.forward(np.concatenate([crops, crops]), 3, net.RGB_MEAN)                # 12 crops: sub-batches of 6, a size without a table
     assert sorted(m.tuned_sizes()) == [3, 6]
@@ -999,3 +1000,53 @@ def test_features_from_cached_packed_weights_equal_features_from_the_weights(tmp
     net.close()
     assert loads == [path, path]
     assert (feats[0] == feats[1]).all() and (feats[0] == feats[2]).all() and np.isfinite(feats[0]).all()
+
+
+def test_shipped_tiling_tables_make_a_cold_process_time_nothing(tsn, monkeypatch, tmp_path):
+    """tsn/default_tiles.json (tools/make_default_tiles.py, measured on an MI355X) holds the tables of both
+    BN-Inception streams at the BASELINE batch sizes; a handle with no tuning cache installs them at creation, so the first forward of
+    a cold process sweeps nothing.  Sizes in between borrow (flagged, never persisted); VQ_TSN_AUTOTUNE=1 leaves the shipped tables
+    out and sweeps; the bits never depend on any of it."""
+    import glob
+    import json
+    bi, net = tsn
+    monkeypatch.delenv("VQ_TSN_AUTOTUNE", raising=False)
+    monkeypatch.delenv("VQ_TSN_SPLIT", raising=False)
+    monkeypatch.setenv("VQ_TUNE_CACHE", str(tmp_path))
+    shipped = json.load(open(net.DEFAULT_TILES_PATH))["tables"]
+    feats = {}
+    for ch in (3, 10):
+        g = bi.bn_inception(ch)
+        w = net.synthetic_weights(g, seed=2)
+        mean = net.RGB_MEAN if ch == 3 else net.FLOW_MEAN
+        crops = np.random.default_rng(ch).integers(0, 256, (60, 224, 224, ch), dtype=np.uint8)
+        m = net.TsnNet(g, w, max_crops=96)
+        assert m.graph_key in shipped and m.default_tables == 4
+        assert sorted(m.tile_tables()) == [(24, True, False), (48, False, False), (48, True, False), (96, False, False)]
+        before = {(n, p): m.layer_tiles(n, paired=p).copy() for n, p, _ in m.tile_tables()}
+        f48, _ = m.forward(crops[:48], 3, mean)                        # sub-batches of 24: the shipped paired table
+        assert sorted(m.tile_tables()) == sorted((n, p, False) for n, p in before)
+        f60, _ = m.forward(crops, 3, mean)                             # sub-batches of 30: borrowed from 24p, nothing timed
+        assert (30, True, True) in m.tile_tables() and (m.layer_tiles(30, paired=True) == before[(24, True)]).all()
+        for key, t in before.items():
+            assert (m.layer_tiles(key[0], paired=key[1]) == t).all()
+        m.close()
+        assert glob.glob(str(tmp_path / "*.json")) == []               # nothing measured: nothing to keep
+        feats[ch] = (crops, mean, g, w, f48, f60)
+    crops, mean, g, w, f48, f60 = feats[3]
+    monkeypatch.setenv("VQ_TSN_AUTOTUNE", "1")                         # the refinement: shipped tables out, every size swept and kept
+    m = net.TsnNet(g, w, max_crops=96)
+    assert m.default_tables == 0 and m.tile_tables() == []
+    g48, _ = m.forward(crops[:48], 3, mean)
+    assert m.tile_tables() == [(24, True, False)]
+    m.close()
+    files = glob.glob(str(tmp_path / "*.json"))
+    assert len(files) == 1 and list(json.load(open(files[0]))) == ["24p"]
+    assert (g48 == f48).all()
+    monkeypatch.setenv("VQ_TSN_AUTOTUNE", "0")                         # never time anything: shipped tables, heuristics elsewhere
+    monkeypatch.setenv("VQ_TUNE_CACHE", "0")
+    m = net.TsnNet(g, w, max_crops=96)
+    assert m.default_tables == 4
+    h60, _ = m.forward(crops, 3, mean)
+    m.close()
+    assert (h60 == f60).all()

@@ -210,3 +210,31 @@ def test_to_prototxt_round_trips_through_the_reader():
         g = bi.bn_inception(c)
         back = bi.parse_prototxt(bi.to_prototxt(g))
         assert back.layers == g.layers and back.input_shape == g.input_shape
+
+
+def test_the_shipped_tiling_tables_are_well_formed():
+    """video-query-algorithms_amd/tsn/default_tiles.json: one table set per BN-Inception stream, tables named "<crops>" (one stream) or
+    "<crops>p" (timed side by side on the two sub-batch streams), [BM, BN, BK, pipelined] per layer with the layer counts of the lowered
+    graphs; paired sizes are the halves of the one-stream sizes."""
+    import json
+    import re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-query-algorithms_amd", "tsn", "default_tiles.json")
+    doc = json.load(open(path))
+    assert len(doc["tables"]) == 2 and doc["sizes"] == [48, 96, 224, 448, 800]
+    for key, tab in doc["tables"].items():
+        assert re.fullmatch(r"[0-9a-f]{20}", key)
+        alone = sorted(int(n) for n in tab if re.fullmatch(r"\d+", n))
+        paired = sorted(int(n[:-1]) for n in tab if re.fullmatch(r"\d+p", n))
+        assert alone == doc["sizes"] and paired == [n // 2 for n in doc["sizes"]]
+        lengths = {len(t) for n, t in tab.items() if n != "one_stream"}
+        assert len(lengths) == 1
+        for n, t in tab.items():
+            if n == "one_stream":
+                assert all(int(v) in doc["sizes"] for v in t)
+                continue
+            rows = np.array(t)
+            assert rows.shape[1] == 4 and (rows >= 0).all()
+            conv = rows[rows[:, 0] > 0]
+            assert len(conv) >= 40 and set(conv[:, 3].tolist()) <= {0, 1, 2, 3}
+            wino = conv[conv[:, 3] == 2]
+            assert len(wino) == 27 and set(wino[:, 1].tolist()) <= {32, 64} and (wino[:, 2] == 8).all()

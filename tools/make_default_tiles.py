@@ -1,0 +1,101 @@
+"""Measure the tiling tables that ship with the library (video-query-algorithms_amd/tsn/default_tiles.json): both BN-Inception streams at
+the BASELINE batch sizes (48, 96, 224, 448, 800 crops: one-stream tables; their halves: the paired tables of the default forward's two
+sub-batches).  Per table the sweep of vq_tsn_tune runs REPEATS times; the candidates are then timed as whole forwards, interleaved, and
+the fastest table is kept -- a single sweep's choice moves the step by 1-2.5 % at cfg 2 and up to 9 % at cfg 3.
+Run on the GPU box:  python3 tools/make_default_tiles.py [out.json]   (writes gpurun_out/default_tiles.json by default; copy it to
+video-query-algorithms_amd/tsn/default_tiles.json).  No tiling changes a result bit (tests/test_tsn_gpu.py)."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+os.environ["VQ_TSN_AUTOTUNE"] = "1"          # no shipped tables in the handles of this process
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import video_query_algorithms_amd as vqa  # noqa: F401
+from video_query_algorithms_amd._lib import call
+from video_query_algorithms_amd.tsn import bn_inception, net
+
+SIZES = (48, 96, 224, 448, 800)
+REPEATS = int(os.environ.get("VQ_TILES_REPEATS", "3"))
+
+
+def time_forwards(m, crops, n, T, mean, paired, reps):
+    """ms per forward of n crops: product mode (two sub-batch streams: the paired tables of n / 2) or one stream (the table of n)."""
+    if paired:
+        m.set_profile(0)
+    else:
+        m.set_profile(1, every=1 << 30)      # one stream; only the first forward carries events
+    tm = C.c_void_p()
+    call("vq_timer_create", C.byref(tm))
+    for _ in range(3):
+        m.forward_device(crops.data_ptr(), n, T, mean)
+    call("vq_timer_start", tm, None)
+    for _ in range(reps):
+        m.forward_device(crops.data_ptr(), n, T, mean)
+    call("vq_timer_stop", tm, None)
+    ms = C.c_float()
+    call("vq_timer_elapsed_ms", tm, C.byref(ms))
+    m.set_profile(0)
+    return ms.value / reps
+
+
+def main():
+    out_path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/default_tiles.json"
+    tables, report = {}, []
+    for ch in (3, 10):
+        g = bn_inception.bn_inception(ch)
+        w = net.synthetic_weights(g, seed=2)
+        m = net.TsnNet(g, w, max_crops=max(SIZES), tune_cache="0")
+        mean = net.RGB_MEAN if ch == 3 else net.FLOW_MEAN
+        crops = torch.randint(0, 256, (max(SIZES), 224, 224, ch), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        tab = tables.setdefault(m.graph_key, {})
+        kept_tables = {False: [], True: []}      # the tables kept for the sizes before this one: candidates for it too (a neighbour's
+                                                 # table sometimes beats every sweep of the size itself)
+        for n in SIZES:
+            T = 1
+            ms_of = {}
+            for paired in (False, True):
+                size = n // 2 if paired else n
+                reps = max(4, min(40, int(4000 / n)))
+                cands = []
+                for r in range(REPEATS):
+                    t0 = time.perf_counter()
+                    m.tune(size, paired)
+                    cands.append(m.layer_tiles(size, paired=paired).copy())
+                    print("ch=%d n=%d %s sweep %d: %.1f s" % (ch, size, "paired" if paired else "alone", r, time.perf_counter() - t0), flush=True)
+                uniq = []
+                for c in cands + kept_tables[paired]:
+                    if not any((c == u).all() for u in uniq):
+                        uniq.append(c)
+                times = [[] for _ in uniq]
+                for _ in range(3):                               # interleaved: the box's clock drifts
+                    for i, c in enumerate(uniq):
+                        m._install_tiles(size, c, paired)
+                        times[i].append(time_forwards(m, crops, n, T, mean, paired, reps))
+                med = [sorted(t)[1] for t in times]
+                best = int(np.argmin(med))
+                m._install_tiles(size, uniq[best], paired)
+                kept_tables[paired].append(uniq[best])
+                ms_of[paired] = med[best]
+                tab["%d%s" % (size, "p" if paired else "")] = uniq[best].tolist()
+                report.append({"channels": ch, "forward_crops": n, "table": "%d%s" % (size, "p" if paired else ""), "candidates": len(uniq),
+                               "ms_per_forward": [round(v, 4) for v in med], "kept": best})
+                print(report[-1], flush=True)
+            if ms_of[False] < 0.99 * ms_of[True]:              # this size runs faster on ONE stream than as two sub-batches
+                tab.setdefault("one_stream", []).append(n)
+                print("ch=%d n=%d: one stream %.3f ms < two sub-batches %.3f ms" % (ch, n, ms_of[False], ms_of[True]), flush=True)
+        m.close()
+        del crops
+    os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+    with open(out_path, "w") as f:
+        json.dump({"device": torch.cuda.get_device_name(0), "made_by": "tools/make_default_tiles.py", "sizes": list(SIZES), "repeats": REPEATS,
+                   "report": report, "tables": tables}, f)
+    print("wrote", out_path)
+
+
+if __name__ == "__main__":
+    main()

@@ -6,7 +6,10 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0")) for r in rows))
 # forwards are delimited by preprocess_kernel launches
-starts = [i for i, k in enumerate(ks) if "preprocess" in k[2]]
+# (a forward on two sub-batch streams begins with one preprocess launch per stream: launches that follow each other within
+# 100 us are one beginning)
+pre = [i for i, k in enumerate(ks) if "preprocess" in k[2]]
+starts = [i for n, i in enumerate(pre) if n == 0 or ks[i][0] - ks[pre[n - 1]][0] > 100_000]
 print("%d kernels, %d forwards" % (len(ks), len(starts)))
 for a, b in list(zip(starts, starts[1:] + [len(ks)]))[-4:]:
     seg = ks[a:b]

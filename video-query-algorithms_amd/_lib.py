@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvqamd.so")
 
-ABI_VERSION = 10                 # include/vq_amd.h: VQ_ABI_VERSION
+ABI_VERSION = 11                 # include/vq_amd.h: VQ_ABI_VERSION
 VQ_F32, VQ_F64 = 0, 1
 VQ_LAYOUT_ROWS, VQ_LAYOUT_TILED = 0, 1
 VQ_OP_CONV, VQ_OP_MAXPOOL, VQ_OP_AVGPOOL, VQ_OP_GLOBAL_AVGPOOL, VQ_OP_CONV_WINOGRAD = 1, 2, 3, 4, 5
@@ -80,6 +80,7 @@ SIGNATURES = {
     "vq_db_scores_grid": [_P, _P, _I32, _P, _I32, _P],
     "vq_db_select": [_P, _F64, _F64, _pI64, _pI64, _pI64], "vq_db_select_fetch": [_P, _P, _I64, _P, _I64],
     "vq_db_select_rows": [_P, _F64, _F64, _P, _I64, _P, _I64, _pI64, _pI64, _pI64],
+    "vq_db_round_layout": [_P, _P], "vq_db_query_round": [_P, _P, _I64, _I32, _F64, _F64], "vq_host_alloc": [_PP, _I64], "vq_host_free": [_P],
     "vq_db_topk": [_P, _I64, _P, _P, _pI64], "vq_db_min_score": [_P, _P, _I32, _pF64],
     "vq_resize_crop": [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _P],
     "vq_resize_crop_planes": [_P, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P],
@@ -90,6 +91,8 @@ SIGNATURES = {
     "vq_tsn_feat_devptr": [_P, _PP, _PP], "vq_tsn_read_tensor": [_P, _I32, _I32, _P],
     "vq_tsn_flops_per_crop": [_P, _pF64], "vq_tsn_launch_items": [_P, _P, _I32, _pI32], "vq_tsn_tuned_sizes": [_P, _P, _I32, _pI32],
     "vq_tsn_layer_tiles": [_P, _I32, _P, _I32], "vq_tsn_set_layer_tiles": [_P, _I32, _P, _I32],
+    "vq_tsn_tile_tables": [_P, _P, _P, _I32, _pI32], "vq_tsn_get_tiles": [_P, _I32, _I32, _P, _I32], "vq_tsn_set_tiles": [_P, _I32, _I32, _P, _I32],
+    "vq_tsn_tune": [_P, _I32, _I32], "vq_tsn_set_split": [_P, _I32, _I32],
     "vq_tsn_set_profile": [_P, _I32], "vq_tsn_set_profile_every": [_P, _I32], "vq_tsn_set_profile_split": [_P, _I32], "vq_tsn_layer_times": [_P, _P, _P, _I32],
     "vq_tvl1_default_params": [C.POINTER(Tvl1Params)],
     "vq_flow_create": [_I32, _I32, _I32, C.POINTER(Tvl1Params), _I32, _PP], "vq_flow_destroy": [_P],

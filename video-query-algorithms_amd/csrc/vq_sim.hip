@@ -854,7 +854,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void select_scan_kernel(int2* blk_cnt, c
 // pass 3: scatter rows in original order.  class-1 rows beyond `limit1` (in order) are dropped.
 __global__ __launch_bounds__(SEL_BLOCK) void select_scatter_kernel(const double* scores, int64_t n, SelPred pred,
                                                                     const int2* blk_off, int64_t* out0, int64_t* out1,
-                                                                    int64_t limit1) {
+                                                                    int64_t limit1, int64_t* pre0, int64_t* pre1, int64_t prefix) {
     const int64_t base = (int64_t)blockIdx.x * SEL_CHUNK + (int64_t)threadIdx.x * SEL_ITEMS;
     int flags[SEL_ITEMS];
     int2 cnt = make_int2(0, 0);
@@ -871,11 +871,103 @@ __global__ __launch_bounds__(SEL_BLOCK) void select_scatter_kernel(const double*
     int64_t o1 = (int64_t)blk_off[blockIdx.x].y + ex.y;
 #pragma unroll
     for (int i = 0; i < SEL_ITEMS; ++i) {
-        if (flags[i] & 1) out0[o0++] = base + i;
+        if (flags[i] & 1) {
+            if (o0 < prefix) pre0[o0] = base + i;            // the head of each list a second time, next to the counts (one copy back)
+            out0[o0++] = base + i;
+        }
         if (flags[i] & 2) {
-            if (limit1 < 0 || o1 < limit1) out1[o1] = base + i;
+            if (limit1 < 0 || o1 < limit1) {
+                out1[o1] = base + i;
+                if (o1 < prefix) pre1[o1] = base + i;
+            }
             ++o1;
         }
+    }
+}
+
+// The three passes above as ONE launch of one workgroup for a small database (n <= kSelSmallN): a thread owns a run of consecutive
+// rows, counts / first-arg-max / offsets meet in LDS.  Same lists, same counts, same arg-max as the three-kernel form (tested).
+constexpr int kSelSmallN = 16384, kSelSmallThreads = 1024;
+__global__ __launch_bounds__(kSelSmallThreads) void select_small_kernel(const double* scores, int n, SelPred pred, int64_t* result, int64_t* out0,
+                                                                        int64_t* out1, int64_t* pre0, int64_t* pre1, int prefix) {
+    __shared__ int2 s_wave[kSelSmallThreads / 64];
+    __shared__ double s_max[kSelSmallThreads / 64];
+    __shared__ int s_arg[kSelSmallThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int per = (n + kSelSmallThreads - 1) / kSelSmallThreads;          // <= 16
+    const int r0 = tid * per, r1 = min(n, r0 + per);
+    int2 cnt = make_int2(0, 0);
+    unsigned flags = 0;                                                     // 2 bits per row of the run
+    double bmax = -INFINITY;
+    int barg = -1;
+    for (int r = r0; r < r1; ++r) {
+        const double v = scores[r];
+        const int f = pred(v);
+        flags |= (unsigned)f << (2 * (r - r0));
+        cnt.x += f & 1;
+        cnt.y += (f >> 1) & 1;
+        if ((f & 2) && (barg < 0 || v > bmax)) {                             // first maximum of the run
+            bmax = v;
+            barg = r;
+        }
+    }
+    int2 inc = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int ax = __shfl_up(inc.x, off, 64), ay = __shfl_up(inc.y, off, 64);
+        if (lane >= off) {
+            inc.x += ax;
+            inc.y += ay;
+        }
+    }
+    // first arg-max across the wave: larger value wins, ties go to the smaller row
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ov = __shfl_down(bmax, off, 64);
+        const int oa = __shfl_down(barg, off, 64);
+        if (lane + off < 64 && oa >= 0 && (barg < 0 || ov > bmax || (ov == bmax && oa < barg))) {
+            bmax = ov;
+            barg = oa;
+        }
+    }
+    if (lane == 63) s_wave[wid] = inc;
+    if (lane == 0) {
+        s_max[wid] = bmax;
+        s_arg[wid] = barg;
+    }
+    __syncthreads();
+    int2 base = make_int2(0, 0), tot = make_int2(0, 0);
+    for (int i = 0; i < kSelSmallThreads / 64; ++i) {
+        if (i < wid) {
+            base.x += s_wave[i].x;
+            base.y += s_wave[i].y;
+        }
+        tot.x += s_wave[i].x;
+        tot.y += s_wave[i].y;
+    }
+    int o0 = base.x + inc.x - cnt.x, o1 = base.y + inc.y - cnt.y;
+    for (int r = r0; r < r1; ++r) {
+        const unsigned f = (flags >> (2 * (r - r0))) & 3u;
+        if (f & 1u) {
+            if (o0 < prefix) pre0[o0] = r;
+            out0[o0++] = r;
+        }
+        if (f & 2u) {
+            if (o1 < prefix) pre1[o1] = r;
+            out1[o1++] = r;
+        }
+    }
+    if (tid == 0) {
+        double gmax = -INFINITY;
+        int garg = -1;
+        for (int i = 0; i < kSelSmallThreads / 64; ++i)                      // in row order: the first maximum wins
+            if (s_arg[i] >= 0 && (garg < 0 || s_max[i] > gmax)) {
+                gmax = s_max[i];
+                garg = s_arg[i];
+            }
+        result[0] = tot.x;
+        result[1] = tot.y;
+        result[2] = garg;
     }
 }
 
@@ -913,6 +1005,143 @@ __global__ void topk_pick_kernel(int pass, uint64_t* state, unsigned int* hist) 
     for (int i = 0; i < 256; ++i) hist[i] = 0;
 }
 
+// The same selection for a SMALL database (n <= kTopkSmallN, k <= kTopkSmallK) as ONE launch of one workgroup: the order keys live in
+// LDS, the eight histogram passes and the stable compaction are separated by barriers instead of 19 launches and three
+// synchronisations (a 10k-clip top-20: ~0.15 ms of launch sequence -> one launch and one copy).  Same survivors in the same (row)
+// order as the general path: keys above the pivot first, then the first `need` rows that tie with it.
+constexpr int kTopkSmallN = 16384, kTopkSmallK = 1024, kTopkSmallThreads = 1024;
+__global__ __launch_bounds__(kTopkSmallThreads) void topk_small_kernel(const double* scores, int n, int k, int64_t* out_rows, double* out_vals,
+                                                                       int64_t* out_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char topk_lds[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(topk_lds);          // [n]
+    __shared__ unsigned int hist[256];
+    __shared__ uint64_t s_prefix;
+    __shared__ unsigned int s_need;
+    __shared__ int2 s_wave[kTopkSmallThreads / 64];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += kTopkSmallThreads) keys[i] = order_key(scores[i]);
+    if (tid == 0) {
+        s_prefix = 0ull;
+        s_need = (unsigned)k;
+    }
+    for (int pass = 0; pass < 8; ++pass) {
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const int shift = 56 - 8 * pass;
+        const uint64_t prefix = s_prefix;
+        const uint64_t mask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+        // the keys of a pass crowd into few bins (every score of a ranking shares its sign and most of its exponent): the lanes that
+        // agree with the wave's first live lane are counted by ONE atomic, the others add themselves
+        for (int i0 = 0; i0 < n; i0 += kTopkSmallThreads) {
+            const int i = i0 + tid;
+            const uint64_t key = i < n ? keys[i] : 0ull;
+            const bool live = key != 0ull && (key & mask) == prefix;
+            const int digit = live ? (int)((key >> shift) & 255) : -1;
+            const unsigned long long act = __ballot(live);
+            if (act) {
+                const int lead = __ffsll((long long)act) - 1;
+                const int first = __shfl(digit, lead, 64);
+                const unsigned long long same = __ballot(digit == first);
+                if ((tid & 63) == lead)
+                    atomicAdd(&hist[first], (unsigned)__popcll(same));
+                else if (live && digit != first)
+                    atomicAdd(&hist[digit], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {                                              // topk_pick_kernel, by one wave: lane l owns bins 4l .. 4l+3
+            const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            unsigned above = h0 + h1 + h2 + h3;                      // inclusive suffix sum over the lanes: bins >= 4l
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = __shfl_down(above, off, 64);
+                if (tid + off < 64) above += o;
+            }
+            const unsigned need = s_need;
+            const unsigned gt3 = above - (h0 + h1 + h2 + h3);        // elements in bins > 4l+3
+            // the bin b the serial walk from 255 downwards stops in: the highest b with count(bins >= b) >= need (b = 0 if none)
+            int found = -1;
+            unsigned rest = 0;
+            if (gt3 + h3 >= need) {
+                found = 4 * tid + 3;
+                rest = need - gt3;
+            } else if (gt3 + h3 + h2 >= need) {
+                found = 4 * tid + 2;
+                rest = need - gt3 - h3;
+            } else if (gt3 + h3 + h2 + h1 >= need) {
+                found = 4 * tid + 1;
+                rest = need - gt3 - h3 - h2;
+            } else if (gt3 + h3 + h2 + h1 + h0 >= need) {
+                found = 4 * tid;
+                rest = need - gt3 - h3 - h2 - h1;
+            }
+            const unsigned long long have = __ballot(found >= 0 && gt3 < need);   // lanes whose own bins contain the stop
+            // the stop lies in the HIGHEST lane for which bins above it hold fewer than `need` and its own close the gap
+            const int top = have ? 63 - __builtin_clzll(have) : -1;
+            if (top < 0) {
+                if (tid == 0) {                                      // fewer than `need` keys under this prefix: bin 0, need minus all above it
+                    s_prefix = prefix;
+                    s_need = need - (above - h0);
+                }
+            } else if (tid == top) {
+                if (found == 0) rest = need - (above - h0);          // the serial walk never tests bin 0: it takes what is left
+                s_prefix = prefix | ((uint64_t)found << shift);
+                s_need = rest;
+            }
+        }
+        __syncthreads();
+    }
+    const uint64_t pivot = s_prefix;
+    const int need = (int)s_need;
+    // stable compaction: a thread owns a run of consecutive rows
+    const int per = (n + kTopkSmallThreads - 1) / kTopkSmallThreads;
+    const int r0 = tid * per, r1 = min(n, r0 + per);
+    int2 cnt = make_int2(0, 0);
+    for (int r = r0; r < r1; ++r) {
+        const uint64_t key = keys[r];
+        cnt.x += key > pivot ? 1 : 0;
+        cnt.y += (key == pivot && key != 0ull) ? 1 : 0;
+    }
+    const int lane = tid & 63, wid = tid >> 6;
+    int2 inc = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int ax = __shfl_up(inc.x, off, 64), ay = __shfl_up(inc.y, off, 64);
+        if (lane >= off) {
+            inc.x += ax;
+            inc.y += ay;
+        }
+    }
+    if (lane == 63) s_wave[wid] = inc;
+    __syncthreads();
+    int2 base = make_int2(0, 0), tot = make_int2(0, 0);
+    for (int i = 0; i < kTopkSmallThreads / 64; ++i) {
+        if (i < wid) {
+            base.x += s_wave[i].x;
+            base.y += s_wave[i].y;
+        }
+        tot.x += s_wave[i].x;
+        tot.y += s_wave[i].y;
+    }
+    int o0 = base.x + inc.x - cnt.x, o1 = base.y + inc.y - cnt.y;
+    const int n_gt = tot.x, n_eq = min(tot.y, need);
+    for (int r = r0; r < r1; ++r) {
+        const uint64_t key = keys[r];
+        if (key > pivot) {
+            out_rows[o0] = r;
+            out_vals[o0] = scores[r];
+            ++o0;
+        } else if (key == pivot && key != 0ull) {
+            if (o1 < need) {
+                out_rows[n_gt + o1] = r;
+                out_vals[n_gt + o1] = scores[r];
+            }
+            ++o1;
+        }
+    }
+    if (tid == 0) out_count[0] = n_gt + n_eq;
+}
+
 // rows of the database -> a dense [cnt][row_elems] block (vq_db_read_rows: the few validated clips a sharded round sends to the
 // rank that solves the bootstrapping problems).  16 bytes per thread.
 __global__ void gather_rows_kernel(const uint4* feats, const int64_t* rows, int64_t cnt, int64_t row_vec16, uint4* out, int tiled_nv, int tiled_d4) {
@@ -936,6 +1165,22 @@ __global__ void gather_scores_kernel(const double* scores, const int64_t* rows, 
 // ------------------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------------------
+// The results of a query round, device block and (behind the query and the weights) host block alike: avg [N][S] f64 | ne [N][S] i32 |
+// scores [N] f64 | result [4] i64 (n_match, n_near, near_argmax, 0) | first kRoundPrefix match rows | first kRoundPrefix near rows;
+// every piece starts on a 64-byte boundary.  off[0..5] = the pieces, off[6] = bytes.
+constexpr int64_t kRoundPrefix = 1024;
+static void round_layout(int64_t n, int S, int64_t off[8]) {
+    auto up = [](int64_t v) { return (v + 63) / 64 * 64; };
+    off[0] = 0;
+    off[1] = off[0] + up(n * S * 8);
+    off[2] = off[1] + up(n * S * 4);
+    off[3] = off[2] + up(n * 8);
+    off[4] = off[3] + 64;
+    off[5] = off[4] + kRoundPrefix * 8;
+    off[6] = off[5] + kRoundPrefix * 8;
+    off[7] = 0;
+}
+
 struct vq_db {
     std::mutex mu;
     int device = 0;
@@ -957,6 +1202,12 @@ struct vq_db {
     double* avg = nullptr;      // [N][S]
     int32_t* ne = nullptr;      // [N][S]
     double* scores = nullptr;   // [N]
+    // avg | ne | scores | sel_result | match prefix | near prefix are ONE device allocation (round_dev), in the order of the host
+    // block of vq_db_query_round: a round's results go back in one copy
+    char* round_dev = nullptr;
+    int64_t round_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // byte offsets of avg, ne, scores, result, matchp, nearp; [6] = total
+    int64_t* matchp = nullptr;       // first kRoundPrefix rows of the last selection's match list
+    int64_t* nearp = nullptr;
     // selection scratch
     int nblk = 0;
     int2* blk_cnt = nullptr;
@@ -979,8 +1230,8 @@ struct vq_db {
 
 static int db_free(vq_db* db) {
     if (db->owns_feats && db->feats) (void)hipFree(db->feats);
-    void* ptrs[] = {db->present, db->t,       db->w,        db->sims,  db->avg,      db->ne,      db->scores, db->blk_cnt,
-                    db->blk_max, db->blk_arg, db->sel_result, db->rows0, db->rows1, db->tk_state, db->tk_hist, db->grid_buf, db->batch_buf};
+    void* ptrs[] = {db->present, db->t,       db->sims,  db->round_dev, db->blk_cnt,
+                    db->blk_max, db->blk_arg, db->rows0, db->rows1, db->tk_state, db->tk_hist, db->grid_buf, db->batch_buf};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     return VQ_OK;
@@ -1160,15 +1411,19 @@ int vq_db_create(int64_t n, int32_t S, int32_t E, int32_t D, int32_t dtype, int3
     } while (0)
     A_(db->feats, fbytes);
     if (n % 16) (void)hipMemset((char*)db->feats + (size_t)n * S * E * D * db->elem(), 0, fbytes - (size_t)n * S * E * D * db->elem());
-    A_(db->t, (size_t)S * E * D * 8);
-    A_(db->w, 8 * 8);
-    A_(db->avg, (size_t)n * S * 8);
-    A_(db->ne, (size_t)n * S * 4);
-    A_(db->scores, (size_t)n * 8);
+    A_(db->t, ((size_t)S * E * D * 8 + 63) / 64 * 64 + 64);      // query | weights [8]: adjacent, like the head of a round's host block
+    db->w = (double*)((char*)db->t + ((size_t)S * E * D * 8 + 63) / 64 * 64);
+    round_layout(n, S, db->round_off);
+    A_(db->round_dev, (size_t)db->round_off[6]);
+    db->avg = (double*)(db->round_dev + db->round_off[0]);
+    db->ne = (int32_t*)(db->round_dev + db->round_off[1]);
+    db->scores = (double*)(db->round_dev + db->round_off[2]);
+    db->sel_result = (int64_t*)(db->round_dev + db->round_off[3]);
+    db->matchp = (int64_t*)(db->round_dev + db->round_off[4]);
+    db->nearp = (int64_t*)(db->round_dev + db->round_off[5]);
     A_(db->blk_cnt, (size_t)db->nblk * sizeof(int2));
     A_(db->blk_max, (size_t)db->nblk * 8);
     A_(db->blk_arg, (size_t)db->nblk * 8);
-    A_(db->sel_result, 3 * 8);
     A_(db->rows0, (size_t)n * 8);
     A_(db->rows1, (size_t)n * 8);
     A_(db->tk_state, 2 * 8);
@@ -1396,6 +1651,9 @@ static int launch_scan_t(vq_db* db, const ScanArgs& a) {
     }
     auto kern = scan_kernel<T, S, E, CH>;
     VQ_DYN_LDS(kern, lds);
+    // (as many waves as fit the chip.  Fewer waves that each walk the same number of clips -- 2 500 waves of exactly four clips for a
+    // 10 000-clip database instead of 3 072 of three or four -- were measured in round 6: 62.9 against 56.8 us per scan; the streams in
+    // flight matter more than the ragged last round.)
     const int64_t want = (a.n + 3) / 4;   // 4 waves (clips in flight) per block
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)db->cus * per_cu));
     kern<<<grid, 256, lds, db->stream>>>(a);
@@ -1423,7 +1681,16 @@ static int launch_scan(vq_db* db, const ScanArgs& a) {
     return VQ_OK;
 }
 
-static int run_select(vq_db* db, const SelPred& pred, int64_t limit1, int64_t host_result[3]) {
+static int run_select(vq_db* db, const SelPred& pred, int64_t limit1, int64_t host_result[3], bool with_prefix = false) {
+    if (db->n <= kSelSmallN && limit1 < 0) {             // a small database: one launch
+        select_small_kernel<<<1, kSelSmallThreads, 0, db->stream>>>(db->scores, (int)db->n, pred, db->sel_result, db->rows0, db->rows1, db->matchp,
+                                                                    db->nearp, with_prefix ? (int)kRoundPrefix : 0);
+        VQ_CHECK_LAUNCH();
+        if (!host_result) return VQ_OK;
+        VQ_HIP(hipMemcpyAsync(host_result, db->sel_result, 3 * 8, hipMemcpyDeviceToHost, db->stream));
+        VQ_HIP(hipStreamSynchronize(db->stream));
+        return VQ_OK;
+    }
     select_count_kernel<<<db->nblk, SEL_BLOCK, 0, db->stream>>>(db->scores, db->n, pred, db->blk_cnt, db->blk_max,
                                                                  db->blk_arg);
     VQ_CHECK_LAUNCH();
@@ -1431,8 +1698,9 @@ static int run_select(vq_db* db, const SelPred& pred, int64_t limit1, int64_t ho
                                                          limit1);
     VQ_CHECK_LAUNCH();
     select_scatter_kernel<<<db->nblk, SEL_BLOCK, 0, db->stream>>>(db->scores, db->n, pred, db->blk_cnt, db->rows0,
-                                                                   db->rows1, limit1);
+                                                                   db->rows1, limit1, db->matchp, db->nearp, with_prefix ? kRoundPrefix : 0);
     VQ_CHECK_LAUNCH();
+    if (!host_result) return VQ_OK;                  // vq_db_query_round: the counts travel with the round's block
     VQ_HIP(hipMemcpyAsync(host_result, db->sel_result, 3 * 8, hipMemcpyDeviceToHost, db->stream));
     VQ_HIP(hipStreamSynchronize(db->stream));
     return VQ_OK;
@@ -1757,6 +2025,95 @@ int vq_db_select_rows(vq_db* db, double threshold, double lower, int64_t* match_
     return fetch_selected(db, match_rows_host, cap_match, near_rows_host, cap_near);
 }
 
+int vq_host_alloc(void** ptr, int64_t bytes) {
+    VQ_REQUIRE(ptr && bytes > 0, "vq_host_alloc: bad argument");
+    *ptr = nullptr;
+    VQ_HIP(hipHostMalloc(ptr, (size_t)bytes, hipHostMallocDefault));
+    return VQ_OK;
+}
+
+int vq_host_free(void* ptr) {
+    if (ptr) VQ_HIP(hipHostFree(ptr));
+    return VQ_OK;
+}
+
+int vq_db_round_layout(vq_db* db, int64_t off[10]) {
+    VQ_REQUIRE(db && off, "NULL argument");
+    auto up = [](int64_t v) { return (v + 63) / 64 * 64; };
+    const int64_t head = up((int64_t)db->S * db->E * db->D * 8) + 64;         // query | weights [8]
+    off[0] = 0;
+    off[1] = head - 64;
+    for (int i = 0; i < 6; ++i) off[2 + i] = head + db->round_off[i];
+    off[8] = head + db->round_off[6];
+    off[9] = kRoundPrefix;
+    return VQ_OK;
+}
+
+int vq_db_query_round(vq_db* db, void* block, int64_t block_bytes, int32_t flags, double threshold, double lower) {
+    VQ_REQUIRE(db && block, "NULL argument");
+    VQ_REQUIRE((flags & ~7) == 0 && flags != 0, "flags: 1 = scan, 2 = scores under the block's weights, 4 = select");
+    const bool do_scan = flags & 1, do_scores = flags & 2, do_select = flags & 4;
+    VQ_REQUIRE(!do_select || do_scores, "a selection needs the scores of the same call");
+    int64_t off[10];
+    vq_db_round_layout(db, off);
+    VQ_REQUIRE(block_bytes >= off[8], "the round block needs %lld bytes (vq_db_round_layout), got %lld", (long long)off[8], (long long)block_bytes);
+    std::lock_guard<std::mutex> lk(db->mu);
+    if (!do_scan && !db->have_avg) return fail(VQ_E_STATE, "vq_db_query_round: no similarities cached (scan first, or set flag 1)");
+    DeviceGuard g(db->device);
+    char* host = (char*)block;
+    if (do_scan) {                                   // query and weights in ONE copy (adjacent on both sides)
+        VQ_HIP(hipMemcpyAsync(db->t, host + off[0], (size_t)(off[1] - off[0]) + (do_scores ? db->S * 8 : 0), hipMemcpyHostToDevice, db->stream));
+        db->have_query = true;
+        db->have_avg = db->have_scores = db->have_sims = false;
+    } else if (do_scores) {
+        VQ_HIP(hipMemcpyAsync(db->w, host + off[1], db->S * 8, hipMemcpyHostToDevice, db->stream));
+    }
+    if (do_scan) {
+        ScanArgs a;
+        a.feats = db->feats;
+        a.t = db->t;
+        a.present = db->present;
+        a.w = do_scores ? db->w : nullptr;
+        a.sims = nullptr;
+        a.avg = db->avg;
+        a.ne = db->ne;
+        a.scores = db->scores;
+        a.n = db->n;
+        a.S = db->S;
+        a.E = db->E;
+        a.D = db->D;
+        const int rc = db->dtype == VQ_F32 ? launch_scan<float>(db, a) : launch_scan<double>(db, a);
+        if (rc != VQ_OK) return rc;
+        db->have_avg = true;
+        db->have_scores = do_scores;
+    } else if (do_scores) {
+        rescore_kernel<<<cdiv(db->n, 256), 256, 0, db->stream>>>(db->avg, db->w, db->scores, db->n, db->S);
+        VQ_CHECK_LAUNCH();
+        db->have_scores = true;
+    }
+    if (do_select) {
+        SelPred pred;
+        pred.mode = 0;
+        pred.th = threshold;
+        pred.lower = lower;
+        pred.pivot = 0;
+        const int rc = run_select(db, pred, -1, nullptr, true);
+        if (rc != VQ_OK) return rc;
+    }
+    // one copy back: from the similarities (a scan) or from the scores (a re-weighting) to the end of what was computed
+    const int first = do_scan ? 0 : 2;
+    const int64_t end = do_select ? db->round_off[6] : (do_scores ? db->round_off[3] : db->round_off[2]);
+    VQ_HIP(hipMemcpyAsync(host + off[2] + db->round_off[first], db->round_dev + db->round_off[first], (size_t)(end - db->round_off[first]),
+                          hipMemcpyDeviceToHost, db->stream));
+    VQ_HIP(hipStreamSynchronize(db->stream));
+    if (do_select) {
+        const int64_t* res = (const int64_t*)(host + off[5]);
+        db->last_n0 = res[0];
+        db->last_n1 = res[1];
+    }
+    return VQ_OK;
+}
+
 static int fetch_selected(vq_db* db, int64_t* match_rows_host, int64_t cap_match, int64_t* near_rows_host, int64_t cap_near) {
     if (db->last_n0 < 0 || db->last_n1 < 0)
         return fail(VQ_E_STATE, "the selection lists were overwritten by a later top-k on this handle (select again)");
@@ -1780,6 +2137,36 @@ int vq_db_topk(vq_db* db, int64_t k, int64_t* rows_host, double* vals_host, int6
     if (!db->have_scores) return fail(VQ_E_STATE, "no scores computed (scan with weights, or rescore)");
     DeviceGuard g(db->device);
     if (k > db->n) k = db->n;
+    if (db->n <= kTopkSmallN && k <= kTopkSmallK) {                  // a small resident database: one launch, one copy back
+        const int64_t bytes = 64 + k * 16;
+        int rc = ensure_grid_buf(db, bytes);
+        if (rc != VQ_OK) return rc;
+        char* base = (char*)db->grid_buf;
+        auto kern = topk_small_kernel;
+        const size_t lds = (size_t)db->n * 8;
+        VQ_DYN_LDS(kern, (size_t)kTopkSmallN * 8);
+        kern<<<1, kTopkSmallThreads, lds, db->stream>>>(db->scores, (int)db->n, (int)k, (int64_t*)(base + 64), (double*)(base + 64 + k * 8), (int64_t*)base);
+        VQ_CHECK_LAUNCH();
+        std::vector<char> host((size_t)bytes);
+        VQ_HIP(hipMemcpyAsync(host.data(), base, (size_t)bytes, hipMemcpyDeviceToHost, db->stream));
+        VQ_HIP(hipStreamSynchronize(db->stream));
+        const int64_t tot = *(const int64_t*)host.data();
+        VQ_REQUIRE(tot >= 0 && tot <= k, "internal: top-k produced %lld > k=%lld rows", (long long)tot, (long long)k);
+        const int64_t* rows = (const int64_t*)(host.data() + 64);
+        const double* vals = (const double*)(host.data() + 64 + k * 8);
+        std::vector<int64_t> order((size_t)tot);
+        for (int64_t i = 0; i < tot; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) {
+            if (vals[x] != vals[y]) return vals[x] > vals[y];
+            return rows[x] < rows[y];
+        });
+        for (int64_t i = 0; i < tot; ++i) {
+            rows_host[i] = rows[order[i]];
+            vals_host[i] = vals[order[i]];
+        }
+        *k_out = tot;
+        return VQ_OK;
+    }
     // radix select: find the key of the k-th largest score
     uint64_t st[2] = {0ull, (uint64_t)k};
     VQ_HIP(hipMemcpyAsync(db->tk_state, st, 16, hipMemcpyHostToDevice, db->stream));

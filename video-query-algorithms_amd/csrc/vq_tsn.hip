@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <set>
 #include <tuple>
 #include <type_traits>
 #include <vector>
@@ -1011,7 +1012,9 @@ struct vq_tsn {
     std::vector<LaunchItem> items;        // the launch sequence (a topological order of the layer graph by levels)
     std::vector<int> item_of_layer;
     int consensus_layer = -1;             // the global-pool layer that writes the feature slot: runs fused with the consensus
-    std::map<int, std::vector<int>> tuned;   // n_crops -> per-layer index into kTiles / Winograd variant (autotuned)
+    std::map<int, std::vector<int>> tuned;   // tile_key(n_crops, paired) -> per-layer index into kTiles / Winograd variant
+    std::map<int, int> split_pref;           // batch size -> 0: this size runs faster on ONE stream than as sub-batches (vq_tsn_set_split); absent: split
+    std::set<int> tuned_borrowed;            // keys whose table was copied from a neighbouring size by ensure_tuned (not measured: never persisted)
     bool autotune = true;                 // VQ_TSN_AUTOTUNE != 0 (read at creation)
     bool group_wino = true;               // VQ_TSN_GROUP != 0 (read at creation): independent Winograd layers share a launch
     bool group_pool = true;               // VQ_TSN_GROUP_POOL != 0 (read at creation): a level's pooling rides in its Winograd launch
@@ -1128,16 +1131,19 @@ static const ConvTile kTiles[] = {
     {128, 128, 32, 1}, {128, 128, 16, 1}, {128, 96, 32, 1}, {128, 96, 16, 1}, {128, 64, 32, 1}, {128, 64, 16, 1},
     {64, 128, 32, 1},  {64, 128, 16, 1},  {64, 64, 32, 1},  {64, 64, 16, 1},  {128, 32, 32, 1}, {128, 32, 16, 1},
     {32, 128, 32, 1},  {32, 128, 16, 1},
+    // (round 6) 256 pixels x 64 channels, four waves one above the other (64 x 64 each): for the 64-channel stem, whose K is short --
+    // a 128-pixel workgroup spends as long in prologue and epilogue as in its 6 K-steps -- and whose weights every workgroup reads whole
+    {256, 64, 32, 0}, {256, 64, 16, 0}, {256, 64, 32, 1}, {256, 64, 16, 1},
     // pooled-input 1x1 layers only: ONE column tile for up to 256 output columns (every pooling window is read once), and the
     // two-phase kernel
     {64, 256, 16, 0}, {64, 256, 8, 3}, {64, 64, 8, 3}, {128, 64, 8, 3}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 
 // The pipelined kernel decodes pixels with host-made reciprocals on 24-bit multiplies: what the shapes must satisfy
-static bool pixel_walk_ok(const ConvArgs& a) {
+static bool pixel_walk_ok(const ConvArgs& a) {       // for the longest walk any tiling takes: 256 pixels
     const long long n_img = cdiv(a.M, a.Ho * a.Wo);
     return n_img * a.H * a.W < (1 << 23) && a.Cs_in < (1 << 23) && a.Kp < (1 << 23) && a.Cout < (1 << 23) && a.stride < (1 << 23) &&
-           recip22_ok((unsigned)a.Wo, (unsigned)a.Wo + 128u) && recip22_ok((unsigned)a.Ho, (unsigned)a.Ho + 130u);
+           recip22_ok((unsigned)a.Wo, (unsigned)a.Wo + 256u) && recip22_ok((unsigned)a.Ho, (unsigned)a.Ho + 258u);
 }
 
 template <int BM, int BN, int WM, int WN, int BK, bool SMALL>
@@ -1166,6 +1172,7 @@ static int launch_conv_pipe(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
     P_(128, 128, 2, 2, 32) P_(128, 128, 2, 2, 16) P_(128, 96, 4, 1, 32) P_(128, 96, 4, 1, 16) P_(128, 64, 2, 2, 32)
     P_(128, 64, 2, 2, 16) P_(64, 128, 2, 2, 32) P_(64, 128, 2, 2, 16) P_(64, 64, 2, 2, 32) P_(64, 64, 2, 2, 16)
     P_(128, 32, 4, 1, 32) P_(128, 32, 4, 1, 16) P_(32, 128, 1, 4, 32) P_(32, 128, 1, 4, 16)
+    P_(256, 64, 4, 1, 32) P_(256, 64, 4, 1, 16)
 #undef P_
     return fail(VQ_E_INVALID, "no pipelined kernel for tile %dx%dx%d", t.bm, t.bn, t.bk);
 }
@@ -1176,7 +1183,7 @@ constexpr size_t kPoolGemmMaxLds = 64 * 1024;                  // pool_gemm_kern
 static size_t pool_gemm_lds(int bm, int K) { return std::max((size_t)bm * (K + 4) * sizeof(float), (size_t)4 * 32 * 36 * sizeof(float)); }
 static bool pool_tile_ok(const ConvTile& t, int K) {
     if (t.pipe == 3) return pool_gemm_lds(t.bm, K) <= kPoolGemmMaxLds;
-    return !t.pipe && t.bm >= 64 && (t.bk == 16 || (t.bm == 64 && t.bn <= 128));
+    return !t.pipe && t.bm >= 64 && t.bm <= 128 && (t.bk == 16 || (t.bm == 64 && t.bn <= 128));
 }
 
 template <int BM, int BN, int WM, int WN, int BK>
@@ -1225,6 +1232,7 @@ static int launch_conv(vq_tsn* net, ConvArgs& a, const ConvTile& t) {
     T_(128, 128, 2, 2, 32) T_(128, 128, 2, 2, 16) T_(128, 96, 4, 1, 32) T_(128, 96, 4, 1, 16) T_(128, 64, 2, 2, 32)
     T_(128, 64, 2, 2, 16) T_(64, 128, 2, 2, 32) T_(64, 128, 2, 2, 16) T_(64, 64, 2, 2, 32) T_(64, 64, 2, 2, 16)
     T_(128, 32, 4, 1, 32) T_(128, 32, 4, 1, 16) T_(32, 128, 1, 4, 32) T_(32, 128, 1, 4, 16)
+    T_(256, 64, 4, 1, 32) T_(256, 64, 4, 1, 16)
 #undef T_
     return fail(VQ_E_INVALID, "no kernel for tile %dx%dx%d", t.bm, t.bn, t.bk);
 }
@@ -1321,7 +1329,7 @@ static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
         // max-pool folded into the loader: any tiling gives the same bits, so an unsupported choice (heuristic, VQ_TSN_TILE)
         // is replaced by the BK = 16 tiling of the same shape
         ConvTile t = kTiles[tile_idx];
-        if (!pool_tile_ok(t, a.Cin)) t = ConvTile{t.bm, std::min(t.bn, 128), 16, 0};
+        if (!pool_tile_ok(t, a.Cin)) t = ConvTile{std::min(t.bm, 128), std::min(t.bn, 128), 16, 0};
         return launch_conv_pool(net, a, t);
     }
     if (stem_rows) {                                   // four chunk columns = four kernel rows: BK = 16 tilings only (same bits for all)
@@ -1472,19 +1480,34 @@ static int run_item(vq_tsn* net, const LaunchItem& it, int crop0, int n_crops, i
 // ``paired``: the size is that of a SUB-BATCH of the default forward (two sub-batches on two streams, side by side): a candidate is timed
 // the way it will run -- the same launch on all sub-batch streams at once, on the crop ranges of the sub-batches -- because the best tiling of a
 // launch that has the chip to itself (few, large workgroups fill it badly) is not the best one beside its twin.
+// A table lives under tile_key(size, paired): a size tuned side by side is another table than the same size tuned alone.
+constexpr int kPairedKey = 1 << 24;
+static inline int tile_key(int n_crops, bool paired) { return n_crops + (paired ? kPairedKey : 0); }
+
+struct EventSet {          // the sweep's events go on every way out
+    std::vector<hipEvent_t> ev;
+    ~EventSet() {
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
+
 static int autotune(vq_tsn* net, int n_crops, bool paired) {
-    std::vector<int>& choice = net->tuned[n_crops];
+    const int key = tile_key(n_crops, paired);
+    std::vector<int>& choice = net->tuned[key];
     choice.assign(net->layers.size(), 0);
+    net->tuned_borrowed.erase(key);
     net->ls = net->stream;
     const int ways = paired ? std::max(1, std::min(net->n_split, net->max_crops / n_crops)) : 1;     // streams that run the launch side by side
-    hipEvent_t e0, e1;
-    std::vector<hipEvent_t> f(ways, nullptr);
-    VQ_HIP(hipEventCreate(&e0));
-    VQ_HIP(hipEventCreate(&e1));
-    for (int l = 1; l < ways; ++l) VQ_HIP(hipEventCreate(&f[l]));
+    EventSet events;
+    events.ev.assign(2 + ways, nullptr);
+    for (int l = 0; l < 2 + ways; ++l)
+        if (l != 2) VQ_HIP(hipEventCreate(&events.ev[l]));
+    const hipEvent_t e0 = events.ev[0], e1 = events.ev[1];
+    hipEvent_t* const f = events.ev.data() + 2;               // f[1 .. ways-1]
     auto timed = [&](const LaunchItem& it, int reps, float* ms) -> int {
         VQ_HIP(hipEventRecord(e0, net->stream));
-        int rc = run_item(net, it, 0, n_crops, n_crops);       // warm
+        int rc = run_item(net, it, 0, n_crops, key);           // warm
         if (rc != VQ_OK) return rc;
         VQ_HIP(hipEventRecord(e1, net->stream));
         VQ_HIP(hipEventSynchronize(e1));
@@ -1499,7 +1522,7 @@ static int autotune(vq_tsn* net, int n_crops, bool paired) {
         for (int r = 0; r < reps; ++r)
             for (int l = 0; l < ways; ++l) {
                 net->ls = l > 0 ? net->split_streams[l] : net->stream;
-                rc = run_item(net, it, l * n_crops, n_crops, n_crops);
+                rc = run_item(net, it, l * n_crops, n_crops, key);
                 net->ls = net->stream;
                 if (rc != VQ_OK) return rc;
             }
@@ -1517,16 +1540,16 @@ static int autotune(vq_tsn* net, int n_crops, bool paired) {
     };
     {   // bring the clock up: the heuristic tilings (choice = 0 entries are replaced below) through the whole launch list
         std::vector<int> saved = choice;
-        net->tuned.erase(n_crops);                            // run_layer falls back to the heuristic without a table
+        net->tuned.erase(key);                                // run_layer falls back to the heuristic without a table
         for (int r = 0; r < 10; ++r)
             for (const LaunchItem& it : net->items) {
-                const int rc = run_item(net, it, 0, n_crops, n_crops);
+                const int rc = run_item(net, it, 0, n_crops, key);
                 if (rc != VQ_OK) return rc;
             }
         VQ_HIP(hipStreamSynchronize(net->stream));
-        net->tuned[n_crops] = saved;
+        net->tuned[key] = saved;
     }
-    std::vector<int>& pick = net->tuned[n_crops];
+    std::vector<int>& pick = net->tuned[key];
     for (const LaunchItem& it : net->items) {
         const int li = it.layers[0];
         if (!is_conv(net->layers[li].op)) continue;
@@ -1558,9 +1581,6 @@ static int autotune(vq_tsn* net, int n_crops, bool paired) {
         }
         for (int m : it.layers) pick[m] = win;
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    for (int l = 1; l < ways; ++l) (void)hipEventDestroy(f[l]);
     return VQ_OK;
 }
 
@@ -1568,14 +1588,27 @@ static int autotune(vq_tsn* net, int n_crops, bool paired) {
 // a tuned one borrows that table (the ragged last batch of a video must not cost 2 s of tuning launches -- every
 // tiling gives the same bits, only the speed differs); anything further away is tuned itself.
 static int ensure_tuned(vq_tsn* net, int n_crops, bool paired) {
-    if (!net->autotune || net->forced_tile >= 0 || net->tuned.find(n_crops) != net->tuned.end()) return VQ_OK;
-    int nearest = 0;
-    for (const auto& kv : net->tuned)
-        if (nearest == 0 || std::abs(kv.first - n_crops) < std::abs(nearest - n_crops)) nearest = kv.first;
-    if (nearest > 0 && 2 * std::max(nearest, n_crops) <= 3 * std::min(nearest, n_crops)) {
-        net->tuned[n_crops] = net->tuned[nearest];
+    const int key = tile_key(n_crops, paired);
+    if (net->forced_tile >= 0 || net->tuned.find(key) != net->tuned.end()) return VQ_OK;
+    // the nearest size timed the same way (side by side / alone); failing that the nearest one timed the other way
+    int nearest = 0, nearest_key = 0;
+    for (int same = 1; same >= 0 && nearest == 0; --same)
+        for (const auto& kv : net->tuned) {
+            const bool kp = kv.first >= kPairedKey;
+            const int size = kv.first - (kp ? kPairedKey : 0);
+            if ((kp == paired) != (same == 1) || net->tuned_borrowed.count(kv.first)) continue;
+            if (10 * std::max(size, n_crops) > 16 * std::min(size, n_crops)) continue;            // further than 1.6x away
+            if (nearest == 0 || std::abs(size - n_crops) < std::abs(nearest - n_crops)) {
+                nearest = size;
+                nearest_key = kv.first;
+            }
+        }
+    if (nearest > 0) {
+        net->tuned[key] = net->tuned[nearest_key];
+        net->tuned_borrowed.insert(key);
         return VQ_OK;
     }
+    if (!net->autotune) return VQ_OK;             // VQ_TSN_AUTOTUNE=0: the occupancy heuristic for sizes without a table
     return autotune(net, n_crops, paired);
 }
 
@@ -2057,7 +2090,7 @@ static int forward_launches(vq_tsn* net, const uint8_t* src, int n_crops, int T,
         for (const LaunchItem& it : net->items)
             for (int sb = 0; sb < n_split; ++sb) {
                 net->ls = sb > 0 ? net->split_streams[sb] : net->stream;
-                const int rc = run_item(net, it, sub_off[sb], sub[sb], sub[sb]);
+                const int rc = run_item(net, it, sub_off[sb], sub[sb], tile_key(sub[sb], true));
                 if (rc != VQ_OK) return rc;
             }
         net->ls = net->stream;
@@ -2074,7 +2107,7 @@ static int forward_launches(vq_tsn* net, const uint8_t* src, int n_crops, int T,
                 net->ev_start = ev[2 * q];
                 net->ev_stop = ev[2 * q + 1];
             }
-            const int rc = run_item(net, net->items[q], 0, n_crops, n_crops);
+            const int rc = run_item(net, net->items[q], 0, n_crops, tile_key(n_crops, false));
             if (rc != VQ_OK) return rc;
         }
     }
@@ -2130,7 +2163,16 @@ int vq_tsn_forward(vq_tsn* net, const uint8_t* crops, int32_t crops_on_device, i
     // sampled ones (they issue exactly the same launches) unless vq_tsn_set_profile_split asked for the product's own mode there.
     int parts_sum = 0;
     for (int v : net->split_parts) parts_sum += v;
-    const bool one_stream = profiling && (ev || !net->profile_split);
+    bool one_stream = profiling && (ev || !net->profile_split);
+    if (!one_stream && !net->split_pref.empty()) {       // a measured preference of the nearest batch size within 1.6x (default: split)
+        int best = 0, pref = 1;
+        for (const auto& kv : net->split_pref)
+            if (10 * std::max(kv.first, n_crops) <= 16 * std::min(kv.first, n_crops) && (best == 0 || std::abs(kv.first - n_crops) < std::abs(best - n_crops))) {
+                best = kv.first;
+                pref = kv.second;
+            }
+        if (pref == 0) one_stream = true;
+    }
     int n_split = (!one_stream && net->n_split > 1 && n_crops % parts_sum == 0) ? net->n_split : 1;
     std::vector<int> sub(n_split, n_crops), sub_off(n_split, 0);
     if (n_split > 1) {
@@ -2273,20 +2315,59 @@ int vq_tsn_launch_items(vq_tsn* net, int32_t* item_of_layer, int32_t n_layers, i
 int vq_tsn_tuned_sizes(vq_tsn* net, int32_t* sizes, int32_t cap, int32_t* n) {
     VQ_REQUIRE(net && n && (cap == 0 || sizes), "NULL argument");
     std::lock_guard<std::mutex> lk(net->mu);
+    std::set<int> distinct;
+    for (const auto& kv : net->tuned) distinct.insert(kv.first >= kPairedKey ? kv.first - kPairedKey : kv.first);
     int k = 0;
-    for (const auto& kv : net->tuned) {
-        if (k < cap) sizes[k] = kv.first;
+    for (int v : distinct) {
+        if (k < cap) sizes[k] = v;
         ++k;
     }
     *n = k;
     return VQ_OK;
 }
 
-int vq_tsn_layer_tiles(vq_tsn* net, int32_t n_crops, int32_t* tiles, int32_t n_layers) {
+int vq_tsn_set_split(vq_tsn* net, int32_t n_crops, int32_t split) {
+    VQ_REQUIRE(net && n_crops > 0, "bad argument");
+    std::lock_guard<std::mutex> lk(net->mu);
+    if (split < 0)
+        net->split_pref.erase(n_crops);
+    else
+        net->split_pref[n_crops] = split ? 1 : 0;
+    return VQ_OK;
+}
+
+int vq_tsn_tune(vq_tsn* net, int32_t n_crops, int32_t paired) {
+    VQ_REQUIRE(net, "net is NULL");
+    VQ_REQUIRE(n_crops > 0 && n_crops * (paired ? std::min(net->n_split, 2) : 1) <= net->max_crops, "n_crops out of range");
+    std::lock_guard<std::mutex> lk(net->mu);
+    DeviceGuard g(net->device);
+    const int rc = autotune(net, n_crops, paired != 0);
+    if (rc != VQ_OK) net->tuned.erase(tile_key(n_crops, paired != 0));
+    VQ_HIP(hipStreamSynchronize(net->stream));
+    return rc;
+}
+
+int vq_tsn_tile_tables(vq_tsn* net, int32_t* sizes, int32_t* flags, int32_t cap, int32_t* n) {
+    VQ_REQUIRE(net && n && (cap == 0 || (sizes && flags)), "NULL argument");
+    std::lock_guard<std::mutex> lk(net->mu);
+    int k = 0;
+    for (const auto& kv : net->tuned) {
+        if (k < cap) {
+            const bool paired = kv.first >= kPairedKey;
+            sizes[k] = paired ? kv.first - kPairedKey : kv.first;
+            flags[k] = (paired ? 1 : 0) | (net->tuned_borrowed.count(kv.first) ? 2 : 0);
+        }
+        ++k;
+    }
+    *n = k;
+    return VQ_OK;
+}
+
+int vq_tsn_get_tiles(vq_tsn* net, int32_t n_crops, int32_t paired, int32_t* tiles, int32_t n_layers) {
     VQ_REQUIRE(net && tiles, "NULL argument");
     VQ_REQUIRE(n_layers == (int)net->layers.size(), "n_layers must be %d", (int)net->layers.size());
     std::lock_guard<std::mutex> lk(net->mu);
-    auto it = net->tuned.find(n_crops);
+    auto it = net->tuned.find(tile_key(n_crops, paired != 0));
     for (int i = 0; i < n_layers; ++i) {
         tiles[4 * i] = tiles[4 * i + 1] = tiles[4 * i + 2] = tiles[4 * i + 3] = 0;
         if (net->layers[i].op == VQ_OP_CONV_WINOGRAD) {   // 32 tiles (128 pixels) x 32 (v+1) channels, 8 channels per step
@@ -2309,7 +2390,17 @@ int vq_tsn_layer_tiles(vq_tsn* net, int32_t n_crops, int32_t* tiles, int32_t n_l
     return VQ_OK;
 }
 
-int vq_tsn_set_layer_tiles(vq_tsn* net, int32_t n_crops, const int32_t* tiles, int32_t n_layers) {
+int vq_tsn_layer_tiles(vq_tsn* net, int32_t n_crops, int32_t* tiles, int32_t n_layers) {
+    VQ_REQUIRE(net, "NULL argument");
+    bool paired = false;
+    {
+        std::lock_guard<std::mutex> lk(net->mu);
+        paired = net->tuned.find(tile_key(n_crops, false)) == net->tuned.end() && net->tuned.find(tile_key(n_crops, true)) != net->tuned.end();
+    }
+    return vq_tsn_get_tiles(net, n_crops, paired ? 1 : 0, tiles, n_layers);
+}
+
+int vq_tsn_set_tiles(vq_tsn* net, int32_t n_crops, int32_t paired, const int32_t* tiles, int32_t n_layers) {
     VQ_REQUIRE(net && tiles, "NULL argument");
     VQ_REQUIRE(n_layers == (int)net->layers.size(), "n_layers must be %d", (int)net->layers.size());
     VQ_REQUIRE(n_crops > 0 && n_crops <= net->max_crops, "n_crops out of range");
@@ -2333,7 +2424,24 @@ int vq_tsn_set_layer_tiles(vq_tsn* net, int32_t n_crops, const int32_t* tiles, i
         choice[i] = found;
     }
     std::lock_guard<std::mutex> lk(net->mu);
-    net->tuned[n_crops] = choice;
+    const int key = tile_key(n_crops, paired != 0);
+    net->tuned[key] = choice;
+    net->tuned_borrowed.erase(key);
+    return VQ_OK;
+}
+
+// "The tiling of a forward of n_crops, however it runs": the one-stream table of that size and the paired tables of the sub-batch
+// sizes the default forward cuts it into.
+int vq_tsn_set_layer_tiles(vq_tsn* net, int32_t n_crops, const int32_t* tiles, int32_t n_layers) {
+    int rc = vq_tsn_set_tiles(net, n_crops, 0, tiles, n_layers);
+    if (rc != VQ_OK) return rc;
+    int parts_sum = 0;
+    for (int v : net->split_parts) parts_sum += v;
+    if (net->n_split > 1 && parts_sum > 0 && n_crops % parts_sum == 0)
+        for (int v : net->split_parts) {
+            rc = vq_tsn_set_tiles(net, n_crops / parts_sum * v, 1, tiles, n_layers);
+            if (rc != VQ_OK) return rc;
+        }
     return VQ_OK;
 }
 

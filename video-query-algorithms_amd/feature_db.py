@@ -23,6 +23,33 @@ def _np_ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
 
+class _RoundBlock:
+    """One page-locked host block of vq_db_query_round (include/vq_amd.h), exposed to numpy.  The arrays a round hands out are views
+    of it; when the last of them is gone the block goes back to its database's pool (or is freed if the database is)."""
+
+    def __init__(self, ptr: int, nbytes: int, pool: dict):
+        self.ptr, self.nbytes, self._pool = ptr, nbytes, pool
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+    def bytes(self) -> np.ndarray:
+        return np.asarray(self)                               # its .base is self: views of it keep the block out of the pool
+
+    def __del__(self):
+        pool = self._pool
+        if not pool["closed"] and len(pool["free"]) < 4:
+            pool["free"].append((self.ptr, self.nbytes))      # reborn as a fresh _RoundBlock by the next round
+        else:
+            try:
+                _lib.load().vq_host_free(C.c_void_p(self.ptr))
+            except Exception:
+                pass
+
+
+class RoundResult:
+    """What one call of :meth:`FeatureDB.query_round` brought back (numpy views of one page-locked block)."""
+    __slots__ = ("avg", "n_e", "scores", "match_rows", "near_rows", "near_argmax")
+
+
 class FeatureDB:
     """N clips x S streams x E ensemble slots x D floats, resident on ``device``."""
 
@@ -298,6 +325,64 @@ class FeatureDB:
         call("vq_db_scan_batch", self._h, t.shape[0], _np_ptr(t), _np_ptr(w), _np_ptr(out) if want else None)
         return out
 
+    # ------------------------------------------------------------------ a query round in one call
+    def _round_block(self) -> _RoundBlock:
+        if getattr(self, "_round_off", None) is None:
+            off = (C.c_int64 * 10)()
+            call("vq_db_round_layout", self._h, off)
+            self._round_off = [int(v) for v in off]
+            self._round_pool = {"free": [], "closed": False}
+        if self._round_pool["free"]:
+            ptr, nbytes = self._round_pool["free"].pop()
+        else:
+            p = C.c_void_p()
+            nbytes = self._round_off[8]
+            call("vq_host_alloc", C.byref(p), nbytes)
+            ptr = p.value
+        return _RoundBlock(ptr, nbytes, self._round_pool)
+
+    def query_round(self, t: np.ndarray | None, weights=None, select=None) -> RoundResult:
+        """ticket.py:120-180,311-356 as ONE call of the library (vq_db_query_round): one lock, one synchronisation, one copy back.
+        ``t`` [S,E,D]: scan under this query (None: the similarities the handle holds); ``weights`` [S]: scores under them;
+        ``select`` = (threshold, lower): the order-preserving partition.  Bit for bit what set_query / scan / similarities / rescore /
+        scores / select return one by one (tested); the arrays are views of page-locked memory that stay valid as long as they live."""
+        blk = self._round_block()
+        off = self._round_off
+        raw = blk.bytes()
+        n, S = self.n, self.S
+
+        def view(piece, dtype, count, shape):
+            return raw[off[piece]:off[piece] + count * dtype().itemsize].view(dtype).reshape(shape)
+        flags = 0
+        if t is not None:
+            view(0, np.float64, S * self.E * self.D, (S, self.E, self.D))[...] = t
+            flags |= 1
+        if weights is not None:
+            view(1, np.float64, S, (S,))[...] = weights
+            flags |= 2
+        th, lower = (float(select[0]), float(select[1])) if select is not None else (0.0, 0.0)
+        if select is not None:
+            flags |= 4
+        call("vq_db_query_round", self._h, C.c_void_p(blk.ptr), blk.nbytes, flags, th, lower)
+        r = RoundResult()
+        r.avg = view(2, np.float64, n * S, (n, S)) if t is not None else None
+        r.n_e = view(3, np.int32, n * S, (n, S)) if t is not None else None
+        r.scores = view(4, np.float64, n, (n,)) if weights is not None else None
+        r.match_rows = r.near_rows = None
+        r.near_argmax = -1
+        if select is not None:
+            res = view(5, np.int64, 4, (4,))
+            nm, nn, r.near_argmax = int(res[0]), int(res[1]), int(res[2])
+            if nm <= off[9] and nn <= off[9]:
+                r.match_rows = view(6, np.int64, nm, (nm,))
+                r.near_rows = view(7, np.int64, nn, (nn,))
+            else:                                             # a list longer than its prefix: the full lists are still on the device
+                m = np.empty(nm, dtype=np.int64)
+                q = np.empty(nn, dtype=np.int64)
+                call("vq_db_select_fetch", self._h, _np_ptr(m) if nm else None, nm, _np_ptr(q) if nn else None, nn)
+                r.match_rows, r.near_rows = m, q
+        return r
+
     def rescore(self, weights: Sequence[float]):
         w = np.ascontiguousarray(weights, dtype=np.float64)
         if w.shape != (self.S,):
@@ -370,6 +455,11 @@ class FeatureDB:
 
     def close(self):
         if self._h:
+            pool = getattr(self, "_round_pool", None)
+            if pool is not None:
+                pool["closed"] = True                         # blocks still referenced by result arrays free themselves
+                while pool["free"]:
+                    _lib.load().vq_host_free(C.c_void_p(pool["free"].pop()[0]))
             _lib.load().vq_db_destroy(self._h)
             self._h = C.c_void_p()
 

@@ -54,9 +54,13 @@ class Hyperparameter:
             graded = db.scores_grid(candidates, rows)                               # [40][L] in one launch
         th = self.threshold_grid[None, :]
         surface = np.tile(0.5 * th, (len(self.weight_grid), 1))
-        for column, y in zip(graded.T, labels):                                     # dict order, one clip at a time
-            margin = column[:, None] - th
-            surface = surface + (np.heaviside(margin, 1) - y) * margin * (1 + y * self.ballast)
+        # every clip's term of hyperparameter.py:60-64 at once ([L][40][31], the same elementwise operations in the same order), then
+        # added to the surface ONE CLIP AT A TIME in dict order: every cell sees the reference's sequence of fp64 additions
+        y = np.array([float(v) for v in labels], dtype=np.float64)[:, None, None]
+        margin = graded.T[:, :, None] - th[None]
+        terms = (np.heaviside(margin, 1) - y) * margin * (1 + y * self.ballast)
+        for term in terms:
+            surface = surface + term
         surface = surface / len(labels)
         iw, it = np.unravel_index(np.argmin(surface), surface.shape)                # first minimum, row-major
         ticket.compute_scores({self.streams[0]: 1.0, self.streams[1]: self.weight_grid[-1]})   # what the 40 passes leave

@@ -41,7 +41,7 @@ import numpy as np
 from .shard import all_gather_rows, merge_topk, shard_range
 
 OP_CLOSE, OP_RESTRICT, OP_SET_QUERY, OP_QUERY_FROM_ROW, OP_SCAN, OP_RESCORE, OP_SIMS, OP_SCORES, OP_GRID, OP_SELECT, OP_TOPK, \
-    OP_MIN, OP_FETCH, OP_SCAN_BATCH, OP_LAYOUT, OP_WRITE_AVG = range(16)
+    OP_MIN, OP_FETCH, OP_SCAN_BATCH, OP_LAYOUT, OP_WRITE_AVG, OP_ROUND = range(17)
 
 
 def _atomic(method):
@@ -278,6 +278,12 @@ class ShardedFeatureDB:
         used = None if slot_used is None else np.asarray(slot_used, dtype=bool)
         if used is not None and used.shape != (self.S, self.E):
             raise ValueError("slot_used must be [S,E]")
+        if used is not None and used.all():
+            used = None
+        before = getattr(self, "_slots_used", "unset")
+        if not isinstance(before, str) and ((used is None and before is None) or (used is not None and before is not None and (used == before).all())):
+            return                                           # the restriction the ranks already hold: nothing to announce
+        self._slots_used = None if used is None else used.copy()
         self._announce(OP_RESTRICT, ints=[-1] if used is None else used.astype(np.int64).reshape(-1))
         self._local_step(lambda: self.local.restrict_slots(used))
 
@@ -421,7 +427,12 @@ class ShardedFeatureDB:
             m, r, am = self.local.select(float(threshold), float(lower))
             best = float(self.local.scores_at([am])[0]) if am >= 0 else 0.0
             return m + self.row0, r + self.row0, (am + self.row0 if am >= 0 else -1), best
-        m, r, am, best = self._local_step(part)
+        return self._merge_selection(*self._local_step(part))
+
+    def _merge_selection(self, m, r, am, best):
+        """This rank's (match rows, near rows, first arg-max row or -1, its score) in GLOBAL row numbers -> the lists of all ranks,
+        rank-major = database order, and the first arg-max over the ranks (two small gathers: sizes, then bodies)."""
+        torch = self._torch
         head = torch.from_numpy(np.concatenate([np.array([m.size, r.size, am], dtype=np.int64),
                                                 np.array([best], dtype=np.float64).view(np.int64)])).to(self._cdev)
         heads = self._host(self._coll(lambda: all_gather_rows(head.reshape(1, 4), self.world, self.group)))
@@ -438,6 +449,71 @@ class ShardedFeatureDB:
                 if top is None or v > top:
                     near_argmax, top = int(heads[g, 2]), v
         return match, near, near_argmax
+
+    @_atomic
+    def query_round(self, t, weights=None, select=None):
+        """ticket.py:120-180,311-356 -- similarities, scores and review partition of one query -- as ONE operation of the sharded
+        database: one announcement (the query, the weights and the band travel with it), every rank's own vq_db_query_round, ONE
+        gather of the per-row results ([n, 2S+1] doubles: avg | n_e | score) and the two small gathers of the selection -- where the
+        separate calls (restrict, set_query, scan, similarities, rescore, scores, select) are seven announcements and six gathers.
+        Same arrays, bit for bit (tests/test_sharded_db_gloo.py, tests/test_sharded_db_gpu.py).  SPMD: every rank passes the same
+        arguments."""
+        from .feature_db import RoundResult
+        torch = self._torch
+        S = self.S
+        tq = None if t is None else np.ascontiguousarray(t, dtype=np.float64)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        if tq is not None and tq.shape != (S, self.E, self.D):
+            raise ValueError("query must be [%d,%d,%d]" % (S, self.E, self.D))
+        if w is not None and w.shape != (S,):
+            raise ValueError("one weight per stream")
+        if select is not None and w is None:
+            raise ValueError("a selection needs the scores of the same call")
+        if tq is None and w is None:
+            raise ValueError("nothing to do")
+        band = None if select is None else (float(select[0]), float(select[1]))
+        flags = (1 if tq is not None else 0) | (2 if w is not None else 0) | (4 if band is not None else 0)
+        self._announce(OP_ROUND, ints=[flags], floats=np.concatenate([np.zeros(0) if tq is None else tq.reshape(-1), np.zeros(0) if w is None else w,
+                                                                        np.zeros(0) if band is None else np.array(band)]))
+
+        def part():
+            if hasattr(self.local, "query_round"):
+                r = self.local.query_round(tq, weights=w, select=band)
+            else:                                                     # a local database without the one-call form: its separate calls
+                r = RoundResult()
+                r.avg = r.n_e = r.scores = r.match_rows = r.near_rows = None
+                r.near_argmax = -1
+                if tq is not None:
+                    self.local.set_query(tq)
+                    self.local.scan(weights=w)
+                    r.avg, r.n_e = self.local.similarities()
+                elif w is not None:
+                    self.local.rescore(w)
+                if w is not None:
+                    r.scores = self.local.scores()
+                if band is not None:
+                    r.match_rows, r.near_rows, r.near_argmax = self.local.select(*band)
+            cols = ([r.avg, r.n_e.astype(np.float64)] if tq is not None else []) + ([r.scores[:, None]] if w is not None else [])
+            best = float(r.scores[r.near_argmax]) if band is not None and r.near_argmax >= 0 else 0.0
+            return r, np.ascontiguousarray(np.concatenate(cols, axis=1)), best
+        r, packed, best = self._local_step(part)
+        full = self._host(self._coll(lambda: all_gather_rows(torch.from_numpy(packed).to(self._cdev), self.n, self.group)))
+        out = RoundResult()
+        out.avg = out.n_e = out.scores = out.match_rows = out.near_rows = None
+        out.near_argmax = -1
+        c = 0
+        if tq is not None:
+            out.avg = np.ascontiguousarray(full[:, :S])
+            out.n_e = full[:, S:2 * S].astype(np.int32)               # counts <= E: exact as doubles
+            c = 2 * S
+        if w is not None:
+            out.scores = np.ascontiguousarray(full[:, c])
+        if band is not None:
+            am = int(r.near_argmax)
+            out.match_rows, out.near_rows, out.near_argmax = self._merge_selection(
+                np.asarray(r.match_rows, dtype=np.int64) + self.row0, np.asarray(r.near_rows, dtype=np.int64) + self.row0,
+                am + self.row0 if am >= 0 else -1, best)
+        return out
 
     @_atomic
     def topk(self, k: int):
@@ -569,6 +645,16 @@ class ShardedFeatureDB:
             self.scores_grid(floats.reshape(int(ints[0]), S), ints[1:])
         elif op == OP_SELECT:
             self.select(float(floats[0]), float(floats[1]))
+        elif op == OP_ROUND:
+            flags, k = int(ints[0]), 0
+            tq = w = band = None
+            if flags & 1:
+                tq, k = floats[:S * E * D].reshape(S, E, D), S * E * D
+            if flags & 2:
+                w, k = floats[k:k + S], k + S
+            if flags & 4:
+                band = (float(floats[k]), float(floats[k + 1]))
+            self.query_round(tq, weights=w, select=band)
         elif op == OP_TOPK:
             self.topk(int(ints[0]))
         elif op == OP_MIN:

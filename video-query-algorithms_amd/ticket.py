@@ -95,6 +95,9 @@ class TicketScoring:
     written: ``similarities``, ``scores``, ``matches`` -- as in the reference."""
 
     feature_db: FeatureDB | None = None      # a resident DB may be attached up front
+    _ahead = None                            # scores / review partition this round's compute_similarities or compute_scores already brought back
+    _hp = None                               # the hyperparameters object of the latest compute_similarities
+    _stream_gap = None                       # per stream: does any clip lack it (compute_scores' KeyError of ticket.py:177)
     _round = None                            # token of this ticket's latest compute_similarities (see _own_similarities)
     _score_weights = None
     feature_db_dtype = np.float64            # dtype used when the DB is built from API records
@@ -112,37 +115,112 @@ class TicketScoring:
             self.feature_db = db
         stream_names = getattr(db, "stream_names", None) or list(target_features.keys())
         slot_splits = getattr(db, "slot_splits", None) or [list(target_features[st].keys()) for st in stream_names]
-        t = np.zeros((db.S, db.E, db.D), dtype=np.float64)
-        slot_used = np.zeros((db.S, db.E), dtype=bool)
-        for s, st in enumerate(stream_names):
-            for e, sp in enumerate(slot_splits[s]):
-                if st in target_features and sp in target_features[st]:
-                    t[s, e] = np.asarray(target_features[st][sp], dtype=np.float64)
-                    slot_used[s, e] = True
-        with _db_lock(db):                    # one resident database may serve several tickets: these four calls are one step
-            db.restrict_slots(slot_used)      # per query; the database's own mask is never modified
-            db.set_query(t)
-            db.scan(weights=None)
-            avg, n_e = db.similarities()
+        # The target's vectors are Python lists (JSON-serialisable, ticket.py:296): turning 6 x 1 024 floats into an array is ~0.15 ms
+        # of interpreter time, more than the whole device side of a 10k-clip round.  The array is kept on the target object and
+        # reused while every vector IS the list object it was made from (TargetClip replaces a vector by a new list whenever it
+        # changes it -- target_clip.py never assigns into one).
+        refs = tuple(target_features[st][sp] for s, st in enumerate(stream_names) for sp in slot_splits[s]
+                     if st in target_features and sp in target_features[st])
+        cached = getattr(self.target, "_vq_query_array", None)
+        if cached is not None and cached[0] == (db.S, db.E, db.D) and len(cached[1]) == len(refs) and all(a is b for a, b in zip(cached[1], refs)):
+            t, slot_used = cached[2], cached[3]
+        else:
+            t = np.zeros((db.S, db.E, db.D), dtype=np.float64)
+            slot_used = np.zeros((db.S, db.E), dtype=bool)
+            for s, st in enumerate(stream_names):
+                for e, sp in enumerate(slot_splits[s]):
+                    if st in target_features and sp in target_features[st]:
+                        t[s, e] = np.asarray(target_features[st][sp], dtype=np.float64)
+                        slot_used[s, e] = True
+            try:
+                self.target._vq_query_array = ((db.S, db.E, db.D), refs, t, slot_used)
+            except AttributeError:
+                pass                                          # a target object that takes no attributes
+        self._ahead = None
+        with _db_lock(db):                    # one resident database may serve several tickets: these calls are one step
+            db.restrict_slots(slot_used)      # per query; the database's own mask is never modified (no device call unless it changes)
             self._round = object()            # whose similarities the database holds now (see _own_similarities)
-            db.sims_owner, db.scores_owner = self._round, None
+            ahead = self._look_ahead(hyperparameters, stream_names) if hasattr(db, "query_round") else None
+            if ahead is not None:
+                # The round in ONE call (vq_db_query_round): the reference calls compute_scores and select_clips_to_review right behind
+                # this method (compute_matches.py:58-89) with the weights / threshold its hyperparameters object holds now, so scores and
+                # review partition are computed and brought back with the similarities; compute_scores / select_clips_to_review use
+                # them when they are called with exactly those arguments and run their own calls otherwise.
+                w, th, lower = ahead
+                r = db.query_round(t, weights=w, select=(th, lower))
+                avg, n_e = r.avg, r.n_e
+                self._ahead = {"w": w.tobytes(), "scores": r.scores, "select": (th, lower), "match_rows": r.match_rows,
+                               "near_rows": r.near_rows, "near_argmax": r.near_argmax}
+                db.sims_owner, db.scores_owner = self._round, (self._round, w.tobytes())
+            else:
+                db.set_query(t)
+                db.scan(weights=None)
+                avg, n_e = db.similarities()
+                db.sims_owner, db.scores_owner = self._round, None
+        self._hp = hyperparameters
         self._stream_names = stream_names
         self._avg, self._n_e = avg, n_e
+        self._stream_gap = None
         self.similarities = SimilarityMap(db.clip_ids, stream_names, avg, n_e, db.row_of)
+
+    @staticmethod
+    def _review_band(hyperparameters):
+        """(threshold, lower limit) select_clips_to_review will most likely be called with (compute_matches.py:78-88)."""
+        th = getattr(hyperparameters, "threshold", None)
+        if th is None:
+            th = getattr(hyperparameters, "default_threshold", None)
+        near = getattr(hyperparameters, "near_miss_default", None)
+        if th is None or near is None:
+            return None
+        return float(th), float(th) - float(near) * (1 - float(th))          # the expression of ticket.py:316
+
+    def _look_ahead(self, hyperparameters, stream_names):
+        """The arguments compute_scores / select_clips_to_review are about to get if the caller is the reference's compute_matches:
+        (weights [S], threshold, lower limit), or None when the hyperparameters object does not say."""
+        weights = getattr(hyperparameters, "weights", None) or getattr(hyperparameters, "default_weights", None)
+        band = self._review_band(hyperparameters)
+        if not isinstance(weights, Mapping) or band is None:
+            return None
+        w = np.zeros(len(stream_names), dtype=np.float64)
+        for stream_type, ws in weights.items():
+            if stream_type not in stream_names:
+                return None
+            w[stream_names.index(stream_type)] = ws
+        return w, band[0], band[1]
 
     # -- ticket.py:165-180 ------------------------------------------------------------------
     def compute_scores(self, weights):
         db = self.feature_db
         w = np.zeros(db.S, dtype=np.float64)
+        if self._stream_gap is None:                 # stream -> does some clip have no similarity for it: one pass per round and stream
+            self._stream_gap = {}
         for stream_type, ws in weights.items():
             s = self._stream_names.index(stream_type) if stream_type in self._stream_names else -1
-            if s < 0 or (self._n_e[:, s] == 0).any():
+            if s >= 0 and s not in self._stream_gap:
+                self._stream_gap[s] = bool((self._n_e[:, s] == 0).any())
+            if s < 0 or self._stream_gap[s]:
                 raise KeyError(stream_type)          # vsim[stream_type] at ticket.py:177
             w[s] = ws
+        ahead = getattr(self, "_ahead", None)
+        if ahead is not None and ahead["w"] == w.tobytes():
+            # computed from THIS round's similarities under exactly these weights and already on the host: nothing to ask the device
+            # (whose scores may meanwhile be another ticket's: select_clips_to_review / _own_scores look after that)
+            self._score_values = ahead["scores"]
+            self._score_weights = w
+            self.scores = ScoreMap(db.clip_ids, self._score_values, db.row_of)
+            return
         with _db_lock(db):
             self._own_similarities()
-            db.rescore(w)
-            self._score_values = db.scores()
+            band = self._review_band(getattr(self, "_hp", None)) if hasattr(db, "query_round") else None
+            if band is not None:                               # re-weighting + the partition select_clips_to_review is about to ask for
+                r = db.query_round(None, weights=w, select=band)
+                self._score_values = r.scores
+                self._ahead = {"w": w.tobytes(), "scores": r.scores, "select": band, "match_rows": r.match_rows,
+                               "near_rows": r.near_rows, "near_argmax": r.near_argmax}
+            else:
+                db.rescore(w)
+                self._score_values = db.scores()
+                self._ahead = None
             self._score_weights = w
             db.scores_owner = (self._round, w.tobytes())
         self.scores = ScoreMap(db.clip_ids, self._score_values, db.row_of)
@@ -185,9 +263,14 @@ class TicketScoring:
         db = self.feature_db
         vals, ids = self._score_values, db.clip_ids
         lower_limit = threshold - near_miss * (1 - threshold)
-        with _db_lock(db):
-            self._own_scores()
-            match_rows, near_rows, near_argmax = db.select(threshold, lower_limit)     # stable partition on the GPU
+        ahead = getattr(self, "_ahead", None)
+        if ahead is not None and ahead["select"] == (threshold, lower_limit) and ahead["w"] == self._score_weights.tobytes():
+            # the partition of exactly these scores under exactly this band came back with them
+            match_rows, near_rows, near_argmax = ahead["match_rows"], ahead["near_rows"], ahead["near_argmax"]
+        else:
+            with _db_lock(db):
+                self._own_scores()
+                match_rows, near_rows, near_argmax = db.select(threshold, lower_limit)     # stable partition on the GPU
         mscores = int(min(max_number_matches / 2, len(match_rows)))
         m_near_scores = int(min(max_number_matches - mscores, len(near_rows)))
         # random.sample draws positions from (len(population), k) only, so sampling positions
@@ -324,9 +407,10 @@ def install(ticket_cls, hyperparameter_cls=None, target_clip_cls=None):
             self._ticket = ticket                          # lets the round use rows of a resident ticket.feature_db
         target_clip_cls.__init__ = remember_ticket
     for name in ("compute_similarities", "compute_scores", "lowest_scoring_user_match", "select_clips_to_review",
-                 "_own_similarities", "_own_scores"):
+                 "_own_similarities", "_own_scores", "_look_ahead"):
         setattr(ticket_cls, name, getattr(TicketScoring, name))
-    for name in ("feature_db", "feature_db_dtype", "device", "_round", "_score_weights"):
+    ticket_cls._review_band = staticmethod(TicketScoring._review_band)
+    for name in ("feature_db", "feature_db_dtype", "device", "_round", "_score_weights", "_ahead", "_hp", "_stream_gap"):
         if not hasattr(ticket_cls, name):
             setattr(ticket_cls, name, getattr(TicketScoring, name))
     if hyperparameter_cls is not None:

@@ -131,6 +131,23 @@ def s2d_stem_weights_xmajor(W: np.ndarray) -> np.ndarray:
 
 
 _PACKER_DIGEST = None
+_DEFAULT_TILES = None
+DEFAULT_TILES_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "default_tiles.json")
+
+
+def _default_tiles() -> dict:
+    """{graph key: {"<n_crops>" | "<n_crops>p": [[BM, BN, BK, pipelined] per layer]}}: the tiling tables shipped with the library
+    (measured on an MI355X by tools/make_default_tiles.py for both BN-Inception streams at the BASELINE batch sizes)."""
+    global _DEFAULT_TILES
+    if _DEFAULT_TILES is None:
+        try:
+            with open(DEFAULT_TILES_PATH) as f:
+                _DEFAULT_TILES = json.load(f).get("tables", {})
+        except (OSError, ValueError):
+            _DEFAULT_TILES = {}
+    return _DEFAULT_TILES
+
+
 
 
 def packer_digest() -> str:
@@ -365,26 +382,48 @@ class TsnNet:
         desc = [(d.op, d.src, d.dst, d.src_coff, d.dst_coff, d.cin, d.cout, d.k, d.stride, d.pad, d.seg_count, d.pre_pool_k) for d in layers]
         shapes = [(tensors[i].h, tensors[i].w, tensors[i].c) for i in range(len(plan.tensors))]
         self._tune_file = None
-        self._tune_saved = set()
+        self._tune_saved = set()        # (n_crops, paired) of the tables that are in the cache file or came with the library
         self._tune_checked = set()      # batch sizes whose first forward (the one that tunes) is behind us
         where = tune_cache if tune_cache is not None else os.environ.get("VQ_TUNE_CACHE", os.path.join(os.path.dirname(_lib.LIB_PATH), ".tune_cache"))
+        split = os.environ.get("VQ_TSN_SPLIT", "2")           # a paired table was timed beside this many twins
+        self.graph_key = hashlib.sha1(json.dumps([desc, shapes]).encode()).hexdigest()[:20]
+
+        def install(table):
+            for name, tiles in table.items():
+                if name == "one_stream":                      # batch sizes measured faster on one stream than as two sub-batches
+                    for n_crops in tiles:
+                        self.set_split(int(n_crops), False)
+                    continue
+                paired = name.endswith("p")
+                n_crops = int(name[:-1] if paired else name)
+                if n_crops <= self.max_crops and (n_crops, paired) not in self._tune_saved:
+                    self._install_tiles(n_crops, np.array(tiles, dtype=np.int32), paired)
+                    self._tune_saved.add((n_crops, paired))
         if where != "0":
-            key = hashlib.sha1(json.dumps([_lib.ABI_VERSION, desc, shapes]).encode()).hexdigest()[:20]
+            key = hashlib.sha1(json.dumps([_lib.ABI_VERSION, desc, shapes, split]).encode()).hexdigest()[:20]
             self._tune_file = os.path.join(where, key + ".json")
             try:
                 with open(self._tune_file) as f:
-                    for n_crops, tiles in json.load(f).items():
-                        if int(n_crops) <= self.max_crops:
-                            self._install_tiles(int(n_crops), np.array(tiles, dtype=np.int32))
-                            self._tune_saved.add(int(n_crops))
+                    install(json.load(f))
             except (OSError, ValueError, _lib.VqError):
                 pass            # no file yet, or one written for another kernel set: tune afresh
+        # The tables shipped with the library (tsn/default_tiles.json: the BASELINE shapes on gfx950, tools/make_default_tiles.py) fill in
+        # what this machine has not measured itself, so that a cold process times nothing.  VQ_TSN_AUTOTUNE=1 leaves them out: every
+        # size is then swept in its first forward (and kept in the cache above) -- the refinement for a machine that differs.
+        self.default_tables = 0
+        if os.environ.get("VQ_TSN_AUTOTUNE") != "1" and os.environ.get("VQ_TSN_DEFAULT_TILES", "1") != "0" and split == "2":
+            try:
+                before = len(self._tune_saved)
+                install(_default_tiles().get(self.graph_key, {}))
+                self.default_tables = len(self._tune_saved) - before
+            except (ValueError, _lib.VqError):
+                pass            # a table written for another kernel set
 
     def _persist_tuning(self, n_crops):
         if self._tune_file is None or n_crops in self._tune_checked:
             return
         self._tune_checked.add(n_crops)
-        sizes = set(self.tuned_sizes())
+        sizes = {(n, p) for n, p, borrowed in self.tile_tables() if not borrowed}      # measured here (or installed from a file)
         if sizes <= self._tune_saved:
             return
         try:
@@ -395,13 +434,13 @@ class TsnNet:
                     table = json.load(f)
             except (OSError, ValueError):
                 pass
-            for n in sizes:
-                table[str(n)] = self.layer_tiles(n).tolist()
+            for n, p in sizes - self._tune_saved:
+                table["%d%s" % (n, "p" if p else "")] = self.layer_tiles(n, paired=p).tolist()
             tmp = "%s.%d.tmp" % (self._tune_file, os.getpid())
             with open(tmp, "w") as f:
                 json.dump(table, f)
             os.replace(tmp, self._tune_file)
-            self._tune_saved = sizes
+            self._tune_saved |= sizes
         except OSError:
             self._tune_file = None      # read-only tree: keep tuning per process
 
@@ -501,12 +540,35 @@ class TsnNet:
         names = [(o.pre_pool[2] + ">" + o.name) if o.pre_pool else o.name for o in self.plan.ops]
         return names, [o.kind for o in self.plan.ops], ms, fl
 
-    def layer_tiles(self, n_crops: int) -> np.ndarray:
-        """[n_layers, 4] (BM, BN, BK, pipelined) implicit-GEMM tiling per conv layer at this batch size."""
+    def layer_tiles(self, n_crops: int, paired: bool | None = None) -> np.ndarray:
+        """[n_layers, 4] (BM, BN, BK, pipelined) implicit-GEMM tiling per conv layer at this batch size.  ``paired``: the table of a
+        SUB-BATCH of this size (timed side by side on the sub-batch streams) / of a one-stream forward; None = the one-stream table,
+        else the paired one, else the heuristic."""
         n = len(self.plan.ops)
         out = np.zeros((n, 4), dtype=np.int32)
-        call("vq_tsn_layer_tiles", self._h, int(n_crops), out.ctypes.data_as(C.c_void_p), n)
+        if paired is None:
+            call("vq_tsn_layer_tiles", self._h, int(n_crops), out.ctypes.data_as(C.c_void_p), n)
+        else:
+            call("vq_tsn_get_tiles", self._h, int(n_crops), 1 if paired else 0, out.ctypes.data_as(C.c_void_p), n)
         return out
+
+    def set_split(self, n_crops: int, split: bool | None):
+        """Forwards of (about) n_crops crops run as sub-batches on separate streams (True, the default), on one stream (False: measured
+        faster at that size), or as the default says again (None)."""
+        call("vq_tsn_set_split", self._h, int(n_crops), -1 if split is None else (1 if split else 0))
+
+    def tune(self, n_crops: int, paired: bool):
+        """Run the timing sweep for one table now (the slots hold whatever they hold: only durations matter)."""
+        call("vq_tsn_tune", self._h, int(n_crops), 1 if paired else 0)
+
+    def tile_tables(self):
+        """[(n_crops, paired, borrowed)] of every tiling table the handle holds (include/vq_amd.h: vq_tsn_tile_tables)."""
+        k = C.c_int32()
+        call("vq_tsn_tile_tables", self._h, None, None, 0, C.byref(k))
+        sizes = np.zeros(max(k.value, 1), dtype=np.int32)
+        flags = np.zeros(max(k.value, 1), dtype=np.int32)
+        call("vq_tsn_tile_tables", self._h, sizes.ctypes.data_as(C.c_void_p), flags.ctypes.data_as(C.c_void_p), sizes.size, C.byref(k))
+        return [(int(s), bool(f & 1), bool(f & 2)) for s, f in zip(sizes[:k.value], flags[:k.value])]
 
     def launch_items(self):
         """(item_of_layer [n_layers], n_items): which kernel launch of a forward executes each layer -- the Winograd
@@ -525,16 +587,21 @@ class TsnNet:
         call("vq_tsn_tuned_sizes", self._h, out.ctypes.data_as(C.c_void_p), out.size, C.byref(k))
         return out[:k.value].tolist()
 
-    def set_layer_tiles(self, n_crops: int, tiles: np.ndarray):
-        """Install a tiling table (from layer_tiles, e.g. of an earlier process) instead of autotuning.  A handle whose tables were set by
-        hand no longer writes the tiling cache: what it would save is the caller's choice (a test forcing one kernel, an A/B), not a
-        measurement, and later sizes may borrow from it."""
+    def set_layer_tiles(self, n_crops: int, tiles: np.ndarray, paired: bool | None = None):
+        """Install a tiling table (from layer_tiles, e.g. of an earlier process) instead of autotuning.  ``paired`` None: for a forward of
+        n_crops however it runs (the one-stream table of that size AND the paired tables of the sub-batches the default forward cuts it
+        into); True / False: that one table.  A handle whose tables were set by hand no longer writes the tiling cache: what it would
+        save is the caller's choice (a test forcing one kernel, an A/B), not a measurement, and later sizes may borrow from it."""
         self._tune_file = None
-        self._install_tiles(n_crops, tiles)
+        if paired is None:
+            t = np.ascontiguousarray(tiles, dtype=np.int32)
+            call("vq_tsn_set_layer_tiles", self._h, int(n_crops), t.ctypes.data_as(C.c_void_p), t.shape[0])
+        else:
+            self._install_tiles(n_crops, tiles, paired)
 
-    def _install_tiles(self, n_crops: int, tiles: np.ndarray):
+    def _install_tiles(self, n_crops: int, tiles: np.ndarray, paired: bool = False):
         t = np.ascontiguousarray(tiles, dtype=np.int32)
-        call("vq_tsn_set_layer_tiles", self._h, int(n_crops), t.ctypes.data_as(C.c_void_p), t.shape[0])
+        call("vq_tsn_set_tiles", self._h, int(n_crops), 1 if paired else 0, t.ctypes.data_as(C.c_void_p), t.shape[0])
 
     def flops_per_crop(self) -> float:
         out = C.c_double()
