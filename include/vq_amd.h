@@ -40,6 +40,7 @@
  *     VQ_TUNE_CACHE=<dir>|0, VQ_WEIGHT_CACHE=<dir>|0   where the tiling tables / packed weights are kept between processes (0 = nowhere)
  *     VQ_DIST_BACKEND=gloo|nccl    torch.distributed backend of the N > 1 entry points (default nccl = RCCL; gloo: CPU tests, one-card rehearsals)
  *     VQ_CLI_TRACE=1               calcSig_wOF.py prints phase stamps; VQ_CLI_GROUP_CLIPS=<n>: clips per flush group (default 16 batches per rank)
+ *     VQ_INGEST_PRIORITY=low|normal|high   queue priority of the streams the frame-ingest kernels run on (default normal; no priority changed the end-to-end rate: profiles/README.md)
  *     VQ_NO_TORCH=0|1              one-rank calcSig_wOF.py runs WITHOUT importing torch (set to 1 by main() before the library is loaded: device buffers
  *                                  and streams from vq_dev_malloc / vq_stream_*, tsn/devmem.py); 0 keeps torch; same bytes either way
  *     VQ_FANOUT_*                  set BY fanout.py for the per-GPU children it starts (rank, world, device, workers): not for users
@@ -62,7 +63,8 @@ extern "C" {
  * 9 (round 5): + vq_jpeg_crops; vq_jpeg_decode*(color | 2) stops at the component planes.
  * 10 (round 5): + vq_dev_malloc / vq_dev_free / vq_stream_create / vq_stream_destroy / vq_stream_synchronize / vq_dev_read.
  * 11 (round 6): + vq_tsn_tile_tables / vq_tsn_get_tiles / vq_tsn_set_tiles / vq_tsn_tune / vq_tsn_set_split (a tiling table is keyed by (batch size, timed side by side on
- *      the sub-batch streams | alone)); vq_db_query_round / vq_db_round_layout / vq_host_alloc / vq_host_free (a query round in one call). */
+ *      the sub-batch streams | alone)); vq_db_query_round / vq_db_round_layout / vq_host_alloc / vq_host_free (a query round in one call);
+ *      vq_stream_create_priority. */
 #define VQ_ABI_VERSION 11
 
 enum {
@@ -269,6 +271,10 @@ int vq_resize_crop_planes(const uint8_t* planes_dev, int32_t n, int32_t h, int32
 int vq_dev_malloc(void** ptr, int64_t bytes, int32_t device);
 int vq_dev_free(void* ptr, int32_t device);
 int vq_stream_create(void** hip_stream, int32_t device);
+/* The same with a queue priority: -1 the lowest the device offers, 0 the middle, +1 the highest.  The frame-ingest kernels in front of the
+ * networks (JPEG entropy decoding, IDCT, pixel and resize passes of LATER batches: calcSig_wOF.py:88-113 decodes inside the loop) run on
+ * streams whose priority VQ_INGEST_PRIORITY sets (measured without effect on the networks: profiles/README.md). */
+int vq_stream_create_priority(void** hip_stream, int32_t device, int32_t priority);
 int vq_stream_destroy(void* hip_stream, int32_t device);
 int vq_stream_synchronize(void* hip_stream, int32_t device);
 int vq_dev_read(void* host, const void* dev, int64_t bytes, int32_t device);

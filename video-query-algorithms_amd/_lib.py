@@ -106,7 +106,7 @@ SIGNATURES = {
     "vq_jpeg_decode_files": [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P],
     "vq_jpeg_decode_path_list": [_P, C.c_char_p, C.c_int64, _I32, _I32, _I32, _I32, _P, _P, _P], "vq_jpeg_info_file": [C.c_char_p, _pI32, _pI32, _pI32],
     "vq_jpeg_crops": [_P, _I32, _I32, _P, _P],
-    "vq_dev_malloc": [_PP, _I64, _I32], "vq_dev_free": [_P, _I32], "vq_stream_create": [_PP, _I32], "vq_stream_destroy": [_P, _I32],
+    "vq_dev_malloc": [_PP, _I64, _I32], "vq_dev_free": [_P, _I32], "vq_stream_create": [_PP, _I32], "vq_stream_create_priority": [_PP, _I32, _I32], "vq_stream_destroy": [_P, _I32],
     "vq_stream_synchronize": [_P, _I32], "vq_dev_read": [_P, _P, _I64, _I32],
     "vq_flow_good_features": [_P, _P, _I32, _I32, _I32, C.c_float, C.c_float, _P, _P, _P],
     "vq_flow_ransac_homography": [_P, _P, _P, _P, _I32, _I32, C.c_float, _I32, C.c_uint32, _I32, _P, _P, _P, _P, _P],

@@ -298,6 +298,17 @@ extern "C" int vq_stream_create(void** stream, int32_t device) {
     return VQ_OK;
 }
 
+extern "C" int vq_stream_create_priority(void** stream, int32_t device, int32_t priority) {
+    VQ_REQUIRE(stream, "NULL argument");
+    DeviceGuard g(device);
+    int least = 0, greatest = 0;                         // numerically: greatest priority <= least priority
+    VQ_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t st;
+    VQ_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, priority < 0 ? least : (priority > 0 ? greatest : (least + greatest) / 2)));
+    *stream = (void*)st;
+    return VQ_OK;
+}
+
 extern "C" int vq_stream_destroy(void* stream, int32_t device) {
     if (!stream) return VQ_OK;
     DeviceGuard g(device);

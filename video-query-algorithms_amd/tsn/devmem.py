@@ -100,10 +100,13 @@ class DevArray:
 class Stream:
     """A non-blocking HIP stream of the library's (``cuda_stream``: its handle, as torch names it)."""
 
-    def __init__(self, device: int):
+    def __init__(self, device: int, priority: int = 0):
         from .._lib import call
         p = C.c_void_p()
-        call("vq_stream_create", C.byref(p), int(device))
+        if priority:
+            call("vq_stream_create_priority", C.byref(p), int(device), int(priority))
+        else:
+            call("vq_stream_create", C.byref(p), int(device))
         self.cuda_stream, self.device = p.value, int(device)
 
     def synchronize(self):
@@ -126,9 +129,11 @@ def empty_u8(shape, device: int):
     return torch.empty(tuple(shape), dtype=torch.uint8, device=torch.device("cuda", int(device)))
 
 
-def new_stream(device: int):
-    if native():
-        return Stream(device)
+def new_stream(device: int, priority: int = 0):
+    """A non-blocking stream; ``priority`` -1 / 0 / +1: the lowest queue priority of the device / the default / the highest (the
+    library's own stream in every case but the default one under torch: torch offers no priority below its default)."""
+    if native() or priority:
+        return Stream(device, priority)
     import torch
     return torch.cuda.Stream(device=torch.device("cuda", int(device)))
 

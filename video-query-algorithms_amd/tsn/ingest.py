@@ -120,8 +120,11 @@ class FrameIngest:
         # a stream of its own (non-blocking): the call may run in a thread of its own for a LATER batch while the network works on the
         # current one on the default stream -- decoding a batch of flow files keeps a few CUs busy for tens of milliseconds
         if st["stream"] is None:
-            # (a high-priority stream was tried for the decode kernels: no gain, 385-391 against 394-412 clips/s end to end)
-            st["stream"] = devmem.new_stream(self.device)
+            # (a high-priority stream was tried for the decode kernels in round 4: no gain, 385-391 against 394-412 clips/s end to end.
+            # Round 6, VQ_INGEST_PRIORITY=low|normal|high on one box: 576 / 576 / 577 and 575 / 531 / 571 clips/s -- the queue priority of the
+            # ingest kernels does not change what the networks get; the default stays normal.)
+            prio = {"low": -1, "normal": 0, "high": 1}.get(os.environ.get("VQ_INGEST_PRIORITY", "normal"), 0)
+            st["stream"] = devmem.new_stream(self.device, prio)
         ingest = st["stream"]
         stream = ingest.cuda_stream
         h, w, _ = jpeg.info(files[0])
