@@ -62,7 +62,7 @@ extern "C" {
  * 8 (round 5): + vq_resize_crop_planes (the ten grey planes of a batch of flow stacks resized / cropped in one launch).
  * 9 (round 5): + vq_jpeg_crops; vq_jpeg_decode*(color | 2) stops at the component planes.
  * 10 (round 5): + vq_dev_malloc / vq_dev_free / vq_stream_create / vq_stream_destroy / vq_stream_synchronize / vq_dev_read.
- * 11 (round 6): + vq_tsn_tile_tables / vq_tsn_get_tiles / vq_tsn_set_tiles / vq_tsn_tune / vq_tsn_set_split (a tiling table is keyed by (batch size, timed side by side on
+ * 11 (round 6): + vq_tsn_tile_tables / vq_tsn_get_tiles / vq_tsn_set_tiles / vq_tsn_tune / vq_tsn_set_split / vq_device_pool_trim (a tiling table is keyed by (batch size, timed side by side on
  *      the sub-batch streams | alone)); vq_db_query_round / vq_db_round_layout / vq_host_alloc / vq_host_free (a query round in one call);
  *      vq_stream_create_priority. */
 #define VQ_ABI_VERSION 11
@@ -438,6 +438,8 @@ int vq_tsn_tuned_sizes(vq_tsn* net, int32_t* sizes, int32_t cap, int32_t* n);
  * BASELINE shapes on gfx950 (tsn/default_tiles.json), a timing sweep inside the first forward of an unseen size (VQ_TSN_AUTOTUNE=0: the
  * occupancy heuristic instead; =1: sweep even where a shipped table exists).  No table changes a result bit. */
 int vq_tsn_tile_tables(vq_tsn* net, int32_t* sizes, int32_t* flags, int32_t cap, int32_t* n);
+/* Give the device blocks closed extractors left in the process-wide pool (VQ_DEVICE_POOL_GB) back to the driver now. */
+int vq_device_pool_trim(void);
 /* Whether a forward of (about) n_crops is cut into sub-batches on separate streams: split = 0: one stream (measured faster at that size:
  * the flow network at 448 crops, tools/make_default_tiles.py), 1: sub-batches, -1: forget the entry.  A forward takes the entry of the
  * nearest size within 1.6x; without one it splits (VQ_TSN_SPLIT).  Same bits either way. */

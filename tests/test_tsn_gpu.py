@@ -1054,3 +1054,31 @@ def test_shipped_tiling_tables_make_a_cold_process_time_nothing(tsn, monkeypatch
     h60, _ = m.forward(crops, 3, mean)
     m.close()
     assert (h60 == f60).all()
+
+
+def test_a_narrow_winograd_layer_at_a_large_batch_is_cut_into_crop_ranges(tsn, monkeypatch):
+    """the Winograd kernel multiplies a slot's pixel indices on 24 bits (crops x H x W < 2^23 per launch).  With 64 or more
+    channels per pixel the 2^31-byte rule for slots implies that; an 8-channel slot of 128 x 128 pixels reaches 2^23 pixels at 512 crops
+    with 270 MB.  The executor caps the crops of such a launch (item_limit) and covers the batch in several crop ranges: 520 crops run,
+    and the first and last crops carry the bits they carry in a batch of four."""
+    bi, net = tsn
+    monkeypatch.delenv("VQ_TSN_TILE", raising=False)
+    h, cin, cout, n = 128, 8, 32, 520
+    g = _mini(bi, cin, h, h, cout, 3, 1, 1)
+    w = net.synthetic_weights(g, seed=11)
+    rng = np.random.default_rng(12)
+    few = rng.integers(0, 256, (4, h, h, cin), dtype=np.uint8)
+    crops = np.empty((n, h, h, cin), dtype=np.uint8)
+    crops[:] = few[0]
+    crops[:2], crops[-2:] = few[:2], few[2:]
+    mean = np.linspace(100.0, 130.0, cin).astype(np.float32)
+    small = net.TsnNet(g, w, max_crops=4, feature_blob="gp", winograd=True)
+    assert small.layer_tiles(4)[0, 3] == 2                                  # the layer is in Winograd form
+    _, ps_small = small.forward(few, 1, mean)
+    small.close()
+    want = to.forward(g.layers, "data", w, to.preprocess(few[:1], mean), keep=("gp",))["gp"].reshape(1, -1)
+    assert np.abs(ps_small[:1] - want).max() <= 2e-5 * np.abs(want).max()
+    big = net.TsnNet(g, w, max_crops=n, feature_blob="gp", winograd=True)
+    _, ps = big.forward(crops, 1, mean)
+    big.close()
+    assert (ps[:2] == ps_small[:2]).all() and (ps[-2:] == ps_small[2:]).all() and (ps[2:-2] == ps_small[0]).all()

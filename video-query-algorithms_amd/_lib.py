@@ -92,7 +92,7 @@ SIGNATURES = {
     "vq_tsn_flops_per_crop": [_P, _pF64], "vq_tsn_launch_items": [_P, _P, _I32, _pI32], "vq_tsn_tuned_sizes": [_P, _P, _I32, _pI32],
     "vq_tsn_layer_tiles": [_P, _I32, _P, _I32], "vq_tsn_set_layer_tiles": [_P, _I32, _P, _I32],
     "vq_tsn_tile_tables": [_P, _P, _P, _I32, _pI32], "vq_tsn_get_tiles": [_P, _I32, _I32, _P, _I32], "vq_tsn_set_tiles": [_P, _I32, _I32, _P, _I32],
-    "vq_tsn_tune": [_P, _I32, _I32], "vq_tsn_set_split": [_P, _I32, _I32],
+    "vq_tsn_tune": [_P, _I32, _I32], "vq_tsn_set_split": [_P, _I32, _I32], "vq_device_pool_trim": [],
     "vq_tsn_set_profile": [_P, _I32], "vq_tsn_set_profile_every": [_P, _I32], "vq_tsn_set_profile_split": [_P, _I32], "vq_tsn_layer_times": [_P, _P, _P, _I32],
     "vq_tvl1_default_params": [C.POINTER(Tvl1Params)],
     "vq_flow_create": [_I32, _I32, _I32, C.POINTER(Tvl1Params), _I32, _PP], "vq_flow_destroy": [_P],
@@ -126,12 +126,31 @@ def _preload_torch_hip():
     libamdhip64.so.7) serves both torch and libvqamd; device pointers are then interchangeable.
     VQ_NO_TORCH=1 (set by the single-GPU command line before anything touches the library): the process will not use torch at all
     (tsn/devmem.py), the library runs on the system's HIP runtime and the 0.8 s import is saved."""
+    global TORCHLESS
     if os.environ.get("VQ_NO_TORCH") == "1" and "torch" not in sys.modules:
+        TORCHLESS = True
         return
+    TORCHLESS = False
     try:
         import torch  # noqa: F401
     except Exception:
         pass
+
+
+# Latched when the library is loaded (None before that): True = this process runs the library on the system's HIP runtime, WITHOUT
+# torch; its device pointers and streams are then not interchangeable with those of a torch imported later (two runtimes).  Everything
+# that decides between the library's own device plumbing and torch's reads THIS, never the environment again (tsn/devmem.native).
+TORCHLESS = None
+
+
+def require_torch_runtime(what: str):
+    """For entry points that hand torch tensors to the library (sharded_db, features_tensor, bench): fail clearly in a process whose
+    library was loaded torch-less instead of passing pointers between two HIP runtimes."""
+    load()
+    if TORCHLESS:
+        raise RuntimeError("%s needs torch and the library on ONE HIP runtime, but libvqamd.so was loaded with VQ_NO_TORCH=1 (the "
+                           "one-rank command line's torch-less mode) in this process; start a fresh process, or import torch before "
+                           "the first use of the package" % what)
 
 
 def load(path: str | None = None):

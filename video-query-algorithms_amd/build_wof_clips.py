@@ -239,7 +239,7 @@ def create_clip(vid_path: str, out_path: str, frames_per_clip: int = 150, frames
     return len(plan)
 
 
-def main(argv=None, program=None) -> int:
+def _main(argv=None, program=None) -> int:
     if "torch" not in sys.modules:
         # nothing here holds a tensor: the library runs on the system's HIP runtime and the 0.8 s import is saved (VQ_NO_TORCH=0 keeps torch;
         # decided before the library is loaded, _lib._preload_torch_hip)
@@ -300,6 +300,20 @@ def main(argv=None, program=None) -> int:
     if os.environ.get("VQ_CLI_TRACE") == "1":
         print("trace: done (torch imported: %s)" % ("torch" in sys.modules), file=sys.stderr, flush=True)
     return 0
+
+
+
+def main(argv=None, program=None) -> int:
+    """The command line's entry point: VQ_NO_TORCH (set for a one-rank run before the library is loaded, where it is latched:
+    _lib.TORCHLESS) is put back when the call returns."""
+    before = os.environ.get("VQ_NO_TORCH")
+    try:
+        return _main(argv=argv, program=program)
+    finally:
+        if before is None:
+            os.environ.pop("VQ_NO_TORCH", None)
+        else:
+            os.environ["VQ_NO_TORCH"] = before
 
 
 if __name__ == '__main__':

@@ -168,7 +168,7 @@ class _CropPipeline:
             ing.close()
 
 
-def main(argv=None, net_factory=None, program=None):
+def _main(argv=None, net_factory=None, program=None):
     """``net_factory(net_proto, net_weights, device, max_crops=, feature_blob=, resize_rule=)`` builds the per-stream extractor
     (default: the HIP ``CaffeNet``; the CPU tests of the sharding logic pass a stand-in).  ``program``: the script the
     per-GPU children are started from (default: this file; a caller that passes its own ``net_factory`` names its own
@@ -439,6 +439,21 @@ def main(argv=None, net_factory=None, program=None):
     io_pool.shutdown()
     stamp("feature files written (torch imported: %s)" % ("torch" in sys.modules))
     return 0
+
+
+
+def main(argv=None, net_factory=None, program=None):
+    """The command line's entry point.  A one-rank run asks for the torch-less mode by setting VQ_NO_TORCH in the environment BEFORE the
+    library is loaded (it is latched there: _lib.TORCHLESS); the variable is put back when the call returns, so that a host that calls
+    main() in-process does not leak it to its later children."""
+    before = os.environ.get("VQ_NO_TORCH")
+    try:
+        return _main(argv=argv, net_factory=net_factory, program=program)
+    finally:
+        if before is None:
+            os.environ.pop("VQ_NO_TORCH", None)
+        else:
+            os.environ["VQ_NO_TORCH"] = before
 
 
 if __name__ == "__main__":

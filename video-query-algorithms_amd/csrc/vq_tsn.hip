@@ -1734,7 +1734,23 @@ static void build_items(vq_tsn* net, const vq_conv_segment* segments) {
             else
                 worst = std::max(worst, slot_bytes_per_crop(L.dst));
         }
-        return (int)std::max<size_t>(1, (size_t)0x7FFFFFF0u / worst);
+        size_t limit = std::max<size_t>(1, (size_t)0x7FFFFFF0u / worst);
+        // the Winograd kernel multiplies pixel indices of a slot on 24 bits (vq_wino.hip: launch_t requires crops x H x W < 2^23 for the
+        // source AND the destination): with >= 64 channels per pixel the byte limit above implies it, a narrower slot at a large batch
+        // needs the cap itself (the launch then covers the batch in several crop ranges, like any other item)
+        for (int li : members) {
+            const vq_layer_desc& L = net->layers[li];
+            if (L.op != VQ_OP_CONV_WINOGRAD) continue;
+            for (int slot : {L.src, L.dst}) {
+                const vq_tensor_desc& t = net->tensors[slot];
+                limit = std::min(limit, std::max<size_t>(1, ((size_t)(1u << 23) - 1) / ((size_t)t.h * t.w)));
+            }
+            // ... and decodes a workgroup's first tile with a multiply-high division that is exact while (tiles + 32) x tiles per image < 2^32
+            const vq_tensor_desc& ts = net->tensors[L.src];
+            const size_t tpi = (size_t)((ts.h + 1) / 2) * ((ts.w + 1) / 2);
+            if ((1ull << 32) / tpi > 64) limit = std::min(limit, std::max<size_t>(1, ((size_t)((1ull << 32) / tpi) - 64) / tpi));
+        }
+        return (int)limit;
     };
     net->items.clear();
     net->item_of_layer.assign(n, -1);
@@ -2320,6 +2336,11 @@ int vq_tsn_tuned_sizes(vq_tsn* net, int32_t* sizes, int32_t cap, int32_t* n) {
         ++k;
     }
     *n = k;
+    return VQ_OK;
+}
+
+int vq_device_pool_trim(void) {
+    vq::device_pool_trim();
     return VQ_OK;
 }
 

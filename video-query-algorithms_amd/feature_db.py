@@ -259,6 +259,7 @@ class FeatureDB:
         """Zero-copy torch view of a result array in the library's device memory -- "avg" [N,S] f64, "ne" [N,S] i32, "scores"
         [N] f64 -- for collectives that take device tensors (RCCL all-gather of score slices).  The caller orders its use
         behind the scan (same stream as ``set_stream``)."""
+        _lib.require_torch_runtime("FeatureDB.device_tensor")
         import torch
         name, shape, typestr = {"avg": ("vq_db_avg_devptr", (self.n, self.S), "<f8"), "ne": ("vq_db_ne_devptr", (self.n, self.S), "<i4"),
                                 "scores": ("vq_db_scores_devptr", (self.n,), "<f8")}[kind]

@@ -65,6 +65,9 @@ class ShardedFeatureDB:
     the others must be inside :meth:`serve`."""
 
     def __init__(self, local, n_total: int, row0: int, clip_ids: Sequence[int], group=None, root: int = 0, served: bool = False, stream=None):
+        if hasattr(local, "_h"):                          # a real FeatureDB (the CPU tests' stand-in has no library handle)
+            from . import _lib
+            _lib.require_torch_runtime("ShardedFeatureDB")
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist

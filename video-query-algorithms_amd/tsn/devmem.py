@@ -22,12 +22,19 @@ import numpy as np
 
 
 def native() -> bool:
-    return os.environ.get("VQ_NO_TORCH") == "1" and "torch" not in sys.modules
+    """True when the library's own device plumbing serves this process.  Decided ONCE, when libvqamd.so is loaded (``_lib.TORCHLESS``):
+    a later ``import torch`` or a change of the environment cannot flip it mid-process (torch's allocations would then be handed to a
+    library that sits on another HIP runtime)."""
+    from .. import _lib
+    if _lib.TORCHLESS is None:
+        _lib.load()
+    return bool(_lib.TORCHLESS)
 
 
 _pool_lock = threading.Lock()
 _pool: dict = {}                      # (device, bytes) -> [pointers]: a batch's buffer goes round instead of through hipMalloc / hipFree
 _POOL_KEEP = 4                        # (hipFree waits for the whole device; the command line holds 3-4 batches of crops at a time)
+_POOL_BYTES = 4 << 30                 # ... and at most this much in all: ragged batch sizes must not pile up a block set per size
 
 
 class _Block:
@@ -43,10 +50,16 @@ class _Block:
             self.ptr = p.value
 
     def __del__(self):
+        # INVARIANT: a block is dropped only after every stream that wrote or read it has been waited for -- vq_jpeg_crops
+        # synchronises its lane's stream before it returns the crops, and forward_device(feat_out=...) waits for the network's stream
+        # before the batch's crops go out of scope (calcSig_wOF.py's batch loop).  The pool keeps no stream order of its own (torch's
+        # caching allocator, which it stands in for, does): a caller that drops a block with work still in flight would let the next
+        # batch's decode write into it.  on_device=True consumers must therefore synchronise before releasing.
         try:
             with _pool_lock:
                 have = _pool.setdefault((self.device, self.nbytes), [])
-                if len(have) < _POOL_KEEP:
+                held = sum(k[1] * len(v) for k, v in _pool.items())
+                if len(have) < _POOL_KEEP and held + self.nbytes <= _POOL_BYTES:
                     have.append(self.ptr)
                     return
             from .._lib import call

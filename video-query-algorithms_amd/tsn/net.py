@@ -485,6 +485,7 @@ class TsnNet:
     def features_tensor(self, n_clips: int):
         """Zero-copy torch view [n_clips, D] fp64 of the consensus features of the last forward (device memory owned
         by the handle: clone it before the next forward).  Synchronises the device first."""
+        _lib.require_torch_runtime("TsnNet.features_tensor")
         import torch
         f, _ = self.feat_devptr()
 
