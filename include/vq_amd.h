@@ -37,6 +37,8 @@
  *   the Python package
  *     VQ_AMD_LIB=<path>            libvqamd.so to load (default: next to the package)
  *     VQ_TSN_WINOGRAD=0            every 3x3 layer in direct form (other rounding: both forms are tested against the fp64 oracle)
+ *     VQ_TSN_WINO16=0              Winograd layers on maps of at most 14 x 14 without the second filter layout: units of 32 tiles only (default: the
+ *                                  tiling table picks 16 or 32 tiles per launch; same bits)
  *     VQ_TUNE_CACHE=<dir>|0, VQ_WEIGHT_CACHE=<dir>|0   where the tiling tables / packed weights are kept between processes (0 = nowhere)
  *     VQ_DIST_BACKEND=gloo|nccl    torch.distributed backend of the N > 1 entry points (default nccl = RCCL; gloo: CPU tests, one-card rehearsals)
  *     VQ_CLI_TRACE=1               calcSig_wOF.py prints phase stamps; VQ_CLI_GROUP_CLIPS=<n>: clips per flush group (default 16 batches per rank)
@@ -62,7 +64,7 @@ extern "C" {
  * 8 (round 5): + vq_resize_crop_planes (the ten grey planes of a batch of flow stacks resized / cropped in one launch).
  * 9 (round 5): + vq_jpeg_crops; vq_jpeg_decode*(color | 2) stops at the component planes.
  * 10 (round 5): + vq_dev_malloc / vq_dev_free / vq_stream_create / vq_stream_destroy / vq_stream_synchronize / vq_dev_read.
- * 11 (round 6): + vq_tsn_tile_tables / vq_tsn_get_tiles / vq_tsn_set_tiles / vq_tsn_tune / vq_tsn_set_split / vq_device_pool_trim (a tiling table is keyed by (batch size, timed side by side on
+ * 11 (round 6): + vq_tsn_tile_tables / vq_tsn_get_tiles / vq_tsn_set_tiles / vq_tsn_tune / vq_tsn_set_split / vq_device_pool_trim; VQ_OP_CONV_WINOGRAD16 (a tiling table is keyed by (batch size, timed side by side on
  *      the sub-batch streams | alone)); vq_db_query_round / vq_db_round_layout / vq_host_alloc / vq_host_free (a query round in one call);
  *      vq_stream_create_priority. */
 #define VQ_ABI_VERSION 11
@@ -319,7 +321,13 @@ enum {
     /* 3x3 / stride 1 / pad 1 convolution evaluated as Winograd F(2x2,3x3): same result up to fp32 rounding
      * (2.25x fewer multiplies).  w_off then addresses the host-transformed filters U = G g G^T laid out
      * [cin/8][16][cout][8] (position 4 i + j of the 4x4 transform, 8 consecutive input channels innermost). */
-    VQ_OP_CONV_WINOGRAD = 5
+    VQ_OP_CONV_WINOGRAD = 5,
+    /* The same, able to run in units of 16 tiles on v_mfma_f32_16x16x4_f32 as well (layers on maps of at most 14 x 14, some of whose
+     * launches have too few 32-tile units for the chip: the tiling table says which form a launch takes -- tile (64, 32|64, 16, 2)
+     * instead of (128, 32|64, 8, 2)).  w_off addresses BOTH layouts, one behind the other: the one above, then [cin/16][16][cout][16],
+     * slot p of the innermost 16 = input channel {0,2,8,10, 4,6,12,14, 1,3,9,11, 5,7,13,15}[p] of the group (csrc/vq_wino.hip).
+     * cin % 16 == 0.  Every form gives the same bits. */
+    VQ_OP_CONV_WINOGRAD16 = 6
 };
 
 /* One executed layer of the frozen network

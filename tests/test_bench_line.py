@@ -69,7 +69,7 @@ def test_the_per_kernel_fields_of_the_line_agree_with_their_neighbours(bench_mod
     assert abs(gflop - 390.06) < 0.4
     # two sub-batch streams overlap: the product-mode step may be SHORTER than the sum of its kernels' one-stream durations
     assert line["ms_per_step"] < single["ms_per_step"]
-    assert abs(roof["traffic_per_step"] - roof["traffic"] * roof["launches_per_step"]) <= 1e-6 * roof["traffic_per_step"]
+    assert abs(roof["traffic_per_step"] - roof["traffic"] * roof["launches_per_step"]) <= 1e-4 * roof["traffic_per_step"]      # both rounded to six digits
     assert "single_stream" in json.dumps(line) and set(single) >= {"value", "ms_per_step", "frac", "conv_ms_per_step", "kernel_frac"}
 
 

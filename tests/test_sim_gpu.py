@@ -668,3 +668,47 @@ def test_comm_group_of_the_c_abi_single_rank(vqa):
     db.set_stream(None)
     call("vq_comm_destroy", comm)
     db.close()
+
+
+def test_the_raw_ctypes_stub_of_the_one_call_round(vqa):
+    """INTEGRATION.md 1, "the whole round as one call": the stub a maintainer with their own wrapper binds -- raw ctypes on the C ABI, a
+    page-locked block laid out as vq_db_round_layout says -- against the package's own objects."""
+    import ctypes as C
+    n = 3000
+    rng = np.random.default_rng(8)
+    feats = np.abs(rng.standard_normal((n, 2, 3, 1024))).astype(np.float32)
+    t = feats[5].astype(np.float64)
+    t = t / (t * t).sum(axis=-1, keepdims=True)
+    ref = vqa.FeatureDB.from_arrays(feats)
+    ref.set_query(t)
+    ref.scan(weights=[1.0, 1.5])
+    want_avg, _ = ref.similarities()
+    want_scores = ref.scores()
+    want_match, want_near, want_am = ref.select(0.8, 0.73)
+    ref.close()
+    lib = C.CDLL(vqa._lib.LIB_PATH)
+    db = C.c_void_p()
+    assert lib.vq_db_create(C.c_int64(n), 2, 3, 1024, 0, 0, C.byref(db)) == 0
+    assert lib.vq_db_upload(db, C.c_int64(0), C.c_int64(n), feats.ctypes.data_as(C.c_void_p)) == 0
+    off = (C.c_int64 * 10)()
+    assert lib.vq_db_round_layout(db, off) == 0
+    blk = C.c_void_p()
+    assert lib.vq_host_alloc(C.byref(blk), C.c_int64(off[8])) == 0
+    raw = np.ctypeslib.as_array(C.cast(blk, C.POINTER(C.c_uint8)), (off[8],))
+    raw[off[0]:off[0] + t.nbytes].view(np.float64)[:] = t.ravel()
+    raw[off[1]:off[1] + 16].view(np.float64)[:] = (1.0, 1.5)
+    assert lib.vq_db_query_round(db, blk, C.c_int64(off[8]), 1 | 2 | 4, C.c_double(0.8), C.c_double(0.73)) == 0
+    avg = raw[off[2]:off[2] + n * 2 * 8].view(np.float64).reshape(n, 2)
+    scores = raw[off[4]:off[4] + n * 8].view(np.float64)
+    n_match, n_near, near_argmax = raw[off[5]:off[5] + 24].view(np.int64)
+    match_rows = raw[off[6]:off[6] + 8 * min(n_match, off[9])].view(np.int64)
+    near_rows = raw[off[7]:off[7] + 8 * min(n_near, off[9])].view(np.int64)
+    assert (avg == want_avg).all() and (scores == want_scores).all()
+    assert (n_match, n_near, near_argmax) == (len(want_match), len(want_near), want_am)
+    assert (match_rows == want_match).all() and (near_rows == want_near).all()
+    # a block that is too small, or a selection without scores: refused with a message, nothing launched
+    assert lib.vq_db_query_round(db, blk, C.c_int64(off[8] - 1), 7, C.c_double(0.8), C.c_double(0.73)) == -1
+    assert lib.vq_db_query_round(db, blk, C.c_int64(off[8]), 1 | 4, C.c_double(0.8), C.c_double(0.73)) == -1
+    lib.vq_last_error.restype = C.c_char_p
+    assert b"selection needs the scores" in lib.vq_last_error()
+    assert lib.vq_host_free(blk) == 0 and lib.vq_db_destroy(db) == 0

@@ -237,6 +237,8 @@ WINO_CASES = [
     (160, 7, 224, 5),              # 7x7: odd size, 4x4 tiles cover 8x8
     (8, 5, 32, 1),                 # minimum: one K step, 9 tiles
     (256, 9, 320, 2),              # 32 K steps, odd size
+    (64, 14, 96, 7),               # 4a/3x3 in small: 343 tiles = 21 units of 16 + 7 tiles, three 32-channel blocks
+    (16, 3, 32, 2),                # one 16-channel step, 4 tiles per image
 ]
 
 
@@ -252,22 +254,42 @@ def test_winograd_conv_layer(tsn, monkeypatch, cin, h, cout, n):
     mean = np.linspace(100.0, 130.0, cin).astype(np.float32)
     want = to.forward(g.layers, "data", w, to.preprocess(crops, mean), keep=("c_bn", "gp"))
     tol = 2e-5 * np.abs(want["c_bn"]).max()
+    from video_query_algorithms_amd import _lib as vlib
     outs = []
-    for bn, bk in ((32, 8), (64, 8)):                                # 32 / 64 output channels per workgroup
+    # 32 / 64 output channels per workgroup, units of 32 tiles; on maps of at most 14 x 14 with Cin % 16 == 0 (VQ_OP_CONV_WINOGRAD16: the
+    # layer carries a second filter layout) also units of 16 tiles on v_mfma_f32_16x16x4 -- the channels meet every output element in the
+    # 32-tile kernel's order, so all forms give the same bits
+    both = cin % 16 == 0 and h <= 14
+    for bm, bn, bk in ((128, 32, 8), (128, 64, 8)) + (((64, 32, 16), (64, 64, 16)) if both else ()):
         m = net.TsnNet(g, w, max_crops=n, feature_blob="gp", winograd=True)
+        assert m.layer_op(0) == (vlib.VQ_OP_CONV_WINOGRAD16 if both else vlib.VQ_OP_CONV_WINOGRAD)
         tiles = m.layer_tiles(n)
-        assert tiles[0].tolist()[2:] == [8, 2]                       # the conv layer is in Winograd form
-        tiles[0] = (128, bn, bk, 2)
+        assert tiles[0, 3] == 2                                      # the conv layer is in Winograd form
+        tiles[0] = (bm, bn, bk, 2)
         m.set_layer_tiles(n, tiles)
         feat, ps = m.forward(crops, 1, mean)
         got = _nchw(m.read_blob("c_bn", n))
-        assert m.layer_tiles(n)[0].tolist() == [128, bn, bk, 2]
+        assert m.layer_tiles(n)[0].tolist() == [bm, bn, bk, 2]
         assert np.abs(got - want["c_bn"]).max() <= tol
         assert (got >= 0).all()
         assert np.abs(ps - want["gp"].reshape(n, -1)).max() <= tol
         outs.append(got)
         m.close()
-    assert (outs[0] == outs[1]).all()
+    assert all((o == outs[0]).all() for o in outs[1:])
+    if not both:                                                      # a layer without the second layout refuses the 16-tile form
+        m = net.TsnNet(g, w, max_crops=n, feature_blob="gp", winograd=True)
+        tiles = m.layer_tiles(n)
+        tiles[0] = (64, 32, 16, 2)
+        with pytest.raises(vlib.VqError):
+            m.set_layer_tiles(n, tiles)
+        m.close()
+    monkeypatch.setenv("VQ_TSN_WINO16", "0")                           # the switch: no second layout anywhere
+    m = net.TsnNet(g, w, max_crops=n, feature_blob="gp", winograd=True)
+    assert m.layer_op(0) == vlib.VQ_OP_CONV_WINOGRAD
+    m.forward(crops, 1, mean)
+    assert (_nchw(m.read_blob("c_bn", n)) == outs[0]).all()
+    m.close()
+    monkeypatch.delenv("VQ_TSN_WINO16")
     m = net.TsnNet(g, w, max_crops=n, feature_blob="gp", winograd=False)
     assert m.layer_tiles(n)[0, 3] != 2
     m.forward(crops, 1, mean)
@@ -644,10 +666,17 @@ def test_every_winograd_variant_writes_all_it_owns(tsn, monkeypatch, channels, s
     m = net.TsnNet(g, w, max_crops=6)
     m.forward(crops, 3, mean)
     got = {}
-    for variant in (0, 1):
+    from video_query_algorithms_amd import _lib as vlib
+    has16 = np.array([m.layer_op(i) == vlib.VQ_OP_CONV_WINOGRAD16 for i in range(len(m.plan.ops))])
+    assert has16.sum() == 19                                          # the 14 x 14 and 7 x 7 Winograd layers carry both layouts
+    for variant in (0, 1, 2, 3):                                      # 2, 3: units of 16 tiles where the layer has the layout for them
         for n, paired, _ in m.tile_tables():
             t = m.layer_tiles(n, paired=paired)
-            t[t[:, 3] == 2, 1] = 32 * (variant + 1)
+            wino = t[:, 3] == 2
+            t[wino, 1] = 32 * ((variant & 1) + 1)
+            t[wino, 0], t[wino, 2] = 128, 8
+            if variant >= 2:
+                t[wino & has16, 0], t[wino & has16, 2] = 64, 16
             m.set_layer_tiles(n, t, paired=paired)
         f, p = m.forward(crops, 3, mean)
         assert np.isfinite(p).all() and np.isfinite(f).all()
@@ -655,7 +684,7 @@ def test_every_winograd_variant_writes_all_it_owns(tsn, monkeypatch, channels, s
             assert np.isfinite(m.read_blob(name, 6)).all(), (variant, name)
         got[variant] = p
     m.close()
-    assert (got[0] == got[1]).all()
+    assert all((got[v] == got[0]).all() for v in (1, 2, 3))
 
 
 @pytest.mark.parametrize("split", ["1", "2", "3", "2,1"])
@@ -907,7 +936,7 @@ def test_bench_two_rank_control_flow_rehearsal(tsn):
         single = out["single_stream"]
         assert single["ms_per_step"] > 0 and single["profiled_steps"] == roof["profiled_steps"] == 2       # --steps 2: every step sampled
         assert single["conv_ms_per_step"] == roof["conv_ms_per_step"] and single["kernel_frac"] == roof["kernel_frac"]
-        assert "single_stream region" in out["config"]["timed_mode"] and roof["traffic_per_step"] == pytest.approx(roof["traffic"] * 36)
+        assert "single_stream region" in out["config"]["timed_mode"] and roof["traffic_per_step"] == pytest.approx(roof["traffic"] * 36, rel=1e-4)
         assert len(lines[0]) < 4096                                 # the driver's record keeps the whole line
     # ``python bench.py --gpus 2`` with NO launcher starts its own ranks (before any GPU call) and prints the same one line
     plain = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}

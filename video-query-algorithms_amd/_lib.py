@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libvqamd.so")
 ABI_VERSION = 11                 # include/vq_amd.h: VQ_ABI_VERSION
 VQ_F32, VQ_F64 = 0, 1
 VQ_LAYOUT_ROWS, VQ_LAYOUT_TILED = 0, 1
-VQ_OP_CONV, VQ_OP_MAXPOOL, VQ_OP_AVGPOOL, VQ_OP_GLOBAL_AVGPOOL, VQ_OP_CONV_WINOGRAD = 1, 2, 3, 4, 5
+VQ_OP_CONV, VQ_OP_MAXPOOL, VQ_OP_AVGPOOL, VQ_OP_GLOBAL_AVGPOOL, VQ_OP_CONV_WINOGRAD, VQ_OP_CONV_WINOGRAD16 = 1, 2, 3, 4, 5, 6
 
 _ERR_NAMES = {-1: "VQ_E_INVALID", -2: "VQ_E_HIP", -3: "VQ_E_NOMEM", -4: "VQ_E_STATE", -5: "VQ_E_UNSUPPORTED"}
 

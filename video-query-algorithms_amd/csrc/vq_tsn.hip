@@ -984,7 +984,8 @@ static inline double first_layer_k2c(const vq_input_desc& in, const vq_layer_des
     return (double)k * k * in.c;
 }
 
-static inline bool is_conv(int op) { return op == VQ_OP_CONV || op == VQ_OP_CONV_WINOGRAD; }
+static inline bool is_wino(int op) { return op == VQ_OP_CONV_WINOGRAD || op == VQ_OP_CONV_WINOGRAD16; }
+static inline bool is_conv(int op) { return op == VQ_OP_CONV || is_wino(op); }
 
 struct ConvTile {
     int bm, bn, bk;
@@ -1368,7 +1369,7 @@ static int launch_conv_layer(vq_tsn* net, int li, int n_crops, int tile_idx) {
     return small ? launch_conv<true>(net, a, kTiles[tile_idx]) : launch_conv<false>(net, a, kTiles[tile_idx]);
 }
 
-static void fill_wino_job(vq_tsn* net, int li, int n_crops, WinoJob& a) {
+static void fill_wino_job(vq_tsn* net, int li, int n_crops, WinoJob& a, int variant) {
     const vq_layer_desc& L = net->layers[li];
     const vq_tensor_desc& ts = net->tensors[L.src];
     const vq_tensor_desc& td = net->tensors[L.dst];
@@ -1389,6 +1390,9 @@ static void fill_wino_job(vq_tsn* net, int li, int n_crops, WinoJob& a) {
     a.tw = (ts.w + 1) / 2;
     a.P = n_crops * a.th * a.tw;
     a.relu = L.relu;
+    // VQ_OP_CONV_WINOGRAD16: both filter layouts, the 32-tile one first; variants 2, 3 run the units of 16 tiles on the second
+    a.t16 = L.op == VQ_OP_CONV_WINOGRAD16 && variant >= 2;
+    if (a.t16) a.u += (size_t)16 * L.cout * L.cin;
     a.in_bytes = (unsigned)((size_t)n_crops * ts.h * ts.w * ts.c * sizeof(float));
     a.out_bytes = (unsigned)((size_t)n_crops * td.h * td.w * td.c * sizeof(float));
     a.u_bytes = (unsigned)((size_t)16 * L.cout * L.cin * sizeof(float));
@@ -1424,13 +1428,20 @@ static int launch_wino_layers(vq_tsn* net, const std::vector<int>& members, int 
     WinoGroup g;
     memset(&g, 0, sizeof g);
     for (int li : members) {
-        if (net->layers[li].op == VQ_OP_CONV_WINOGRAD) {
+        if (is_wino(net->layers[li].op)) {
             VQ_REQUIRE(g.n_jobs < kWinoMaxJobs, "a Winograd launch carries at most %d convolutions", kWinoMaxJobs);
-            fill_wino_job(net, li, n_crops, g.job[g.n_jobs++]);
+            fill_wino_job(net, li, n_crops, g.job[g.n_jobs++], variant);
         } else {
             VQ_REQUIRE(g.n_pools < kWinoMaxPools, "a Winograd launch carries at most %d pooling layers", kWinoMaxPools);
             fill_pool_args(net, li, n_crops, g.pool[g.n_pools++]);
         }
+    }
+    bool both = true;
+    for (int li : members)
+        if (net->layers[li].op == VQ_OP_CONV_WINOGRAD) both = false;
+    if (variant >= 2 && !both) {                         // a table written for another layout: the same channel blocks on 32 tiles (same bits)
+        variant -= 2;
+        for (int q = 0; q < g.n_jobs; ++q) VQ_REQUIRE(!g.job[q].t16, "internal: mixed Winograd layouts in one launch");
     }
     return launch_wino_group(g, variant, net->ls, net->ev_start, net->ev_stop);
 }
@@ -1550,9 +1561,10 @@ static int autotune(vq_tsn* net, int n_crops, bool paired) {
     for (const LaunchItem& it : net->items) {
         const int li = it.layers[0];
         if (!is_conv(net->layers[li].op)) continue;
-        const bool wino = net->layers[li].op == VQ_OP_CONV_WINOGRAD;
+        const bool wino = is_wino(net->layers[li].op);
         std::vector<std::pair<float, int>> seen;
-        for (int t = 0; t < (wino ? kWinoVariants : kNumTiles); ++t) {
+        const int n_wino = net->layers[li].op == VQ_OP_CONV_WINOGRAD16 ? 2 * kWinoVariants : kWinoVariants;     // + the 16-tile units
+        for (int t = 0; t < (wino ? n_wino : kNumTiles); ++t) {
             if (!wino && net->layers[li].pre_pool_k > 0 && !pool_tile_ok(kTiles[t], net->layers[li].cin)) continue;
             if (!wino && net->layers[li].pre_pool_k == 0 && pool_only_tile(kTiles[t])) continue;
             // a column tile that is mostly padding cannot win: do not let a timing fluke choose it
@@ -1621,7 +1633,7 @@ static int run_layer(vq_tsn* net, int li, int n_crops, int tune_key) {
         }
         return launch_conv_layer(net, li, n_crops, t);
     }
-    if (L.op == VQ_OP_CONV_WINOGRAD) {
+    if (is_wino(L.op)) {
         auto it = net->tuned.find(tune_key);
         return launch_wino_layers(net, std::vector<int>{li}, n_crops, it != net->tuned.end() ? it->second[li] : 0);
     }
@@ -1712,7 +1724,7 @@ static void build_items(vq_tsn* net, const vq_conv_segment* segments) {
             if (op != VQ_OP_MAXPOOL && op != VQ_OP_AVGPOOL) continue;
             bool here = false, next = false;
             for (int j = 0; j < n; ++j)
-                if (net->layers[j].op == VQ_OP_CONV_WINOGRAD) {
+                if (is_wino(net->layers[j].op)) {
                     here |= level[j] == level[i];
                     next |= level[j] == level[i] + 1;
                 }
@@ -1740,7 +1752,7 @@ static void build_items(vq_tsn* net, const vq_conv_segment* segments) {
         // needs the cap itself (the launch then covers the batch in several crop ranges, like any other item)
         for (int li : members) {
             const vq_layer_desc& L = net->layers[li];
-            if (L.op != VQ_OP_CONV_WINOGRAD) continue;
+            if (!is_wino(L.op)) continue;
             for (int slot : {L.src, L.dst}) {
                 const vq_tensor_desc& t = net->tensors[slot];
                 limit = std::min(limit, std::max<size_t>(1, ((size_t)(1u << 23) - 1) / ((size_t)t.h * t.w)));
@@ -1757,9 +1769,9 @@ static void build_items(vq_tsn* net, const vq_conv_segment* segments) {
     for (int lv = 0; lv < n_levels; ++lv) {
         std::vector<int> wino, pools;
         for (int i = 0; i < n; ++i)
-            if (level[i] == lv && net->layers[i].op == VQ_OP_CONV_WINOGRAD && net->group_wino) wino.push_back(i);
+            if (level[i] == lv && is_wino(net->layers[i].op) && net->group_wino) wino.push_back(i);
         for (int i = 0; i < n; ++i) {
-            if (level[i] != lv || (net->layers[i].op == VQ_OP_CONV_WINOGRAD && net->group_wino)) continue;
+            if (level[i] != lv || (is_wino(net->layers[i].op) && net->group_wino)) continue;
             const int op = net->layers[i].op;
             // the level's pooling rides in its Winograd launch (few short workgroups that fill the tail)
             if (!wino.empty() && (op == VQ_OP_MAXPOOL || op == VQ_OP_AVGPOOL) && (int)pools.size() < kWinoMaxPools && net->group_pool) {
@@ -1774,12 +1786,20 @@ static void build_items(vq_tsn* net, const vq_conv_segment* segments) {
             net->items.push_back(it);
         }
         // longest K loop first: the hardware hands out workgroups in index order, so the short ones fill the tail
-        std::stable_sort(wino.begin(), wino.end(), [&](int x, int y) { return net->layers[x].cin > net->layers[y].cin; });
-        for (size_t q = 0; q < wino.size(); q += kWinoMaxJobs) {
+        // (a launch carries layers of one filter layout: the 32-tile form first, then the 16-tile form; a level of BN-Inception has one)
+        std::stable_sort(wino.begin(), wino.end(), [&](int x, int y) {
+            if (net->layers[x].op != net->layers[y].op) return net->layers[x].op < net->layers[y].op;
+            return net->layers[x].cin > net->layers[y].cin;
+        });
+        for (size_t q = 0; q < wino.size();) {
+            size_t end = q;
+            while (end < wino.size() && end - q < (size_t)kWinoMaxJobs && net->layers[wino[end]].op == net->layers[wino[q]].op) ++end;
             LaunchItem it;
             it.kind = 1;
-            it.layers.assign(wino.begin() + q, wino.begin() + std::min(wino.size(), q + kWinoMaxJobs));
-            if (q == 0) it.layers.insert(it.layers.end(), pools.begin(), pools.end());
+            it.layers.assign(wino.begin() + q, wino.begin() + end);
+            const bool first = q == 0;
+            q = end;
+            if (first) it.layers.insert(it.layers.end(), pools.begin(), pools.end());
             it.max_crops = item_limit(it.layers);
             for (int m : it.layers) net->item_of_layer[m] = (int)net->items.size();
             net->items.push_back(it);
@@ -1872,11 +1892,13 @@ int vq_tsn_create(const vq_tensor_desc* tensors, int32_t n_tensors, const vq_lay
             VQ_REQUIRE(L.cin % KPAD == 0 || L.src_coff == 0, "layer %d: small-Cin convolution must read a whole slot", i);
             VQ_REQUIRE(L.cin % KPAD == 0 || L.cin == ts.c, "layer %d: small-Cin convolution must read a whole slot", i);
             macs += (double)td.h * td.w * L.cout * first_layer_k2c(*input, L);   // algorithmic, un-padded
-        } else if (L.op == VQ_OP_CONV_WINOGRAD) {
+        } else if (is_wino(L.op)) {
             VQ_REQUIRE(L.k == 3 && L.stride == 1 && L.pad == 1 && L.seg_count == 0, "layer %d: Winograd form is 3x3 / stride 1 / pad 1, one destination", i);
-            VQ_REQUIRE(L.cin % 8 == 0 && L.cout % 32 == 0, "layer %d: Winograd form needs Cin %% 8 == 0 and Cout %% 32 == 0", i);
+            VQ_REQUIRE(L.cin % (L.op == VQ_OP_CONV_WINOGRAD16 ? 16 : 8) == 0 && L.cout % 32 == 0,
+                       "layer %d: Winograd form needs Cin %% 8 == 0 (16-tile units: %% 16) and Cout %% 32 == 0", i);
             VQ_REQUIRE(td.h == ts.h && td.w == ts.w, "layer %d: conv output size mismatch", i);
-            VQ_REQUIRE(L.w_off >= 0 && L.w_off % 4 == 0 && L.w_off + (int64_t)16 * L.cout * L.cin <= blob_floats,
+            VQ_REQUIRE(L.w_off >= 0 && L.w_off % 4 == 0 &&
+                           L.w_off + (int64_t)(L.op == VQ_OP_CONV_WINOGRAD16 ? 2 : 1) * 16 * L.cout * L.cin <= blob_floats,
                        "layer %d: transformed filters outside the blob", i);
             VQ_REQUIRE(L.b_off >= 0 && L.b_off % 4 == 0 && L.b_off + L.cout <= blob_floats, "layer %d: bias outside the blob", i);
             macs += (double)td.h * td.w * L.cout * L.cin * 9;   // algorithmic (direct-form) count
@@ -2270,7 +2292,7 @@ int vq_tsn_set_profile_every(vq_tsn* net, int32_t every) {
 static double wino_weight(const vq_tsn* net, int li) {
     const vq_layer_desc& L = net->layers[li];
     const vq_tensor_desc& td = net->tensors[L.dst];
-    if (L.op != VQ_OP_CONV_WINOGRAD) {
+    if (!is_wino(L.op)) {
         const vq_tensor_desc& ts = net->tensors[L.src];
         return ((double)ts.h * ts.w + (double)td.h * td.w) * L.cin * 4.0 / 4e12;
     }
@@ -2388,12 +2410,12 @@ int vq_tsn_get_tiles(vq_tsn* net, int32_t n_crops, int32_t paired, int32_t* tile
     auto it = net->tuned.find(tile_key(n_crops, paired != 0));
     for (int i = 0; i < n_layers; ++i) {
         tiles[4 * i] = tiles[4 * i + 1] = tiles[4 * i + 2] = tiles[4 * i + 3] = 0;
-        if (net->layers[i].op == VQ_OP_CONV_WINOGRAD) {   // 32 tiles (128 pixels) x 32 (v+1) channels, 8 channels per step
+        if (is_wino(net->layers[i].op)) {   // 32 tiles (128 pixels) x 32 (v+1) channels, 8 channels per step
             const int lead = net->items[net->item_of_layer[i]].layers[0];   // a grouped launch runs ONE variant: its first member's
             const int v = it != net->tuned.end() ? it->second[lead] : 0;
-            tiles[4 * i] = 128;
-            tiles[4 * i + 1] = 32 * (v + 1);
-            tiles[4 * i + 2] = 8;
+            tiles[4 * i] = v >= 2 ? 64 : 128;             // pixels per unit: 16 or 32 tiles of 2 x 2
+            tiles[4 * i + 1] = 32 * ((v & 1) + 1);
+            tiles[4 * i + 2] = v >= 2 ? 16 : 8;           // channels per step
             tiles[4 * i + 3] = 2;
             continue;
         }
@@ -2424,11 +2446,13 @@ int vq_tsn_set_tiles(vq_tsn* net, int32_t n_crops, int32_t paired, const int32_t
     VQ_REQUIRE(n_crops > 0 && n_crops <= net->max_crops, "n_crops out of range");
     std::vector<int> choice(net->layers.size(), 0);
     for (int i = 0; i < n_layers; ++i) {
-        if (net->layers[i].op == VQ_OP_CONV_WINOGRAD) {
+        if (is_wino(net->layers[i].op)) {
             const int bn = tiles[4 * i + 1], bk = tiles[4 * i + 2];
-            VQ_REQUIRE(tiles[4 * i + 3] == 2 && (bn == 32 || bn == 64) && bk == 8, "layer %d: no Winograd variant for tile %dx%dx%d", i,
-                       tiles[4 * i], bn, bk);
-            choice[i] = bn / 32 - 1;
+            const bool t16 = tiles[4 * i] == 64 && bk == 16;
+            VQ_REQUIRE(tiles[4 * i + 3] == 2 && (bn == 32 || bn == 64) && (t16 || (tiles[4 * i] == 128 && bk == 8)) &&
+                           (!t16 || net->layers[i].op == VQ_OP_CONV_WINOGRAD16),
+                       "layer %d: no Winograd variant for tile %dx%dx%d", i, tiles[4 * i], bn, bk);
+            choice[i] = bn / 32 - 1 + (t16 ? 2 : 0);
             continue;
         }
         if (net->layers[i].op != VQ_OP_CONV) continue;

@@ -142,6 +142,7 @@ struct WinoJob {
     int Cs_out, coff_out, Cout;
     int th, tw, P;       // 2x2 output tiles per image (rows, columns) and in the whole launch
     int relu;
+    int t16;             // 1: u is the second layout of a VQ_OP_CONV_WINOGRAD16 layer -- [Cin/16][16][Cout][16 slots] -- and the units have 16 tiles
     int tiles_n;         // 32*NB-channel blocks of Cout
     int unit0, n_units;  // workgroups [unit0, unit0 + n_units) of the launch belong to this job (unit0 % 8 == 0)
     unsigned in_bytes, u_bytes, out_bytes;   // extents for the buffer descriptors (out-of-range offsets read as zero / are dropped)
@@ -165,7 +166,7 @@ struct WinoGroup {
     PoolArgs pool[kWinoMaxPools];
 };
 
-constexpr int kWinoVariants = 2;   // output-channel blocks of 32 per workgroup: variant v -> v + 1
+constexpr int kWinoVariants = 2;   // output-channel blocks of 32 per workgroup: variant v -> (v & 1) + 1; v >= 2: units of 16 tiles (layers that carry both layouts)
 
 // Fill the derived fields of the jobs (unit ranges, magic constants) for `variant` and launch on `stream`.
 // ev_start / ev_stop (both or neither): events that receive the kernel's own begin / end timestamps

@@ -32,6 +32,8 @@
 //
 // A launch carries up to kWinoMaxJobs independent convolutions (WinoGroup: the 3x3 and the first double-3x3 arm of an
 // inception module): their workgroups fill each other's tail rounds and one kernel boundary disappears.
+// Layers on maps of at most 14 x 14 carry a second filter layout and can run in units of SIXTEEN tiles on v_mfma_f32_16x16x4_f32
+// (wino16_unit below; the tiling table picks per launch): where a launch has too few 32-tile units for 256 compute units.
 // The k order of every output element is fixed (channels ascending in groups of 8), so all variants and groupings
 // produce identical bits.  Rounding differs from the direct kernel (Winograd F(2,3) error is ~1-2.5x the direct fp32
 // error, measured against the fp64 oracle: tests/test_tsn_gpu.py).
@@ -329,7 +331,225 @@ __device__ __forceinline__ void wino_unit(const WinoJob& a, int unit, float* hs)
     VQ_PHASE(3)
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The SIXTEEN-tile unit (round 6; layers on maps of at most 14 x 14, VQ_OP_CONV_WINOGRAD16): 16 tiles x 32 NB output channels x
+// all 16 positions on v_mfma_f32_16x16x4_f32, 16 channels per step.
+// Why: at 96 crops a 14 x 14 layer has 147 blocks of 32 tiles and a 7 x 7 layer 48, i.e. 336-1 176 units per launch for the 256
+// compute units: the last round of units leaves most of the chip idle (a 14 x 14 layer reaches 164 algorithmic TFLOP/s at 96 crops and
+// 237 at 448; a 7 x 7 layer 115 and 174).  Half as many tiles per unit = twice the units of half the length: the rounds quantise half
+// as coarsely.  Filter traffic per multiply doubles (a fragment serves 16 tiles instead of 32); the activations' halves.
+// Same bits as the 32-tile kernel: an fp32 MFMA is a k-ordered chain of fused multiply-adds (one rounding per product), and the
+// channel that k index kq of step-MFMA g multiplies is chosen so that every output element meets its channels in the 32-tile
+// kernel's order -- within 16 channels 0,4,1,5,2,6,3,7,8,12,9,13,10,14,11,15: slot p = 4 kq + g of a lane's 16-byte fragment holds
+// channel kPerm16[p] = {0,2,8,10, 4,6,12,14, 1,3,9,11, 5,7,13,15}.  The host lays the filters out [Cin/16][16 positions][Cout][16
+// slots] in that order (tsn/net.py: winograd_filters16); the loader scatters a pixel's four consecutive channels 4 q .. 4 q + 3 as two
+// 8-byte pairs (channels 4q, 4q+2 -> slots s, s+1; 4q+1, 4q+3 -> s+8, s+9; s = {0,4,2,6}[q]).
+//   lanes:    tile l & 15, k quarter l >> 4 (A = filters: row = output channel l & 15 of a 16-channel block; B = activations);
+//             a lane's 4 accumulator registers of a (position, block) are output channels 4 (l >> 4) + r of tile l & 15.
+//   LDS:      h[r][j][tile][16 slots]: a wave instruction reads or writes 1 KB of contiguous memory (no bank conflicts).
+//   epilogue: as the 32-tile kernel's (j in registers, i through LDS, 16-byte stores), on 16 tiles.
+constexpr int BP16 = 16;                                // tiles per unit
+constexpr int KC16 = 16;                                // channels per step
+constexpr int HS16_STAGE = 4 * 4 * BP16 * KC16;         // floats
+constexpr int EP16_FLOATS = 2 * 4 * BP16 * EP_ROW;      // [i][x][tile][EP_ROW]
+constexpr int LDS16_FLOATS = EP16_FLOATS > 2 * HS16_STAGE ? EP16_FLOATS : 2 * HS16_STAGE;
+
 template <int NB>
+__device__ __forceinline__ void wino16_unit(const WinoJob& a, int unit, float* hs) {
+    constexpr int NBLK = 2 * NB;                        // 16-channel blocks per unit
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_remap(unit, a.n_units);
+    const int pb = (int)magic_div((unsigned)tile, a.m_tiles_n);
+    const int p0 = pb * BP16;
+    const int n0 = (tile - pb * a.tiles_n) * (32 * NB);
+    const int tpi = a.th * a.tw;
+    const int img0 = (int)magic_div((unsigned)p0, a.m_tpi);
+    const int rem0 = p0 - img0 * tpi;
+    const int ty0 = (int)magic_div((unsigned)rem0, a.m_tw);
+    const int tx0 = rem0 - ty0 * a.tw;
+
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
+
+    // ---- loader: patch row r = wave of tile t = lane >> 2, channels 4 q .. 4 q + 3 (q = lane & 3) of the step's 16 ---------------
+    unsigned poff[4];
+    const int lq = lane & 3;
+    {
+        const int t = lane >> 2;
+        const TileAt ta = tile_at(t, img0, ty0, tx0, a.th, a.tw, a.s_th, a.s_tw);
+        const int y = 2 * ta.ty - 1 + wave, x0 = 2 * ta.tx - 1;
+        const bool row_ok = p0 + t < a.P && (unsigned)y < (unsigned)a.H;
+        const int base = (imul24(imul24(ta.img * a.H + y, a.W) + x0, a.Cs_in) + a.coff_in + lq * 4) * 4;
+        const int px = a.Cs_in * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            poff[c] = (row_ok && (unsigned)(x0 + c) < (unsigned)a.W) ? (unsigned)(base + c * px) : 0xFFFFFFFFu;
+    }
+    // slots of the pair (channels 4q, 4q+2): {0, 4, 2, 6}[q]; the pair (4q+1, 4q+3) sits 8 slots further
+    const int slot_a = ((lq & 1) << 2) | (lq & 2);
+    const int hs_store = (wave * 4 * BP16 + (lane >> 2)) * KC16 + slot_a;       // + j * BP16 * KC16 (+ stage)
+
+    // ---- consumer: positions (i = wave, j = 0..3) ------------------------------------------------------------------------------
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
+    const float sgn = wave == 1 ? 1.0f : -1.0f;
+    const floatx2 sgn2 = {sgn, sgn};
+    const int fa_off = (ra * 4 * BP16 + l15) * KC16 + kq * 4;                   // + j * BP16 * KC16
+    const int fb_off = (rb * 4 * BP16 + l15) * KC16 + kq * 4;
+    unsigned uvoff[NBLK];                                  // lane part of the filter fragment address: output channel l15 of block b
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) uvoff[b] = (n0 + 16 * b < a.Cout) ? (unsigned)(((16 * b + l15) * 16 + kq * 4) * 4) : 0xFFFFFFFFu;
+    const unsigned u_step = (unsigned)(16 * a.Cout * 16 * 4);         // bytes between consecutive 16-channel groups
+    const unsigned u_wave = (unsigned)(((wave * 4) * a.Cout + n0) * 16 * 4);
+    const unsigned u_pos = (unsigned)(a.Cout * 16 * 4);               // bytes between positions
+
+    floatx4 acc[4][NBLK];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) acc[j][b] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    if (wave == 1) {                                                  // position (1,1) starts at the bias
+        const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, (unsigned)a.Cout * 4u, 0x00020000);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b)
+            acc[1][b] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, (unsigned)((n0 + 16 * b + 4 * kq) * 4), 0, 0));
+    }
+
+    floatx4 d[4];              // patch row in flight (next step)
+    floatx4 bq[4][NBLK];       // filter fragments of the current step (slot g of a fragment = the A operand of step-MFMA g)
+
+#define VQ_W16_LOAD_PATCH(KSTEP)                                                                                \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                               \
+        d[c] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, poff[c], (KSTEP) * (KC16 * 4), 0));
+#define VQ_W16_LOAD_U(KSTEP, J)                                                                                 \
+    _Pragma("unroll") for (int b = 0; b < NBLK; ++b)                                                            \
+        bq[J][b] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(                           \
+            u_rsrc, uvoff[b], (KSTEP) * u_step + u_wave + (J) * u_pos, 0));
+// column half of the input transform, then the two channel pairs of the quad to their slots
+#define VQ_W16_PUT(J, V)                                                                                        \
+    {                                                                                                           \
+        const floatx4 v_ = (V);                                                                                 \
+        *reinterpret_cast<floatx2*>(dst + (J) * BP16 * KC16) = (floatx2){v_.x, v_.z};                           \
+        *reinterpret_cast<floatx2*>(dst + (J) * BP16 * KC16 + 8) = (floatx2){v_.y, v_.w};                       \
+    }
+#define VQ_W16_STORE_H(ST)                                                                                      \
+    {                                                                                                           \
+        float* dst = hs + (ST) * HS16_STAGE + hs_store;                                                         \
+        VQ_W16_PUT(0, pk_sub(d[0], d[2]))                                                                       \
+        VQ_W16_PUT(1, pk_add(d[1], d[2]))                                                                       \
+        VQ_W16_PUT(2, pk_sub(d[2], d[1]))                                                                       \
+        VQ_W16_PUT(3, pk_sub(d[1], d[3]))                                                                       \
+    }
+#define VQ_W16_READ_A(ST, GRP, SET)                                                                             \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                             \
+        a0[SET][q] = *reinterpret_cast<const floatx4*>(hs + (ST) * HS16_STAGE + fa_off + (2 * (GRP) + q) * BP16 * KC16); \
+        a1[SET][q] = *reinterpret_cast<const floatx4*>(hs + (ST) * HS16_STAGE + fb_off + (2 * (GRP) + q) * BP16 * KC16); \
+    }
+// One step: 4 positions x 4 step-MFMAs x NBLK blocks, in two groups of two positions; consecutive MFMAs never chain on one accumulator
+// (v_mfma_f32_16x16x4: 32-cycle issue, 40-cycle dependent latency).
+#define VQ_W16_STEP(ST, KSTEP, NEXT)                                                                            \
+    {                                                                                                           \
+        floatx4 a0[2][2], a1[2][2];                                                                             \
+        VQ_W16_READ_A(ST, 0, 0)                                                                                 \
+        _Pragma("unroll") for (int g2 = 0; g2 < 2; ++g2) {                                                      \
+            if (g2 + 1 < 2) VQ_W16_READ_A(ST, g2 + 1, (g2 + 1) & 1)                                             \
+            floatx4 av[2];                                                                                      \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                       \
+                av[q] = pk_fma(a1[g2 & 1][q], sgn2, a0[g2 & 1][q]);                                             \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                       \
+                _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                   \
+                    _Pragma("unroll") for (int b = 0; b < NBLK; ++b)                                            \
+                        acc[2 * g2 + q][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[2 * g2 + q][b][e], av[q][e], acc[2 * g2 + q][b], 0, 0, 0); \
+            if (NEXT) {                                                                                         \
+                _Pragma("unroll") for (int q = 0; q < 2; ++q) VQ_W16_LOAD_U((KSTEP) + 1, 2 * g2 + q)            \
+            }                                                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+        }                                                                                                       \
+    }
+
+    const int nk = a.Cin / KC16;
+    VQ_W16_LOAD_PATCH(0)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) VQ_W16_LOAD_U(0, j)
+    VQ_W16_STORE_H(0)
+    __syncthreads();
+    int kc = 0;
+    for (; kc + 1 < nk; ++kc) {
+        const int st = kc & 1;
+        VQ_W16_LOAD_PATCH(kc + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        VQ_W16_STEP(st, kc, true)
+        VQ_W16_STORE_H(st ^ 1)
+        __syncthreads();
+    }
+    VQ_W16_STEP(kc & 1, kc, false)
+#undef VQ_W16_LOAD_PATCH
+#undef VQ_W16_LOAD_U
+#undef VQ_W16_PUT
+#undef VQ_W16_STORE_H
+#undef VQ_W16_STEP
+#undef VQ_W16_READ_A
+
+    // ---- epilogue: Y = A^T M A ------------------------------------------------------------------------------------------------------
+    // last stage: thread (tile et, channel quad ec, output column b_ = bsel) finishes two output pixels of every 32-channel block
+    const int et = (tid >> 3) & 15, ec = tid & 7, bsel = tid >> 7;
+    const TileAt te = tile_at(et, img0, ty0, tx0, a.th, a.tw, a.s_th, a.s_tw);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
+    const int oy = 2 * te.ty, ox = 2 * te.tx;
+    const int obase = (imul24(imul24(te.img * a.H + oy, a.W) + ox, a.Cs_out) + a.coff_out + n0 + ec * 4) * 4;
+    const bool tile_ok = p0 + et < a.P;
+    unsigned ooff[2];                                      // a_ = 0, 1 at column b_ = bsel; 0xFFFFFFFF: the store is dropped
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        ooff[u] = (tile_ok && oy + u < a.H && ox + bsel < a.W) ? (unsigned)(obase + (u * a.W + bsel) * a.Cs_out * 4) : 0xFFFFFFFFu;
+    float* ep_w = hs + ((wave * 2) * BP16 + l15) * EP_ROW + 4 * kq;      // + x * BP16 * EP_ROW + 16 (block & 1)
+    const float* ep_r = hs + et * EP_ROW + ec * 4;                        // + (i * 2 + b_) * BP16 * EP_ROW
+    __syncthreads();            // all waves are done with the K-loop image of the LDS
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            const int b = 2 * nb + bb;
+            floatx4 t0, t1;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const floatx2 m0 = {acc[0][b][2 * h2], acc[0][b][2 * h2 + 1]}, m1 = {acc[1][b][2 * h2], acc[1][b][2 * h2 + 1]};
+                const floatx2 m2 = {acc[2][b][2 * h2], acc[2][b][2 * h2 + 1]}, m3 = {acc[3][b][2 * h2], acc[3][b][2 * h2 + 1]};
+                const floatx2 s0 = pk_add2(pk_add2(m0, m1), m2), s1 = pk_sub2(pk_sub2(m1, m2), m3);
+                t0[2 * h2] = s0.x;
+                t0[2 * h2 + 1] = s0.y;
+                t1[2 * h2] = s1.x;
+                t1[2 * h2 + 1] = s1.y;
+            }
+            *reinterpret_cast<floatx4*>(ep_w + 16 * bb) = t0;
+            *reinterpret_cast<floatx4*>(ep_w + BP16 * EP_ROW + 16 * bb) = t1;
+        }
+        __syncthreads();
+        {
+            const floatx4 v0 = *reinterpret_cast<const floatx4*>(ep_r + (0 * 2 + bsel) * BP16 * EP_ROW);
+            const floatx4 v1 = *reinterpret_cast<const floatx4*>(ep_r + (1 * 2 + bsel) * BP16 * EP_ROW);
+            const floatx4 v2 = *reinterpret_cast<const floatx4*>(ep_r + (2 * 2 + bsel) * BP16 * EP_ROW);
+            const floatx4 v3 = *reinterpret_cast<const floatx4*>(ep_r + (3 * 2 + bsel) * BP16 * EP_ROW);
+            floatx4 y0 = pk_add(pk_add(v0, v1), v2);          // a_ = 0
+            floatx4 y1 = pk_sub(pk_sub(v1, v2), v3);          // a_ = 1
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    y0[r] = relu1(y0[r]);
+                    y1[r] = relu1(y1[r]);
+                }
+            }
+            const bool blk_ok = n0 + 32 * nb < a.Cout;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, y0), out_rsrc, blk_ok ? ooff[0] : 0xFFFFFFFFu, nb * (32 * 4), 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, y1), out_rsrc, blk_ok ? ooff[1] : 0xFFFFFFFFu, nb * (32 * 4), 0);
+        }
+        if (nb + 1 < NB) __syncthreads();
+    }
+}
+
+template <int NB, int TB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 1 ? 4 : 2, NB == 1 ? 4 : 2)))
 void wino_f2x2_3x3_kernel(WinoGroup g) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -360,18 +580,21 @@ void wino_f2x2_3x3_kernel(WinoGroup g) {
     const WinoJob& a = g.job[j];
     const int unit = b - a.unit0;
     if (unit >= a.n_units) return;                       // padding workgroups between jobs
-    wino_unit<NB>(a, unit, hs);
+    if constexpr (TB == 16)
+        wino16_unit<NB>(a, unit, hs);
+    else
+        wino_unit<NB>(a, unit, hs);
 }
 
 unsigned magic_u32(unsigned d) { return d == 1 ? 0u : (unsigned)(0x100000000ull / d) + 1u; }   // 0 = "divide by one"
 
-template <int NB>
+template <int NB, int TB>
 int launch_t(WinoGroup& g, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     int units = 0;
     for (int q = 0; q < g.n_jobs; ++q) {
         WinoJob& a = g.job[q];
         a.tiles_n = cdiv(a.Cout, 32 * NB);
-        const long long n = (long long)cdiv(a.P, BP) * a.tiles_n;
+        const long long n = (long long)cdiv(a.P, TB) * a.tiles_n;
         VQ_REQUIRE(n > 0 && n < (1 << 24), "Winograd job %d: %lld workgroups", q, n);
         a.unit0 = units;
         a.n_units = (int)n;
@@ -400,8 +623,8 @@ int launch_t(WinoGroup& g, hipStream_t stream, hipEvent_t ev_start, hipEvent_t e
         units += (int)n;
     }
     g.total_units = units;
-    auto kern = wino_f2x2_3x3_kernel<NB>;
-    const size_t lds = LDS_FLOATS * sizeof(float);
+    auto kern = wino_f2x2_3x3_kernel<NB, TB>;
+    const size_t lds = (TB == 16 ? LDS16_FLOATS : LDS_FLOATS) * sizeof(float);
     VQ_LAUNCH(kern, units, 256, lds, stream, ev_start, ev_stop, g);
     VQ_CHECK_LAUNCH();
     return VQ_OK;
@@ -421,8 +644,11 @@ int launch_wino_group(WinoGroup& g, int variant, hipStream_t stream, hipEvent_t 
         VQ_REQUIRE(a.in_bytes <= 0x7FFFFFF0u && a.out_bytes <= 0x7FFFFFF0u,
                    "Winograd convolution: a launch addresses its slots with signed 32-bit byte offsets (split the batch)");
     }
-    if (variant == 0) return launch_t<1>(g, stream, ev_start, ev_stop);
-    if (variant == 1) return launch_t<2>(g, stream, ev_start, ev_stop);
+    VQ_REQUIRE((variant >= 2) == (g.job[0].t16 != 0), "Winograd variant %d on the other filter layout", variant);
+    if (variant == 0) return launch_t<1, 32>(g, stream, ev_start, ev_stop);
+    if (variant == 1) return launch_t<2, 32>(g, stream, ev_start, ev_stop);
+    if (variant == 2) return launch_t<1, 16>(g, stream, ev_start, ev_stop);
+    if (variant == 3) return launch_t<2, 16>(g, stream, ev_start, ev_stop);
     return fail(VQ_E_INVALID, "no Winograd kernel variant %d", variant);
 }
 

@@ -81,6 +81,25 @@ def winograd_filters(W: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(U, dtype=np.float32)
 
 
+WINO16_PERM = (0, 2, 8, 10, 4, 6, 12, 14, 1, 3, 9, 11, 5, 7, 13, 15)     # csrc/vq_wino.hip: slot p of a 16-channel group holds channel PERM[p]
+WINO16_MAX_MAP = 14                                                      # maps of at most 14 x 14 run the 16-tile units
+
+
+def winograd_filters16(W: np.ndarray) -> np.ndarray:
+    """The same transformed filters for the 16-tile units (VQ_OP_CONV_WINOGRAD16): [Cin/16][16][Cout][16 slots], slot p of a group =
+    input channel WINO16_PERM[p] -- the order in which v_mfma_f32_16x16x4 must meet the channels to sum them as the 32-tile kernel does."""
+    cout, cin = W.shape[:2]
+    U = np.matmul(np.matmul(_WINO_G, W.astype(np.float64)), _WINO_G.T)                  # [o][c][i][j]
+    U = U.reshape(cout, cin // 16, 16, 16)[:, :, list(WINO16_PERM), :].transpose(1, 3, 0, 2)   # [c/16][xi][o][slot]
+    return np.ascontiguousarray(U, dtype=np.float32)
+
+
+def wino16_default() -> bool:
+    """Winograd layers on maps of at most 14 x 14 carry the filter layout of the 16-tile units too (the tiling table then picks 16 or 32
+    tiles per launch) unless VQ_TSN_WINO16=0 (same bits either way)."""
+    return os.environ.get("VQ_TSN_WINO16", "1") != "0"
+
+
 def winograd_default() -> bool:
     """3x3 stride-1 convolutions run in Winograd form unless VQ_TSN_WINOGRAD=0."""
     return os.environ.get("VQ_TSN_WINOGRAD", "1") != "0"
@@ -239,6 +258,7 @@ class TsnNet:
         self.max_crops = int(max_crops)
         self.device = device
         self.winograd = winograd_default() if winograd is None else bool(winograd)
+        self.wino16 = wino16_default()
         plan = self.plan
         cin_pad = pad4(self.in_channels)
         self.in_h, self.in_w = plan.tensors[0].h, plan.tensors[0].w
@@ -275,7 +295,7 @@ class TsnNet:
         cache_file = None
         where = os.environ.get("VQ_WEIGHT_CACHE", os.path.join(os.path.dirname(_lib.LIB_PATH), ".weight_cache"))
         if cache_key is not None and where != "0":
-            opts = [_lib.ABI_VERSION, packer_digest(), BK, cache_key, repr(plan.ops), repr(plan.tensors), bool(self.winograd), bool(self.stem_s2d), bool(self.stem_xmajor), float(bn_eps), cin_pad]
+            opts = [_lib.ABI_VERSION, packer_digest(), BK, cache_key, repr(plan.ops), repr(plan.tensors), bool(self.winograd), bool(self.wino16), bool(self.stem_s2d), bool(self.stem_xmajor), float(bn_eps), cin_pad]
             cache_file = os.path.join(where, hashlib.sha1(json.dumps(opts).encode()).hexdigest()[:24])
         cached = _load_packed(cache_file, len(plan.ops)) if cache_file else None
         if cached is not None:
@@ -319,10 +339,16 @@ class TsnNet:
                         W64, b = fold_bn(weights[op.name], weights[op.bn] if op.bn else None, bn_eps, keep64=True)
                         if W64.shape != (op.cout, op.cin, 3, 3):
                             raise ValueError("weights of %s have shape %s" % (op.name, W64.shape))
-                        packed = winograd_filters(W64)
+                        src_t = plan.tensors[op.src]
+                        if self.wino16 and op.cin % 16 == 0 and max(src_t.h, src_t.w) <= WINO16_MAX_MAP:
+                            # few tiles per launch: both layouts, the tiling table picks units of 32 or of 16 tiles per launch (same bits)
+                            packed = np.concatenate([winograd_filters(W64).reshape(-1), winograd_filters16(W64).reshape(-1)])
+                            d.op = _lib.VQ_OP_CONV_WINOGRAD16
+                        else:
+                            packed = winograd_filters(W64)
+                            d.op = _lib.VQ_OP_CONV_WINOGRAD
                         if not op.bias:
                             b = np.zeros_like(b)
-                        d.op = _lib.VQ_OP_CONV_WINOGRAD
                     elif self.stem_s2d and op.src == 0:
                         W, b = fold_bn(weights[op.name], weights[op.bn] if op.bn else None, bn_eps)
                         if W.shape != (op.cout, op.cin, op.k, op.k):
@@ -373,6 +399,7 @@ class TsnNet:
              blob.ctypes.data_as(C.c_void_p), blob.size, C.byref(inp), plan.feature_slot, self.max_crops, device,
              C.byref(self._h))
         self.feature_dim = plan.feature_dim
+        self._layer_ops = [int(layers[i].op) for i in range(len(plan.ops))]
         self._tensor_c = [tensors[i].c for i in range(len(plan.tensors))]
         self._tensor_hw = [(tensors[i].h, tensors[i].w) for i in range(len(plan.tensors))]
         # Tiling tables survive the process: the first forward of a batch size times 24 tilings per layer (~2 s of
@@ -570,6 +597,10 @@ class TsnNet:
         flags = np.zeros(max(k.value, 1), dtype=np.int32)
         call("vq_tsn_tile_tables", self._h, sizes.ctypes.data_as(C.c_void_p), flags.ctypes.data_as(C.c_void_p), sizes.size, C.byref(k))
         return [(int(s), bool(f & 1), bool(f & 2)) for s, f in zip(sizes[:k.value], flags[:k.value])]
+
+    def layer_op(self, i: int) -> int:
+        """The op code layer i was lowered to (include/vq_amd.h: VQ_OP_*)."""
+        return int(self._layer_ops[i])
 
     def launch_items(self):
         """(item_of_layer [n_layers], n_items): which kernel launch of a forward executes each layer -- the Winograd
