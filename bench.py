@@ -814,12 +814,14 @@ def bench_e2e_cli(device_index):
         for c in range(32):                                   # the first 32 clips once more as a tree of their own (links)
             os.symlink(os.path.join(root, "frames", "video", "clip_%04d" % (c + 1)), os.path.join(root, "frames32", "video", "clip_%04d" % (c + 1)))
         times = []
-        # the first run also tunes the tilings of the 800-crop batch; the 256-clip job is then timed three times (the same binary moves by
+        # the first run builds the weight cache (its tilings come with the library); the 256-clip job is then timed three times (the same binary moves by
         # +-10 % from run to run on one box: thread scheduling around the first batch) and the MEDIAN is the value
         for rep, tree in enumerate(("frames", "frames", "frames", "frames", "frames32")):
             out_dir = os.path.join(root, "features%d" % rep)
             argv = [os.path.join(root, tree), "rgb", "rgb_seed2.caffemodel", "flow", "flow_seed5.caffemodel", "--outFeatures_dir", out_dir,
                     "--modelname", "UCF101_split1", "--num_worker", "16", "--gpus", str(device_index), "--device_jpeg"]
+            if os.environ.get("VQ_BENCH_BATCH_CLIPS"):                  # A/B of the command line's --batch_clips (tools/e2e_ab.sh)
+                argv += ["--batch_clips", os.environ["VQ_BENCH_BATCH_CLIPS"]]
             t0 = time.perf_counter()
             with contextlib.redirect_stdout(io.StringIO()):
                 rc = calcSig_wOF.main(argv, net_factory=factory)
@@ -854,10 +856,8 @@ def bench_e2e_cli(device_index):
             argv = [sys.executable, cli, os.path.join(root, "frames"), os.path.join(root, "rgb.prototxt"), "synthetic:2", os.path.join(root, "flow.prototxt"),
                     "synthetic:5", "--outFeatures_dir", os.path.join(root, "fresh"), "--modelname", "UCF101_split1", "--num_worker", "16",
                     "--gpus", str(device_index), "--device_jpeg"]
-            # the child stands for a user's invocation on an otherwise idle GPU: this process gives back the device blocks its closed
-            # extractors pooled (tens of GB: the child's own 2 x 16 GB of hipMalloc otherwise wait for the driver behind them)
-            call("vq_device_pool_trim")
-            torch.cuda.synchronize()
+            # (round 6: draining this process's block pool first -- vq_device_pool_trim -- made the child SLOWER, 3.6 s against 1.2-2.1: a
+            # hipMalloc of 2 x 16 GB right behind another process's hipFree of 100+ GB waits for the driver to reclaim them)
             t0 = time.perf_counter()
             r = subprocess.run(argv, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
             fresh_s = time.perf_counter() - t0
@@ -891,7 +891,7 @@ def bench_e2e_cli(device_index):
             "config": {"workload": "calcSig_wOF.py --device_jpeg --num_worker 16, 256 clips x 30 frames of 340x256, T=25 (the reference's default), "
                                    "both streams, one GPU, network handles rebuilt per run (packed weights from the cache next to the library, as on every "
                                    "run after a machine's first)"},
-            "note": "whole process time of main(): directory parsing, reading 70 400 files (8 batches of 32 clips per stream), JPEG decoding, resize + crop, 800 + 800 crops "
+            "note": "whole process time of main(): directory parsing, reading 70 400 files (16 batches of 16 clips per stream: --batch_clips' default), JPEG decoding, resize + crop, 400 + 400 crops "
                     "through the two networks (which also loads / folds / uploads the weights), CSV writing"}
 
 

@@ -220,7 +220,7 @@ def test_the_shipped_tiling_tables_are_well_formed():
     import re
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-query-algorithms_amd", "tsn", "default_tiles.json")
     doc = json.load(open(path))
-    assert len(doc["tables"]) == 2 and doc["sizes"] == [48, 96, 224, 448, 800]
+    assert len(doc["tables"]) == 2 and doc["sizes"] == [48, 96, 224, 400, 448, 800]
     for key, tab in doc["tables"].items():
         assert re.fullmatch(r"[0-9a-f]{20}", key)
         alone = sorted(int(n) for n in tab if re.fullmatch(r"\d+", n))

@@ -1,5 +1,5 @@
 """Measure the tiling tables that ship with the library (video-query-algorithms_amd/tsn/default_tiles.json): both BN-Inception streams at
-the BASELINE batch sizes (48, 96, 224, 448, 800 crops: one-stream tables; their halves: the paired tables of the default forward's two
+the BASELINE batch sizes (48, 96, 224, 400, 448, 800 crops: one-stream tables; their halves: the paired tables of the default forward's two
 sub-batches).  Per table the sweep of vq_tsn_tune runs REPEATS times; the candidates are then timed as whole forwards, interleaved, and
 the fastest table is kept -- a single sweep's choice moves the step by 1-2.5 % at cfg 2 and up to 9 % at cfg 3.
 Run on the GPU box:  python3 tools/make_default_tiles.py [out.json]   (writes gpurun_out/default_tiles.json by default; copy it to
@@ -18,7 +18,7 @@ import video_query_algorithms_amd as vqa  # noqa: F401
 from video_query_algorithms_amd._lib import call
 from video_query_algorithms_amd.tsn import bn_inception, net
 
-SIZES = (48, 96, 224, 448, 800)
+SIZES = (48, 96, 224, 400, 448, 800)       # 96: BASELINE configs[1]; 448: configs[2]; 400 / 800: the command line's batch at T = 25 (16 / 32 clips)
 REPEATS = int(os.environ.get("VQ_TILES_REPEATS", "3"))
 
 
