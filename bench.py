@@ -891,7 +891,7 @@ def bench_e2e_cli(device_index):
             "config": {"workload": "calcSig_wOF.py --device_jpeg --num_worker 16, 256 clips x 30 frames of 340x256, T=25 (the reference's default), "
                                    "both streams, one GPU, network handles rebuilt per run (packed weights from the cache next to the library, as on every "
                                    "run after a machine's first)"},
-            "note": "whole process time of main(): directory parsing, reading 70 400 files (16 batches of 16 clips per stream: --batch_clips' default), JPEG decoding, resize + crop, 400 + 400 crops "
+            "note": "whole process time of main(): directory parsing, reading 70 400 files (8 batches of 32 clips per stream), JPEG decoding, resize + crop, 800 + 800 crops "
                     "through the two networks (which also loads / folds / uploads the weights), CSV writing"}
 
 

@@ -65,9 +65,9 @@ def build_parser():
     parser.add_argument('--featureBlob_size', type=int, default=1024, help='expected size of the feature blob')
     # additions (not in the reference)
     parser.add_argument('--frame_ext', type=str, default='.jpg', help='frame file extension (.jpg needs cv2 or PIL)')
-    parser.add_argument('--batch_clips', type=int, default=16,
-                        help='clips per forward pass (16 x T = 400 crops per stream at the default T: the networks run as efficiently as on 800, '
-                             'the first batch is decoded in half the time and the activation slots take 8 GB per stream instead of 16)')
+    parser.add_argument('--batch_clips', type=int, default=32,
+                        help='clips per forward pass (32 x T = 800 crops per stream at the default T; 16 runs the networks as efficiently with '
+                             'half the activation memory and a shorter start, but no faster end to end: profiles/README.md)')
     parser.add_argument('--host_resize', action='store_true',
                         help='resize + crop the frames on the host (numpy) instead of on the GPU; same bytes either way')
     parser.add_argument('--exact_resize', action='store_true',

@@ -286,9 +286,10 @@ class ShardedFeatureDB:
         before = getattr(self, "_slots_used", "unset")
         if not isinstance(before, str) and ((used is None and before is None) or (used is not None and before is not None and (used == before).all())):
             return                                           # the restriction the ranks already hold: nothing to announce
-        self._slots_used = None if used is None else used.copy()
+        self._slots_used = "unset"                           # until every rank has taken the new restriction
         self._announce(OP_RESTRICT, ints=[-1] if used is None else used.astype(np.int64).reshape(-1))
         self._local_step(lambda: self.local.restrict_slots(used))
+        self._slots_used = None if used is None else used.copy()
 
     @_atomic
     def set_query(self, t):
