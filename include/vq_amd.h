@@ -65,7 +65,7 @@ extern "C" {
  * 9 (round 5): + vq_jpeg_crops; vq_jpeg_decode*(color | 2) stops at the component planes.
  * 10 (round 5): + vq_dev_malloc / vq_dev_free / vq_stream_create / vq_stream_destroy / vq_stream_synchronize / vq_dev_read.
  * 11 (round 6): + vq_tsn_tile_tables / vq_tsn_get_tiles / vq_tsn_set_tiles / vq_tsn_tune / vq_tsn_set_split / vq_device_pool_trim; VQ_OP_CONV_WINOGRAD16 (a tiling table is keyed by (batch size, timed side by side on
- *      the sub-batch streams | alone)); vq_db_query_round / vq_db_round_layout / vq_host_alloc / vq_host_free (a query round in one call);
+ *      the sub-batch streams | alone)); vq_db_query_round / vq_db_round_layout / vq_host_alloc / vq_host_free (a query round in one call); vq_db_loss_surface;
  *      vq_stream_create_priority. */
 #define VQ_ABI_VERSION 11
 
@@ -200,6 +200,14 @@ int vq_db_write_avg(vq_db* db, const double* avg_host, const int32_t* n_e_host);
  * labelled clips that the loss (hyperparameter.py:60-64) actually reads. */
 int vq_db_scores_grid(vq_db* db, const double* w_grid_host, int32_t G, const int64_t* rows_host, int32_t L,
                       double* out_host);
+
+/* Hyperparameter.optimize_weights' loss surface (hyperparameter.py:57-64) in ONE launch: for each of the G grid weights (w_grid [G][S]) the
+ * scores of the L labelled rows (as vq_db_scores_grid), and over the T grid thresholds
+ *     out[g][t] = 0.5 th[t] + sum over the labels IN ORDER of (heaviside(score - th[t], 1) - y) * (score - th[t]) * (1 + y * ballast)
+ * with the reference's elementwise operations in its order (fp64, no contraction): every cell sees the sequence of additions of the
+ * reference's loop over `inferred_validations` (the caller divides by L).  labels: 1.0 / 0.0 per row.  L <= 4096. */
+int vq_db_loss_surface(vq_db* db, const double* w_grid_host, int32_t G, const int64_t* rows_host, const double* labels_host, int32_t L,
+                       const double* th_grid_host, int32_t T, double ballast, double* out_host);
 
 /* Order-preserving partition of the scores, Ticket.select_clips_to_review (ticket.py:325-340):
  * match = {v >= threshold}, near = {lower <= v < threshold}, near_argmax = first row of the

@@ -78,6 +78,7 @@ SIGNATURES = {
     "vq_db_read_similarities": [_P, _P, _P, _P], "vq_db_read_scores": [_P, _P],
     "vq_db_scores_devptr": [_P, _PP], "vq_db_avg_devptr": [_P, _PP], "vq_db_ne_devptr": [_P, _PP], "vq_db_read_rows": [_P, _P, _I32, _P], "vq_db_read_scores_at": [_P, _P, _I32, _P], "vq_db_write_avg": [_P, _P, _P],
     "vq_db_scores_grid": [_P, _P, _I32, _P, _I32, _P],
+    "vq_db_loss_surface": [_P, _P, _I32, _P, _P, _I32, _P, _I32, _F64, _P],
     "vq_db_select": [_P, _F64, _F64, _pI64, _pI64, _pI64], "vq_db_select_fetch": [_P, _P, _I64, _P, _I64],
     "vq_db_select_rows": [_P, _F64, _F64, _P, _I64, _P, _I64, _pI64, _pI64, _pI64],
     "vq_db_round_layout": [_P, _P], "vq_db_query_round": [_P, _P, _I64, _I32, _F64, _F64], "vq_host_alloc": [_PP, _I64], "vq_host_free": [_P],

@@ -661,6 +661,38 @@ __global__ void grid_kernel(const double* avg, const double* w_grid, const int64
     out[i] = score_from_avg(av, w, S);
 }
 
+// hyperparameter.py:57-64 in one launch: the 40 rescorings of the labelled rows AND the loss surface over the threshold grid.  Block g =
+// grid weight g: its L scores (score_from_avg, as grid_kernel) go to LDS, then thread t walks the labels IN ORDER for threshold t:
+//     surface[g][t] = 0.5 th[t] + sum_l (heaviside(score_l - th[t], 1) - y_l) * (score_l - th[t]) * (1 + y_l * ballast)
+// -- the elementwise operations of the reference's numpy expression in its order (this file is compiled without contraction), one clip
+// at a time in the dict's order: every cell sees the reference's sequence of fp64 operations (the division by L stays on the host).
+__global__ void loss_surface_kernel(const double* avg, const double* w_grid, const int64_t* rows, const double* labels, const double* th_grid,
+                                    double* out, int L, int T, int S, double ballast) {
+    extern __shared__ double ls_scores[];                      // [L]
+    const int g = blockIdx.x;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        double av[8], w[8];
+        for (int s = 0; s < S; ++s) {
+            av[s] = avg[rows[l] * S + s];
+            w[s] = w_grid[g * S + s];
+        }
+        ls_scores[l] = score_from_avg(av, w, S);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        const double th = th_grid[t];
+        double surf = 0.5 * th;
+        for (int l = 0; l < L; ++l) {
+            const double y = labels[l];
+            const double margin = ls_scores[l] - th;
+            const double h = margin < 0.0 ? 0.0 : (margin >= 0.0 ? 1.0 : margin);     // np.heaviside(margin, 1); NaN stays NaN
+            const double c = 1.0 + y * ballast;
+            surf = surf + ((h - y) * margin) * c;
+        }
+        out[g * T + t] = surf;
+    }
+}
+
 // target_clip.py:311-313: t = r / (r . r), one block per (s,e) vector of row `row`, fp64 throughout.
 // element k of vector (row, v): row-major, or inside the tiled layout [tile][v][k / 4][row % 16][4]
 __device__ __forceinline__ int64_t feat_index(bool tiled, int64_t row, int v, int k, int NV, int D) {
@@ -1970,6 +2002,34 @@ int vq_db_scores_grid(vq_db* db, const double* w_grid_host, int32_t G, const int
                                                                     (double*)(base + wb + rb), G, L, db->S);
     VQ_CHECK_LAUNCH();
     VQ_HIP(hipMemcpyAsync(out_host, base + wb + rb, ob, hipMemcpyDeviceToHost, db->stream));
+    VQ_HIP(hipStreamSynchronize(db->stream));
+    return VQ_OK;
+}
+
+int vq_db_loss_surface(vq_db* db, const double* w_grid_host, int32_t G, const int64_t* rows_host, const double* labels_host, int32_t L,
+                       const double* th_grid_host, int32_t T, double ballast, double* out_host) {
+    VQ_REQUIRE(db && w_grid_host && rows_host && labels_host && th_grid_host && out_host, "NULL argument");
+    VQ_REQUIRE(G > 0 && L > 0 && T > 0 && L <= 4096, "G, L, T must be positive (L <= 4096 labelled clips)");
+    for (int l = 0; l < L; ++l)
+        VQ_REQUIRE(rows_host[l] >= 0 && rows_host[l] < db->n, "rows[%d] = %lld outside [0,%lld)", l, (long long)rows_host[l], (long long)db->n);
+    std::lock_guard<std::mutex> lk(db->mu);
+    if (!db->have_avg) return fail(VQ_E_STATE, "no similarities cached (call vq_db_scan first)");
+    DeviceGuard g(db->device);
+    // one staging block: weights | rows | labels | thresholds in, the surface out
+    const int64_t wb = (int64_t)G * db->S * 8, rb = (int64_t)L * 8, tb = (int64_t)T * 8, ob = (int64_t)G * T * 8;
+    int rc = ensure_grid_buf(db, wb + 2 * rb + tb + ob);
+    if (rc != VQ_OK) return rc;
+    std::vector<char> stage((size_t)(wb + 2 * rb + tb));
+    memcpy(stage.data(), w_grid_host, (size_t)wb);
+    memcpy(stage.data() + wb, rows_host, (size_t)rb);
+    memcpy(stage.data() + wb + rb, labels_host, (size_t)rb);
+    memcpy(stage.data() + wb + 2 * rb, th_grid_host, (size_t)tb);
+    char* base = (char*)db->grid_buf;
+    VQ_HIP(hipMemcpyAsync(base, stage.data(), stage.size(), hipMemcpyHostToDevice, db->stream));      // pageable: staged before the call returns
+    loss_surface_kernel<<<G, 64, (size_t)L * 8, db->stream>>>(db->avg, (const double*)base, (const int64_t*)(base + wb), (const double*)(base + wb + rb),
+                                                               (const double*)(base + wb + 2 * rb), (double*)(base + wb + 2 * rb + tb), L, T, db->S, ballast);
+    VQ_CHECK_LAUNCH();
+    VQ_HIP(hipMemcpyAsync(out_host, base + wb + 2 * rb + tb, ob, hipMemcpyDeviceToHost, db->stream));
     VQ_HIP(hipStreamSynchronize(db->stream));
     return VQ_OK;
 }

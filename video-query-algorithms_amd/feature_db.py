@@ -416,6 +416,19 @@ class FeatureDB:
         call("vq_db_scores_grid", self._h, _np_ptr(wg), wg.shape[0], _np_ptr(r), r.shape[0], _np_ptr(out))
         return out
 
+    def loss_surface(self, w_grid: np.ndarray, rows: Sequence[int], labels: Sequence[float], th_grid: np.ndarray, ballast: float) -> np.ndarray:
+        """hyperparameter.py:57-64 in one launch: [G, T] sums of the loss over the labelled rows (in order) for every grid weight and
+        grid threshold, starting from 0.5 * threshold; the caller divides by the number of labels (include/vq_amd.h)."""
+        wg = np.ascontiguousarray(w_grid, dtype=np.float64)
+        r = np.ascontiguousarray(rows, dtype=np.int64).reshape(-1)
+        y = np.ascontiguousarray(labels, dtype=np.float64).reshape(-1)
+        th = np.ascontiguousarray(th_grid, dtype=np.float64).reshape(-1)
+        if wg.ndim != 2 or wg.shape[1] != self.S or y.shape != r.shape:
+            raise ValueError("w_grid must be [G,%d] and one label per row" % self.S)
+        out = np.empty((wg.shape[0], th.size), dtype=np.float64)
+        call("vq_db_loss_surface", self._h, _np_ptr(wg), wg.shape[0], _np_ptr(r), _np_ptr(y), r.size, _np_ptr(th), th.size, float(ballast), _np_ptr(out))
+        return out
+
     def select(self, threshold: float, lower: float):
         """Order-preserving partition (ticket.py:325-340): (match_rows, near_rows, near_argmax).  Partition and
         copy-out are one locked call of the library, so handles shared between broker threads stay consistent."""

@@ -48,10 +48,19 @@ class Hyperparameter:
         first, second = (ticket._stream_names.index(st) for st in self.streams[:2])
         candidates = np.zeros((len(self.weight_grid), db.S))
         candidates[:, first], candidates[:, second] = 1.0, self.weight_grid
+        on_device = hasattr(db, "loss_surface") and 0 < len(labels) <= 4096
         with getattr(db, "lock", None) or contextlib.nullcontext():
             if hasattr(ticket, "_own_similarities"):
                 ticket._own_similarities()      # a resident database shared between tickets: this ticket's similarities (ticket.py)
-            graded = db.scores_grid(candidates, rows)                               # [40][L] in one launch
+            if on_device:
+                # the 40 rescorings AND the 40 x 31 loss surface in one launch: per cell the reference's fp64 operations, the labelled clips
+                # added one at a time in the dict's order (csrc/vq_sim.hip: loss_surface_kernel) -- what the numpy lines below do on the host
+                surface = db.loss_surface(candidates, rows, [float(v) for v in labels], self.threshold_grid, self.ballast)
+            else:
+                graded = db.scores_grid(candidates, rows)                           # [40][L] in one launch
+        if on_device:
+            surface = surface / len(labels)
+            return self._pick(ticket, surface)
         th = self.threshold_grid[None, :]
         surface = np.tile(0.5 * th, (len(self.weight_grid), 1))
         # every clip's term of hyperparameter.py:60-64 at once ([L][40][31], the same elementwise operations in the same order), then
@@ -62,6 +71,10 @@ class Hyperparameter:
         for term in terms:
             surface = surface + term
         surface = surface / len(labels)
+        return self._pick(ticket, surface)
+
+    def _pick(self, ticket, surface):
+        """Weights and threshold from the loss surface (hyperparameter.py:66-76)."""
         iw, it = np.unravel_index(np.argmin(surface), surface.shape)                # first minimum, row-major
         ticket.compute_scores({self.streams[0]: 1.0, self.streams[1]: self.weight_grid[-1]})   # what the 40 passes leave
         on_rim = iw in (0, len(self.weight_grid) - 1) or it in (0, len(self.threshold_grid) - 1)

@@ -415,5 +415,5 @@ def install(ticket_cls, hyperparameter_cls=None, target_clip_cls=None):
             setattr(ticket_cls, name, getattr(TicketScoring, name))
     if hyperparameter_cls is not None:
         from .hyperparameter import Hyperparameter
-        for name in ("optimize_weights", "_labelled_rows", "_refine"):
+        for name in ("optimize_weights", "_labelled_rows", "_refine", "_pick"):
             setattr(hyperparameter_cls, name, Hyperparameter.__dict__[name])
