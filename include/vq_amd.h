@@ -22,6 +22,7 @@
  *   the library
  *     VQ_DEVICE_POOL_GB=<n>        device blocks of closed TSN extractors kept for the next one of the same shape (default 40, 0 = off)
  *     VQ_TSN_SPLIT=<n> | a,b,..    sub-batches of a forward on separate HIP streams (default 2; 1 = one stream)
+ *     VQ_SCAN_LEAN=0|1             force the register-lean / register-resident instantiation of the row-major scan (default: by database shape)
  *     VQ_TSN_AUTOTUNE=0|1          0: batch sizes without a tiling table run the occupancy heuristic (nothing is ever timed); 1: the tables
  *                                  shipped beside the library are left out and every size is timed in its first forward; unset: shipped
  *                                  tables, and a timing sweep only for sizes further than 1.6x from every table
