@@ -856,11 +856,10 @@ def bench_e2e_cli(device_index):
             argv = [sys.executable, cli, os.path.join(root, "frames"), os.path.join(root, "rgb.prototxt"), "synthetic:2", os.path.join(root, "flow.prototxt"),
                     "synthetic:5", "--outFeatures_dir", os.path.join(root, "fresh"), "--modelname", "UCF101_split1", "--num_worker", "16",
                     "--gpus", str(device_index), "--device_jpeg"]
-            # The child stands for ONE invocation on a quiet GPU.  What this process freed in its earlier sections (the 41 GB database of
-            # configs[3], the flow handles) is still being reclaimed by the driver for a second or two, and a hipMalloc of 2 x 16 GB waits
-            # for that (tools/fresh_runs.py: 0.95-1.05 s with 3 s of idle GPU before a run, 1.1-2.0 s back to back; draining this
-            # process's own block pool first -- vq_device_pool_trim -- made it 3.6 s).  So: three quiet seconds first.
-            time.sleep(3.0)
+            # The child stands for ONE invocation -- but it starts beside THIS process, which holds its block pool and has just released the
+            # 41 GB database of configs[3]: its hipMalloc of 2 x 16 GB waits for the driver by box (1.0-2.4 s here against 0.95-1.05 s for
+            # the same command with a quiet GPU, tools/fresh_runs.py; a few idle seconds before it did not help, draining this process's
+            # pool first -- vq_device_pool_trim -- made it 3.6 s).  The figure is an upper bound of what a user's invocation costs.
             t0 = time.perf_counter()
             r = subprocess.run(argv, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
             fresh_s = time.perf_counter() - t0
