@@ -433,8 +433,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 // next tile, or one LDS store of it -- and a scheduling fence, so a wave keeps its SIMD's matrix pipe fed
 // while it stages (an in-order wave cannot overlap a BLOCK of vector work with more than one MFMA).
 // ------------------------------------------------------------------------------------------------
+// (round 6: the 128 x 64 x 16 and 64 x 128 x 16 tilings need 134 registers left alone; held to 128 -- no spill -- they fit FOUR workgroups per
+// compute unit instead of three: conv1 0.245 -> 0.239 ms, the cfg-2 step in product mode +2 % in alternating builds on one box.  The BK = 32
+// tilings of the same area spill 140-232 bytes per lane under that limit and keep their 154-160 registers.)
+#ifndef VQ_PIPE_WPE
+#define VQ_PIPE_WPE 4
+#endif
 template <int BM, int BN, int WM, int WN, int BK, bool SMALL_CIN>
-__global__ __launch_bounds__(256) void conv_igemm_pipe_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM * BN == 128 * 64 && BK == 16 ? VQ_PIPE_WPE : 1, 8)))
+void conv_igemm_pipe_kernel(ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int NT = 256;                    // threads per workgroup
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
